@@ -1,0 +1,130 @@
+"""Pins the CPU oracle (oracle/segmif_oracle.py) to golden vectors produced by the real
+upstream reference (oracle/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import detweights as dw
+import segmif_oracle as so
+
+TOL = 2e-5  # oracle and reference run the same fp32 torch-CPU ops; only op order differs
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def load(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+@pytest.fixture(scope="module")
+def sd_fus():
+    return dw.det_state_dict(so.fusion_shapes(), seed=0)
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    for bb in ("mit_b0", "mit_b1", "mit_b3"):
+        ours = {k: list(v) for k, v in so.network3_shapes(bb, 9).items()}
+        assert ours == keys["Network3:" + bb]
+    assert {k: list(v) for k, v in so.fusion_shapes().items()} == keys["Fusion_Network3_ac"]
+    assert len(keys["Network3:mit_b3"]) == 589 and len(keys["Fusion_Network3_ac"]) == 97
+
+
+def test_mit_b0_ragged(golden_dir):
+    g = load(golden_dir, "mit_b0_72x104.npz")
+    sd = dw.det_state_dict(so.network3_shapes("mit_b0", 9), seed=0)
+    x = torch.from_numpy(g["x"])
+    assert torch.equal(x, dw.det_input("b0_72x104", (1, 3, 72, 104)))
+    feats = so.mit_forward_features(sd, "denoise_net.encoder.", x, "mit_b0")
+    assert [tuple(f.shape) for f in feats] == [(1, 32, 18, 26), (1, 64, 9, 13), (1, 160, 5, 7), (1, 256, 3, 4)]
+    for i, f in enumerate(feats):
+        assert rel_err(f, g[f"f{i + 1}"]) < TOL
+    o0, o1 = so.mit_forward_fusion(sd, "denoise_net.encoder.", x, "mit_b0")
+    assert rel_err(o0[:, :, 1::5, 2::7], g["fus0_sample"]) < TOL
+    assert rel_err(o1[:, :, 1::5, 2::7], g["fus1_sample"]) < TOL
+    assert abs(float(o0.double().mean()) - float(g["fus0_mean"])) < 1e-6
+    assert rel_err(so.network3_forward(sd, x, "mit_b0"), g["seg"]) < TOL
+
+
+def test_f2_mit_b0_features_do_not_fit_fusion_net(golden_dir, sd_fus):
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    assert meta["F2_mit_b0_fusion_raises"] is True
+    x = torch.zeros(1, 3, 32, 32)
+    with pytest.raises(RuntimeError):
+        so.fusion_network3_ac(sd_fus, x[:, :1], x, torch.zeros(1, 32, 32, 32), torch.zeros(1, 64, 32, 32))
+
+
+def test_pair_b1(golden_dir, sd_fus):
+    g = load(golden_dir, "pair_b1_64x96.npz")
+    sd = dw.det_state_dict(so.network3_shapes("mit_b1", 9), seed=0)
+    ir, vis, mask = (torch.from_numpy(g[k]) for k in ("ir", "vis", "mask"))
+    feats = so.mit_forward_features(sd, "denoise_net.encoder.", mask, "mit_b1")
+    for i, f in enumerate(feats):
+        assert rel_err(f, g[f"f{i + 1}"]) < TOL
+    r = so.pair_forward(sd, sd_fus, ir, vis, mask, "mit_b1", return_all=True)
+    assert rel_err(r["out0"][:, :, 1::5, 2::7], g["out0_sample"]) < TOL
+    assert rel_err(r["out1"][:, :, 1::5, 2::7], g["out1_sample"]) < TOL
+    for k in ("y_fused", "fused", "seg", "logits"):
+        assert rel_err(r[k], g[k]) < 5e-5, k
+    stable = torch.from_numpy(g["margin"]) > 1e-4
+    assert torch.equal(r["labels"][stable], torch.from_numpy(g["labels"]).long()[stable])
+    assert int(stable.sum()) > 0.99 * stable.numel()
+
+
+def test_fusion_blocks(golden_dir, sd_fus):
+    g = load(golden_dir, "fusion_blocks.npz")
+    y = so.drdb(sd_fus, "DRDB1", torch.from_numpy(g["drdb_x"]))
+    assert rel_err(y, g["drdb_y"]) < TOL
+    o1, o2 = so.feature_fusion_module(sd_fus, "ffm", *(torch.from_numpy(g[k]) for k in ("ffm_x1", "ffm_x2", "ffm_seg")))
+    assert rel_err(o1, g["ffm_o1"]) < TOL and rel_err(o2, g["ffm_o2"]) < TOL
+
+
+def test_mit_blocks(golden_dir):
+    g = load(golden_dir, "mit_blocks.npz")
+    sd = dw.det_state_dict(so.network3_shapes("mit_b1", 9), seed=0)
+    e = "denoise_net.encoder."
+    t = torch.from_numpy(g["tokens"])
+    assert rel_err(so.sr_attention(sd, e + "block2.1.attn", t, 8, 12, 2, 4), g["attn"]) < TOL
+    assert rel_err(so.mix_ffn(sd, e + "block2.1.mlp", t, 8, 12), g["ffn"]) < TOL
+    assert rel_err(so.mit_block(sd, e + "block2.1", t, 8, 12, 2, 4), g["block"]) < TOL
+    pt, ph, pw = so.overlap_patch_embed(sd, e + "patch_embed2", torch.from_numpy(g["pe_x"]), 3, 2)
+    assert [ph, pw] == g["pe_hw"].tolist() == [9, 12]
+    assert rel_err(pt, g["pe_tokens"]) < TOL
+    t4 = torch.from_numpy(g["tokens4"])
+    assert rel_err(so.sr_attention(sd, e + "block4.0.attn", t4, 2, 3, 8, 1), g["attn4"]) < TOL
+
+
+def test_colour_round_trip_and_miou():
+    x = dw.det_input("rgb", (2, 3, 8, 9))
+    back = so.ycrcb2rgb(so.rgb2ycrcb(x))
+    assert rel_err(back, x) < 2e-3  # the upstream matrices are only approximately inverse
+    conf = so.confusion([0, 1, 1, 2, 255], [0, 1, 2, 2, 0], n_class=3)
+    assert conf.tolist() == [[1, 0, 0], [0, 1, 1], [0, 0, 1]]
+    m, iou = so.miou(conf)
+    assert np.allclose(iou, [1.0, 0.5, 0.5]) and abs(m - 2 / 3) < 1e-12
+
+
+def test_full_size_checksum_b3(golden_dir, sd_fus):
+    """mit_b3 @ 480x640 pair forward: oracle vs the reference's recorded samples/labels."""
+    g = load(golden_dir, "pair_b3_480x640_checksum.npz")
+    sd = dw.det_state_dict(so.network3_shapes("mit_b3", 9), seed=0)
+    H, W = 480, 640
+    ir = dw.det_input("b3_ir", (1, 1, H, W))
+    vis = dw.det_input("b3_vis", (1, 3, H, W))
+    mask = dw.det_input("b3_mask", (1, 1, H, W)).repeat(1, 3, 1, 1)
+    with torch.no_grad():
+        r = so.pair_forward(sd, sd_fus, ir, vis, mask, "mit_b3", return_all=True)
+    for name in ("out0", "out1", "y_fused", "fused", "seg", "logits"):
+        got = r[name].reshape(-1)[torch.from_numpy(g[name + "_idx"])]
+        scale = max(abs(g[name + "_stats"][2]), abs(g[name + "_stats"][3]))
+        assert float((got - torch.from_numpy(g[name + "_val"])).abs().max()) / scale < 5e-5, name
+    stable = torch.from_numpy(g["margin_f16"].astype(np.float32)) > 1e-3
+    assert torch.equal(r["labels"][stable], torch.from_numpy(g["labels"]).long()[stable])
+    assert len(np.unique(g["labels"])) >= 5  # non-degenerate segmentation on synthetic input
