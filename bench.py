@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py — IR+visible image-pairs/s, forward (BASELINE.json metric) on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic pairs already resident in HBM:
+  out0,out1 = seg.denoise_net.encoder.forward_fusion(mask3)   (MiT encoder + 2 bilinear resizes)
+  Yf        = fusion(ir, vis, out0, out1)                      (Fusion_Network3_ac)
+  fused     = clamp01(YCrCb2RGB([Yf, Cr(vis), Cb(vis)]))
+  logits    = seg(fused) -> bilinear x4 -> argmax              (Network3 = MiT encoder + SegFormer head)
+exactly the in-memory chain of test_fusion.py:100-111 + test_segmentation.py:169-174.
+
+Launch: `python bench.py --gpus 1` or, for N > 1,
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+One process per GPU; the path shards over independent pairs, so there is no data-path collective
+(weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+# algorithmic work, GFLOP per pair forward at 480x640 (torch FlopCounterMode, 2*MAC)
+GFLOP_PER_PAIR = {"mit_b1": 700.2, "mit_b3": 827.1}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
+    ap.add_argument("--backbone", default="mit_b3")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(backbone, H, W):
+    """The oracle (CPU port of the reference path) timed on this host's cores on a bounded sample."""
+    import detweights as dw
+    import segmif_oracle as so
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd_seg = dw.det_state_dict(so.network3_shapes(backbone, 9), seed=0)
+    sd_fus = dw.det_state_dict(so.fusion_shapes(), seed=0)
+    ir = dw.det_input("cpu_ir", (1, 1, H, W))
+    vis = dw.det_input("cpu_vis", (1, 3, H, W))
+    mask = dw.det_input("cpu_mask", (1, 1, H, W)).repeat(1, 3, 1, 1)
+    n = 0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        while True:
+            so.pair_forward(sd_seg, sd_fus, ir, vis, mask, backbone)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > 10.0 or n >= 4:
+                break
+    return {"value": n / dt, "unit": "img-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} pair(s) of {backbone} {H}x{W} at batch 1 through oracle/segmif_oracle.py "
+                      f"(torch-CPU fp32), {dt:.1f} s, no warm-up"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import detweights as dw
+    from segmif_amd import ops
+    from segmif_amd.core import Fusion_Network3_ac, Network3, fuse_to_rgb
+
+    B, H, W = args.batch, args.height, args.width
+    seg = Network3(args.backbone, 9, pretrained=None)
+    fus = Fusion_Network3_ac()
+    dw.load_det_weights(seg, seed=0)
+    dw.load_det_weights(fus, seed=0)
+    seg, fus = seg.cuda().eval(), fus.cuda().eval()
+    ir = dw.det_input(f"bench_ir_{rank}", (B, 1, H, W)).cuda()
+    vis = dw.det_input(f"bench_vis_{rank}", (B, 3, H, W)).cuda()
+    mask = dw.det_input(f"bench_mask_{rank}", (B, 1, H, W)).repeat(1, 3, 1, 1).cuda()
+
+    def step():
+        out0, out1 = seg.denoise_net.encoder.forward_fusion(mask)
+        y_f = fus(ir, vis, out0, out1)
+        fused = fuse_to_rgb(vis, y_f)
+        return seg.predict_labels(fused, (H, W))
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            labels = step()
+        timer = None
+        if not args.no_kernel_timer:
+            timer = ops.LaunchTimer("drdb_dcov")
+            ops.set_launch_timer(timer)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            labels = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        ops.set_launch_timer(None)
+    assert labels.shape == (B, H, W)
+
+    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / elapsed
+        out = {
+            "metric": "IR+visible image-pairs/sec fwd", "value": value, "unit": "img-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.backbone} pair forward (forward_fusion + Fusion_Network3_ac + Network3 "
+                                   f"+ x4 bilinear + argmax), {H}x{W}, {B} pairs per GPU per step, eval mode, "
+                                   "seeded deterministic weights",
+                       "backbone": args.backbone, "height": H, "width": W, "pairs_per_gpu": B,
+                       "parallelism": f"replicas x{world} (independent pairs, no collective)"},
+        }
+        gf = GFLOP_PER_PAIR.get(args.backbone)
+        if gf is not None and (H, W) == (480, 640):
+            out["whole_path_tflops"] = value * gf / 1000.0 / world
+        if timer is not None:
+            n, ms, flops = timer.summary()
+            achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out["roofline"] = {
+                "kernel": "igemm_kernel<256,32,*,MODE_CONV> (DRDB dilated 3x3 conv, fp32 MFMA)",
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "launches_timed": n, "avg_launch_ms": ms, "avg_launch_gflop": flops / 1e9,
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.backbone, H, W)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/*
+ * segmif_hip.h — C ABI of libsegmif_hip.so: the MI355X (gfx950) kernels behind SegMiF's
+ * fusion + segmentation hot path.
+ *
+ * The upstream reference (JinyuanLiu-CV/SegMiF) is pure Python: it has no FFI of its own and
+ * delegates all arithmetic to aten ops.  The entry points below are therefore what a binding
+ * for this path binds *instead of* those aten calls; each one cites the reference call site(s)
+ * it replaces (paths relative to the reference root).  segmif_amd/_lib.py is the ctypes binding;
+ * INTEGRATION.md shows how the reference's core/ package is swapped for segmif_amd.core.
+ *
+ * Conventions
+ *  - all tensors are fp32, device-resident, activation layout NHWC == tokens (B, H*W, C);
+ *    a "row" is one pixel/token; leading dimensions (ld*) are in floats.
+ *  - no allocation, no global state, re-entrant per stream; work is enqueued on `stream`
+ *    (a hipStream_t passed as void*).  Returns 0 on success, a hipError_t / negative
+ *    SEGMIF_E* code otherwise.
+ *  - pointers must be 16-byte aligned where a vector path applies (documented per call).
+ */
+#ifndef SEGMIF_HIP_H
+#define SEGMIF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEGMIF_ABI_VERSION 1
+#define SEGMIF_EINVAL (-22)
+#define SEGMIF_ENOSYS (-38)
+
+/* activation codes for fused epilogues */
+enum { SEGMIF_ACT_NONE = 0, SEGMIF_ACT_RELU = 1, SEGMIF_ACT_PRELU = 2, SEGMIF_ACT_GELU = 3 };
+
+int segmif_abi_version(void);
+/* name of the device the library sees (debug aid); returns 0 and fills buf. */
+int segmif_device_name(char* buf, int len);
+
+/*
+ * Implicit-GEMM convolution / linear on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *
+ *   out[z][m][n] = epi( sum_k A(m,k) * Wt[z][n][k] + bias[n] )
+ *   epi(y) = act(y)                      res == NULL
+ *          = res[z][m][n] + act(y)       res != NULL
+ *
+ * A(m,k) is gathered on the fly (no im2col buffer):
+ *   conv:  m = (b, oy, ox) over B*OH*OW, k = (ky, kx, c) tap-major / channel-minor,
+ *          A = in[b][oy*stride - pad + ky*dil][ox*stride - pad + kx*dil][c]  (0 outside),
+ *          `in` is NHWC with pixel pitch lda (lets a conv read the first Cin channels of a
+ *          wider concat buffer) ;
+ *   dense: A = in[m*lda + k]  (KH = KW = 1, stride 1, pad 0 — nn.Linear / 1x1 conv);
+ *   dense, two sources (k < K1 from in, k >= K1 from in2 with pitch lda2) when in2 != NULL.
+ * Wt is [N][Kp] row-major, Kp = K rounded up to 16 and zero-filled (see segmif_pack_conv_weight).
+ * out pitch ldo (lets a conv write its channels in place into a concat buffer).
+ *
+ * Replaces: nn.Conv2d / nn.Linear / F.conv2d call sites on the path —
+ *   core/mix_transformer.py:47,51 (fc1/fc2), :96,102,112 (q/kv/proj), :100 (sr conv), :193 (patch
+ *   embed); core/segformer_head.py:23,77,80; core/model_fusion.py:135-155 (DRDB convs, with the
+ *   torch.cat of :137-153 folded into ldo), :351-353,:359-360 (CrossPath linears), :1051-1065
+ *   (conv1/2/21/22/3/4 with the shared PReLU of :1038).
+ */
+typedef struct SegmifIgemm {
+  const float* in;     /* activations */
+  const float* in2;    /* optional second dense source (NULL otherwise) */
+  const float* wt;     /* packed weights [N][Kp] */
+  const float* bias;   /* [N] or NULL */
+  const float* res;    /* residual [M][ldr] or NULL */
+  const float* prelu;  /* device scalar slope, used when act == SEGMIF_ACT_PRELU */
+  float* out;
+  int64_t M;           /* rows per z-slice: B*OH*OW */
+  int32_t N, K;        /* K = KH*KW*Cin (un-padded) */
+  int32_t lda, lda2, K1, ldo, ldr;
+  /* conv geometry (dense: KH=KW=1, stride=1, pad=0, dil=1, H=OH, W=OW, Cin=K) */
+  int32_t H, W, Cin, KH, KW, stride, pad, dil, OH, OW;
+  int32_t act;
+  /* batching over gridDim.z (e.g. per-image weights): element strides, 0 = shared */
+  int32_t nz;
+  int64_t in_zstride, in2_zstride, wt_zstride, out_zstride, res_zstride;
+  int32_t tile;        /* -1 = auto; otherwise index into the tile table (bench / tests) */
+} SegmifIgemm;
+
+int segmif_igemm_f32(const SegmifIgemm* desc, void* stream);
+/* number of tile configurations and a printable name for each (bench / tests) */
+int segmif_igemm_num_tiles(void);
+const char* segmif_igemm_tile_name(int tile);
+
+/*
+ * Repack an OIHW conv weight (Cout, Cin, KH, KW) — or a Linear weight (N, K) with KH=KW=1 — into
+ * the [N][Kp] tap-major/channel-minor layout segmif_igemm_f32 consumes. dst holds N*Kp floats,
+ * Kp = ((KH*KW*Cin + 15) / 16) * 16; the tail is zero-filled.
+ */
+int segmif_pack_conv_weight(const float* src_oihw, float* dst, int N, int Cin, int KH, int KW, void* stream);
+
+/*
+ * LayerNorm over the last dimension: y = (x - mean) / sqrt(var + eps) * gamma + beta,
+ * biased variance, two-pass in registers.  rows x C, pitches ldx/ldy. C % 4 == 0, C <= 1024.
+ * Replaces nn.LayerNorm at core/mix_transformer.py:101,152-153,196,320,328,336,344 and
+ * core/model_fusion.py:359-360 (eps 1e-6 / 1e-5: SURVEY F6).
+ */
+int segmif_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                         int64_t rows, int C, int ldx, int ldy, float eps, void* stream);
+
+/*
+ * Mix-FFN middle: depthwise 3x3 (pad 1) + bias + exact-erf GELU on tokens viewed as an
+ * NHWC image (B, H, W, C); w9 is the depthwise weight repacked to [9][C].  C % 4 == 0.
+ * Replaces DWConv.forward + nn.GELU: core/mix_transformer.py:48-49, :381-387.
+ */
+int segmif_dwconv3x3_gelu_f32(const float* x, const float* w9, const float* bias, float* y,
+                              int B, int H, int W, int C, void* stream);
+
+/*
+ * Bilinear resize, align_corners=False, NHWC: (B, IH, IW, C) -> (B, OH, OW, C) written with
+ * pixel pitch ldo at channel offset 0 of `y` (lets the SegFormer head write straight into its
+ * concat buffer).  16-byte vector path when C, ldx, ldo are multiples of 4; scalar otherwise (9-class logits).
+ * Replaces F.interpolate at core/mix_transformer.py:364-373, core/segformer_head.py:67-73,
+ * core/model_fusion.py:1095 and test_segmentation.py:170.
+ */
+int segmif_bilinear_nhwc_f32(const float* x, float* y, int B, int IH, int IW, int OH, int OW, int C,
+                             int ldx, int ldo, void* stream);
+
+/*
+ * Fused spatial-reduction attention: O = softmax(Q K^T * scale) V per (batch, head), never
+ * materialising the N x Nk score matrix.  q: (B, N, ldq) with head h at columns [h*hd, (h+1)*hd);
+ * k and v: (B, Nk, ldkv) (the kv Linear output: k = kv, v = kv + C); out: (B, N, ldo).
+ * hd in {32, 64}.  QK^T and PV run on fp32 MFMA, softmax is per-lane (online, exact expf).
+ * Replaces core/mix_transformer.py:107-111.
+ */
+int segmif_sr_attention_f32(const float* q, const float* k, const float* v, float* out,
+                            int B, int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo,
+                            float scale, void* stream);
+
+/*
+ * Linear ("efficient") cross attention context, step 1: per (batch, head) partial sums of
+ * K^T V over row blocks.  kv: (B, N, 2*C), C = heads*d, d == 8: k = cols [0,C), v = [C,2C).
+ * partial: (B, nblk, heads*d*d) DOUBLES with nblk = segmif_linattn_num_blocks(N) (fp32 inside a
+ * 32-row run, fp64 across runs: the sum feeds a softmax).
+ * Step 2 (segmif_linattn_fold_f32) reduces the partials in fp64, applies
+ * softmax over the k-index (dim=-2) of (K^T V)*scale, and folds the block-diagonal context into
+ * the following end_proj weight:  Weff[b][n][kofs + h*d + i] = sum_j ctx[b][h][i][j] * Wend[n][wofs + h*d + j].
+ * Replaces core/model_fusion.py:281-286 and :316-326 (ctx and q@ctx) together with the cat +
+ * end_proj of :357-360, which becomes one dense igemm over [y3 | u_i] with per-image weights.
+ */
+int segmif_linattn_num_blocks(int64_t N);
+int segmif_linattn_partial_f32(const float* kv, double* partial, int B, int64_t N, int heads, int d,
+                               int ldkv, void* stream);
+int segmif_linattn_fold_f32(const double* partial, const float* wend, float* weff, int B, int nblk,
+                            int heads, int d, int Nout, int ldw, int wofs, int ldweff, int kofs,
+                            float scale, void* stream);
+
+/*
+ * Pointwise helpers (bandwidth-bound, NCHW <-> NHWC at the module boundary).
+ *  - segmif_seg_normalize: (x*255 - mean_c)/std_c on a (B,3,H,W) NCHW image -> NHWC (B,H,W,3)
+ *    (core/model_fusion.py:1083-1085).
+ *  - segmif_nchw_to_nhwc / segmif_nhwc_to_nchw: layout transposes (B, C, HW) <-> (B, HW, C).
+ *  - segmif_fuse_ycrcb: fused RGB = clamp01(YCrCb2RGB([Yf, Cr(vis), Cb(vis)])) with
+ *    vis NCHW RGB, yf (B,1,H,W); out NCHW (core/model_fusion.py:69-111 + test_fusion.py:102-111).
+ */
+int segmif_seg_normalize_f32(const float* x_nchw, float* y_nhwc, int B, int H, int W, void* stream);
+int segmif_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int64_t HW, int ldo, void* stream);
+int segmif_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int64_t HW, int ldx, void* stream);
+int segmif_fuse_ycrcb_f32(const float* vis_nchw, const float* yf, float* out_nchw, int B, int64_t HW, void* stream);
+/* argmax over C of NHWC logits -> int32 labels (test_segmentation.py:174); ties -> lowest index */
+int segmif_argmax_nhwc_i32(const float* x, int32_t* labels, int64_t rows, int C, int ldx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGMIF_HIP_H */

@@ -1,0 +1,84 @@
+"""ctypes binding of libsegmif_hip.so (C ABI in include/segmif_hip.h).
+
+There is no fallback: if the gfx950 library is missing this module raises, it never routes
+work to torch ops or to the CPU oracle.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libsegmif_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_GELU = 0, 1, 2, 3
+
+
+class SegmifIgemm(ctypes.Structure):
+    _fields_ = [
+        ("in_", c_void_p), ("in2", c_void_p), ("wt", c_void_p), ("bias", c_void_p), ("res", c_void_p),
+        ("prelu", c_void_p), ("out", c_void_p),
+        ("M", c_int64), ("N", c_int32), ("K", c_int32),
+        ("lda", c_int32), ("lda2", c_int32), ("K1", c_int32), ("ldo", c_int32), ("ldr", c_int32),
+        ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("KH", c_int32), ("KW", c_int32),
+        ("stride", c_int32), ("pad", c_int32), ("dil", c_int32), ("OH", c_int32), ("OW", c_int32),
+        ("act", c_int32), ("nz", c_int32),
+        ("in_zstride", c_int64), ("in2_zstride", c_int64), ("wt_zstride", c_int64),
+        ("out_zstride", c_int64), ("res_zstride", c_int64),
+        ("tile", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/segmif_hip.h declares
+SIGNATURES = {
+    "segmif_abi_version": (c_int, []),
+    "segmif_device_name": (c_int, [c_char_p, c_int]),
+    "segmif_igemm_f32": (c_int, [POINTER(SegmifIgemm), c_void_p]),
+    "segmif_igemm_num_tiles": (c_int, []),
+    "segmif_igemm_tile_name": (c_char_p, [c_int]),
+    "segmif_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "segmif_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    "segmif_dwconv3x3_gelu_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "segmif_bilinear_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "segmif_sr_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_int, c_int, c_float, c_void_p]),
+    "segmif_linattn_num_blocks": (c_int, [c_int64]),
+    "segmif_linattn_partial_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
+    "segmif_linattn_fold_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_int, c_float, c_void_p]),
+    "segmif_seg_normalize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "segmif_nchw_to_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
+    "segmif_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
+    "segmif_fuse_ycrcb_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "segmif_argmax_nhwc_i32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once). Raises HipLibraryMissing — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m segmif_amd.build` "
+            "(hipcc --offload-arch=gfx950). segmif_amd has no CPU or torch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    if lib.segmif_abi_version() != 1:
+        raise HipLibraryMissing("libsegmif_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code}")

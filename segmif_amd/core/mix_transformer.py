@@ -1,0 +1,277 @@
+"""MiT (Mix Vision Transformer) encoder on the MI355X HIP kernels.
+
+Drop-in mirror of the reference's core/mix_transformer.py: same class names, constructor
+arguments, forward signatures and state_dict keys (the nn.Linear / nn.Conv2d / nn.LayerNorm
+children exist only as parameter containers with the reference's names and shapes — their own
+forward is never called).  All arithmetic runs in segmif_amd/csrc kernels:
+
+  OverlapPatchEmbed (ref :158-198)  implicit-GEMM strided conv (igemm.hip) + LayerNorm(1e-5)
+  Attention         (ref :56-115)   q / kv / proj GEMMs, sr conv as a patchify GEMM + LayerNorm(1e-5),
+                                    fused QK^T-softmax-PV kernel (attention.hip)
+  Mlp + DWConv      (ref :18-53, :376-387)  fc1 GEMM, depthwise3x3+bias+GELU kernel, fc2 GEMM
+  Block             (ref :118-155)  residual adds folded into the proj / fc2 GEMM epilogues
+
+Tokens (B, N, C) are NHWC images, so nothing is ever transposed inside the encoder; the NCHW
+feature maps the reference returns are handed out as channels-last views of the same storage.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ._util import PackedCache, drop_path_scale, init_reference_style
+
+__all__ = ["Mlp", "Attention", "Block", "OverlapPatchEmbed", "MixVisionTransformer", "DWConv",
+           "mit_b0", "mit_b1", "mit_b2", "mit_b3", "mit_b4", "mit_b5"]
+
+
+class DWConv(nn.Module):
+    """Parameter holder for the 3x3 depthwise conv (key: dwconv.weight / dwconv.bias)."""
+
+    def __init__(self, dim=768):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if act_layer is not nn.GELU:
+            raise NotImplementedError("the fused depthwise kernel implements exact GELU only")
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.dwconv = DWConv(hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        self._pk = PackedCache()
+        init_reference_style(self)
+
+    def forward(self, x, H, W, residual=None):
+        """x: (B, N, C) tokens.  Returns fc2(gelu(dwconv(fc1(x)))) (+ residual, written in place)."""
+        pk = self._pk
+        h = ops.linear(x, pk.get("fc1", self.fc1.weight, ops.pack_weight), self.fc1.out_features,
+                       bias=self.fc1.bias)
+        h = ops.dwconv3x3_gelu(h, pk.get("dw", self.dwconv.dwconv.weight, ops.pack_dw_weight),
+                               self.dwconv.dwconv.bias, H, W)
+        if self.drop.p > 0 and self.training:
+            h = self.drop(h)
+        y = ops.linear(h, pk.get("fc2", self.fc2.weight, ops.pack_weight), self.fc2.out_features,
+                       bias=self.fc2.bias, res=residual, out=residual)
+        if self.drop.p > 0 and self.training:
+            y = self.drop(y)
+        return y
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., sr_ratio=1):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} should be divided by num_heads {num_heads}."
+        if attn_drop or proj_drop:
+            raise NotImplementedError("attention / projection dropout is 0 in every MiT variant")
+        self.dim = dim
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.sr_ratio = sr_ratio
+        if sr_ratio > 1:
+            self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.norm = nn.LayerNorm(dim)
+        self._pk = PackedCache()
+        init_reference_style(self)
+
+    def forward(self, x, H, W, residual=None):
+        B, N, C = x.shape
+        pk = self._pk
+        q = ops.linear(x, pk.get("q", self.q.weight, ops.pack_weight), C, bias=self.q.bias)
+        if self.sr_ratio > 1:
+            red = ops.conv2d(x.view(B, H, W, C), pk.get("sr", self.sr.weight, ops.pack_weight), C, self.sr_ratio,
+                             stride=self.sr_ratio, bias=self.sr.bias)
+            red = red.view(B, -1, C)
+            red = ops.layernorm(red, self.norm.weight, self.norm.bias, self.norm.eps, out=red)
+        else:
+            red = x
+        kv = ops.linear(red, pk.get("kv", self.kv.weight, ops.pack_weight), 2 * C, bias=self.kv.bias)
+        a = ops.sr_attention(q, kv, self.num_heads, self.scale)
+        return ops.linear(a, pk.get("proj", self.proj.weight, ops.pack_weight), C, bias=self.proj.bias,
+                          res=residual, out=residual)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, sr_ratio=1):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                              attn_drop=attn_drop, proj_drop=drop, sr_ratio=sr_ratio)
+        self.drop_path = _DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        init_reference_style(self)
+
+    def forward(self, x, H, W):
+        return self.forward_(x.clone(), H, W)
+
+    def forward_(self, x, H, W):
+        """x <- x + dp(attn(LN(x))); x <- x + dp(mlp(LN(x))).  `x` is updated IN PLACE and returned
+        (the encoder owns its token buffer; the public forward() works on a copy)."""
+        stochastic = self.training and isinstance(self.drop_path, _DropPath) and self.drop_path.drop_prob > 0
+        xn = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        if not stochastic:
+            x = self.attn(xn, H, W, residual=x)
+            xn = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=xn)
+            return self.mlp(xn, H, W, residual=x)
+        # train-mode stochastic depth (timm DropPath): per-sample Bernoulli scaling of each branch
+        x = x + drop_path_scale(self.attn(xn, H, W), self.drop_path.drop_prob)
+        xn = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=xn)
+        return x + drop_path_scale(self.mlp(xn, H, W), self.drop_path.drop_prob)
+
+
+class _DropPath(nn.Module):
+    """Holds the stochastic-depth rate (applied inside Block.forward)."""
+
+    def __init__(self, drop_prob=0.):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+
+class OverlapPatchEmbed(nn.Module):
+    """Image to patch embedding: conv(k, stride, pad k//2) + LayerNorm(eps 1e-5)."""
+
+    def __init__(self, img_size=224, patch_size=7, stride=4, in_chans=3, embed_dim=768):
+        super().__init__()
+        img_size = img_size if isinstance(img_size, (tuple, list)) else (img_size, img_size)
+        patch_size = patch_size if isinstance(patch_size, (tuple, list)) else (patch_size, patch_size)
+        self.img_size = tuple(img_size)
+        self.patch_size = tuple(patch_size)
+        self.stride = stride
+        self.H, self.W = img_size[0] // patch_size[0], img_size[1] // patch_size[1]
+        self.num_patches = self.H * self.W
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride,
+                              padding=(patch_size[0] // 2, patch_size[1] // 2))
+        self.norm = nn.LayerNorm(embed_dim)
+        self._pk = PackedCache()
+        init_reference_style(self)
+
+    def forward(self, x):
+        """x: logical NCHW (any strides; channels-last storage is consumed without a copy).
+        Returns (tokens (B, H*W, C), H, W) like the reference."""
+        xh = ops.to_nhwc(x)
+        k = self.patch_size[0]
+        y = ops.conv2d(xh, self._pk.get("proj", self.proj.weight, ops.pack_weight), self.proj.out_channels, k,
+                       stride=self.stride, pad=k // 2, bias=self.proj.bias)
+        B, H, W, C = y.shape
+        t = y.view(B, H * W, C)
+        ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps, out=t)
+        return t, H, W
+
+
+class MixVisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dims=[64, 128, 256, 512],
+                 num_heads=[1, 2, 4, 8], mlp_ratios=[4, 4, 4, 4], qkv_bias=False, qk_scale=None, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0., norm_layer=nn.LayerNorm,
+                 depths=[3, 4, 6, 3], sr_ratios=[8, 4, 2, 1]):
+        super().__init__()
+        self.num_classes = num_classes
+        self.depths = depths
+        self.embed_dims = embed_dims
+        chans = [in_chans] + list(embed_dims[:3])
+        sizes = [img_size, img_size // 4, img_size // 8, img_size // 16]
+        rates = torch.linspace(0, drop_path_rate, sum(depths)).tolist()
+        offset = 0
+        for s in range(4):
+            setattr(self, f"patch_embed{s + 1}", OverlapPatchEmbed(
+                img_size=sizes[s], patch_size=7 if s == 0 else 3, stride=4 if s == 0 else 2,
+                in_chans=chans[s], embed_dim=embed_dims[s]))
+            setattr(self, f"block{s + 1}", nn.ModuleList([
+                Block(dim=embed_dims[s], num_heads=num_heads[s], mlp_ratio=mlp_ratios[s], qkv_bias=qkv_bias,
+                      qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=rates[offset + i],
+                      norm_layer=norm_layer, sr_ratio=sr_ratios[s]) for i in range(depths[s])]))
+            setattr(self, f"norm{s + 1}", norm_layer(embed_dims[s]))
+            offset += depths[s]
+        init_reference_style(self)
+
+    def reset_drop_path(self, drop_path_rate):
+        rates = torch.linspace(0, drop_path_rate, sum(self.depths)).tolist()
+        offset = 0
+        for s in range(4):
+            for i, blk in enumerate(getattr(self, f"block{s + 1}")):
+                if isinstance(blk.drop_path, _DropPath):
+                    blk.drop_path.drop_prob = rates[offset + i]
+            offset += self.depths[s]
+
+    def freeze_patch_emb(self):
+        self.patch_embed1.requires_grad = False
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed1', 'pos_embed2', 'pos_embed3', 'pos_embed4', 'cls_token'}
+
+    def forward_features_nhwc(self, x):
+        """-> 4 NHWC feature maps [(B, H/4, W/4, C1), ...]."""
+        feats = []
+        for s in range(4):
+            t, H, W = getattr(self, f"patch_embed{s + 1}")(x)
+            for blk in getattr(self, f"block{s + 1}"):
+                t = blk.forward_(t, H, W)
+            norm = getattr(self, f"norm{s + 1}")
+            t = ops.layernorm(t, norm.weight, norm.bias, norm.eps, out=t)
+            f = t.view(t.shape[0], H, W, t.shape[2])
+            feats.append(f)
+            x = ops.as_nchw(f)
+        return feats
+
+    def forward_features(self, x):
+        return [ops.as_nchw(f) for f in self.forward_features_nhwc(x)]
+
+    def forward(self, x):
+        return self.forward_features(x)
+
+    def forward_fusion(self, x):
+        """Stage-1 / stage-2 features bilinearly resized to the input resolution (ref :358-375)."""
+        H, W = x.shape[2], x.shape[3]
+        feats = self.forward_features_nhwc(x)
+        return ops.as_nchw(ops.bilinear(feats[0], H, W)), ops.as_nchw(ops.bilinear(feats[1], H, W))
+
+
+def _variant(dims, depths):
+    return dict(patch_size=4, embed_dims=dims, num_heads=[1, 2, 5, 8], mlp_ratios=[4, 4, 4, 4], qkv_bias=True,
+                norm_layer=partial(nn.LayerNorm, eps=1e-6), depths=depths, sr_ratios=[8, 4, 2, 1],
+                drop_rate=0.0, drop_path_rate=0.1)
+
+
+class mit_b0(MixVisionTransformer):
+    def __init__(self, **kwargs):
+        super().__init__(**_variant([32, 64, 160, 256], [2, 2, 2, 2]))
+
+
+class mit_b1(MixVisionTransformer):
+    def __init__(self, **kwargs):
+        super().__init__(**_variant([64, 128, 320, 512], [2, 2, 2, 2]))
+
+
+class mit_b2(MixVisionTransformer):
+    def __init__(self, **kwargs):
+        super().__init__(**_variant([64, 128, 320, 512], [3, 4, 6, 3]))
+
+
+class mit_b3(MixVisionTransformer):
+    def __init__(self, **kwargs):
+        super().__init__(**_variant([64, 128, 320, 512], [3, 4, 18, 3]))
+
+
+class mit_b4(MixVisionTransformer):
+    def __init__(self, **kwargs):
+        super().__init__(**_variant([64, 128, 320, 512], [3, 8, 27, 3]))
+
+
+class mit_b5(MixVisionTransformer):
+    def __init__(self, **kwargs):
+        super().__init__(**_variant([64, 128, 320, 512], [3, 6, 40, 3]))

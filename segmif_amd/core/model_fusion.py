@@ -1,0 +1,340 @@
+"""Fusion + segmentation networks of SegMiF on the MI355X HIP kernels.
+
+Mirror of the classes the reference's scripts use from core/model_fusion.py: WeTr (:9-68),
+RGB2YCrCb / YCrCb2RGB (:69-111), DRDB (:117-157), CrossAttention / CrossAttention2 (:250-328),
+CrossPath (:329-361), FeatureFusionModule (:430-463), Fusion_Network3_ac (:1026-1067),
+Network3 (:1068-1104) — same constructor/forward signatures and state_dict keys.  The ~20 unused
+ablation variants of that file are out of scope.
+
+Layout: every feature map is NHWC.  A DRDB owns one (B, H, W, 224) buffer; each dilated conv reads
+the first Cin channels and writes its 32 output channels in place (the five torch.cat copies of
+ref :137-153 do not exist).  The cross-modal interaction is linear attention: its K^T V reduction,
+softmax and Q@ctx are folded into a per-image end_proj weight (csrc/linattn.hip).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from . import mix_transformer
+from ._util import PackedCache, init_reference_style, require_device
+from .segformer_head import SegFormerHead
+
+__all__ = ["WeTr", "RGB2YCrCb", "YCrCb2RGB", "DRDB", "CrossAttention", "CrossAttention2", "CrossPath",
+           "FeatureFusionModule", "Fusion_Network3_ac", "Network3", "Mean", "fuse_to_rgb"]
+
+
+class WeTr(nn.Module):
+    def __init__(self, backbone, num_classes=20, embedding_dim=256, pretrained=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.embedding_dim = embedding_dim
+        self.backbone = backbone
+        self.feature_strides = [4, 8, 16, 32]
+        self.encoder = getattr(mix_transformer, backbone)()
+        self.in_channels = self.encoder.embed_dims
+        if pretrained:
+            self.initialize()
+        self.decoder = SegFormerHead(feature_strides=self.feature_strides, in_channels=self.in_channels,
+                                     embedding_dim=self.embedding_dim, num_classes=self.num_classes)
+        self.classifier = nn.Conv2d(in_channels=self.in_channels[-1], out_channels=self.num_classes,
+                                    kernel_size=1, bias=False)
+
+    def initialize(self):
+        state_dict = torch.load('pretrained/' + self.backbone + '.pth')
+        state_dict.pop('head.weight')
+        state_dict.pop('head.bias')
+        self.encoder.load_state_dict(state_dict)
+
+    def get_param_groups(self):
+        """[encoder non-norm, encoder norm, decoder + classifier]  (ref :44-60)."""
+        groups = [[], [], []]
+        for name, param in self.encoder.named_parameters():
+            groups[1 if "norm" in name else 0].append(param)
+        groups[2].extend(self.decoder.parameters())
+        groups[2].append(self.classifier.weight)
+        return groups
+
+    def forward_nhwc(self, x):
+        # the reference also evaluates classifier(_x4) and discards it (ref :66); it does not
+        # influence the result and is not computed here.
+        return self.decoder.forward_nhwc(self.encoder.forward_features_nhwc(x))
+
+    def forward(self, x):
+        require_device(x, "WeTr input")
+        return ops.as_nchw(self.forward_nhwc(x))
+
+
+def RGB2YCrCb(input_im):
+    """(B,3,H,W) RGB -> YCrCb (ref :69-91). Pointwise plumbing on whatever device the input is on."""
+    R, G, B = input_im[:, 0:1], input_im[:, 1:2], input_im[:, 2:3]
+    Y = 0.299 * R + 0.587 * G + 0.114 * B
+    return torch.cat((Y, (R - Y) * 0.713 + 0.5, (B - Y) * 0.564 + 0.5), dim=1)
+
+
+def YCrCb2RGB(input_im):
+    """(B,3,H,W) YCrCb -> RGB (ref :93-111)."""
+    mat = input_im.new_tensor([[1.0, 1.0, 1.0], [1.403, -0.714, 0.0], [0.0, -0.344, 1.773]])
+    bias = input_im.new_tensor([0.0, -0.5, -0.5])
+    flat = input_im.permute(0, 2, 3, 1).reshape(-1, 3)
+    out = (flat + bias).mm(mat)
+    return out.reshape(input_im.shape[0], input_im.shape[2], input_im.shape[3], 3).permute(0, 3, 1, 2)
+
+
+def fuse_to_rgb(vis, y_fused):
+    """test_fusion.py:102-111 in one kernel: clamp01(YCrCb2RGB([y_fused, Cr(vis), Cb(vis)]))."""
+    return ops.fuse_ycrcb(vis, y_fused)
+
+
+class DRDB(nn.Module):
+    def __init__(self, in_ch=64, growth_rate=32):
+        super().__init__()
+        self.in_ch, self.growth = in_ch, growth_rate
+        ch = in_ch
+        for i in range(1, 6):
+            setattr(self, f"Dcov{i}", nn.Conv2d(ch, growth_rate, 3, padding=2, dilation=2))
+            ch += growth_rate
+        self.conv = nn.Conv2d(ch, in_ch, 1, padding=0)
+        self.total_ch = ch
+        self._pk = PackedCache()
+
+    def new_buffer(self, B, H, W, device):
+        return torch.empty((B, H, W, self.total_ch), device=device, dtype=torch.float32)
+
+    def forward_buffer(self, buf, out=None):
+        """buf: (B,H,W,224) whose first in_ch channels hold x. Returns x + relu(conv1x1(concat))."""
+        ch = self.in_ch
+        for i in range(1, 6):
+            conv = getattr(self, f"Dcov{i}")
+            ops.conv2d(buf[..., :ch], self._pk.get(f"d{i}", conv.weight, ops.pack_weight), self.growth, 3,
+                       pad=2, dil=2, bias=conv.bias, act=ops.ACT_RELU, out=buf[..., ch:ch + self.growth], tag="drdb_dcov")
+            ch += self.growth
+        return ops.linear(buf, self._pk.get("conv", self.conv.weight, ops.pack_weight), self.in_ch,
+                          bias=self.conv.bias, act=ops.ACT_RELU, res=buf[..., :self.in_ch], out=out)
+
+    def forward(self, x):
+        require_device(x, "DRDB input")
+        B, _, H, W = x.shape
+        buf = self.new_buffer(B, H, W, x.device)
+        buf[..., :self.in_ch].copy_(x.permute(0, 2, 3, 1))
+        return ops.as_nchw(self.forward_buffer(buf))
+
+
+class CrossAttention(nn.Module):
+    """Context from the segmentation feature, queries = the two modality features (ref :250-288)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} should be divided by num_heads {num_heads}."
+        self.dim, self.num_heads = dim, num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.kv3 = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self._pk = PackedCache()
+
+    def context_partial(self, seg):
+        kv = ops.linear(seg, self._pk.get("kv3", self.kv3.weight, ops.pack_weight), 2 * self.dim, bias=self.kv3.bias)
+        return ops.linattn_partial(kv, self.num_heads)
+
+
+class CrossAttention2(nn.Module):
+    """Contexts from each modality, query = the segmentation feature (ref :290-328)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} should be divided by num_heads {num_heads}."
+        self.dim, self.num_heads = dim, num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.kv1 = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.kv2 = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self._pk = PackedCache()
+
+    def context_partial(self, which, x):
+        lin = self.kv1 if which == 1 else self.kv2
+        kv = ops.linear(x, self._pk.get(f"kv{which}", lin.weight, ops.pack_weight), 2 * self.dim, bias=lin.bias)
+        return ops.linattn_partial(kv, self.num_heads)
+
+
+class CrossPath(nn.Module):
+    def __init__(self, dim, reduction=1, num_heads=8, norm_layer=nn.LayerNorm):
+        super().__init__()
+        if reduction != 1 or dim // num_heads != 8 or num_heads != 8:
+            raise NotImplementedError("the linear-attention kernels are built for dim 64, 8 heads of 8 (the "
+                                      "only configuration SegMiF instantiates)")
+        self.dim = dim
+        self.channel_proj1 = nn.Linear(dim, dim * 2)
+        self.channel_proj2 = nn.Linear(dim, dim * 2)
+        self.channel_proj3 = nn.Linear(dim, dim * 2)
+        self.act1 = nn.ReLU(inplace=True)
+        self.act2 = nn.ReLU(inplace=True)
+        self.act3 = nn.ReLU(inplace=True)
+        self.cross_attn = CrossAttention(dim, num_heads=num_heads)
+        self.cross_attn2 = CrossAttention2(dim, num_heads=num_heads)
+        self.end_proj1 = nn.Linear(dim * 2, dim)
+        self.end_proj2 = nn.Linear(dim * 2, dim)
+        self.norm1 = norm_layer(dim)
+        self.norm2 = norm_layer(dim)
+        self._pk = PackedCache()
+
+    def forward_tokens(self, x1, x2, seg, out1=None, out2=None):
+        """x1, x2, seg: (B, N, 64) rows views.  Returns LN(x_i + end_proj_i(cat(z_i, v_i))) written to out_i."""
+        C = self.dim
+        pk = self._pk
+        proj = []
+        for i, x in ((1, x1), (2, x2), (3, seg)):
+            lin = getattr(self, f"channel_proj{i}")
+            proj.append(ops.linear(x, pk.get(f"cp{i}", lin.weight, ops.pack_weight), 2 * C, bias=lin.bias,
+                                   act=ops.ACT_RELU))
+        p1, p2, p3 = proj  # each (B, N, 128) = [y_i | u_i]   (ref :351-353)
+        part3 = self.cross_attn.context_partial(p3[..., C:])  # ctx3 from u3
+        part1 = self.cross_attn2.context_partial(1, p1[..., :C])  # ctx1 from y1
+        part2 = self.cross_attn2.context_partial(2, p2[..., :C])  # ctx2 from y2
+        B = x1.shape[0]
+        outs = []
+        for i, (x, p, part, o) in enumerate(((x1, p1, part1, out1), (x2, p2, part2, out2)), start=1):
+            end = getattr(self, f"end_proj{i}")
+            weff = torch.empty((B, C, 2 * C), device=x.device, dtype=torch.float32)
+            # cat(z_i, v_i) @ Wend^T  ==  [y3 | u_i] @ Weff^T with the contexts folded in (ref :357-360)
+            ops.linattn_fold(part, end.weight, weff, wofs=0, kofs=0, scale=self.cross_attn2.scale)
+            ops.linattn_fold(part3, end.weight, weff, wofs=C, kofs=C, scale=self.cross_attn.scale)
+            y = ops.linear(p3[..., :C], weff, C, bias=end.bias, res=x, x2=p[..., C:], batched_weight=True)
+            norm = getattr(self, f"norm{i}")
+            outs.append(ops.layernorm(y, norm.weight, norm.bias, norm.eps, out=o if o is not None else y))
+        return outs[0], outs[1]
+
+    def forward(self, x1, x2, segfeature):
+        require_device(x1, "CrossPath input")
+        return self.forward_tokens(x1.contiguous(), x2.contiguous(), segfeature.contiguous())
+
+
+class FeatureFusionModule(nn.Module):
+    def __init__(self, dim, reduction=1, num_heads=8, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.cross = CrossPath(dim=dim, reduction=reduction, num_heads=num_heads)
+        init_reference_style(self)
+
+    def forward_nhwc(self, x1, x2, seg, out1=None, out2=None):
+        """NHWC in / out; out_i may be channel slices of wider buffers (e.g. a DRDB concat buffer)."""
+        B, H, W, C = x1.shape
+        tok = lambda t: None if t is None else t.view(B, H * W, t.shape[-1])
+        r1, r2 = self.cross.forward_tokens(tok(x1), tok(x2), tok(seg), tok(out1), tok(out2))
+        return r1.view(B, H, W, C), r2.view(B, H, W, C)
+
+    def forward(self, x1, x2, segfeature):
+        require_device(x1, "FeatureFusionModule input")
+        r1, r2 = self.forward_nhwc(ops.to_nhwc(x1), ops.to_nhwc(x2), ops.to_nhwc(segfeature))
+        return ops.as_nchw(r1), ops.as_nchw(r2)
+
+
+class Fusion_Network3_ac(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1_ir = nn.Conv2d(1, 64, 3, padding=1)
+        self.conv1_vis = nn.Conv2d(1, 64, 3, padding=1)
+        self.DRDB1 = DRDB(in_ch=64)
+        self.DRDB2 = DRDB(in_ch=64)
+        self.DRDB3 = DRDB(in_ch=64)
+        self.DRDB4 = DRDB(in_ch=64)
+        self.conv2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.relu = nn.PReLU()
+        self.ffm = FeatureFusionModule(64)
+        self.ffm2 = FeatureFusionModule(64)  # present in checkpoints, never used by forward
+        self.conv3 = nn.Conv2d(64, 64, 1, padding=0)
+        self.conv4 = nn.Conv2d(128, 64, 1, padding=0)
+        self.conv21 = nn.Conv2d(64, 32, 3, padding=1)
+        self.conv22 = nn.Conv2d(32, 1, 3, padding=1)
+        self._pk = PackedCache()
+
+    def _w(self, name):
+        return self._pk.get(name, getattr(self, name).weight, ops.pack_weight)
+
+    @staticmethod
+    def _first_channel_nhwc(x):
+        """x[:, 0:1] of an NCHW image as an NHWC (B,H,W,1) tensor (identical memory for C == 1)."""
+        B, _, H, W = x.shape
+        return x[:, 0:1].contiguous().view(B, H, W, 1)
+
+    def forward(self, ir, vis, out1, out2):
+        require_device(ir, "Fusion_Network3_ac input")
+        if out1.shape[1] != 64 or out2.shape[1] != 128:
+            # same failure the reference hits inside conv3/conv4 (mit_b0 features do not fit)
+            raise RuntimeError(f"Fusion_Network3_ac expects 64/128-channel segmentation features, got "
+                               f"{out1.shape[1]}/{out2.shape[1]} channels")
+        B, _, H, W = ir.shape
+        dev, slope = ir.device, self.relu.weight
+        PRELU = ops.ACT_PRELU
+        bufs = []
+        for x, conv, drdb in ((ir, self.conv1_ir, self.DRDB1), (vis, self.conv1_vis, self.DRDB2)):
+            buf = drdb.new_buffer(B, H, W, dev)
+            name = "conv1_ir" if conv is self.conv1_ir else "conv1_vis"
+            ops.conv2d(self._first_channel_nhwc(x), self._w(name), 64, 3, pad=1, bias=conv.bias, act=PRELU,
+                       prelu=slope, out=buf[..., :64])
+            bufs.append(buf)
+        x1 = self.DRDB1.forward_buffer(bufs[0])
+        x2 = self.DRDB2.forward_buffer(bufs[1])
+        seg = ops.linear(ops.to_nhwc(out1), self._w("conv3"), 64, bias=self.conv3.bias)
+        # first interaction writes straight into the DRDB3 / DRDB4 concat buffers (reused storage)
+        x1, x2 = self.ffm.forward_nhwc(x1, x2, seg, out1=bufs[0][..., :64], out2=bufs[1][..., :64])
+        x1 = self.DRDB3.forward_buffer(bufs[0])
+        x2 = self.DRDB4.forward_buffer(bufs[1])
+        del bufs
+        seg = ops.linear(ops.to_nhwc(out2), self._w("conv4"), 64, bias=self.conv4.bias)
+        cat = torch.empty((B, H, W, 128), device=dev, dtype=torch.float32)
+        self.ffm.forward_nhwc(x1, x2, seg, out1=cat[..., :64], out2=cat[..., 64:])
+        f = ops.conv2d(cat, self._w("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)
+        f = ops.conv2d(f, self._w("conv21"), 32, 3, pad=1, bias=self.conv21.bias, act=PRELU, prelu=slope)
+        f = ops.conv2d(f, self._w("conv22"), 1, 3, pad=1, bias=self.conv22.bias, act=PRELU, prelu=slope)
+        return f.view(B, 1, H, W)
+
+
+class Network3(nn.Module):
+    def __init__(self, backbone, num_classes=20, embedding_dim=256, pretrained=True):
+        super().__init__()
+        self.fusion_nums = 2
+        self.seg_nums = 2
+        self.fusion_channel = 48
+        self.seg_channel = 64
+        self.denoise_net = WeTr(backbone, num_classes, embedding_dim, pretrained)
+        self.mean = [123.675, 116.28, 103.53]
+        self.std = [58.395, 57.12, 57.375]
+
+    def _segment_nhwc(self, fused):
+        require_device(fused, "Network3 input")
+        # (x*255 - mean)/std fused with the NCHW -> NHWC transpose (ref :1083-1085)
+        return self.denoise_net.forward_nhwc(ops.as_nchw(ops.seg_normalize(fused)))
+
+    def forward(self, fused_seg1):
+        return fused_seg1, fused_seg1, ops.as_nchw(self._segment_nhwc(fused_seg1))
+
+    def predict_labels(self, fused, size=None):
+        """test_segmentation.py:169-174 on device: logits -> bilinear to `size` -> argmax (int32, B,H,W)."""
+        seg = self._segment_nhwc(fused)
+        H, W = size if size is not None else fused.shape[2:]
+        return ops.argmax_nhwc(ops.bilinear(seg, H, W))
+
+    def _loss(self, fused_seg1, label, criterion):
+        seg_map = ops.as_nchw(self._segment_nhwc(fused_seg1))
+        outputs = F.interpolate(seg_map, size=label.shape[1:], mode='bilinear', align_corners=False)
+        return criterion(outputs, label.type(torch.long))
+
+    def denoise_net_parameters(self):
+        return self.denoise_net.parameters()
+
+
+class Mean(nn.Module):
+    """Y-channel substitution baseline (ref :184-214): put `mask` in the Y channel of `vis`,
+    convert back to RGB, clamp to [0,1] and min-max normalise over the whole batch."""
+
+    def __init__(self):
+        super().__init__()
+        self.fusion_nums = 2
+        self.seg_nums = 2
+        self.fusion_channel = 48
+        self.seg_channel = 64
+        self.mean = [123.675, 116.28, 103.53]
+        self.std = [58.395, 57.12, 57.375]
+
+    def forward(self, mask, vis):
+        require_device(vis, "Mean input")
+        rgb = ops.fuse_ycrcb(vis, mask[:, 0:1])
+        lo, hi = rgb.min(), rgb.max()
+        return (rgb - lo) / (hi - lo)

@@ -1,0 +1,118 @@
+"""SegFormer all-MLP decode head on the MI355X HIP kernels.
+
+Mirror of the reference's core/segformer_head.py (:13-82): same names, signatures and state_dict
+keys (`linear_c{1-4}.proj`, `linear_fuse.{conv,bn}`, `linear_pred`).  The reference builds
+`linear_fuse` with mmcv's ConvModule (conv without bias -> BatchNorm2d -> ReLU); `ConvModule` below
+is a parameter container with the same child names.
+
+Data flow (NHWC): each scale's Linear writes (c1) or is bilinearly resized (c2..c4) straight into
+its channel slice of one (B, H/4, W/4, 4E) buffer — the torch.cat of ref :77 never happens — then
+the 1x1 fuse conv runs as a GEMM with eval-mode BatchNorm folded into its weight/bias and ReLU in
+the epilogue, then the 1x1 prediction conv.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ._util import PackedCache, require_device
+
+__all__ = ["MLP", "ConvModule", "SegFormerHead"]
+
+
+class MLP(nn.Module):
+    """Linear embedding of one feature scale (ref :13-24)."""
+
+    def __init__(self, input_dim=2048, embed_dim=768):
+        super().__init__()
+        self.proj = nn.Linear(input_dim, embed_dim)
+        self._pk = PackedCache()
+
+    def forward_nhwc(self, x_nhwc, out=None):
+        return ops.linear(x_nhwc, self._pk.get("proj", self.proj.weight, ops.pack_weight),
+                          self.proj.out_features, bias=self.proj.bias, out=out)
+
+    def forward(self, x):
+        """(B, C, H, W) -> (B, H*W, E) like the reference."""
+        y = self.forward_nhwc(ops.to_nhwc(x))
+        return y.view(y.shape[0], -1, y.shape[3])
+
+
+class ConvModule(nn.Module):
+    """conv (bias only without a norm) -> bn -> ReLU: child names follow mmcv 1.x."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, norm_cfg=None, **kwargs):
+        super().__init__()
+        if kernel_size != 1:
+            raise NotImplementedError("the SegFormer head only uses a 1x1 fuse conv")
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, bias=norm_cfg is None)
+        self.with_norm = norm_cfg is not None
+        if self.with_norm:
+            self.bn = nn.BatchNorm2d(out_channels)
+        self.activate = nn.ReLU(inplace=True)
+        nn.init.kaiming_normal_(self.conv.weight, mode="fan_out", nonlinearity="relu")
+        self._pk = PackedCache()
+
+    def _folded(self):
+        """(packed weight, bias) with eval-mode BatchNorm folded in: y = conv(x) * s + t."""
+        if not self.with_norm:
+            return self._pk.get("w", self.conv.weight, ops.pack_weight), self.conv.bias
+        bn = self.bn
+        srcs = (self.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+        def fold():
+            s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            w = (self.conv.weight.double().flatten(1) * s[:, None]).float()
+            t = (bn.bias.double() - bn.running_mean.double() * s).float().contiguous()
+            return ops.pack_weight(w.contiguous()), t
+
+        return self._pk.get_multi("folded", srcs, fold)
+
+    def forward_nhwc(self, x_nhwc):
+        if self.training and self.with_norm:
+            raise NotImplementedError(
+                "train-mode BatchNorm (batch statistics) is not implemented on the HIP path yet; call .eval()")
+        w, b = self._folded()
+        return ops.linear(x_nhwc, w, self.conv.out_channels, bias=b, act=ops.ACT_RELU)
+
+    def forward(self, x):
+        return ops.as_nchw(self.forward_nhwc(ops.to_nhwc(x)))
+
+
+class SegFormerHead(nn.Module):
+    def __init__(self, feature_strides=None, in_channels=128, embedding_dim=256, num_classes=20, **kwargs):
+        super().__init__()
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        assert len(feature_strides) == len(self.in_channels)
+        assert min(feature_strides) == feature_strides[0]
+        self.feature_strides = feature_strides
+        c1, c2, c3, c4 = self.in_channels
+        self.linear_c4 = MLP(input_dim=c4, embed_dim=embedding_dim)
+        self.linear_c3 = MLP(input_dim=c3, embed_dim=embedding_dim)
+        self.linear_c2 = MLP(input_dim=c2, embed_dim=embedding_dim)
+        self.linear_c1 = MLP(input_dim=c1, embed_dim=embedding_dim)
+        self.dropout = nn.Dropout2d(0.1)
+        self.linear_fuse = ConvModule(in_channels=embedding_dim * 4, out_channels=embedding_dim, kernel_size=1,
+                                      norm_cfg=dict(type='BN', requires_grad=True))
+        self.linear_pred = nn.Conv2d(embedding_dim, self.num_classes, kernel_size=1)
+        self._pk = PackedCache()
+
+    def forward_nhwc(self, feats):
+        """feats: [c1..c4] NHWC -> logits NHWC (B, H/4, W/4, num_classes)."""
+        c1, c2, c3, c4 = feats
+        B, H1, W1, _ = c1.shape
+        E = self.linear_c1.proj.out_features
+        cat = torch.empty((B, H1, W1, 4 * E), device=c1.device, dtype=torch.float32)
+        for slot, (mlp, c) in enumerate(((self.linear_c4, c4), (self.linear_c3, c3), (self.linear_c2, c2))):
+            ops.bilinear(mlp.forward_nhwc(c), H1, W1, out=cat[..., slot * E:(slot + 1) * E])
+        self.linear_c1.forward_nhwc(c1, out=cat[..., 3 * E:])
+        y = self.linear_fuse.forward_nhwc(cat)
+        if self.training:
+            y = ops.to_nhwc(self.dropout(ops.as_nchw(y)))  # Dropout2d: whole channels, train mode only
+        return ops.linear(y, self._pk.get("pred", self.linear_pred.weight, ops.pack_weight), self.num_classes,
+                          bias=self.linear_pred.bias)
+
+    def forward(self, x):
+        c1 = x[0]
+        require_device(c1, "SegFormerHead input")
+        return ops.as_nchw(self.forward_nhwc([ops.to_nhwc(c) for c in x]))

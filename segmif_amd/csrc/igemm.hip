@@ -1,0 +1,412 @@
+// Implicit-GEMM convolution / linear for gfx950 on the exact-fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: 64 cycles per SIMD per instruction, 157 TFLOP/s chip peak).
+//
+// One kernel family serves every dense contraction on SegMiF's hot path: the dilated 3x3 convs
+// of the DRDB blocks (core/model_fusion.py:121-157 — 59 % of a pair's FLOPs), the plain 3x3 / 1x1
+// convs of the fusion net, the overlap-patch / spatial-reduction convs and all nn.Linear layers
+// of the MiT encoder and SegFormer head.  Activations are NHWC (== the reference's token layout),
+// so the im2col matrix is never built: each thread gathers 16-byte channel runs for its rows
+// straight from the image, zero-filling the padding halo, and stages them through LDS.
+//
+// Tiling (256 threads = 4 waves, one per SIMD; wave64):
+//   block tile BM x BN, K step BK; wave tile WM x WN made of 32x32 MFMA sub-tiles.
+//   LDS holds A[BM][BK+4] and B[BN][BK+4], double buffered; the +4 float row pad makes the
+//   ds_read_b128 fragment reads conflict free (row stride 20 or 36 dwords: 16 lanes of a read
+//   group land on 16 distinct 4-bank slots).
+//   Fragment trick: lane (r = lane&31, h = lane>>5) reads ONE float4 = k-offsets 4h..4h+3 of row r
+//   and issues 4 MFMAs from it; MFMA s consumes the k-pair {s, 4+s}.  The k order inside a sum is
+//   free as long as A and B agree, so one 16-byte LDS read feeds four 64-cycle matrix ops.
+//   Global -> register -> LDS staging is software pipelined: tile k+1's loads are issued before
+//   tile k's MFMAs and written to the other LDS buffer after them (one barrier per K step).
+//   Block ids are remapped so that each XCD (private L2) owns a contiguous range of M tiles:
+//   neighbouring tiles share their 3x3 halo rows.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "segmif_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_GENERIC = 2, MODE_DENSE2 = 3 };
+
+struct IgemmK {
+  const float* in;
+  const float* in2;
+  const float* wt;
+  const float* bias;
+  const float* res;
+  const float* prelu;
+  float* out;
+  long long M;
+  int N, K, Kp;
+  int lda, lda2, K1, ldo, ldr;
+  int H, W, Cin, KH, KW, stride, pad, dil, OH, OW;
+  int act;
+  long long in_zs, in2_zs, wt_zs, out_zs, res_zs;
+  int ntm, ntn;
+};
+
+__device__ __forceinline__ float gelu_exact(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int MODE>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
+  constexpr int BKP = BK + 4;
+  constexpr int UPR = BK / 4;  // float4 units per tile row
+  constexpr int RPP = 256 / UPR;  // rows covered by one pass of the 256 threads
+  constexpr int AU = BM / RPP;  // A units per thread
+  constexpr int BU = (BN + RPP - 1) / RPP;  // B units per thread (last may be partial)
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "block must hold exactly 4 waves");
+  static_assert(BM % RPP == 0, "A tile must be a whole number of passes");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;  // [2][BM][BKP]
+  float* Bs = smem + 2 * BM * BKP;  // [2][BN][BKP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // XCD-aware (bijective) tile remap: dispatcher puts block b on XCD b % 8.
+  int bid = blockIdx.x;
+  {
+    const int nwg = p.ntm * p.ntn;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = bid / p.ntn, nt = bid - mt * p.ntn;
+  const long long m0 = (long long)mt * BM;
+  const int n0 = nt * BN;
+  const long long z = blockIdx.z;
+  const float* __restrict__ in = p.in + z * p.in_zs;
+  const float* __restrict__ in2 = (MODE == MODE_DENSE2) ? p.in2 + z * p.in2_zs : nullptr;
+  const float* __restrict__ wt = p.wt + z * p.wt_zs;
+
+  const int kq = tid % UPR;
+  const int row_t = tid / UPR;
+
+  // ---- per-thread row state for the A gather -------------------------------------------------
+  bool a_ok[AU];
+  long long a_off[AU];  // dense: row*lda ; conv: image base in pixels
+  int a_iy0[AU], a_ix0[AU];
+#pragma unroll
+  for (int j = 0; j < AU; ++j) {
+    const long long m = m0 + row_t + j * RPP;
+    a_ok[j] = m < p.M;
+    if (MODE == MODE_DENSE || MODE == MODE_DENSE2) {
+      a_off[j] = m;
+      a_iy0[j] = a_ix0[j] = 0;
+    } else {
+      const long long ohw = (long long)p.OH * p.OW;
+      const long long b = m / ohw;
+      const int rem = (int)(m - b * ohw);
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_off[j] = b * p.H * p.W;
+      a_iy0[j] = oy * p.stride - p.pad;
+      a_ix0[j] = ox * p.stride - p.pad;
+    }
+  }
+  bool b_ok[BU];
+  const float* b_ptr[BU];
+#pragma unroll
+  for (int j = 0; j < BU; ++j) {
+    const int nrow = row_t + j * RPP;
+    b_ok[j] = (nrow < BN) && (n0 + nrow < p.N);
+    b_ptr[j] = wt + (long long)(n0 + nrow) * p.Kp + kq * 4;
+  }
+
+  f32x4 ra[AU], rb[BU];
+  int tap_ky = 0, tap_kx = 0, tap_c0 = 0;  // CONV mode: wave-uniform position of the next K tile
+
+  auto gload = [&](int kc) {
+    const int k0 = kc * BK;
+#pragma unroll
+    for (int j = 0; j < BU; ++j) {
+      rb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (b_ok[j]) rb[j] = *reinterpret_cast<const f32x4*>(b_ptr[j] + k0);
+    }
+    if (MODE == MODE_DENSE) {
+#pragma unroll
+      for (int j = 0; j < AU; ++j) {
+        ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a_ok[j]) ra[j] = *reinterpret_cast<const f32x4*>(in + a_off[j] * p.lda + k0 + kq * 4);
+      }
+    } else if (MODE == MODE_DENSE2) {
+      const bool second = k0 >= p.K1;
+#pragma unroll
+      for (int j = 0; j < AU; ++j) {
+        ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a_ok[j]) {
+          const float* src = second ? in2 + a_off[j] * p.lda2 + (k0 - p.K1) + kq * 4
+                                    : in + a_off[j] * p.lda + k0 + kq * 4;
+          ra[j] = *reinterpret_cast<const f32x4*>(src);
+        }
+      }
+    } else if (MODE == MODE_CONV) {
+      const int dy = tap_ky * p.dil, dx = tap_kx * p.dil;
+#pragma unroll
+      for (int j = 0; j < AU; ++j) {
+        const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+        ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+          const long long pix = a_off[j] + (long long)iy * p.W + ix;
+          ra[j] = *reinterpret_cast<const f32x4*>(in + pix * p.lda + tap_c0 + kq * 4);
+        }
+      }
+      tap_c0 += BK;
+      if (tap_c0 >= p.Cin) {
+        tap_c0 = 0;
+        if (++tap_kx == p.KW) {
+          tap_kx = 0;
+          ++tap_ky;
+        }
+      }
+    } else {  // MODE_GENERIC: any Cin / K, scalar gathers (patch_embed1: Cin = 3; conv1_*: Cin = 1)
+#pragma unroll
+      for (int j = 0; j < AU; ++j) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = k0 + kq * 4 + e;
+          v[e] = 0.f;
+          if (a_ok[j] && k < p.K) {
+            const int tap = k / p.Cin, c = k - tap * p.Cin;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const int iy = a_iy0[j] + ky * p.dil, ix = a_ix0[j] + kx * p.dil;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+              v[e] = in[(a_off[j] + (long long)iy * p.W + ix) * p.lda + c];
+          }
+        }
+        ra[j] = f32x4{v[0], v[1], v[2], v[3]};
+      }
+    }
+  };
+
+  auto sstore = [&](int buf) {
+    float* a_dst = As + buf * (BM * BKP) + row_t * BKP + kq * 4;
+#pragma unroll
+    for (int j = 0; j < AU; ++j) *reinterpret_cast<f32x4*>(a_dst + j * RPP * BKP) = ra[j];
+    float* b_dst = Bs + buf * (BN * BKP) + row_t * BKP + kq * 4;
+#pragma unroll
+    for (int j = 0; j < BU; ++j)
+      if (row_t + j * RPP < BN) *reinterpret_cast<f32x4*>(b_dst + j * RPP * BKP) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  const int nk = p.Kp / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+
+  const int frag_off = (lane & 31) * BKP + (lane >> 5) * 4;
+  for (int kc = 0; kc < nk; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nk) gload(kc + 1);
+    const float* a_base = As + cur * (BM * BKP) + (wm * WM) * BKP + frag_off;
+    const float* b_base = Bs + cur * (BN * BKP) + (wn * WN) * BKP + frag_off;
+#pragma unroll
+    for (int t = 0; t < BK / 8; ++t) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BKP + t * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BKP + t * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (kc + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation (+ residual), 128-byte row segments per half wave ----------
+  float* __restrict__ out = p.out + z * p.out_zs;
+  const float* __restrict__ res = p.res ? p.res + z * p.res_zs : nullptr;
+  const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 32 + (lane & 31);
+      if (n >= p.N) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const long long m = m0 + wm * WM + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        float y = acc[i][j][v] + bv;
+        if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
+        else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
+        else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
+        if (res) y += res[m * p.ldr + n];
+        out[m * p.ldo + n] = y;
+      }
+    }
+  }
+}
+
+struct TileCfg {
+  int BM, BN, BK;
+  const char* name;
+};
+constexpr int kNumTiles = 9;
+const TileCfg kTiles[kNumTiles] = {
+    {256, 32, 16, "256x32x16"}, {256, 32, 32, "256x32x32"}, {128, 64, 16, "128x64x16"},
+    {128, 64, 32, "128x64x32"}, {128, 128, 16, "128x128x16"}, {128, 128, 32, "128x128x32"},
+    {64, 64, 16, "64x64x16"},   {256, 64, 16, "256x64x16"},   {256, 64, 32, "256x64x32"},
+};
+
+template <int BM, int BN, int WM, int WN, int BK, int MODE>
+int launch(const IgemmK& k, int nz, hipStream_t stream) {
+  constexpr size_t smem = 2ull * (BM + BN) * (BK + 4) * sizeof(float);
+  auto fn = igemm_kernel<BM, BN, WM, WN, BK, MODE>;
+  if (smem > 64 * 1024) {
+    static bool raised = false;  // idempotent attribute; benign race
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      raised = true;
+    }
+  }
+  dim3 grid((unsigned)(k.ntm * k.ntn), 1, (unsigned)nz);
+  hipLaunchKernelGGL(fn, grid, dim3(256), smem, stream, k);
+  return (int)hipGetLastError();
+}
+
+template <int MODE>
+int dispatch_tile(int tile, const IgemmK& k, int nz, hipStream_t s) {
+  switch (tile) {
+    case 0: return launch<256, 32, 64, 32, 16, MODE>(k, nz, s);
+    case 1: return launch<256, 32, 64, 32, 32, MODE>(k, nz, s);
+    case 2: return launch<128, 64, 64, 32, 16, MODE>(k, nz, s);
+    case 3: return launch<128, 64, 64, 32, 32, MODE>(k, nz, s);
+    case 4: return launch<128, 128, 64, 64, 16, MODE>(k, nz, s);
+    case 5: return launch<128, 128, 64, 64, 32, MODE>(k, nz, s);
+    case 6: return launch<64, 64, 32, 32, 16, MODE>(k, nz, s);
+    case 7: return launch<256, 64, 64, 64, 16, MODE>(k, nz, s);
+    case 8: return launch<256, 64, 64, 64, 32, MODE>(k, nz, s);
+  }
+  return SEGMIF_EINVAL;
+}
+
+// GENERIC (scalar gather) is only ever used for the two tiny-Cin stem convs: keep two tiles.
+int dispatch_generic(int tile, const IgemmK& k, int nz, hipStream_t s) {
+  switch (tile) {
+    case 0: return launch<256, 32, 64, 32, 16, MODE_GENERIC>(k, nz, s);
+    case 2: return launch<128, 64, 64, 32, 16, MODE_GENERIC>(k, nz, s);
+    case 6: return launch<64, 64, 32, 32, 16, MODE_GENERIC>(k, nz, s);
+  }
+  return SEGMIF_EINVAL;
+}
+
+int pick_tile(long long M, int N, int nz, bool bk32_ok, bool generic) {
+  auto blocks = [&](int t) {
+    return ((M + kTiles[t].BM - 1) / kTiles[t].BM) * ((N + kTiles[t].BN - 1) / kTiles[t].BN) * nz;
+  };
+  if (generic) return N <= 32 ? 0 : (blocks(2) >= 512 ? 2 : 6);
+  int cand[4], nc = 0;
+  if (N <= 32) {
+    cand[nc++] = 0;
+  } else if (N <= 64) {
+    cand[nc++] = 7; cand[nc++] = 2; cand[nc++] = 6;
+  } else {
+    cand[nc++] = 4; cand[nc++] = 2; cand[nc++] = 6;
+  }
+  int best = cand[nc - 1];
+  for (int i = 0; i < nc; ++i)
+    if (blocks(cand[i]) >= 512) { best = cand[i]; break; }
+  // BK = 32 variants sit right after their BK = 16 sibling (none for 64x64)
+  if (bk32_ok && best != 6) best += 1;
+  return best;
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int Cin, int KH,
+                                   int KW, int Kp) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)N * Kp) return;
+  const int n = (int)(i / Kp), k = (int)(i - (long long)n * Kp);
+  float v = 0.f;
+  if (k < KH * KW * Cin) {
+    const int tap = k / Cin, c = k - tap * Cin;
+    const int ky = tap / KW, kx = tap - ky * KW;
+    v = src[(((long long)n * Cin + c) * KH + ky) * KW + kx];
+  }
+  dst[i] = v;
+}
+
+}  // namespace
+
+extern "C" int segmif_igemm_num_tiles(void) { return kNumTiles; }
+extern "C" const char* segmif_igemm_tile_name(int t) { return (t >= 0 && t < kNumTiles) ? kTiles[t].name : "?"; }
+
+extern "C" int segmif_pack_conv_weight(const float* src, float* dst, int N, int Cin, int KH, int KW, void* stream) {
+  if (!src || !dst || N <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return SEGMIF_EINVAL;
+  const int Kp = (KH * KW * Cin + 15) / 16 * 16;
+  const long long total = (long long)N * Kp;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, N, Cin, KH, KW, Kp);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
+  if (!d || !d->in || !d->wt || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return SEGMIF_EINVAL;
+  IgemmK k;
+  k.in = d->in; k.in2 = d->in2; k.wt = d->wt; k.bias = d->bias; k.res = d->res; k.prelu = d->prelu; k.out = d->out;
+  k.M = d->M; k.N = d->N; k.K = d->K; k.Kp = (d->K + 15) / 16 * 16;
+  k.lda = d->lda; k.lda2 = d->lda2; k.K1 = d->K1; k.ldo = d->ldo; k.ldr = d->ldr;
+  k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad;
+  k.dil = d->dil; k.OH = d->OH; k.OW = d->OW; k.act = d->act;
+  k.in_zs = d->in_zstride; k.in2_zs = d->in2_zstride; k.wt_zs = d->wt_zstride; k.out_zs = d->out_zstride;
+  k.res_zs = d->res_zstride;
+  const int nz = d->nz > 0 ? d->nz : 1;
+  if (d->act == SEGMIF_ACT_PRELU && !d->prelu) return SEGMIF_EINVAL;
+  if (d->res && d->ldr <= 0) return SEGMIF_EINVAL;
+
+  const bool is_conv = !(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0);
+  int mode;
+  if (d->in2) {
+    if (is_conv || d->K1 % 32 != 0 || (d->K - d->K1) % 16 != 0 || d->lda % 4 || d->lda2 % 4) return SEGMIF_EINVAL;
+    mode = MODE_DENSE2;
+  } else if (!is_conv) {
+    mode = (d->K % 16 == 0 && d->lda % 4 == 0) ? MODE_DENSE : MODE_GENERIC;
+  } else {
+    mode = (d->Cin % 16 == 0 && d->lda % 4 == 0) ? MODE_CONV : MODE_GENERIC;
+  }
+  if (mode != MODE_GENERIC && (((uintptr_t)d->in & 15) || (d->in2 && ((uintptr_t)d->in2 & 15)))) mode = d->in2 ? -1 : MODE_GENERIC;
+  if (mode < 0 || ((uintptr_t)d->wt & 15)) return SEGMIF_EINVAL;
+  if (mode == MODE_GENERIC && (d->KH * d->KW * d->Cin != d->K)) return SEGMIF_EINVAL;
+
+  const bool bk32_ok = (k.Kp % 32 == 0) && (mode != MODE_CONV || d->Cin % 32 == 0) &&
+                       (mode != MODE_DENSE2 || (d->K1 % 32 == 0));
+  int tile = d->tile;
+  if (tile < 0) tile = pick_tile(d->M, d->N, nz, bk32_ok, mode == MODE_GENERIC);
+  if (tile >= kNumTiles) return SEGMIF_EINVAL;
+  if (kTiles[tile].BK == 32 && !bk32_ok) return SEGMIF_EINVAL;
+  k.ntm = (int)((d->M + kTiles[tile].BM - 1) / kTiles[tile].BM);
+  k.ntn = (d->N + kTiles[tile].BN - 1) / kTiles[tile].BN;
+  hipStream_t s = (hipStream_t)stream;
+  switch (mode) {
+    case MODE_DENSE: return dispatch_tile<MODE_DENSE>(tile, k, nz, s);
+    case MODE_CONV: return dispatch_tile<MODE_CONV>(tile, k, nz, s);
+    case MODE_DENSE2: return dispatch_tile<MODE_DENSE2>(tile, k, nz, s);
+    default: return dispatch_generic(tile, k, nz, s);
+  }
+}

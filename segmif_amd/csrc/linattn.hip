@@ -1,0 +1,123 @@
+// Linear ("efficient") cross attention of the fusion net's CrossPath
+// (core/model_fusion.py:263-288 CrossAttention, :303-328 CrossAttention2).
+//
+// The reference computes, per image and head (d = 8, 8 heads, N = H*W = 307 200 tokens):
+//     ctx = softmax_{dim=-2}( (K^T V) * d^-1/2 )      an 8x8 matrix
+//     x   = Q @ ctx                                    (N x 8) @ (8 x 8)
+// and then concatenates two such results and applies end_proj (128 -> 64).  No N x N matrix exists,
+// so the work is a long reduction over N followed by a tiny matrix.  We split it as
+//   1. segmif_linattn_partial_f32: row-block partial sums of K^T V for all heads (bandwidth bound:
+//      one pass over kv), accumulated in fp32 over 32-row chunks and in fp64 across chunks — the
+//      reduction feeds a softmax, so its rounding is the accuracy-critical step;
+//   2. segmif_linattn_fold_f32: fp64 sum of the partials, softmax over the k index, and folding of
+//      the block-diagonal context into the end_proj weight:
+//          Weff[b][n][kofs + h*d + i] = sum_j ctx[b][h][i][j] * Wend[n][wofs + h*d + j]
+//      so that Q @ ctx followed by cat + end_proj becomes ONE dense GEMM over [y3 | u_i] with a
+//      per-image 64x128 weight (segmif_igemm_f32, two-source mode) — z/v (2 x 157 MB per image)
+//      are never written.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "segmif_hip.h"
+
+namespace {
+
+constexpr int LA_ROWS = 1024;  // rows per block
+constexpr int LA_CHUNK = 32;  // rows per LDS chunk / fp32 accumulation run
+
+// heads*d == 64, d == 8: 512 (h, i, j) entries, two per thread.
+__global__ __launch_bounds__(256) void linattn_partial_kernel(const float* __restrict__ kv, double* __restrict__ partial,
+                                                              long long N, int ldkv, int nblk) {
+  __shared__ __attribute__((aligned(16))) float rows[LA_CHUNK][128 + 4];
+  const int tid = threadIdx.x;
+  const int blk = blockIdx.x, b = blockIdx.y;
+  const int hh = tid >> 5, i = (tid >> 2) & 7, j0 = (tid & 3) * 2;
+  const long long r0 = (long long)blk * LA_ROWS;
+  const float* base = kv + ((long long)b * N) * ldkv;
+  double acc0 = 0.0, acc1 = 0.0;
+  const int lr = tid >> 3, lq = tid & 7;  // loader: 32 rows x 8 threads, 4 float4 each
+  for (int c = 0; c < LA_ROWS / LA_CHUNK; ++c) {
+    const long long row = r0 + c * LA_CHUNK + lr;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < N) val = *reinterpret_cast<const float4*>(base + row * ldkv + (lq + 8 * u) * 4);
+      *reinterpret_cast<float4*>(&rows[lr][(lq + 8 * u) * 4]) = val;
+    }
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < LA_CHUNK; ++r) {
+      const float kk = rows[r][hh * 8 + i];
+      s0 = fmaf(kk, rows[r][64 + hh * 8 + j0], s0);
+      s1 = fmaf(kk, rows[r][64 + hh * 8 + j0 + 1], s1);
+    }
+    acc0 += (double)s0;
+    acc1 += (double)s1;
+    __syncthreads();
+    if (r0 + (c + 1) * LA_CHUNK >= N) break;
+  }
+  double* dst = partial + ((long long)b * nblk + blk) * 512 + hh * 64 + i * 8 + j0;
+  dst[0] = acc0;
+  dst[1] = acc1;
+}
+
+__global__ __launch_bounds__(256) void linattn_fold_kernel(const double* __restrict__ partial,
+                                                           const float* __restrict__ wend, float* __restrict__ weff,
+                                                           int nblk, int Nout, int ldw, int wofs, int ldweff, int kofs,
+                                                           float scale) {
+  __shared__ double ctx[512];  // [h][i][j]
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const double* p = partial + (long long)b * nblk * 512;
+  double a0 = 0.0, a1 = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    a0 += p[(long long)k * 512 + tid];
+    a1 += p[(long long)k * 512 + 256 + tid];
+  }
+  ctx[tid] = a0 * (double)scale;
+  ctx[256 + tid] = a1 * (double)scale;
+  __syncthreads();
+  if (tid < 64) {  // one (h, j) column per thread: softmax over i (dim = -2)
+    const int hh = tid >> 3, j = tid & 7;
+    double mx = -1e300;
+    for (int i = 0; i < 8; ++i) mx = fmax(mx, ctx[hh * 64 + i * 8 + j]);
+    double e[8], sum = 0.0;
+    for (int i = 0; i < 8; ++i) {
+      e[i] = exp(ctx[hh * 64 + i * 8 + j] - mx);
+      sum += e[i];
+    }
+    for (int i = 0; i < 8; ++i) ctx[hh * 64 + i * 8 + j] = e[i] / sum;
+  }
+  __syncthreads();
+  // Weff[b][n][kofs + c] for c = h*8 + i in [0, 64)
+  for (int o = tid; o < Nout * 64; o += 256) {
+    const int n = o >> 6, c = o & 63, hh = c >> 3, i = c & 7;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = fmaf((float)ctx[hh * 64 + i * 8 + j], wend[(long long)n * ldw + wofs + hh * 8 + j], acc);
+    weff[((long long)b * Nout + n) * ldweff + kofs + c] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int segmif_linattn_num_blocks(int64_t N) { return (int)((N + LA_ROWS - 1) / LA_ROWS); }
+
+extern "C" int segmif_linattn_partial_f32(const float* kv, double* partial, int B, int64_t N, int heads, int d,
+                                          int ldkv, void* stream) {
+  if (!kv || !partial || B <= 0 || N <= 0 || heads != 8 || d != 8 || ldkv < 128 || (ldkv & 3)) return SEGMIF_EINVAL;
+  if (((uintptr_t)kv & 15) || ((uintptr_t)partial & 7)) return SEGMIF_EINVAL;
+  const int nblk = segmif_linattn_num_blocks(N);
+  hipLaunchKernelGGL(linattn_partial_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, kv,
+                     partial, (long long)N, ldkv, nblk);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_linattn_fold_f32(const double* partial, const float* wend, float* weff, int B, int nblk,
+                                       int heads, int d, int Nout, int ldw, int wofs, int ldweff, int kofs, float scale,
+                                       void* stream) {
+  if (!partial || !wend || !weff || B <= 0 || nblk <= 0 || heads != 8 || d != 8 || Nout <= 0) return SEGMIF_EINVAL;
+  hipLaunchKernelGGL(linattn_fold_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     partial, wend, weff, nblk, Nout, ldw, wofs, ldweff, kofs, scale);
+  return (int)hipGetLastError();
+}

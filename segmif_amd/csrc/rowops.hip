@@ -1,0 +1,334 @@
+// Bandwidth-bound kernels of the SegMiF hot path (gfx950, wave64): LayerNorm, the Mix-FFN
+// depthwise 3x3 + GELU, bilinear resize, layout transposes and the per-pixel colour / normalise /
+// argmax helpers.  All are NHWC (== token layout) with 16-byte vector accesses; the roofline for
+// every kernel here is HBM (~6.3 TB/s achievable), so the rule is: one read, one write, float4.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "segmif_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: G lanes cooperate on one row (G = 8..64, power of two), values stay in registers,
+// two-pass mean / biased variance like aten's (core/mix_transformer.py:152-153 etc.).
+// ---------------------------------------------------------------------------------------------
+template <int G, int IT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        long long rows, int C, int ldx, int ldy, float eps) {
+  constexpr int RPB = 256 / G;  // rows per block
+  const int tid = threadIdx.x;
+  const int sub = tid % G;
+  const long long row = (long long)blockIdx.x * RPB + tid / G;
+  const bool row_ok = row < rows;
+  const int nvec = C >> 2;
+  f32x4 v[IT];
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int u = sub + it * G;
+    v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row_ok && u < nvec) v[it] = *reinterpret_cast<const f32x4*>(x + row * ldx + 4 * u);
+    sum += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+  }
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int u = sub + it * G;
+    if (u < nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[it][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+  const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int u = sub + it * G;
+    if (row_ok && u < nvec) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * u);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + 4 * u);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd * g[e] + bb[e];
+      *reinterpret_cast<f32x4*>(y + row * ldy + 4 * u) = o;
+    }
+  }
+}
+
+template <int G, int IT>
+int launch_ln(const float* x, const float* g, const float* b, float* y, long long rows, int C, int ldx, int ldy,
+              float eps, hipStream_t s) {
+  constexpr int RPB = 256 / G;
+  hipLaunchKernelGGL((layernorm_kernel<G, IT>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, x, g, b, y,
+                     rows, C, ldx, ldy, eps);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise 3x3 + bias + exact GELU.  A thread owns (x, 4 channels) and slides down TY rows with
+// a 3x3 register window, so each input row is fetched once per strip (+ the 2-row halo) and the
+// x-neighbours come from adjacent lanes' cache lines.
+// ---------------------------------------------------------------------------------------------
+constexpr int DW_TY = 8;
+
+__device__ __forceinline__ float gelu_exact(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __restrict__ x, const float* __restrict__ w9,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int H, int W, int C) {
+  const int c4n = C >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)W * c4n) return;
+  const int xo = (int)(idx / c4n), c = (int)(idx - (long long)xo * c4n) * 4;
+  const int y0 = blockIdx.y * DW_TY;
+  const long long img = (long long)blockIdx.z * H * W;
+  f32x4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w9 + t * C + c);
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+  const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+  auto load_row = [&](int yy, f32x4& l, f32x4& m, f32x4& r) {
+    l = m = r = zero;
+    if ((unsigned)yy < (unsigned)H) {
+      const float* p = x + (img + (long long)yy * W + xo) * C + c;
+      m = *reinterpret_cast<const f32x4*>(p);
+      if (xo > 0) l = *reinterpret_cast<const f32x4*>(p - C);
+      if (xo + 1 < W) r = *reinterpret_cast<const f32x4*>(p + C);
+    }
+  };
+  f32x4 win[3][3];
+  load_row(y0 - 1, win[0][0], win[0][1], win[0][2]);
+  load_row(y0, win[1][0], win[1][1], win[1][2]);
+#pragma unroll
+  for (int dy = 0; dy < DW_TY; ++dy) {
+    const int yo = y0 + dy;
+    if (yo >= H) break;
+    load_row(yo + 1, win[2][0], win[2][1], win[2][2]);
+    f32x4 acc = bv;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc += win[ky][kx] * wv[ky * 3 + kx];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = gelu_exact(acc[e]);
+    *reinterpret_cast<f32x4*>(y + (img + (long long)yo * W + xo) * C + c) = o;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      win[0][kx] = win[1][kx];
+      win[1][kx] = win[2][kx];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear resize, align_corners=False (aten area_pixel_compute_source_index semantics):
+//   src = max(0, scale * (dst + 0.5) - 0.5), scale = in / out (fp32), i1 = min(i0 + 1, in - 1).
+// ---------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int IH,
+                                                       int IW, int OH, int OW, int C, int ldx, int ldo, float sy,
+                                                       float sx, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cvn = C / V;
+  const int c = (int)(idx % cvn) * V;
+  long long pix = idx / cvn;
+  const int ox = (int)(pix % OW);
+  pix /= OW;
+  const int oy = (int)(pix % OH);
+  const long long b = pix / OH;
+  const float fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.f);
+  const float fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = min(y0 + 1, IH - 1), x1 = min(x0 + 1, IW - 1);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float* base = x + b * IH * IW * ldx + c;
+  const float* p00 = base + ((long long)y0 * IW + x0) * ldx;
+  const float* p01 = base + ((long long)y0 * IW + x1) * ldx;
+  const float* p10 = base + ((long long)y1 * IW + x0) * ldx;
+  const float* p11 = base + ((long long)y1 * IW + x1) * ldx;
+  float* dst = y + ((b * OH + oy) * OW + ox) * ldo + c;
+  if (V == 4) {
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(p00), v01 = *reinterpret_cast<const f32x4*>(p01);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(p10), v11 = *reinterpret_cast<const f32x4*>(p11);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    *reinterpret_cast<f32x4*>(dst) = o;
+  } else {
+    *dst = hy * (hx * *p00 + lx * *p01) + ly * (hx * *p10 + lx * *p11);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched 2-D transpose through LDS: in (B, R, Cc) pitch ldi -> out (B, Cc, R) pitch ldo.
+// NCHW -> NHWC is R = C, Cc = HW; NHWC -> NCHW is R = HW, Cc = C.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, long long R,
+                                                        long long Cc, long long ldi, long long ldo,
+                                                        long long in_bs, long long out_bs) {
+  __shared__ float tile[32][33];
+  const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+  const float* xi = x + (long long)blockIdx.z * in_bs;
+  float* yo = y + (long long)blockIdx.z * out_bs;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const long long r = r0 + ty + j, c = c0 + tx;
+    if (r < R && c < Cc) tile[ty + j][tx] = xi[r * ldi + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const long long c = c0 + ty + j, r = r0 + tx;
+    if (r < R && c < Cc) yo[c * ldo + r] = tile[tx][ty + j];
+  }
+}
+
+// (x*255 - mean_c) / std_c, NCHW (B,3,H,W) -> NHWC (B,H,W,3)   core/model_fusion.py:1079-1085
+__global__ __launch_bounds__(256) void seg_normalize_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            long long HW, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const long long b = idx / HW, p = idx - b * HW;
+  const float mean[3] = {123.675f, 116.28f, 103.53f};
+  const float stdv[3] = {58.395f, 57.12f, 57.375f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) y[idx * 3 + c] = (x[(b * 3 + c) * HW + p] * 255.f - mean[c]) / stdv[c];
+}
+
+// fused = clamp01(YCrCb2RGB([Yf, Cr(vis), Cb(vis)]))  core/model_fusion.py:69-111, test_fusion.py:102-111
+__global__ __launch_bounds__(256) void fuse_ycrcb_kernel(const float* __restrict__ vis, const float* __restrict__ yf,
+                                                         float* __restrict__ out, long long HW, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const long long b = idx / HW, p = idx - b * HW;
+  const float R = vis[(b * 3 + 0) * HW + p], G = vis[(b * 3 + 1) * HW + p], Bc = vis[(b * 3 + 2) * HW + p];
+  const float Y = 0.299f * R + 0.587f * G + 0.114f * Bc;
+  const float Cr = (R - Y) * 0.713f + 0.5f;
+  const float Cb = (Bc - Y) * 0.564f + 0.5f;
+  const float t0 = yf[idx] + 0.0f, t1 = Cr + -0.5f, t2 = Cb + -0.5f;
+  // row-vector times the 3x3 matrix of model_fusion.py:96-98, accumulated in aten mm order
+  float r = t0 * 1.0f + t1 * 1.403f + t2 * 0.0f;
+  float g = t0 * 1.0f + t1 * -0.714f + t2 * -0.344f;
+  float bl = t0 * 1.0f + t1 * 0.0f + t2 * 1.773f;
+  out[(b * 3 + 0) * HW + p] = fminf(fmaxf(r, 0.f), 1.f);
+  out[(b * 3 + 1) * HW + p] = fminf(fmaxf(g, 0.f), 1.f);
+  out[(b * 3 + 2) * HW + p] = fminf(fmaxf(bl, 0.f), 1.f);
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x, int32_t* __restrict__ labels,
+                                                     long long rows, int C, int ldx) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const float* p = x + r * ldx;
+  float best = p[0];
+  int bi = 0;
+  for (int c = 1; c < C; ++c) {
+    const float v = p[c];
+    if (v > best) {
+      best = v;
+      bi = c;
+    }
+  }
+  labels[r] = bi;
+}
+
+}  // namespace
+
+extern "C" int segmif_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
+                                    int C, int ldx, int ldy, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0 || (C & 3) || C > 1024 || (ldx & 3) || (ldy & 3))
+    return SEGMIF_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return SEGMIF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int nvec = C >> 2;
+  if (nvec <= 8) return launch_ln<8, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s);
+  if (nvec <= 16) return launch_ln<16, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s);
+  if (nvec <= 32) return launch_ln<32, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s);
+  if (nvec <= 64) return launch_ln<64, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s);
+  if (nvec <= 128) return launch_ln<64, 2>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s);
+  return launch_ln<64, 4>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s);
+}
+
+extern "C" int segmif_dwconv3x3_gelu_f32(const float* x, const float* w9, const float* bias, float* y, int B, int H,
+                                         int W, int C, void* stream) {
+  if (!x || !w9 || !bias || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return SEGMIF_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w9 | (uintptr_t)bias) & 15) return SEGMIF_EINVAL;
+  const long long per_row = (long long)W * (C >> 2);
+  dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)((H + DW_TY - 1) / DW_TY), (unsigned)B);
+  hipLaunchKernelGGL(dwconv3x3_gelu_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w9, bias, y, H, W, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_bilinear_nhwc_f32(const float* x, float* y, int B, int IH, int IW, int OH, int OW, int C,
+                                        int ldx, int ldo, void* stream) {
+  if (!x || !y || B <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || ldx < C || ldo < C)
+    return SEGMIF_EINVAL;
+  const bool vec = !((C | ldx | ldo) & 3) && !(((uintptr_t)x | (uintptr_t)y) & 15);
+  const long long total = (long long)B * OH * OW * (vec ? (C >> 2) : C);
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (vec)
+    hipLaunchKernelGGL(bilinear_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, y, IH, IW, OH, OW, C, ldx, ldo,
+                       sy, sx, total);
+  else
+    hipLaunchKernelGGL(bilinear_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, y, IH, IW, OH, OW, C, ldx, ldo,
+                       sy, sx, total);
+  return (int)hipGetLastError();
+}
+
+static int launch_transpose(const float* x, float* y, int B, long long R, long long Cc, long long ldi, long long ldo,
+                            long long in_bs, long long out_bs, hipStream_t s) {
+  dim3 grid((unsigned)((Cc + 31) / 32), (unsigned)((R + 31) / 32), (unsigned)B);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, x, y, R, Cc, ldi, ldo, in_bs, out_bs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int64_t HW, int ldo, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || HW <= 0 || ldo < C) return SEGMIF_EINVAL;
+  return launch_transpose(x, y, B, C, HW, HW, ldo, (long long)C * HW, (long long)HW * ldo, (hipStream_t)stream);
+}
+
+extern "C" int segmif_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int64_t HW, int ldx, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || HW <= 0 || ldx < C) return SEGMIF_EINVAL;
+  return launch_transpose(x, y, B, HW, C, ldx, HW, (long long)HW * ldx, (long long)C * HW, (hipStream_t)stream);
+}
+
+extern "C" int segmif_seg_normalize_f32(const float* x, float* y, int B, int H, int W, void* stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0) return SEGMIF_EINVAL;
+  const long long HW = (long long)H * W, total = HW * B;
+  hipLaunchKernelGGL(seg_normalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     y, HW, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_fuse_ycrcb_f32(const float* vis, const float* yf, float* out, int B, int64_t HW, void* stream) {
+  if (!vis || !yf || !out || B <= 0 || HW <= 0) return SEGMIF_EINVAL;
+  const long long total = (long long)HW * B;
+  hipLaunchKernelGGL(fuse_ycrcb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vis,
+                     yf, out, (long long)HW, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_argmax_nhwc_i32(const float* x, int32_t* labels, int64_t rows, int C, int ldx, void* stream) {
+  if (!x || !labels || rows <= 0 || C <= 0 || ldx < C) return SEGMIF_EINVAL;
+  hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, labels,
+                     (long long)rows, C, ldx);
+  return (int)hipGetLastError();
+}

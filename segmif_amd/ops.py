@@ -1,0 +1,344 @@
+"""Thin tensor-level wrappers over the C ABI (include/segmif_hip.h).
+
+Conventions: fp32 CUDA(HIP) tensors, NHWC / token layout.  A "rows view" is any tensor whose last
+dimension is dense (stride 1) and whose leading dimensions collapse to `rows` with one pitch
+(stride(-2)); channel slices of a wider NHWC buffer (`buf[..., :64]`) are rows views, which is how
+convs read from and write into concat buffers without copies.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_PRELU, ACT_RELU  # noqa: F401
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"segmif_amd: {name} must be a tensor on the MI355X device "
+                           "(the HIP path has no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"segmif_amd: {name} must be float32, got {t.dtype}")
+    return t
+
+
+def rows_view(t, name="tensor"):
+    """-> (rows, C, pitch). Validates that `t` is a rows view."""
+    _req(t, name)
+    if t.dim() < 2:
+        raise RuntimeError(f"{name}: need at least 2 dims")
+    if t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise RuntimeError(f"{name}: last dim must be dense")
+    ld = t.stride(-2)
+    rows = t.shape[-2]
+    expect = ld * t.shape[-2]
+    for d in range(t.dim() - 3, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != expect:
+            raise RuntimeError(f"{name}: leading dims do not collapse to rows (shape {tuple(t.shape)}, "
+                               f"strides {t.stride()})")
+        expect *= t.shape[d]
+        rows *= t.shape[d]
+    return rows, t.shape[-1], ld
+
+
+def pack_weight(w):
+    """OIHW conv weight or (N, K) linear weight -> packed [N, Kp] (tap-major, channel-minor)."""
+    _req(w, "weight")
+    if w.dim() == 2:
+        N, cin, kh, kw = w.shape[0], w.shape[1], 1, 1
+    else:
+        N, cin, kh, kw = w.shape
+    w = w.detach().contiguous()
+    kp = (kh * kw * cin + 15) // 16 * 16
+    out = torch.empty((N, kp), device=w.device, dtype=torch.float32)
+    _lib.check(_lib.load().segmif_pack_conv_weight(w.data_ptr(), out.data_ptr(), N, cin, kh, kw, _stream()),
+               "segmif_pack_conv_weight")
+    return out
+
+
+class LaunchTimer:
+    """Brackets tagged kernel launches with HIP events on the launch stream (torch's current
+    stream) so bench.py can report the dominant kernel's average duration live."""
+
+    def __init__(self, tag):
+        self.tag = tag
+        self.events = []  # (start, end, flops)
+
+    def bracket(self, fn, flops):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.events.append((s, e, flops))
+
+    def summary(self):
+        """-> (launches, mean ms per launch, mean flops per launch); call after a device sync."""
+        if not self.events:
+            return 0, 0.0, 0.0
+        ms = [s.elapsed_time(e) for s, e, _ in self.events]
+        return len(ms), sum(ms) / len(ms), sum(f for _, _, f in self.events) / len(ms)
+
+
+_timer = None
+
+
+def set_launch_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def _igemm(desc, tag=None):
+    def go():
+        _lib.check(_lib.load().segmif_igemm_f32(ctypes.byref(desc), _stream()), "segmif_igemm_f32")
+
+    if _timer is not None and tag is not None and tag == _timer.tag:
+        _timer.bracket(go, 2.0 * desc.M * max(desc.nz, 1) * desc.N * desc.K)
+    else:
+        go()
+
+
+def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None, x2=None, tile=-1,
+           batched_weight=False):
+    """out = res + act(x @ wt^T + bias).  x: rows view (..., K); wt: packed (N, Kp).
+    x2: optional second source (..., K2): A = [x | x2] along K (no concat materialised).
+    batched_weight: wt is (B, N, Kp) with one weight per leading batch index of x (x.dim() == 3)."""
+    rows, K1, lda = rows_view(x, "x")
+    K = K1
+    d = _lib.SegmifIgemm()
+    d.in_ = x.data_ptr()
+    if x2 is not None:
+        rows2, K2, lda2 = rows_view(x2, "x2")
+        if rows2 != rows:
+            raise RuntimeError("x and x2 row counts differ")
+        d.in2, d.lda2, d.K1 = x2.data_ptr(), lda2, K1
+        K = K1 + K2
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+    orow, oc, ldo = rows_view(out, "out")
+    if orow != rows or oc != N:
+        raise RuntimeError(f"out shape {tuple(out.shape)} does not match rows={rows}, N={N}")
+    _req(wt, "wt")
+    kp = (K + 15) // 16 * 16
+    nz = 1
+    if batched_weight:
+        if x.dim() != 3 or wt.dim() != 3 or wt.shape[0] != x.shape[0] or not wt.is_contiguous():
+            raise RuntimeError("batched_weight needs x (B, n, K) and contiguous wt (B, N, Kp)")
+        nz = x.shape[0]
+        rows = x.shape[1]
+        d.in_zstride = x.stride(0)
+        d.wt_zstride = wt.stride(0)
+        d.out_zstride = out.stride(0)
+        if x2 is not None:
+            d.in2_zstride = x2.stride(0)
+    if tuple(wt.shape[-2:]) != (N, kp) or not wt.is_contiguous():
+        raise RuntimeError(f"packed weight must be contiguous (..., {N}, {kp}), got {tuple(wt.shape)}")
+    d.wt = wt.data_ptr()
+    d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
+    d.prelu = _req(prelu, "prelu").data_ptr() if prelu is not None else None
+    d.out = out.data_ptr()
+    if res is not None:
+        rrow, rc, ldr = rows_view(res, "res")
+        if rc != N or rrow != orow:
+            raise RuntimeError("residual shape mismatch")
+        d.res, d.ldr = res.data_ptr(), ldr
+        if batched_weight:
+            d.res_zstride = res.stride(0)
+    d.M, d.N, d.K = rows, N, K
+    d.lda, d.ldo = lda, ldo
+    d.H = d.OH = 1
+    d.W = d.OW = 1
+    d.Cin = K
+    d.KH = d.KW = d.stride = d.dil = 1
+    d.pad = 0
+    d.act, d.nz, d.tile = act, nz, tile
+    _igemm(d)
+    return out
+
+
+def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
+           tile=-1, tag=None):
+    """NHWC convolution.  x: (B, H, W, Cin) rows view (may be a channel slice of a wider buffer);
+    wt packed (N, Kp); out: (B, OH, OW, N) rows view (may be a channel slice) or None."""
+    if x.dim() != 4:
+        raise RuntimeError("conv2d expects (B, H, W, C)")
+    _, cin, lda = rows_view(x, "x")
+    B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    OH = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, OH, OW, N), device=x.device, dtype=torch.float32)
+    orow, oc, ldo = rows_view(out, "out")
+    if tuple(out.shape) != (B, OH, OW, N):
+        raise RuntimeError(f"out shape {tuple(out.shape)} != {(B, OH, OW, N)}")
+    K = k * k * cin
+    kp = (K + 15) // 16 * 16
+    if tuple(_req(wt, "wt").shape) != (N, kp) or not wt.is_contiguous():
+        raise RuntimeError(f"packed weight must be contiguous ({N}, {kp}), got {tuple(wt.shape)}")
+    d = _lib.SegmifIgemm()
+    d.in_, d.wt, d.out = x.data_ptr(), wt.data_ptr(), out.data_ptr()
+    d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
+    d.prelu = _req(prelu, "prelu").data_ptr() if prelu is not None else None
+    if res is not None:
+        rrow, rc, ldr = rows_view(res, "res")
+        if rc != N or rrow != orow:
+            raise RuntimeError("residual shape mismatch")
+        d.res, d.ldr = res.data_ptr(), ldr
+    d.M, d.N, d.K = B * OH * OW, N, K
+    d.lda, d.ldo = lda, ldo
+    d.H, d.W, d.Cin, d.KH, d.KW = H, W, cin, k, k
+    d.stride, d.pad, d.dil, d.OH, d.OW = stride, pad, dil, OH, OW
+    d.act, d.nz, d.tile = act, 1, tile
+    _igemm(d, tag)
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out=None):
+    rows, C, ldx = rows_view(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    orow, oc, ldy = rows_view(out, "out")
+    if (orow, oc) != (rows, C):
+        raise RuntimeError("layernorm out shape mismatch")
+    _lib.check(_lib.load().segmif_layernorm_f32(x.data_ptr(), _req(gamma).data_ptr(), _req(beta).data_ptr(),
+                                                out.data_ptr(), rows, C, ldx, ldy, float(eps), _stream()),
+               "segmif_layernorm_f32")
+    return out
+
+
+def pack_dw_weight(w):
+    """(C, 1, 3, 3) depthwise weight -> [9][C]."""
+    return _req(w).detach().reshape(w.shape[0], 9).t().contiguous()
+
+
+def dwconv3x3_gelu(x, w9, bias, H, W):
+    """x: contiguous tokens (B, H*W, C) -> same shape."""
+    _req(x, "x")
+    if not x.is_contiguous() or x.dim() != 3 or x.shape[1] != H * W:
+        raise RuntimeError("dwconv3x3_gelu expects contiguous (B, H*W, C)")
+    B, _, C = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().segmif_dwconv3x3_gelu_f32(x.data_ptr(), _req(w9).data_ptr(), _req(bias).data_ptr(),
+                                                     out.data_ptr(), B, H, W, C, _stream()),
+               "segmif_dwconv3x3_gelu_f32")
+    return out
+
+
+def bilinear(x, OH, OW, out=None):
+    """x: (B, IH, IW, C) rows view -> (B, OH, OW, C) (out may be a channel slice of a wider buffer)."""
+    if x.dim() != 4:
+        raise RuntimeError("bilinear expects (B, H, W, C)")
+    _, C, ldx = rows_view(x, "x")
+    B, IH, IW = x.shape[0], x.shape[1], x.shape[2]
+    if out is None:
+        out = torch.empty((B, OH, OW, C), device=x.device, dtype=torch.float32)
+    _, oc, ldo = rows_view(out, "out")
+    if tuple(out.shape) != (B, OH, OW, C):
+        raise RuntimeError("bilinear out shape mismatch")
+    _lib.check(_lib.load().segmif_bilinear_nhwc_f32(x.data_ptr(), out.data_ptr(), B, IH, IW, OH, OW, C, ldx, ldo,
+                                                    _stream()), "segmif_bilinear_nhwc_f32")
+    return out
+
+
+def sr_attention(q, kv, heads, scale):
+    """q: (B, N, C) contiguous; kv: (B, Nk, 2C) contiguous (k | v) -> (B, N, C)."""
+    _req(q, "q"), _req(kv, "kv")
+    B, N, C = q.shape
+    Nk = kv.shape[1]
+    hd = C // heads
+    if not q.is_contiguous() or not kv.is_contiguous() or kv.shape[2] != 2 * C:
+        raise RuntimeError("sr_attention expects contiguous q (B,N,C) and kv (B,Nk,2C)")
+    out = torch.empty_like(q)
+    kptr = kv.data_ptr()
+    _lib.check(_lib.load().segmif_sr_attention_f32(q.data_ptr(), kptr, kptr + 4 * C, out.data_ptr(), B, heads, N, Nk,
+                                                   hd, C, 2 * C, C, float(scale), _stream()),
+               "segmif_sr_attention_f32")
+    return out
+
+
+def linattn_partial(kv, heads=8):
+    """kv: (B, N, 2C) contiguous -> fp64 partial sums (B, nblk, heads*d*d)."""
+    _req(kv, "kv")
+    B, N, C2 = kv.shape
+    d = C2 // 2 // heads
+    nblk = _lib.load().segmif_linattn_num_blocks(N)
+    part = torch.empty((B, nblk, heads * d * d), device=kv.device, dtype=torch.float64)
+    _lib.check(_lib.load().segmif_linattn_partial_f32(kv.data_ptr(), part.data_ptr(), B, N, heads, d, kv.stride(1),
+                                                      _stream()), "segmif_linattn_partial_f32")
+    return part
+
+
+def linattn_fold(part, wend, weff, wofs, kofs, scale, heads=8):
+    """Fold softmax((K^T V)*scale) into end_proj: writes weff[:, :, kofs:kofs+64] (weff: (B, Nout, Kp))."""
+    B, nblk, e = part.shape
+    d = int(round((e // heads) ** 0.5))
+    Nout = wend.shape[0]
+    _lib.check(_lib.load().segmif_linattn_fold_f32(part.data_ptr(), _req(wend).data_ptr(), _req(weff).data_ptr(), B,
+                                                   nblk, heads, d, Nout, wend.stride(0), wofs, weff.stride(1), kofs,
+                                                   float(scale), _stream()), "segmif_linattn_fold_f32")
+    return weff
+
+
+def seg_normalize(x):
+    """(B,3,H,W) NCHW contiguous -> normalised NHWC (B,H,W,3)."""
+    _req(x, "x")
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    if C != 3:
+        raise RuntimeError("seg_normalize expects 3 channels")
+    out = torch.empty((B, H, W, 3), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().segmif_seg_normalize_f32(x.data_ptr(), out.data_ptr(), B, H, W, _stream()),
+               "segmif_seg_normalize_f32")
+    return out
+
+
+def to_nhwc(x):
+    """Logical NCHW tensor (any strides) -> contiguous NHWC (B,H,W,C) tensor, zero-copy when the
+    input is already channels-last in memory."""
+    _req(x, "x")
+    B, C, H, W = x.shape
+    p = x.permute(0, 2, 3, 1)
+    if p.is_contiguous():
+        return p
+    x = x.contiguous()
+    out = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().segmif_nchw_to_nhwc_f32(x.data_ptr(), out.data_ptr(), B, C, H * W, C, _stream()),
+               "segmif_nchw_to_nhwc_f32")
+    return out
+
+
+def as_nchw(x_nhwc):
+    """NHWC storage presented with the reference's logical (B, C, H, W) shape (channels_last strides)."""
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def to_nchw_contiguous(x_nhwc):
+    _req(x_nhwc, "x")
+    B, H, W, C = x_nhwc.shape
+    _, _, ldx = rows_view(x_nhwc, "x")
+    out = torch.empty((B, C, H, W), device=x_nhwc.device, dtype=torch.float32)
+    _lib.check(_lib.load().segmif_nhwc_to_nchw_f32(x_nhwc.data_ptr(), out.data_ptr(), B, C, H * W, ldx, _stream()),
+               "segmif_nhwc_to_nchw_f32")
+    return out
+
+
+def fuse_ycrcb(vis, yf):
+    """vis (B,3,H,W) RGB NCHW, yf (B,1,H,W) -> clamp01(YCrCb2RGB([yf, Cr(vis), Cb(vis)])) NCHW."""
+    vis = _req(vis, "vis").contiguous()
+    yf = _req(yf, "yf").contiguous()
+    B, _, H, W = vis.shape
+    out = torch.empty_like(vis)
+    _lib.check(_lib.load().segmif_fuse_ycrcb_f32(vis.data_ptr(), yf.data_ptr(), out.data_ptr(), B, H * W, _stream()),
+               "segmif_fuse_ycrcb_f32")
+    return out
+
+
+def argmax_nhwc(x):
+    rows, C, ldx = rows_view(x, "x")
+    out = torch.empty(x.shape[:-1], device=x.device, dtype=torch.int32)
+    _lib.check(_lib.load().segmif_argmax_nhwc_i32(x.data_ptr(), out.data_ptr(), rows, C, ldx, _stream()),
+               "segmif_argmax_nhwc_i32")
+    return out

@@ -1,0 +1,239 @@
+"""GPU parity tests, kernel level: every C-ABI entry point of libsegmif_hip.so against an fp64
+torch-CPU statement of the same aten op the reference calls.  Tolerance: the north-star bound is
+1e-3 relative in fp32; the kernels are exact-fp32 (MFMA f32 / fmaf), so the gate here is 2e-5 of
+the output's max magnitude."""
+import itertools
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from segmif_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * (hi - lo) + lo).float()
+
+
+def err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def act_ref(y, act, slope=None):
+    if act == 1:
+        return F.relu(y)
+    if act == 2:
+        return torch.where(y >= 0, y, slope * y)
+    if act == 3:
+        return F.gelu(y)
+    return y
+
+
+TILES_ALL = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8]
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 64, 64), (300, 512, 2048), (4099, 9, 256), (257, 128, 32), (77, 1, 64),
+                                   (640, 256, 1024), (513, 320, 320)])
+def test_igemm_dense_all_tiles(ops, M, N, K):
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref_lin = x.double() @ w.double().t() + b.double()
+    wt = ops.pack_weight(w.cuda())
+    for tile in TILES_ALL:
+        if tile in (1, 3, 5, 8) and K % 32:
+            continue
+        for act, use_res in ((0, False), (1, True), (3, False)):
+            ref = act_ref(ref_lin, act)
+            if use_res:
+                ref = ref + r.double()
+            y = ops.linear(x.cuda(), wt, N, bias=b.cuda(), act=act, res=r.cuda() if use_res else None, tile=tile)
+            assert err(y, ref) < TOL, (tile, act, use_res)
+
+
+def test_igemm_dense_pitched_views_and_prelu(ops):
+    M, K, N = 900, 64, 32
+    buf = rnd(M, 224, seed=5).cuda()
+    w, b = rnd(N, K, seed=6), rnd(N, seed=7)
+    slope = torch.tensor([0.2], device="cuda")
+    out = torch.full((M, 224), 7.0, device="cuda")
+    ops.linear(buf[:, :K], ops.pack_weight(w.cuda()), N, bias=b.cuda(), act=2, prelu=slope, out=out[:, 64:96])
+    ref = act_ref(buf[:, :K].cpu().double() @ w.double().t() + b.double(), 2, 0.2)
+    assert err(out[:, 64:96], ref) < TOL
+    assert float((out[:, :64] - 7).abs().max()) == 0 and float((out[:, 96:] - 7).abs().max()) == 0
+
+
+def test_igemm_two_source_batched_weight(ops):
+    B, n, C = 3, 700, 64
+    p3, p1, x = rnd(B, n, 128, seed=8), rnd(B, n, 128, seed=9), rnd(B, n, C, seed=10)
+    weff, bias = rnd(B, C, 128, seed=11), rnd(C, seed=12)
+    y = ops.linear(p3.cuda()[..., :C], weff.cuda(), C, bias=bias.cuda(), res=x.cuda(), x2=p1.cuda()[..., C:],
+                   batched_weight=True)
+    a = torch.cat((p3[..., :C], p1[..., C:]), dim=-1).double()
+    ref = x.double() + torch.einsum("bnk,bok->bno", a, weff.double()) + bias.double()
+    assert err(y, ref) < TOL
+
+
+CONV_CASES = [
+    # B, H, W, Cin, N, k, stride, pad, dil
+    (2, 20, 28, 64, 32, 3, 1, 2, 2),  # DRDB dilated conv
+    (2, 20, 28, 192, 32, 3, 1, 2, 2),
+    (1, 17, 23, 64, 128, 3, 2, 1, 1),  # overlap patch embed, odd size
+    (2, 37, 41, 3, 32, 7, 4, 3, 1),  # stage-1 patch embed (scalar gather path)
+    (1, 9, 13, 128, 128, 4, 4, 0, 1),  # sr conv dropping the remainder
+    (2, 16, 24, 1, 64, 3, 1, 1, 1),  # conv1_ir / conv1_vis
+    (2, 16, 24, 32, 1, 3, 1, 1, 1),  # conv22
+    (1, 33, 47, 128, 64, 3, 1, 1, 1),  # conv2
+    (1, 8, 8, 320, 320, 2, 2, 0, 1),  # stage-3 sr conv
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_igemm_conv(ops, case):
+    B, H, W, Cin, N, k, s, p, d = case
+    x, w, b = rnd(B, Cin, H, W, seed=13), rnd(N, Cin, k, k, seed=14), rnd(N, seed=15)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p, dilation=d).permute(0, 2, 3, 1)
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wt = ops.pack_weight(w.cuda())
+    tiles = [-1] if (Cin % 16) else TILES_ALL
+    for tile in tiles:
+        if tile in (1, 3, 5, 8) and Cin % 32:
+            continue
+        y = ops.conv2d(xh, wt, N, k, stride=s, pad=p, dil=d, bias=b.cuda(), tile=tile)
+        assert err(y, ref) < TOL, tile
+
+
+def test_drdb_concat_in_place(ops):
+    """A conv reading the first Cin channels of a 224-wide buffer and writing its 32 channels in place."""
+    B, H, W = 2, 14, 18
+    buf = rnd(B, H, W, 224, seed=16).cuda()
+    before = buf.clone()
+    w, b = rnd(32, 96, 3, 3, seed=17), rnd(32, seed=18)
+    ops.conv2d(buf[..., :96], ops.pack_weight(w.cuda()), 32, 3, pad=2, dil=2, bias=b.cuda(), act=1,
+               out=buf[..., 96:128])
+    xin = before[..., :96].cpu().double().permute(0, 3, 1, 2)
+    ref = F.relu(F.conv2d(xin, w.double(), b.double(), padding=2, dilation=2)).permute(0, 2, 3, 1)
+    assert err(buf[..., 96:128], ref) < TOL
+    assert torch.equal(buf[..., :96], before[..., :96]) and torch.equal(buf[..., 128:], before[..., 128:])
+
+
+@pytest.mark.parametrize("C", [32, 64, 128, 160, 256, 320, 512, 1024])
+def test_layernorm(ops, C):
+    rows = 1003
+    x, g, b = rnd(rows, C, seed=19, lo=-3, hi=5), rnd(C, seed=20), rnd(C, seed=21)
+    for eps in (1e-6, 1e-5):
+        y = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), eps)
+        assert err(y, F.layer_norm(x.double(), (C,), g.double(), b.double(), eps)) < TOL
+    wide = torch.zeros(rows, C + 32, device="cuda")
+    ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-5, out=wide[:, :C])
+    assert err(wide[:, :C], F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-5)) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 13, 128), (1, 30, 40, 1280), (1, 1, 1, 32), (2, 8, 12, 512), (1, 17, 5, 64)])
+def test_dwconv_gelu(ops, B, H, W, C):
+    x, w, b = rnd(B, H * W, C, seed=22, lo=-2, hi=2), rnd(C, 1, 3, 3, seed=23), rnd(C, seed=24)
+    img = x.double().transpose(1, 2).reshape(B, C, H, W)
+    ref = F.gelu(F.conv2d(img, w.double(), b.double(), padding=1, groups=C)).flatten(2).transpose(1, 2)
+    y = ops.dwconv3x3_gelu(x.cuda(), ops.pack_dw_weight(w.cuda()), b.cuda(), H, W)
+    assert err(y, ref) < TOL
+
+
+@pytest.mark.parametrize("B,IH,IW,OH,OW,C", [(2, 16, 24, 64, 96, 64), (1, 15, 20, 120, 160, 256), (1, 5, 7, 18, 26, 32),
+                                             (2, 18, 26, 72, 104, 9), (1, 30, 40, 30, 40, 8)])
+def test_bilinear(ops, B, IH, IW, OH, OW, C):
+    x = rnd(B, IH, IW, C, seed=25)
+    ref = F.interpolate(x.double().permute(0, 3, 1, 2), size=[OH, OW], mode="bilinear", align_corners=False)
+    y = ops.bilinear(x.cuda(), OH, OW)
+    assert err(y, ref.permute(0, 2, 3, 1)) < TOL
+    if C % 4 == 0:
+        wide = torch.zeros(B, OH, OW, 3 * C, device="cuda")
+        ops.bilinear(x.cuda(), OH, OW, out=wide[..., C:2 * C])
+        assert err(wide[..., C:2 * C], ref.permute(0, 2, 3, 1)) < TOL
+
+
+@pytest.mark.parametrize("B,heads,N,Nk,hd", [(2, 2, 96, 6, 64), (1, 1, 19200, 300, 64), (2, 5, 1200, 300, 64),
+                                             (1, 8, 300, 300, 64), (1, 2, 1024, 64, 32), (1, 1, 130, 1, 64),
+                                             (1, 1, 4096, 1024, 64), (1, 5, 35, 35, 32)])
+def test_sr_attention(ops, B, heads, N, Nk, hd):
+    C = heads * hd
+    q, kv = rnd(B, N, C, seed=26, lo=-2, hi=2), rnd(B, Nk, 2 * C, seed=27, lo=-2, hi=2)
+    scale = hd ** -0.5
+    qh = q.double().reshape(B, N, heads, hd).permute(0, 2, 1, 3)
+    kvh = kv.double().reshape(B, Nk, 2, heads, hd)
+    k, v = kvh[:, :, 0].permute(0, 2, 1, 3), kvh[:, :, 1].permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ k.transpose(-2, -1) * scale, -1) @ v).transpose(1, 2).reshape(B, N, C)
+    y = ops.sr_attention(q.cuda(), kv.cuda(), heads, scale)
+    assert err(y, ref) < TOL
+
+
+def test_sr_attention_large_logits(ops):
+    """Online-softmax rescale path: one key dominates late in the sequence."""
+    B, heads, N, Nk, hd = 1, 1, 64, 100, 64
+    q, kv = rnd(B, N, hd, seed=28), rnd(B, Nk, 2 * hd, seed=29)
+    kv[:, 77, :hd] = 40.0 * q[0, 5]  # spike: row 5's max jumps at tile 2
+    ref = torch.softmax(q.double() @ kv[..., :hd].double().transpose(-2, -1) * 0.125, -1) @ kv[..., hd:].double()
+    assert err(ops.sr_attention(q.cuda(), kv.cuda(), heads, 0.125), ref) < TOL
+
+
+@pytest.mark.parametrize("B,N", [(2, 3000), (1, 1024), (3, 37), (1, 70000)])
+def test_linear_attention_context_and_fold(ops, B, N):
+    heads, d, C = 8, 8, 64
+    kv = rnd(B, N, 2 * C, seed=30)
+    wend = rnd(C, 2 * C, seed=31)
+    scale = d ** -0.5
+    part = ops.linattn_partial(kv.cuda(), heads)
+    kvh = kv.double().reshape(B, N, 2, heads, d)
+    k, v = kvh[:, :, 0].permute(0, 2, 1, 3), kvh[:, :, 1].permute(0, 2, 1, 3)
+    raw = k.transpose(-2, -1) @ v  # (B, h, d, d)
+    assert err(part.sum(1).reshape(B, heads, d, d), raw) < 1e-6
+    ctx = torch.softmax(raw * scale, dim=-2)
+    weff = torch.zeros(B, C, 2 * C, device="cuda")
+    ops.linattn_fold(part, wend.cuda(), weff, wofs=C, kofs=C, scale=scale)
+    ops.linattn_fold(part, wend.cuda(), weff, wofs=0, kofs=0, scale=scale)
+    # Weff[b][n][kofs + h*d + i] = sum_j ctx[b,h,i,j] * Wend[n][wofs + h*d + j]
+    for ofs in (0, C):
+        wpart = wend.double()[:, ofs:ofs + C].reshape(C, heads, d)
+        ref = torch.einsum("bhij,nhj->bnhi", ctx, wpart).reshape(B, C, C)
+        assert err(weff[:, :, ofs:ofs + C], ref) < TOL
+
+
+def test_pointwise_and_layout(ops):
+    import segmif_oracle as so
+    x = rnd(2, 3, 11, 17, seed=32, lo=0, hi=1)
+    y = ops.seg_normalize(x.cuda())
+    mean = torch.tensor(so.SEG_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(so.SEG_STD).view(1, 3, 1, 1)
+    assert err(y, ((x.double() * 255 - mean) / std).permute(0, 2, 3, 1)) < TOL
+    t = rnd(2, 37, 5, 9, seed=33)
+    assert torch.equal(ops.to_nhwc(t.cuda()).cpu(), t.permute(0, 2, 3, 1).contiguous())
+    cl = t.cuda().contiguous(memory_format=torch.channels_last)
+    assert ops.to_nhwc(cl).data_ptr() == cl.data_ptr()  # zero-copy for channels-last storage
+    assert torch.equal(ops.to_nchw_contiguous(t.permute(0, 2, 3, 1).contiguous().cuda()).cpu(), t)
+    vis, yf = rnd(2, 3, 11, 17, seed=34, lo=0, hi=1), rnd(2, 1, 11, 17, seed=35, lo=-0.2, hi=1.3)
+    ycc = so.rgb2ycrcb(vis.double())
+    ref = so.ycrcb2rgb(torch.cat((yf.double(), ycc[:, 1:2], ycc[:, 2:3]), 1)).clamp(0, 1)
+    assert err(ops.fuse_ycrcb(vis.cuda(), yf.cuda()), ref) < TOL
+    logits = rnd(3, 7, 9, 9, seed=36)
+    assert torch.equal(ops.argmax_nhwc(logits.cuda()).cpu().long(), logits.argmax(-1))
+
+
+def test_bad_arguments_fail_loudly(ops):
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(4, 64), torch.zeros(8, 64).cuda(), 8)  # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(4, 64).cuda(), torch.zeros(8, 48).cuda(), 8)  # wrong packed shape
+    with pytest.raises(RuntimeError):
+        ops.layernorm(torch.zeros(4, 30).cuda(), torch.ones(30).cuda(), torch.zeros(30).cuda(), 1e-5)  # C % 4
