@@ -28,6 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 # algorithmic work, GFLOP per pair forward at 480x640 (torch FlopCounterMode, 2*MAC)
 GFLOP_PER_PAIR = {"mit_b1": 700.2, "mit_b3": 827.1}
+CPU_BASELINE_THREADS = 32
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
 
 
@@ -49,7 +50,9 @@ def cpu_baseline(backbone, H, W):
     """The oracle (CPU port of the reference path) timed on this host's cores on a bounded sample."""
     import detweights as dw
     import segmif_oracle as so
-    torch.set_num_threads(os.cpu_count() or 1)
+    # one thread per physical core up to 32: beyond that torch-CPU/oneDNN goes backwards on this
+    # path (256 threads on the GPU box's host: 284 s per pair, measured in round 1)
+    torch.set_num_threads(max(1, min(CPU_BASELINE_THREADS, os.cpu_count() or 1)))
     sd_seg = dw.det_state_dict(so.network3_shapes(backbone, 9), seed=0)
     sd_fus = dw.det_state_dict(so.fusion_shapes(), seed=0)
     ir = dw.det_input("cpu_ir", (1, 1, H, W))
@@ -62,7 +65,7 @@ def cpu_baseline(backbone, H, W):
             so.pair_forward(sd_seg, sd_fus, ir, vis, mask, backbone)
             n += 1
             dt = time.perf_counter() - t0
-            if dt > 10.0 or n >= 4:
+            if dt > 10.0 or n >= 3:
                 break
     return {"value": n / dt, "unit": "img-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} pair(s) of {backbone} {H}x{W} at batch 1 through oracle/segmif_oracle.py "

@@ -317,25 +317,19 @@ int dispatch_generic(int tile, const IgemmK& k, int nz, hipStream_t s) {
   return SEGMIF_EINVAL;
 }
 
-int pick_tile(long long M, int N, int nz, bool bk32_ok, bool generic) {
+// Tile choice, from the MI355X sweep in profiles/r01_kernel_bench.txt: BK = 32 never pays (its LDS
+// footprint costs a block per CU), 64x64 wins whenever the grid is not enormous, the big tiles only
+// pay for long-K / wide-N problems with tens of thousands of 64x64 tiles.
+int pick_tile(long long M, int N, int K, int nz, bool generic) {
   auto blocks = [&](int t) {
     return ((M + kTiles[t].BM - 1) / kTiles[t].BM) * ((N + kTiles[t].BN - 1) / kTiles[t].BN) * nz;
   };
-  if (generic) return N <= 32 ? 0 : (blocks(2) >= 512 ? 2 : 6);
-  int cand[4], nc = 0;
-  if (N <= 32) {
-    cand[nc++] = 0;
-  } else if (N <= 64) {
-    cand[nc++] = 7; cand[nc++] = 2; cand[nc++] = 6;
-  } else {
-    cand[nc++] = 4; cand[nc++] = 2; cand[nc++] = 6;
-  }
-  int best = cand[nc - 1];
-  for (int i = 0; i < nc; ++i)
-    if (blocks(cand[i]) >= 512) { best = cand[i]; break; }
-  // BK = 32 variants sit right after their BK = 16 sibling (none for 64x64)
-  if (bk32_ok && best != 6) best += 1;
-  return best;
+  if (N <= 32) return 0;
+  if (generic) return blocks(6) >= 16384 ? 2 : 6;
+  if (N >= 128 && K >= 512 && blocks(4) >= 1024) return 4;
+  if (N <= 64 && K >= 128 && blocks(7) >= 2048) return 7;
+  if (blocks(6) >= 16384) return 2;
+  return 6;
 }
 
 __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int Cin, int KH,
@@ -397,7 +391,7 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
   const bool bk32_ok = (k.Kp % 32 == 0) && (mode != MODE_CONV || d->Cin % 32 == 0) &&
                        (mode != MODE_DENSE2 || (d->K1 % 32 == 0));
   int tile = d->tile;
-  if (tile < 0) tile = pick_tile(d->M, d->N, nz, bk32_ok, mode == MODE_GENERIC);
+  if (tile < 0) tile = pick_tile(d->M, d->N, d->K, nz, mode == MODE_GENERIC);
   if (tile >= kNumTiles) return SEGMIF_EINVAL;
   if (kTiles[tile].BK == 32 && !bk32_ok) return SEGMIF_EINVAL;
   k.ntm = (int)((d->M + kTiles[tile].BM - 1) / kTiles[tile].BM);
