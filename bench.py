@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 # algorithmic work, GFLOP per pair forward at 480x640 (torch FlopCounterMode, 2*MAC)
 GFLOP_PER_PAIR = {"mit_b1": 700.2, "mit_b3": 827.1}
-CPU_BASELINE_THREADS = 32
+CPU_BASELINE_THREADS = 16  # fastest of {16,32,64,128,256} on the GPU box host (profiles/r01_cpu_threads.txt)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
 
 

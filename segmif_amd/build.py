@@ -12,7 +12,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libsegmif_hip.so")
-SOURCES = ["igemm.hip", "attention.hip", "rowops.hip", "linattn.hip", "common.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "attention.hip", "rowops.hip", "linattn.hip", "common.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(ROOT, "include")]
 
@@ -26,7 +26,7 @@ def _hipcc():
 
 def _digest():
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for f in SOURCES + [os.path.join(ROOT, "include", "segmif_hip.h")]:
+    for f in SOURCES + ["igemm_common.h", os.path.join(ROOT, "include", "segmif_hip.h")]:
         p = f if os.path.isabs(f) else os.path.join(CSRC, f)
         with open(p, "rb") as fh:
             h.update(fh.read())

@@ -24,34 +24,14 @@
 #include <stdint.h>
 
 #include "segmif_hip.h"
+#include "igemm_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+using namespace segmif;
 
 namespace {
 
 enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_GENERIC = 2, MODE_DENSE2 = 3 };
-
-struct IgemmK {
-  const float* in;
-  const float* in2;
-  const float* wt;
-  const float* bias;
-  const float* res;
-  const float* prelu;
-  float* out;
-  long long M;
-  int N, K, Kp;
-  int lda, lda2, K1, ldo, ldr;
-  int H, W, Cin, KH, KW, stride, pad, dil, OH, OW;
-  int act;
-  long long in_zs, in2_zs, wt_zs, out_zs, res_zs;
-  int ntm, ntn;
-};
-
-__device__ __forceinline__ float gelu_exact(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
 
 template <int BM, int BN, int WM, int WN, int BK, int MODE>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
@@ -267,12 +247,14 @@ struct TileCfg {
   int BM, BN, BK;
   const char* name;
 };
-constexpr int kNumTiles = 9;
+constexpr int kNumTiles = 11;  // 0-8: implicit-GEMM tiles; 9, 10: halo-tiled 3x3 (conv3x3.hip)
 const TileCfg kTiles[kNumTiles] = {
     {256, 32, 16, "256x32x16"}, {256, 32, 32, "256x32x32"}, {128, 64, 16, "128x64x16"},
     {128, 64, 32, "128x64x32"}, {128, 128, 16, "128x128x16"}, {128, 128, 32, "128x128x32"},
     {64, 64, 16, "64x64x16"},   {256, 64, 16, "256x64x16"},   {256, 64, 32, "256x64x32"},
+    {256, 64, 16, "halo8x32c16"}, {256, 64, 8, "halo8x32c8"},
 };
+constexpr int kHaloTile0 = 9;
 
 template <int BM, int BN, int WM, int WN, int BK, int MODE>
 int launch(const IgemmK& k, int nz, hipStream_t stream) {
@@ -391,12 +373,18 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
   const bool bk32_ok = (k.Kp % 32 == 0) && (mode != MODE_CONV || d->Cin % 32 == 0) &&
                        (mode != MODE_DENSE2 || (d->K1 % 32 == 0));
   int tile = d->tile;
+  hipStream_t s = (hipStream_t)stream;
+  const bool halo_ok = mode == MODE_CONV && nz == 1 && conv3x3_halo_eligible(k);
+  if (tile < 0 && halo_ok) tile = kHaloTile0 + (d->N > 32 ? 0 : 1);
+  if (tile >= kHaloTile0 && tile < kNumTiles) {
+    if (!halo_ok) return SEGMIF_EINVAL;
+    return conv3x3_halo_launch(k, tile - kHaloTile0, s);
+  }
   if (tile < 0) tile = pick_tile(d->M, d->N, d->K, nz, mode == MODE_GENERIC);
   if (tile >= kNumTiles) return SEGMIF_EINVAL;
   if (kTiles[tile].BK == 32 && !bk32_ok) return SEGMIF_EINVAL;
   k.ntm = (int)((d->M + kTiles[tile].BM - 1) / kTiles[tile].BM);
   k.ntn = (d->N + kTiles[tile].BN - 1) / kTiles[tile].BN;
-  hipStream_t s = (hipStream_t)stream;
   switch (mode) {
     case MODE_DENSE: return dispatch_tile<MODE_DENSE>(tile, k, nz, s);
     case MODE_CONV: return dispatch_tile<MODE_CONV>(tile, k, nz, s);

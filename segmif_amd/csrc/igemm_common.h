@@ -1,0 +1,38 @@
+// Private to segmif_amd/csrc: kernel-side argument block shared by the implicit-GEMM kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "segmif_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace segmif {
+
+struct IgemmK {
+  const float* in;
+  const float* in2;
+  const float* wt;
+  const float* bias;
+  const float* res;
+  const float* prelu;
+  float* out;
+  long long M;
+  int N, K, Kp;
+  int lda, lda2, K1, ldo, ldr;
+  int H, W, Cin, KH, KW, stride, pad, dil, OH, OW;
+  int act;
+  long long in_zs, in2_zs, wt_zs, out_zs, res_zs;
+  int ntm, ntn;
+};
+
+__device__ __forceinline__ float gelu_exact(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+
+// halo-tiled 3x3 stride-1 convolution (conv3x3.hip); variant 0: 16-channel chunks, 1: 8-channel chunks
+bool conv3x3_halo_eligible(const IgemmK& k);
+int conv3x3_halo_launch(const IgemmK& k, int variant, hipStream_t stream);
+
+}  // namespace segmif

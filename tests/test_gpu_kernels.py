@@ -108,7 +108,9 @@ def test_igemm_conv(ops, case):
     ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p, dilation=d).permute(0, 2, 3, 1)
     xh = x.permute(0, 2, 3, 1).contiguous().cuda()
     wt = ops.pack_weight(w.cuda())
-    tiles = [-1] if (Cin % 16) else TILES_ALL
+    tiles = [-1] if (Cin % 16) else list(TILES_ALL)
+    if k == 3 and s == 1 and p == d and N <= 64 and Cin % 16 == 0:
+        tiles += [9, 10]  # halo-tiled 3x3 variants (conv3x3.hip)
     for tile in tiles:
         if tile in (1, 3, 5, 8) and Cin % 32:
             continue

@@ -43,7 +43,7 @@ def bench_conv(B, H, W, Cin, N, k, pad, dil, tiles, names, cbuf=None, stride=1, 
     out = torch.empty(B, OH, OW, N, device="cuda")
     flops = 2.0 * B * OH * OW * N * k * k * Cin
     for t in tiles:
-        if names[t].endswith("x32") and Cin % 32 and t >= 0:
+        if t >= 0 and names[t].endswith("x32") and Cin % 32:
             continue
         try:
             ms = timeit(lambda: ops.conv2d(x[..., :Cin], w, N, k, stride=stride, pad=pad, dil=dil, bias=b, act=1,
@@ -75,6 +75,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--convs-only", action="store_true")
     args = ap.parse_args()
     lib = _lib.load()
     import ctypes
@@ -85,12 +86,14 @@ def main():
     B, H, W = args.batch, 480, 640
     print("== DRDB dilated 3x3 (reads a 224-pitch concat buffer)")
     for cin in ((64, 192) if args.quick else (64, 96, 128, 160, 192)):
-        bench_conv(B, H, W, cin, 32, 3, 2, 2, [0, 1], names, cbuf=224)
+        bench_conv(B, H, W, cin, 32, 3, 2, 2, [0, 9, 10], names, cbuf=224)
     print("== fusion-net plain convs")
-    bench_conv(B, H, W, 128, 64, 3, 1, 1, [2, 3, 7, 8, 6], names)
-    bench_conv(B, H, W, 64, 32, 3, 1, 1, [0, 1], names)
-    bench_conv(B, H, W, 32, 1, 3, 1, 1, [0, 1], names)
+    bench_conv(B, H, W, 128, 64, 3, 1, 1, [7, 9, 10], names)
+    bench_conv(B, H, W, 64, 32, 3, 1, 1, [0, 9, 10], names)
+    bench_conv(B, H, W, 32, 1, 3, 1, 1, [0, 9, 10], names)
     bench_conv(B, H, W, 1, 64, 3, 1, 1, [-1], names)
+    if args.convs_only:
+        return
     print("== fusion-net 1x1 / CrossPath linears (M = B*H*W)")
     M = B * H * W
     bench_dense(M, 64, 224, [2, 3, 7, 8], names)
