@@ -74,19 +74,14 @@ def cpu_baseline(backbone, H, W):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from segmif_amd import dist
+    rank, local_rank, world = dist.env_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist.init()  # RCCL process group when WORLD_SIZE > 1; replicas only, no data-path collective
 
     import detweights as dw
     from segmif_amd import ops
@@ -108,11 +103,7 @@ def main():
         fused = fuse_to_rgb(vis, y_f)
         return seg.predict_labels(fused, (H, W))
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    fence = dist.fence
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -130,10 +121,7 @@ def main():
         ops.set_launch_timer(None)
     assert labels.shape == (B, H, W)
 
-    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = dist.max_over_ranks(elapsed)
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -156,7 +144,7 @@ def main():
             n, ms, flops = timer.summary()
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out["roofline"] = {
-                "kernel": "igemm_kernel<256,32,*,MODE_CONV> (DRDB dilated 3x3 conv, fp32 MFMA)",
+                "kernel": "conv3x3_halo_kernel<32,8,2> (DRDB dilated 3x3 conv, fp32 MFMA)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                 "launches_timed": n, "avg_launch_ms": ms, "avg_launch_gflop": flops / 1e9,
@@ -165,8 +153,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.backbone, H, W)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    dist.shutdown()
 
 
 if __name__ == "__main__":

@@ -375,7 +375,7 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
   int tile = d->tile;
   hipStream_t s = (hipStream_t)stream;
   const bool halo_ok = mode == MODE_CONV && nz == 1 && conv3x3_halo_eligible(k);
-  if (tile < 0 && halo_ok) tile = kHaloTile0 + (d->N > 32 ? 0 : 1);
+  if (tile < 0 && halo_ok) tile = kHaloTile0 + 1;  // 8-channel chunks: best on every shape (profiles/r01_kernel_bench_halo.txt)
   if (tile >= kHaloTile0 && tile < kNumTiles) {
     if (!halo_ok) return SEGMIF_EINVAL;
     return conv3x3_halo_launch(k, tile - kHaloTile0, s);
