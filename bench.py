@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture the step into a hipGraph and replay it")
     return ap.parse_args()
 
 
@@ -97,11 +98,14 @@ def main():
     vis = dw.det_input(f"bench_vis_{rank}", (B, 3, H, W)).cuda()
     mask = dw.det_input(f"bench_mask_{rank}", (B, 1, H, W)).repeat(1, 3, 1, 1).cuda()
 
+    from segmif_amd.pipeline import PairForward
+    pipe = PairForward(seg, fus)
+    if args.graph:
+        args.no_kernel_timer = True  # HIP events cannot be recorded inside a captured graph
+        pipe.capture(ir, vis, mask)
+
     def step():
-        out0, out1 = seg.denoise_net.encoder.forward_fusion(mask)
-        y_f = fus(ir, vis, out0, out1)
-        fused = fuse_to_rgb(vis, y_f)
-        return seg.predict_labels(fused, (H, W))
+        return pipe(ir, vis, mask)[1]
 
     fence = dist.fence
 
@@ -135,7 +139,8 @@ def main():
                                    f"+ x4 bilinear + argmax), {H}x{W}, {B} pairs per GPU per step, eval mode, "
                                    "seeded deterministic weights",
                        "backbone": args.backbone, "height": H, "width": W, "pairs_per_gpu": B,
-                       "parallelism": f"replicas x{world} (independent pairs, no collective)"},
+                       "parallelism": f"replicas x{world} (independent pairs, no collective)",
+                       "launch": "hipGraph replay" if args.graph else "eager"},
         }
         gf = GFLOP_PER_PAIR.get(args.backbone)
         if gf is not None and (H, W) == (480, 640):

@@ -144,6 +144,10 @@ int segmif_sr_attention_f32(const float* q, const float* k, const float* v, floa
 int segmif_linattn_num_blocks(int64_t N);
 int segmif_linattn_partial_f32(const float* kv, double* partial, int B, int64_t N, int heads, int d,
                                int ldkv, void* stream);
+/* Fused form of (kv Linear without bias) + segmif_linattn_partial_f32: y is the (B, N, 64) input of the
+ * kv projection (pitch ldy), wkv its raw (128, 64) row-major weight; kv is never written to HBM. */
+int segmif_linattn_kvpartial_f32(const float* y, const float* wkv, double* partial, int B, int64_t N,
+                                 int heads, int d, int ldy, void* stream);
 int segmif_linattn_fold_f32(const double* partial, const float* wend, float* weff, int B, int nblk,
                             int heads, int d, int Nout, int ldw, int wofs, int ldweff, int kofs,
                             float scale, void* stream);

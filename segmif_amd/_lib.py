@@ -43,6 +43,7 @@ SIGNATURES = {
                                         c_int, c_int, c_int, c_float, c_void_p]),
     "segmif_linattn_num_blocks": (c_int, [c_int64]),
     "segmif_linattn_partial_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
+    "segmif_linattn_kvpartial_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "segmif_linattn_fold_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_float, c_void_p]),
     "segmif_seg_normalize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -132,6 +132,8 @@ class CrossAttention(nn.Module):
         self._pk = PackedCache()
 
     def context_partial(self, seg):
+        if self.kv3.bias is None:  # the configuration SegMiF uses: fused projection + reduction
+            return ops.linattn_kvpartial(seg, self.kv3.weight, self.num_heads)
         kv = ops.linear(seg, self._pk.get("kv3", self.kv3.weight, ops.pack_weight), 2 * self.dim, bias=self.kv3.bias)
         return ops.linattn_partial(kv, self.num_heads)
 
@@ -150,6 +152,8 @@ class CrossAttention2(nn.Module):
 
     def context_partial(self, which, x):
         lin = self.kv1 if which == 1 else self.kv2
+        if lin.bias is None:
+            return ops.linattn_kvpartial(x, lin.weight, self.num_heads)
         kv = ops.linear(x, self._pk.get(f"kv{which}", lin.weight, ops.pack_weight), 2 * self.dim, bias=lin.bias)
         return ops.linattn_partial(kv, self.num_heads)
 

@@ -20,6 +20,9 @@
 
 #include "segmif_hip.h"
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 constexpr int LA_ROWS = 1024;  // rows per block
@@ -62,41 +65,146 @@ __global__ __launch_bounds__(256) void linattn_partial_kernel(const float* __res
   dst[1] = acc1;
 }
 
-__global__ __launch_bounds__(256) void linattn_fold_kernel(const double* __restrict__ partial,
-                                                           const float* __restrict__ wend, float* __restrict__ weff,
-                                                           int nblk, int Nout, int ldw, int wofs, int ldweff, int kofs,
-                                                           float scale) {
+__global__ __launch_bounds__(1024) void linattn_fold_kernel(const double* __restrict__ partial,
+                                                            const float* __restrict__ wend, float* __restrict__ weff,
+                                                            int nblk, int Nout, int ldw, int wofs, int ldweff, int kofs,
+                                                            float scale) {
+  __shared__ double part[4][512];
   __shared__ double ctx[512];  // [h][i][j]
   const int tid = threadIdx.x, b = blockIdx.x;
+  const int e = tid & 255, slice = tid >> 8;
   const double* p = partial + (long long)b * nblk * 512;
   double a0 = 0.0, a1 = 0.0;
-  for (int k = 0; k < nblk; ++k) {
-    a0 += p[(long long)k * 512 + tid];
-    a1 += p[(long long)k * 512 + 256 + tid];
+  for (int k = slice; k < nblk; k += 4) {  // fixed order per slice: deterministic
+    a0 += p[(long long)k * 512 + e];
+    a1 += p[(long long)k * 512 + 256 + e];
   }
-  ctx[tid] = a0 * (double)scale;
-  ctx[256 + tid] = a1 * (double)scale;
+  part[slice][e] = a0;
+  part[slice][256 + e] = a1;
+  __syncthreads();
+  if (tid < 512) ctx[tid] = (((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]) * (double)scale;
   __syncthreads();
   if (tid < 64) {  // one (h, j) column per thread: softmax over i (dim = -2)
     const int hh = tid >> 3, j = tid & 7;
     double mx = -1e300;
     for (int i = 0; i < 8; ++i) mx = fmax(mx, ctx[hh * 64 + i * 8 + j]);
-    double e[8], sum = 0.0;
+    double ev[8], sum = 0.0;
     for (int i = 0; i < 8; ++i) {
-      e[i] = exp(ctx[hh * 64 + i * 8 + j] - mx);
-      sum += e[i];
+      ev[i] = exp(ctx[hh * 64 + i * 8 + j] - mx);
+      sum += ev[i];
     }
-    for (int i = 0; i < 8; ++i) ctx[hh * 64 + i * 8 + j] = e[i] / sum;
+    for (int i = 0; i < 8; ++i) ctx[hh * 64 + i * 8 + j] = ev[i] / sum;
   }
   __syncthreads();
   // Weff[b][n][kofs + c] for c = h*8 + i in [0, 64)
-  for (int o = tid; o < Nout * 64; o += 256) {
+  for (int o = tid; o < Nout * 64; o += 1024) {
     const int n = o >> 6, c = o & 63, hh = c >> 3, i = c & 7;
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = fmaf((float)ctx[hh * 64 + i * 8 + j], wend[(long long)n * ldw + wofs + hh * 8 + j], acc);
     weff[((long long)b * Nout + n) * ldweff + kofs + c] = acc;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused kv projection + K^T V partial reduction: kv = y @ Wkv^T is formed tile by tile on the
+// fp32 matrix pipe, parked in LDS and reduced per head without ever being written to HBM
+// (2 x 157 MB per image per context otherwise).  One block = 1024 rows = 8 sub-tiles of 128 rows.
+// ---------------------------------------------------------------------------------------------
+constexpr int KVP = 68;   // pitch of the y / Wkv tiles (64 + 4: conflict-free ds_read_b128)
+constexpr int KVT = 132;  // pitch of the kv tile
+
+__global__ __launch_bounds__(256) void linattn_kvpartial_kernel(const float* __restrict__ y,
+                                                                const float* __restrict__ wkv,
+                                                                double* __restrict__ partial, long long N, int ldy,
+                                                                int nblk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;               // [128][KVP]  Wkv rows (k | v outputs) x 64 inputs
+  float* As = Ws + 128 * KVP;     // [128][KVP]  y tile
+  float* KVs = As + 128 * KVP;    // [128][KVT]  kv tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int blk = blockIdx.x, b = blockIdx.y;
+  const long long r0 = (long long)blk * LA_ROWS;
+  const float* base = y + (long long)b * N * ldy;
+  const int lrow = tid >> 4, lq = (tid & 15) * 4;  // loader: 16 rows x 16 float4 per pass, 8 passes
+
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    *reinterpret_cast<f32x4*>(Ws + (lrow + 16 * j) * KVP + lq) =
+        *reinterpret_cast<const f32x4*>(wkv + (lrow + 16 * j) * 64 + lq);
+
+  f32x4 ra[8];
+  auto gload = [&](int sub) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long row = r0 + sub * 128 + lrow + 16 * j;
+      ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < N) ra[j] = *reinterpret_cast<const f32x4*>(base + row * ldy + lq);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(As + (lrow + 16 * j) * KVP + lq) = ra[j];
+  };
+
+  const int hh = tid >> 5, ei = (tid >> 2) & 7, j0 = (tid & 3) * 2;
+  double acc0 = 0.0, acc1 = 0.0;
+  const int nsub = (int)((((N - r0) < LA_ROWS ? (N - r0) : LA_ROWS) + 127) / 128);
+  gload(0);
+  sstore();
+  __syncthreads();
+  for (int sub = 0; sub < nsub; ++sub) {
+    if (sub + 1 < nsub) gload(sub + 1);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    const float* a_base = As + (wm * 64 + r) * KVP + 4 * h;
+    const float* b_base = Ws + (wn * 64 + r) * KVP + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f32x4 a[2], bb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * KVP + 8 * t);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bb[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * KVP + 8 * t);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s2], bb[j][s2], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          KVs[(wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h) * KVT + wn * 64 + j * 32 + r] = acc[i][j][v];
+    __syncthreads();  // kv tile complete; every wave is done reading As
+    if (sub + 1 < nsub) sstore();
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+    for (int rr = 0; rr < 128; ++rr) {
+      const float kk = KVs[rr * KVT + hh * 8 + ei];
+      const float2 vv = *reinterpret_cast<const float2*>(KVs + rr * KVT + 64 + hh * 8 + j0);
+      s0 = fmaf(kk, vv.x, s0);
+      s1 = fmaf(kk, vv.y, s1);
+    }
+    acc0 += (double)s0;
+    acc1 += (double)s1;
+    __syncthreads();  // reduce done before the next tile overwrites KVs; next As visible
+  }
+  double* dst = partial + ((long long)b * nblk + blk) * 512 + hh * 64 + ei * 8 + j0;
+  dst[0] = acc0;
+  dst[1] = acc1;
 }
 
 }  // namespace
@@ -117,7 +225,25 @@ extern "C" int segmif_linattn_fold_f32(const double* partial, const float* wend,
                                        int heads, int d, int Nout, int ldw, int wofs, int ldweff, int kofs, float scale,
                                        void* stream) {
   if (!partial || !wend || !weff || B <= 0 || nblk <= 0 || heads != 8 || d != 8 || Nout <= 0) return SEGMIF_EINVAL;
-  hipLaunchKernelGGL(linattn_fold_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(linattn_fold_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream,
                      partial, wend, weff, nblk, Nout, ldw, wofs, ldweff, kofs, scale);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_linattn_kvpartial_f32(const float* y, const float* wkv, double* partial, int B, int64_t N,
+                                            int heads, int d, int ldy, void* stream) {
+  if (!y || !wkv || !partial || B <= 0 || N <= 0 || heads != 8 || d != 8 || ldy < 64 || (ldy & 3)) return SEGMIF_EINVAL;
+  if ((((uintptr_t)y | (uintptr_t)wkv) & 15) || ((uintptr_t)partial & 7)) return SEGMIF_EINVAL;
+  const int nblk = segmif_linattn_num_blocks(N);
+  constexpr size_t smem = (size_t)(2 * 128 * KVP + 128 * KVT) * sizeof(float);
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)linattn_kvpartial_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(linattn_kvpartial_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), smem, (hipStream_t)stream,
+                     y, wkv, partial, (long long)N, ldy, nblk);
   return (int)hipGetLastError();
 }

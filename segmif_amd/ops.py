@@ -91,6 +91,10 @@ def set_launch_timer(timer):
     _timer = timer
 
 
+def launch_timer_active():
+    return _timer is not None
+
+
 def _igemm(desc, tag=None):
     def go():
         _lib.check(_lib.load().segmif_igemm_f32(ctypes.byref(desc), _stream()), "segmif_igemm_f32")
@@ -268,6 +272,22 @@ def linattn_partial(kv, heads=8):
     part = torch.empty((B, nblk, heads * d * d), device=kv.device, dtype=torch.float64)
     _lib.check(_lib.load().segmif_linattn_partial_f32(kv.data_ptr(), part.data_ptr(), B, N, heads, d, kv.stride(1),
                                                       _stream()), "segmif_linattn_partial_f32")
+    return part
+
+
+def linattn_kvpartial(y, wkv, heads=8):
+    """Fused kv projection (no bias) + K^T V partial sums. y: (B, N, 64) rows view; wkv: raw (128, 64)
+    Linear weight -> fp64 partial sums (B, nblk, 512); kv itself never reaches HBM."""
+    _req(y, "y"), _req(wkv, "wkv")
+    if y.dim() != 3 or y.shape[2] != 64 or y.stride(2) != 1 or y.stride(0) != y.shape[1] * y.stride(1):
+        raise RuntimeError("linattn_kvpartial expects a (B, N, 64) rows view")
+    if tuple(wkv.shape) != (128, 64) or not wkv.is_contiguous():
+        raise RuntimeError("linattn_kvpartial expects the raw contiguous (128, 64) kv weight")
+    B, N, _ = y.shape
+    nblk = _lib.load().segmif_linattn_num_blocks(N)
+    part = torch.empty((B, nblk, 512), device=y.device, dtype=torch.float64)
+    _lib.check(_lib.load().segmif_linattn_kvpartial_f32(y.data_ptr(), wkv.data_ptr(), part.data_ptr(), B, N, heads, 8,
+                                                        y.stride(1), _stream()), "segmif_linattn_kvpartial_f32")
     return part
 
 

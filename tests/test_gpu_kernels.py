@@ -212,6 +212,21 @@ def test_linear_attention_context_and_fold(ops, B, N):
         assert err(weff[:, :, ofs:ofs + C], ref) < TOL
 
 
+@pytest.mark.parametrize("B,N", [(2, 3000), (1, 1024), (2, 129), (1, 70001)])
+def test_fused_kv_projection_partial(ops, B, N):
+    """segmif_linattn_kvpartial_f32 == kv Linear + segmif_linattn_partial_f32 (same per-head sums)."""
+    C = 64
+    p = rnd(B, N, 2 * C, seed=40, lo=0.0, hi=1.0)  # y is a ReLU output: non-negative
+    wkv = rnd(2 * C, C, seed=41, lo=-0.3, hi=0.3)
+    y = p.cuda()[..., :C]  # pitched view, as CrossPath passes it
+    part = ops.linattn_kvpartial(y, wkv.cuda())
+    kv = p[..., :C].double() @ wkv.double().t()
+    kvh = kv.reshape(B, N, 2, 8, 8)
+    k, v = kvh[:, :, 0].permute(0, 2, 1, 3), kvh[:, :, 1].permute(0, 2, 1, 3)
+    raw = k.transpose(-2, -1) @ v
+    assert err(part.sum(1).reshape(B, 8, 8, 8), raw) < 2e-6
+
+
 def test_pointwise_and_layout(ops):
     import segmif_oracle as so
     x = rnd(2, 3, 11, 17, seed=32, lo=0, hi=1)
