@@ -78,6 +78,10 @@ typedef struct SegmifIgemm {
   int32_t nz;
   int64_t in_zstride, in2_zstride, wt_zstride, out_zstride, res_zstride;
   int32_t tile;        /* -1 = auto; otherwise index into the tile table (bench / tests) */
+  /* optional second batching level: z = zb * nz2 + z2 (e.g. zb = image, z2 = attention head) */
+  int32_t nz2;         /* 0 / 1 = unused */
+  int32_t ldw;         /* weight row pitch in floats; 0 = Kp (packed). Lets K / V slices of a kv tensor act as weights */
+  int64_t in_zstride2, wt_zstride2, out_zstride2, res_zstride2;
 } SegmifIgemm;
 
 int segmif_igemm_f32(const SegmifIgemm* desc, void* stream);
@@ -91,6 +95,28 @@ const char* segmif_igemm_tile_name(int tile);
  * Kp = ((KH*KW*Cin + 15) / 16) * 16; the tail is zero-filled.
  */
 int segmif_pack_conv_weight(const float* src_oihw, float* dst, int N, int Cin, int KH, int KW, void* stream);
+
+/*
+ * Weight gradient of the same problem: dW[n][k] = sum_m dY[m][n] * A(m,k), contraction over rows on
+ * fp32 MFMA, deterministic two-pass reduction (per-chunk partials, then an fp64 sum) written in the
+ * parameter's own layout: dw[n*dw_sn + k'*...] — OIHW for convs, (N, K) for linears; for dense
+ * problems the output element (n, k) goes to dw[n*dw_sn + k*dw_sk] (dw_sn = K, dw_sk = 1 normally;
+ * other strides let attention backward write dK / dV in place).  `desc` describes the FORWARD problem
+ * (in, lda, geometry, M, N, K; nz / in_zstride / out_zstride reused as batch count, input and dW batch
+ * strides).  workspace: segmif_wgrad_workspace_size(M, N, K) * max(nz,1) floats.  accumulate: dw += .
+ * Backward of every nn.Conv2d / nn.Linear listed under segmif_igemm_f32.
+ */
+int64_t segmif_wgrad_workspace_size(int64_t M, int N, int K);
+int segmif_wgrad_f32(const SegmifIgemm* desc, const float* dy, int ldy, int64_t dy_zstride, float* dw,
+                     int64_t dw_sn, int64_t dw_sk, float* workspace, int accumulate, void* stream);
+/* column sums of a rows x N matrix (bias gradients), two-pass, fp64 accumulation.
+ * workspace: segmif_colsum_blocks(rows) * N doubles. */
+int segmif_colsum_blocks(int64_t rows);
+int segmif_colsum_f32(const float* x, float* out, double* workspace, int64_t rows, int N, int ldx,
+                      int accumulate, void* stream);
+/* dx = dy * act'(.): ref = activation OUTPUT for ReLU / PReLU (slope > 0), PRE-activation for GELU. */
+int segmif_act_bwd_f32(const float* dy, const float* ref, float* dx, int64_t rows, int C, int ldy, int ldr,
+                       int ldx, int act, const float* slope, void* stream);
 
 /*
  * LayerNorm over the last dimension: y = (x - mean) / sqrt(var + eps) * gamma + beta,
@@ -166,6 +192,53 @@ int segmif_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int64_t HW, 
 int segmif_fuse_ycrcb_f32(const float* vis_nchw, const float* yf, float* out_nchw, int B, int64_t HW, void* stream);
 /* argmax over C of NHWC logits -> int32 labels (test_segmentation.py:174); ties -> lowest index */
 int segmif_argmax_nhwc_i32(const float* x, int32_t* labels, int64_t rows, int C, int ldx, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Training path (backward of the ops above; autograd in the reference: loss.backward() at
+ * train.py:226, :384).  Contractions reuse segmif_igemm_f32 (input gradients, with transposed /
+ * rotated weights) and segmif_wgrad_f32; the entries below cover the rest.  Every reduction is
+ * two-pass and deterministic.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* LayerNorm backward: dx, plus per-block partial rows [dgamma | dbeta] (nblk x 2C floats) that the
+ * caller sums with segmif_colsum_f32.  nblk = segmif_layernorm_bwd_blocks(rows, C). */
+int segmif_layernorm_bwd_blocks(int64_t rows, int C);
+int segmif_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx, float* partial,
+                             int64_t rows, int C, int ldx, int ldy, int lddx, float eps, void* stream);
+
+/* Mix-FFN middle backward.  Part 1: z = dwconv(h)+b is recomputed, dz = dy * gelu'(z) is stored and
+ * per-block partials [9 taps | bias][C] are written (segmif_dwconv_bwd_partial_rows rows x 10C floats;
+ * sum with segmif_colsum_f32).  Part 2: dh = segmif_dwconv3x3_plain_f32(dz, taps flipped). C % 128 == 0. */
+int64_t segmif_dwconv_bwd_partial_rows(int B, int H, int W);
+int segmif_dwconv3x3_gelu_bwd_f32(const float* h, const float* w9, const float* bias, const float* dy, float* dz,
+                                  float* partial, int B, int H, int W, int C, void* stream);
+int segmif_dwconv3x3_plain_f32(const float* x, const float* w9, float* y, int B, int H, int W, int C, void* stream);
+
+/* adjoint of segmif_bilinear_nhwc_f32 (gather form): dy (B,OH,OW,C) -> dx (B,IH,IW,C) */
+int segmif_bilinear_nhwc_bwd_f32(const float* dy, float* dx, int B, int IH, int IW, int OH, int OW, int C,
+                                 int lddy, int lddx, void* stream);
+
+/* attention training path (scores materialised): p = softmax(s*scale) in place; ds = p*(dp - sum(p*dp))*scale in place */
+int segmif_row_softmax_f32(float* s, int64_t rows, int L, int ld, float scale, void* stream);
+int segmif_row_softmax_bwd_f32(const float* p, float* dp, int64_t rows, int L, int ld, float scale, void* stream);
+
+/* softmax cross-entropy with ignore_index over NHWC logits (train.py:156,224; model_fusion.py:1096):
+ * partial[2*blk] = sum of losses, partial[2*blk+1] = valid count (doubles, segmif_softmax_ce_blocks(rows)
+ * blocks); dlogits (optional) = softmax - onehot, 0 for ignored rows, NOT divided by the count. */
+int segmif_softmax_ce_blocks(int64_t rows);
+int segmif_softmax_ce_f32(const float* logits, const int64_t* labels, float* dlogits, double* partial,
+                          int64_t rows, int C, int ld, int ldd, int ignore_index, void* stream);
+
+/* input gradient of a strided convolution (overlap patch embed, sr conv); wd = weight as [tap][n][c] */
+int segmif_conv_dgrad_strided_f32(const float* dy, const float* wd, float* dx, int B, int H, int W, int Cin, int N,
+                                  int KH, int KW, int stride, int pad, int OH, int OW, int lddy, int lddx, void* stream);
+
+/* multi-tensor AdamW (utils/optimizer.py:6 -> torch.optim.AdamW arithmetic). table: device array of
+ * {float* p; const float* g; float* m; float* v; int64 n; float lr; float wd;} entries
+ * (segmif_adamw_entry_bytes() each); chunk_entry / chunk_off map each block to (entry, offset). */
+int segmif_adamw_entry_bytes(void);
+int segmif_adamw_f32(const void* table, const int32_t* chunk_entry, const int64_t* chunk_off, int nchunks,
+                     int chunk_elems, float beta1, float beta2, float eps, int step, void* stream);
 
 #ifdef __cplusplus
 }

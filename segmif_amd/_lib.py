@@ -24,7 +24,8 @@ class SegmifIgemm(ctypes.Structure):
         ("act", c_int32), ("nz", c_int32),
         ("in_zstride", c_int64), ("in2_zstride", c_int64), ("wt_zstride", c_int64),
         ("out_zstride", c_int64), ("res_zstride", c_int64),
-        ("tile", c_int32),
+        ("tile", c_int32), ("nz2", c_int32), ("ldw", c_int32),
+        ("in_zstride2", c_int64), ("wt_zstride2", c_int64), ("out_zstride2", c_int64), ("res_zstride2", c_int64),
     ]
 
 
@@ -36,6 +37,13 @@ SIGNATURES = {
     "segmif_igemm_num_tiles": (c_int, []),
     "segmif_igemm_tile_name": (c_char_p, [c_int]),
     "segmif_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "segmif_wgrad_workspace_size": (c_int64, [c_int64, c_int, c_int]),
+    "segmif_wgrad_f32": (c_int, [POINTER(SegmifIgemm), c_void_p, c_int, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                 c_int, c_void_p]),
+    "segmif_colsum_blocks": (c_int, [c_int64]),
+    "segmif_colsum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "segmif_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                   c_void_p]),
     "segmif_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     "segmif_dwconv3x3_gelu_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "segmif_bilinear_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -46,6 +54,23 @@ SIGNATURES = {
     "segmif_linattn_kvpartial_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "segmif_linattn_fold_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_float, c_void_p]),
+    "segmif_layernorm_bwd_blocks": (c_int, [c_int64, c_int]),
+    "segmif_layernorm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                         c_int, c_float, c_void_p]),
+    "segmif_dwconv_bwd_partial_rows": (c_int64, [c_int, c_int, c_int]),
+    "segmif_dwconv3x3_gelu_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                              c_int, c_int, c_void_p]),
+    "segmif_dwconv3x3_plain_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "segmif_bilinear_nhwc_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                             c_void_p]),
+    "segmif_row_softmax_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "segmif_row_softmax_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "segmif_softmax_ce_blocks": (c_int, [c_int64]),
+    "segmif_softmax_ce_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                      c_void_p]),
+    "segmif_conv_dgrad_strided_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
+    "segmif_adamw_entry_bytes": (c_int, []),
+    "segmif_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]),
     "segmif_seg_normalize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "segmif_nchw_to_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
     "segmif_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),

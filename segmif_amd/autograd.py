@@ -1,0 +1,381 @@
+"""torch.autograd.Function wrappers: forward AND backward run in the HIP kernels (C ABI); autograd
+only records the graph.  Layout conventions as in ops.py (NHWC / tokens, fp32).
+
+Backward building blocks
+  input gradients  : segmif_igemm_f32 with transposed (linear) / rotated+swapped (stride-1 conv)
+                     weights; segmif_conv_dgrad_strided_f32 for strided convs
+  weight gradients : segmif_wgrad_f32 (fp32 MFMA over the row dimension, deterministic 2-pass)
+  bias gradients   : segmif_colsum_f32
+  the rest         : LayerNorm / dwconv+GELU / bilinear / row-softmax / cross-entropy kernels
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from .ops import ACT_GELU, ACT_NONE, ACT_PRELU, ACT_RELU, _req, _stream, rows_view
+
+
+# ------------------------------------------------------------------------------------------------
+# raw helpers over the backward ABI
+# ------------------------------------------------------------------------------------------------
+def colsum(x2d, out=None, accumulate=False):
+    rows, N, ld = rows_view(x2d, "x")
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((N,), device=x2d.device, dtype=torch.float32)
+    ws = torch.empty((lib.segmif_colsum_blocks(rows) * N,), device=x2d.device, dtype=torch.float64)
+    _lib.check(lib.segmif_colsum_f32(x2d.data_ptr(), out.data_ptr(), ws.data_ptr(), rows, N, ld, int(accumulate),
+                                     _stream()), "segmif_colsum_f32")
+    return out
+
+
+def act_bwd(dy, ref, act, slope=None):
+    rows, C, ldy = rows_view(dy, "dy")
+    _, _, ldr = rows_view(ref, "ref")
+    dx = torch.empty(dy.shape, device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.load().segmif_act_bwd_f32(dy.data_ptr(), ref.data_ptr(), dx.data_ptr(), rows, C, ldy, ldr, C, act,
+                                              slope.data_ptr() if slope is not None else None, _stream()),
+               "segmif_act_bwd_f32")
+    return dx
+
+
+def _wgrad(desc, dy, ldy, dw, dy_zstride=0, sn=0, sk=1, nz=1):
+    lib = _lib.load()
+    ws = torch.empty((lib.segmif_wgrad_workspace_size(desc.M, desc.N, desc.K) * max(nz, 1),), device=dw.device,
+                     dtype=torch.float32)
+    _lib.check(lib.segmif_wgrad_f32(ctypes.byref(desc), dy.data_ptr(), ldy, dy_zstride, dw.data_ptr(), sn, sk,
+                                    ws.data_ptr(), 0, _stream()), "segmif_wgrad_f32")
+    return dw
+
+
+def linear_wgrad(x, dy, N):
+    """dW (N, K) = dy^T x.  x: rows view (..., K); dy: rows view (..., N)."""
+    rows, K, lda = rows_view(x, "x")
+    rows2, n2, ldy = rows_view(dy, "dy")
+    assert rows == rows2 and n2 == N
+    d = _lib.SegmifIgemm()
+    d.in_ = x.data_ptr()
+    d.M, d.N, d.K, d.lda = rows, N, K, lda
+    d.H = d.W = d.OH = d.OW = 1
+    d.Cin = K
+    d.KH = d.KW = d.stride = d.dil = 1
+    dw = torch.empty((N, K), device=x.device, dtype=torch.float32)
+    return _wgrad(d, dy, ldy, dw, sn=K, sk=1)
+
+
+def conv_wgrad(x, dy, w_shape, k, stride, pad, dil):
+    """dW in OIHW. x: (B,H,W,Cin) rows view; dy: (B,OH,OW,N) rows view."""
+    N, cin = w_shape[0], w_shape[1]
+    B, H, W, _ = x.shape
+    _, _, lda = rows_view(x, "x")
+    rows, n2, ldy = rows_view(dy, "dy")
+    d = _lib.SegmifIgemm()
+    d.in_ = x.data_ptr()
+    d.M, d.N, d.K, d.lda = rows, N, k * k * cin, lda
+    d.H, d.W, d.Cin, d.KH, d.KW = H, W, cin, k, k
+    d.stride, d.pad, d.dil, d.OH, d.OW = stride, pad, dil, dy.shape[1], dy.shape[2]
+    dw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
+    return _wgrad(d, dy, ldy, dw)
+
+
+def _slope_grad(dy, y, slope):
+    """d(loss)/d(slope) of the shared scalar PReLU: sum over y < 0 of dy * pre, pre = y / slope."""
+    # TODO(next): fold into act_bwd's kernel; parameter-scalar reduction, negligible next to the convs
+    neg = y < 0
+    return (dy * torch.where(neg, y, torch.zeros_like(y))).sum().reshape(1) / slope
+
+
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ w^T + b); w is the raw (N, K) Linear weight or a (N, K, 1, 1) conv weight."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        N = w.shape[0]
+        w2 = w.reshape(N, -1)
+        K = w2.shape[1]
+        wt = w2.contiguous() if K % 16 == 0 else ops.pack_weight(w2)
+        y = ops.linear(x, wt, N, bias=b, act=act, prelu=slope)
+        ctx.act = act
+        ctx.save_for_backward(x, w, y if act in (ACT_RELU, ACT_PRELU) else None, slope)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, slope = ctx.saved_tensors
+        N = w.shape[0]
+        w2 = w.reshape(N, -1)
+        K = w2.shape[1]
+        dy = dy.contiguous()
+        dslope = None
+        if ctx.act in (ACT_RELU, ACT_PRELU):
+            if ctx.act == ACT_PRELU and ctx.needs_input_grad[4]:
+                dslope = _slope_grad(dy, y, slope)
+            dz = act_bwd(dy, y, ctx.act, slope)
+        else:
+            dz = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wtT = w2.t().contiguous()  # (K, N): "weights" of the input-gradient GEMM
+            wtT = wtT if N % 16 == 0 else ops.pack_weight(wtT)
+            dx = ops.linear(dz, wtT, K)
+        if ctx.needs_input_grad[1]:
+            dw = linear_wgrad(x, dz, N).reshape(w.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dz)
+        return dx, dw, db, None, dslope
+
+
+class ConvFn(torch.autograd.Function):
+    """NHWC convolution y = act(conv(x, w) + b), w in OIHW."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, k, stride, pad, dil, act, slope):
+        N = w.shape[0]
+        y = ops.conv2d(x, ops.pack_weight(w), N, k, stride=stride, pad=pad, dil=dil, bias=b, act=act, prelu=slope)
+        ctx.geom = (k, stride, pad, dil, act)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act in (ACT_RELU, ACT_PRELU) else None, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, slope = ctx.saved_tensors
+        k, stride, pad, dil, act = ctx.geom
+        N, cin = w.shape[0], w.shape[1]
+        dy = dy.contiguous()
+        dslope = None
+        if act in (ACT_RELU, ACT_PRELU):
+            if act == ACT_PRELU and ctx.needs_input_grad[8]:
+                dslope = _slope_grad(dy, y, slope)
+            dz = act_bwd(dy, y, act, slope)
+        else:
+            dz = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            B, H, W, _ = x.shape
+            if stride == 1:
+                # full correlation with the 180-degree rotated, in/out-swapped kernel
+                wr = w.flip(2, 3).transpose(0, 1).contiguous()
+                dx = ops.conv2d(dz, ops.pack_weight(wr), cin, k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
+            else:
+                wd = w.permute(2, 3, 0, 1).contiguous()  # [ky][kx][n][c]
+                dx = torch.empty((B, H, W, cin), device=x.device, dtype=torch.float32)
+                _lib.check(_lib.load().segmif_conv_dgrad_strided_f32(
+                    dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, H, W, cin, N, k, k, stride, pad, dz.shape[1],
+                    dz.shape[2], N, cin, _stream()), "segmif_conv_dgrad_strided_f32")
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(x, dz, w.shape, k, stride, pad, dil)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dz)
+        return dx, dw, db, None, None, None, None, None, dslope
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y = ops.layernorm(x, gamma, beta, eps)
+        ctx.eps = eps
+        ctx.save_for_backward(x, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, C, ldx = rows_view(x, "x")
+        lib = _lib.load()
+        nblk = lib.segmif_layernorm_bwd_blocks(rows, C)
+        partial = torch.empty((nblk, 2 * C), device=x.device, dtype=torch.float32)
+        dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        _lib.check(lib.segmif_layernorm_bwd_f32(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
+                                                partial.data_ptr(), rows, C, ldx, C, C, float(ctx.eps), _stream()),
+                   "segmif_layernorm_bwd_f32")
+        gb = colsum(partial)
+        return dx, gb[:C], gb[C:], None
+
+
+class DwconvGeluFn(torch.autograd.Function):
+    """tokens (B, H*W, C) -> gelu(dwconv3x3(tokens as image) + b); w is the (C,1,3,3) depthwise weight."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, H, W):
+        y = ops.dwconv3x3_gelu(h, ops.pack_dw_weight(w), b, H, W)
+        ctx.hw = (H, W)
+        ctx.save_for_backward(h, w, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w, b = ctx.saved_tensors
+        H, W = ctx.hw
+        B, _, C = h.shape
+        dy = dy.contiguous()
+        lib = _lib.load()
+        w9 = ops.pack_dw_weight(w)
+        prow = lib.segmif_dwconv_bwd_partial_rows(B, H, W)
+        partial = torch.empty((prow, 10 * C), device=h.device, dtype=torch.float32)
+        dz = torch.empty_like(h)
+        _lib.check(lib.segmif_dwconv3x3_gelu_bwd_f32(h.data_ptr(), w9.data_ptr(), b.data_ptr(), dy.data_ptr(),
+                                                     dz.data_ptr(), partial.data_ptr(), B, H, W, C, _stream()),
+                   "segmif_dwconv3x3_gelu_bwd_f32")
+        sums = colsum(partial).view(10, C)
+        dw = sums[:9].t().reshape(C, 1, 3, 3)
+        db = sums[9]
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty_like(h)
+            w9f = w9.flip(0).contiguous()
+            _lib.check(lib.segmif_dwconv3x3_plain_f32(dz.data_ptr(), w9f.data_ptr(), dh.data_ptr(), B, H, W, C,
+                                                      _stream()), "segmif_dwconv3x3_plain_f32")
+        return dh, dw, db, None, None
+
+
+class BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        return ops.bilinear(x, OH, OW)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        B, OH, OW, C = dy.shape
+        IH, IW = ctx.in_hw
+        dx = torch.empty((B, IH, IW, C), device=dy.device, dtype=torch.float32)
+        _lib.check(_lib.load().segmif_bilinear_nhwc_bwd_f32(dy.data_ptr(), dx.data_ptr(), B, IH, IW, OH, OW, C, C, C,
+                                                            _stream()), "segmif_bilinear_nhwc_bwd_f32")
+        return dx, None, None
+
+
+def _batched_heads_gemm(a, a_ld, a_bs, a_hs, w, w_ld, w_bs, w_hs, out, o_ld, o_bs, o_hs, B, heads, M, N, K):
+    """out[b,h] (M x N) = a[b,h] (M x K) @ w[b,h]^T (N x K); every operand addressed by
+    (batch stride, head stride, row pitch) so q/k/v slices of the fused projections are used in place."""
+    d = _lib.SegmifIgemm()
+    d.in_, d.wt, d.out = a, w, out
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldo, d.ldw = a_ld, o_ld, w_ld
+    d.H = d.W = d.OH = d.OW = 1
+    d.Cin = K
+    d.KH = d.KW = d.stride = d.dil = 1
+    d.nz, d.nz2 = B, heads
+    d.in_zstride, d.wt_zstride, d.out_zstride = a_bs, w_bs, o_bs
+    d.in_zstride2, d.wt_zstride2, d.out_zstride2 = a_hs, w_hs, o_hs
+    d.tile = -1
+    _lib.check(_lib.load().segmif_igemm_f32(ctypes.byref(d), _stream()), "segmif_igemm_f32")
+
+
+class SrAttentionFn(torch.autograd.Function):
+    """softmax(q k^T scale) v per (batch, head); forward = the fused kernel, backward = score
+    recomputation with batched fp32-MFMA GEMMs + row-softmax kernels (Nk is a few hundred keys)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads, scale):
+        ctx.heads, ctx.scale = heads, scale
+        ctx.save_for_backward(q, kv)
+        return ops.sr_attention(q, kv, heads, scale)
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv = ctx.saved_tensors
+        heads, scale = ctx.heads, ctx.scale
+        do = do.contiguous()
+        B, N, C = q.shape
+        Nk = kv.shape[1]
+        hd = C // heads
+        dev = q.device
+        lib = _lib.load()
+        Lp = (Nk + 15) // 16 * 16  # score row pitch (zero padded so it can be a GEMM K dimension)
+        P = torch.zeros((B, heads, N, Lp), device=dev, dtype=torch.float32)
+        dP = torch.zeros((B, heads, N, Lp), device=dev, dtype=torch.float32)
+        kptr, vptr = kv.data_ptr(), kv.data_ptr() + 4 * C
+        # S = q k^T ; dP = do v^T    (weights = k / v slices of kv, pitch 2C)
+        _batched_heads_gemm(q.data_ptr(), C, N * C, hd, kptr, 2 * C, Nk * 2 * C, hd, P.data_ptr(), Lp,
+                            heads * N * Lp, N * Lp, B, heads, N, Nk, hd)
+        _batched_heads_gemm(do.data_ptr(), C, N * C, hd, vptr, 2 * C, Nk * 2 * C, hd, dP.data_ptr(), Lp,
+                            heads * N * Lp, N * Lp, B, heads, N, Nk, hd)
+        rows = B * heads * N
+        _lib.check(lib.segmif_row_softmax_f32(P.data_ptr(), rows, Nk, Lp, float(scale), _stream()), "row_softmax")
+        _lib.check(lib.segmif_row_softmax_bwd_f32(P.data_ptr(), dP.data_ptr(), rows, Nk, Lp, float(scale), _stream()),
+                   "row_softmax_bwd")
+        dS = dP  # in place
+        # dq = dS k : weights = k^T per (b, h) as [hd][Lp]
+        kT = torch.zeros((B, heads, hd, Lp), device=dev, dtype=torch.float32)
+        kT[..., :Nk] = kv[..., :C].reshape(B, Nk, heads, hd).permute(0, 2, 3, 1)
+        dq = torch.empty_like(q)
+        _batched_heads_gemm(dS.data_ptr(), Lp, heads * N * Lp, N * Lp, kT.data_ptr(), Lp, heads * hd * Lp, hd * Lp,
+                            dq.data_ptr(), C, N * C, hd, B, heads, N, hd, Lp)
+        # dk^T[d][key] = sum_n q[n][d] dS[n][key] ; dv^T[d][key] = sum_n do[n][d] P[n][key]  (wgrad form).
+        # Written with key stride 2C into a (B, Lp, 2C) buffer: rows >= Nk are padding and are sliced away.
+        dkv = torch.empty((B, Lp, 2 * C), device=dev, dtype=torch.float32)
+        ws = torch.empty((lib.segmif_wgrad_workspace_size(N, hd, Lp) * B,), device=dev, dtype=torch.float32)
+        for src, probs, col0 in ((q, dS, 0), (do, P, C)):
+            for hh in range(heads):
+                d = _lib.SegmifIgemm()
+                d.in_ = probs.data_ptr() + 4 * hh * N * Lp
+                d.M, d.N, d.K, d.lda = N, hd, Lp, Lp
+                d.H = d.W = d.OH = d.OW = 1
+                d.Cin = Lp
+                d.KH = d.KW = d.stride = d.dil = 1
+                d.nz = B
+                d.in_zstride = heads * N * Lp
+                d.out_zstride = Lp * 2 * C
+                out = dkv.data_ptr() + 4 * (col0 + hh * hd)
+                # element (n = d, k = key) -> dkv[b][key][col0 + hh*hd + d]
+                _lib.check(lib.segmif_wgrad_f32(ctypes.byref(d), src.data_ptr() + 4 * hh * hd, C, N * C, out, 1,
+                                                2 * C, ws.data_ptr(), 0, _stream()), "segmif_wgrad_f32")
+        return dq, dkv[:, :Nk], None, None
+
+
+class SoftmaxCEFn(torch.autograd.Function):
+    """mean cross-entropy over non-ignored pixels of NHWC logits (B,H,W,C) vs labels (B,H,W) int64."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        rows, C, ld = rows_view(logits, "logits")
+        labels = labels.contiguous()
+        lib = _lib.load()
+        nblk = lib.segmif_softmax_ce_blocks(rows)
+        partial = torch.empty((nblk, 2), device=logits.device, dtype=torch.float64)
+        dlog = torch.empty(logits.shape, device=logits.device, dtype=torch.float32)
+        _lib.check(lib.segmif_softmax_ce_f32(logits.data_ptr(), labels.data_ptr(), dlog.data_ptr(), partial.data_ptr(),
+                                             rows, C, ld, C, int(ignore_index), _stream()), "segmif_softmax_ce_f32")
+        tot = partial.sum(0)
+        ctx.save_for_backward(dlog, tot[1:2])
+        return (tot[0] / tot[1]).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        dlog, cnt = ctx.saved_tensors
+        return dlog * (g / cnt.float()), None, None
+
+
+# functional front-ends ------------------------------------------------------------------------------
+def linear(x, w, b=None, act=ACT_NONE, slope=None):
+    return LinearFn.apply(x, w, b, act, slope)
+
+
+def conv2d(x, w, b=None, k=3, stride=1, pad=0, dil=1, act=ACT_NONE, slope=None):
+    return ConvFn.apply(x, w, b, k, stride, pad, dil, act, slope)
+
+
+def layernorm(x, gamma, beta, eps):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+def dwconv_gelu(h, w, b, H, W):
+    return DwconvGeluFn.apply(h, w, b, H, W)
+
+
+def bilinear(x, OH, OW):
+    return BilinearFn.apply(x, OH, OW)
+
+
+def sr_attention(q, kv, heads, scale):
+    return SrAttentionFn.apply(q, kv, heads, scale)
+
+
+def softmax_ce(logits_nhwc, labels, ignore_index=255):
+    return SoftmaxCEFn.apply(logits_nhwc, labels, ignore_index)

@@ -76,3 +76,14 @@ def require_device(t, what):
         raise RuntimeError(
             f"segmif_amd.core: {what} lives on {t.device}; this package runs on the MI355X HIP kernels only "
             "(no CPU fallback). Move the module and its inputs to the GPU with .cuda().")
+
+
+def wants_grad(module, *tensors):
+    """True when this call must record an autograd graph: grad mode is on and either an input or one
+    of the module's parameters requires grad.  The HIP inference path (in-place buffers, cached
+    packed weights) is used otherwise."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        return True
+    return any(p.requires_grad for p in module.parameters())

@@ -20,8 +20,9 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from .. import autograd as ag
 from .. import ops
-from ._util import PackedCache, drop_path_scale, init_reference_style
+from ._util import PackedCache, drop_path_scale, init_reference_style, wants_grad
 
 __all__ = ["Mlp", "Attention", "Block", "OverlapPatchEmbed", "MixVisionTransformer", "DWConv",
            "mit_b0", "mit_b1", "mit_b2", "mit_b3", "mit_b4", "mit_b5"]
@@ -50,8 +51,16 @@ class Mlp(nn.Module):
         self._pk = PackedCache()
         init_reference_style(self)
 
+    def forward_train(self, x, H, W):
+        h = ag.linear(x, self.fc1.weight, self.fc1.bias)
+        h = ag.dwconv_gelu(h, self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W)
+        return ag.linear(self.drop(h), self.fc2.weight, self.fc2.bias)
+
     def forward(self, x, H, W, residual=None):
         """x: (B, N, C) tokens.  Returns fc2(gelu(dwconv(fc1(x)))) (+ residual, written in place)."""
+        if wants_grad(self, x):
+            y = self.forward_train(x.contiguous(), H, W)
+            return y if residual is None else residual + y
         pk = self._pk
         h = ops.linear(x, pk.get("fc1", self.fc1.weight, ops.pack_weight), self.fc1.out_features,
                        bias=self.fc1.bias)
@@ -87,7 +96,22 @@ class Attention(nn.Module):
         self._pk = PackedCache()
         init_reference_style(self)
 
+    def forward_train(self, x, H, W):
+        B, N, C = x.shape
+        q = ag.linear(x, self.q.weight, self.q.bias)
+        if self.sr_ratio > 1:
+            red = ag.conv2d(x.view(B, H, W, C), self.sr.weight, self.sr.bias, k=self.sr_ratio, stride=self.sr_ratio)
+            red = ag.layernorm(red.reshape(B, -1, C), self.norm.weight, self.norm.bias, self.norm.eps)
+        else:
+            red = x
+        kv = ag.linear(red, self.kv.weight, self.kv.bias)
+        a = ag.sr_attention(q, kv, self.num_heads, self.scale)
+        return ag.linear(a, self.proj.weight, self.proj.bias)
+
     def forward(self, x, H, W, residual=None):
+        if wants_grad(self, x):
+            y = self.forward_train(x.contiguous(), H, W)
+            return y if residual is None else residual + y
         B, N, C = x.shape
         pk = self._pk
         q = ops.linear(x, pk.get("q", self.q.weight, ops.pack_weight), C, bias=self.q.bias)
@@ -116,7 +140,17 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         init_reference_style(self)
 
+    def forward_train(self, x, H, W):
+        """autograd path: functional, nothing in place; stochastic depth when self.training."""
+        dp = self.drop_path.drop_prob if (self.training and isinstance(self.drop_path, _DropPath)) else 0.0
+        a = self.attn.forward_train(ag.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), H, W)
+        x = x + (drop_path_scale(a, dp) if dp > 0 else a)
+        m = self.mlp.forward_train(ag.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), H, W)
+        return x + (drop_path_scale(m, dp) if dp > 0 else m)
+
     def forward(self, x, H, W):
+        if wants_grad(self, x):
+            return self.forward_train(x.contiguous(), H, W)
         return self.forward_(x.clone(), H, W)
 
     def forward_(self, x, H, W):
@@ -163,8 +197,13 @@ class OverlapPatchEmbed(nn.Module):
     def forward(self, x):
         """x: logical NCHW (any strides; channels-last storage is consumed without a copy).
         Returns (tokens (B, H*W, C), H, W) like the reference."""
-        xh = ops.to_nhwc(x)
         k = self.patch_size[0]
+        if wants_grad(self, x):
+            xh = x.permute(0, 2, 3, 1).contiguous()  # autograd-aware layout change
+            y = ag.conv2d(xh, self.proj.weight, self.proj.bias, k=k, stride=self.stride, pad=k // 2)
+            B, H, W, C = y.shape
+            return ag.layernorm(y.view(B, H * W, C), self.norm.weight, self.norm.bias, self.norm.eps), H, W
+        xh = ops.to_nhwc(x)
         y = ops.conv2d(xh, self._pk.get("proj", self.proj.weight, ops.pack_weight), self.proj.out_channels, k,
                        stride=self.stride, pad=k // 2, bias=self.proj.bias)
         B, H, W, C = y.shape
@@ -217,12 +256,16 @@ class MixVisionTransformer(nn.Module):
     def forward_features_nhwc(self, x):
         """-> 4 NHWC feature maps [(B, H/4, W/4, C1), ...]."""
         feats = []
+        train = wants_grad(self, x)
         for s in range(4):
             t, H, W = getattr(self, f"patch_embed{s + 1}")(x)
             for blk in getattr(self, f"block{s + 1}"):
-                t = blk.forward_(t, H, W)
+                t = blk.forward_train(t, H, W) if train else blk.forward_(t, H, W)
             norm = getattr(self, f"norm{s + 1}")
-            t = ops.layernorm(t, norm.weight, norm.bias, norm.eps, out=t)
+            if train:
+                t = ag.layernorm(t, norm.weight, norm.bias, norm.eps)
+            else:
+                t = ops.layernorm(t, norm.weight, norm.bias, norm.eps, out=t)
             f = t.view(t.shape[0], H, W, t.shape[2])
             feats.append(f)
             x = ops.as_nchw(f)

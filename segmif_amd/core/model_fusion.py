@@ -15,9 +15,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import autograd as ag
 from .. import ops
 from . import mix_transformer
-from ._util import PackedCache, init_reference_style, require_device
+from ._util import PackedCache, init_reference_style, require_device, wants_grad
 from .segformer_head import SegFormerHead
 
 __all__ = ["WeTr", "RGB2YCrCb", "YCrCb2RGB", "DRDB", "CrossAttention", "CrossAttention2", "CrossPath",
@@ -303,6 +304,11 @@ class Network3(nn.Module):
 
     def _segment_nhwc(self, fused):
         require_device(fused, "Network3 input")
+        if torch.is_grad_enabled() and fused.requires_grad:
+            # gradient flows back to the fused image (train.py:368): keep the normalisation in autograd
+            mean = fused.new_tensor(self.mean).view(1, 3, 1, 1)
+            std = fused.new_tensor(self.std).view(1, 3, 1, 1)
+            return self.denoise_net.forward_nhwc((fused * 255 - mean) / std)
         # (x*255 - mean)/std fused with the NCHW -> NHWC transpose (ref :1083-1085)
         return self.denoise_net.forward_nhwc(ops.as_nchw(ops.seg_normalize(fused)))
 
@@ -316,8 +322,15 @@ class Network3(nn.Module):
         return ops.argmax_nhwc(ops.bilinear(seg, H, W))
 
     def _loss(self, fused_seg1, label, criterion):
-        seg_map = ops.as_nchw(self._segment_nhwc(fused_seg1))
-        outputs = F.interpolate(seg_map, size=label.shape[1:], mode='bilinear', align_corners=False)
+        """CE(bilinear-up(seg_map), label) (ref :1090-1097).  With an nn.CrossEntropyLoss criterion the
+        whole chain (x4 bilinear, softmax-CE with ignore_index, their backward) runs in HIP kernels."""
+        seg = self._segment_nhwc(fused_seg1)
+        H, W = label.shape[1:]
+        if isinstance(criterion, nn.CrossEntropyLoss) and criterion.weight is None and criterion.reduction == "mean" \
+                and getattr(criterion, "label_smoothing", 0.0) == 0.0:
+            up = ag.bilinear(seg, H, W) if seg.requires_grad else ops.bilinear(seg, H, W)
+            return ag.softmax_ce(up, label.type(torch.long), criterion.ignore_index)
+        outputs = F.interpolate(ops.as_nchw(seg), size=label.shape[1:], mode='bilinear', align_corners=False)
         return criterion(outputs, label.type(torch.long))
 
     def denoise_net_parameters(self):

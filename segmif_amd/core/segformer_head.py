@@ -13,8 +13,9 @@ the epilogue, then the 1x1 prediction conv.
 import torch
 import torch.nn as nn
 
+from .. import autograd as ag
 from .. import ops
-from ._util import PackedCache, require_device
+from ._util import PackedCache, require_device, wants_grad
 
 __all__ = ["MLP", "ConvModule", "SegFormerHead"]
 
@@ -97,8 +98,35 @@ class SegFormerHead(nn.Module):
         self.linear_pred = nn.Conv2d(embedding_dim, self.num_classes, kernel_size=1)
         self._pk = PackedCache()
 
+    def forward_train_nhwc(self, feats):
+        """autograd path (BatchNorm on running statistics; batch-statistics mode is not built yet)."""
+        c1, c2, c3, c4 = feats
+        B, H1, W1, _ = c1.shape
+        fuse = self.linear_fuse
+        if self.training and fuse.with_norm:
+            raise NotImplementedError("train-mode BatchNorm (batch statistics) has no HIP backward yet: use "
+                                      ".eval() (the reference's train_seg runs in eval mode after its first "
+                                      "validation, SURVEY F11)")
+        parts = []
+        for mlp, c in ((self.linear_c4, c4), (self.linear_c3, c3), (self.linear_c2, c2)):
+            parts.append(ag.bilinear(ag.linear(c.contiguous(), mlp.proj.weight, mlp.proj.bias), H1, W1))
+        parts.append(ag.linear(c1.contiguous(), self.linear_c1.proj.weight, self.linear_c1.proj.bias))
+        cat = torch.cat(parts, dim=-1)
+        w = fuse.conv.weight.flatten(1)
+        b = fuse.conv.bias
+        if fuse.with_norm:  # fold eval-mode BN differentiably: grads reach conv.weight, bn.weight, bn.bias
+            s = fuse.bn.weight / torch.sqrt(fuse.bn.running_var + fuse.bn.eps)
+            w = w * s[:, None]
+            b = fuse.bn.bias - fuse.bn.running_mean * s
+        y = ag.linear(cat, w, b, act=ops.ACT_RELU)
+        if self.training:
+            y = self.dropout(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+        return ag.linear(y, self.linear_pred.weight, self.linear_pred.bias)
+
     def forward_nhwc(self, feats):
         """feats: [c1..c4] NHWC -> logits NHWC (B, H/4, W/4, num_classes)."""
+        if wants_grad(self, *feats):
+            return self.forward_train_nhwc(feats)
         c1, c2, c3, c4 = feats
         B, H1, W1, _ = c1.shape
         E = self.linear_c1.proj.out_features

@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
   const int mt = bid / p.ntn, nt = bid - mt * p.ntn;
   const long long m0 = (long long)mt * BM;
   const int n0 = nt * BN;
-  const long long z = blockIdx.z;
-  const float* __restrict__ in = p.in + z * p.in_zs;
-  const float* __restrict__ in2 = (MODE == MODE_DENSE2) ? p.in2 + z * p.in2_zs : nullptr;
-  const float* __restrict__ wt = p.wt + z * p.wt_zs;
+  const long long zb = blockIdx.z / p.nz2, z2 = blockIdx.z - zb * p.nz2;
+  const float* __restrict__ in = p.in + zb * p.in_zs + z2 * p.in_zs2;
+  const float* __restrict__ in2 = (MODE == MODE_DENSE2) ? p.in2 + zb * p.in2_zs : nullptr;
+  const float* __restrict__ wt = p.wt + zb * p.wt_zs + z2 * p.wt_zs2;
 
   const int kq = tid % UPR;
   const int row_t = tid / UPR;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
   for (int j = 0; j < BU; ++j) {
     const int nrow = row_t + j * RPP;
     b_ok[j] = (nrow < BN) && (n0 + nrow < p.N);
-    b_ptr[j] = wt + (long long)(n0 + nrow) * p.Kp + kq * 4;
+    b_ptr[j] = wt + (long long)(n0 + nrow) * p.ldw + kq * 4;
   }
 
   f32x4 ra[AU], rb[BU];
@@ -218,8 +218,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
   }
 
   // ---- epilogue: bias + activation (+ residual), 128-byte row segments per half wave ----------
-  float* __restrict__ out = p.out + z * p.out_zs;
-  const float* __restrict__ res = p.res ? p.res + z * p.res_zs : nullptr;
+  float* __restrict__ out = p.out + zb * p.out_zs + z2 * p.out_zs2;
+  const float* __restrict__ res = p.res ? p.res + zb * p.res_zs + z2 * p.res_zs2 : nullptr;
   const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -352,7 +352,11 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
   k.dil = d->dil; k.OH = d->OH; k.OW = d->OW; k.act = d->act;
   k.in_zs = d->in_zstride; k.in2_zs = d->in2_zstride; k.wt_zs = d->wt_zstride; k.out_zs = d->out_zstride;
   k.res_zs = d->res_zstride;
-  const int nz = d->nz > 0 ? d->nz : 1;
+  k.nz2 = d->nz2 > 0 ? d->nz2 : 1;
+  k.in_zs2 = d->in_zstride2; k.wt_zs2 = d->wt_zstride2; k.out_zs2 = d->out_zstride2; k.res_zs2 = d->res_zstride2;
+  k.ldw = d->ldw > 0 ? d->ldw : k.Kp;
+  if (k.ldw % 4) return SEGMIF_EINVAL;
+  const int nz = (d->nz > 0 ? d->nz : 1) * k.nz2;
   if (d->act == SEGMIF_ACT_PRELU && !d->prelu) return SEGMIF_EINVAL;
   if (d->res && d->ldr <= 0) return SEGMIF_EINVAL;
 
@@ -374,7 +378,7 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
                        (mode != MODE_DENSE2 || (d->K1 % 32 == 0));
   int tile = d->tile;
   hipStream_t s = (hipStream_t)stream;
-  const bool halo_ok = mode == MODE_CONV && nz == 1 && conv3x3_halo_eligible(k);
+  const bool halo_ok = mode == MODE_CONV && nz == 1 && k.ldw == k.Kp && conv3x3_halo_eligible(k);
   if (tile < 0 && halo_ok) tile = kHaloTile0 + 1;  // 8-channel chunks: best on every shape (profiles/r01_kernel_bench_halo.txt)
   if (tile >= kHaloTile0 && tile < kNumTiles) {
     if (!halo_ok) return SEGMIF_EINVAL;

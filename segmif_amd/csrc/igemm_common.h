@@ -23,6 +23,9 @@ struct IgemmK {
   int H, W, Cin, KH, KW, stride, pad, dil, OH, OW;
   int act;
   long long in_zs, in2_zs, wt_zs, out_zs, res_zs;
+  int nz2;  // z = zb * nz2 + z2; second-level strides below (0 when unused)
+  long long in_zs2, wt_zs2, out_zs2, res_zs2;
+  int ldw;  // weight row pitch (floats), normally Kp
   int ntm, ntn;
 };
 

@@ -1,0 +1,321 @@
+// Weight gradients of the convolutions / linears on the SegMiF hot path, on the exact-fp32 matrix pipe.
+//
+//   dW[n][k] = sum_m dY[m][n] * A(m, k)        A = the same on-the-fly im2col gather as igemm.hip
+//
+// The contraction index is the pixel/token index m (millions of rows), the output is small
+// (N x K).  Both operands sit in memory with m as their ROW index, so LDS tiles are kept [m][n] and
+// [m][k] exactly as loaded and the MFMA fragments are read "down the columns": for the k-pair
+// {2j, 2j+1} of v_mfma_f32_32x32x2_f32, lane (r, h) reads dY[m0 + 2j + h][n0 + r] and
+// X[m0 + 2j + h][k0 + r] — consecutive lanes hit consecutive banks, the two halves are separate
+// lane groups, so the ds_read_b32 stream is conflict free without padding.
+//
+// Parallelisation: grid = (n-tiles * k-tiles, 1, m-chunks).  A block owns a (32*NT) x (32*KT)
+// tile of dW (NT*KT = 4 waves, one 32x32 sub-tile each) and one contiguous chunk of rows; the
+// per-chunk partials are summed by a second, deterministic pass (fp64 accumulation) straight into
+// the parameter's OIHW / (N, K) gradient layout — no atomics, bitwise reproducible.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "igemm_common.h"
+#include "segmif_hip.h"
+
+namespace segmif {
+namespace {
+
+constexpr int MR = 32;  // rows per LDS tile
+
+struct WgradK {
+  const float* dy;
+  const float* in;
+  float* partial;  // [chunks][N][Kp]
+  long long M;
+  int N, K, Kp;
+  int ldy, lda;
+  int H, W, Cin, KH, KW, stride, pad, dil, OH, OW;
+  int conv;  // 0 dense, 1 conv (Cin % 4 == 0), 2 generic scalar gather
+  int yvec;  // dY rows are 16-byte loadable
+  long long rows_per_chunk;
+  int nkt, nnt, chunks;
+  long long in_zs, dy_zs;  // batch strides (gridDim.z = batches * chunks)
+};
+
+template <int NT, int KT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
+  constexpr int BN = 32 * NT, BK = 32 * KT;
+  constexpr int YU = MR * BN / 4 / 256 > 0 ? MR * BN / 4 / 256 : 1;  // float4 units per thread (dY tile)
+  constexpr int XU = MR * BK / 4 / 256;  // float4 units per thread (X tile)
+  static_assert(NT * KT == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float Ys[2][MR * BN];
+  __shared__ __attribute__((aligned(16))) float Xs[2][MR * BK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wn = wave % NT, wk = wave / NT;
+  const int nt = blockIdx.x % p.nnt, kt = blockIdx.x / p.nnt;
+  const int n0 = nt * BN, k0 = kt * BK;
+  const int zb = blockIdx.z / p.chunks, chunk = blockIdx.z - zb * p.chunks;
+  const float* __restrict__ dyp = p.dy + (long long)zb * p.dy_zs;
+  const float* __restrict__ inp = p.in + (long long)zb * p.in_zs;
+  const long long m_begin = (long long)chunk * p.rows_per_chunk;
+  const long long m_end = (m_begin + p.rows_per_chunk < p.M) ? m_begin + p.rows_per_chunk : p.M;
+
+  // loaders: dY tile MR x BN, X tile MR x BK, 16 B per thread per unit
+  constexpr int YUPR = BN / 4, XUPR = BK / 4;
+  f32x4 ry[YU], rx[XU];
+  auto gload = [&](long long m0) {
+#pragma unroll
+    for (int j = 0; j < YU; ++j) {
+      const int u = tid + 256 * j;
+      const int row = u / YUPR, q = (u % YUPR) * 4;
+      ry[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const long long m = m0 + row;
+      if (u < MR * YUPR && m < m_end) {
+        const float* src = dyp + m * p.ldy + n0 + q;
+        if (p.yvec && n0 + q + 3 < p.N) ry[j] = *reinterpret_cast<const f32x4*>(src);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n0 + q + e < p.N) ry[j][e] = src[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+      const int u = tid + 256 * j;
+      const int row = u / XUPR, q = (u % XUPR) * 4;
+      rx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const long long m = m0 + row;
+      const int k = k0 + q;
+      if (m < m_end && k < p.K) {
+        if (p.conv == 0) {
+          rx[j] = *reinterpret_cast<const f32x4*>(inp + m * p.lda + k);  // K % 4 == 0 for dense
+        } else {
+          const long long ohw = (long long)p.OH * p.OW;
+          const long long b = m / ohw;
+          const int rem = (int)(m - b * ohw);
+          const int oy = rem / p.OW, ox = rem - oy * p.OW;
+          if (p.conv == 1) {  // 4 consecutive k share a tap (Cin % 4 == 0)
+            const int tap = k / p.Cin, c = k - tap * p.Cin;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const int iy = oy * p.stride - p.pad + ky * p.dil, ix = ox * p.stride - p.pad + kx * p.dil;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+              rx[j] = *reinterpret_cast<const f32x4*>(inp + ((b * p.H + iy) * p.W + ix) * p.lda + c);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int kk = k + e;
+              if (kk < p.K) {
+                const int tap = kk / p.Cin, c = kk - tap * p.Cin;
+                const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                const int iy = oy * p.stride - p.pad + ky * p.dil, ix = ox * p.stride - p.pad + kx * p.dil;
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                  rx[j][e] = inp[((b * p.H + iy) * p.W + ix) * p.lda + c];
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < YU; ++j) {
+      const int u = tid + 256 * j;
+      if (u < MR * YUPR) *reinterpret_cast<f32x4*>(&Ys[buf][u * 4]) = ry[j];
+    }
+#pragma unroll
+    for (int j = 0; j < XU; ++j) *reinterpret_cast<f32x4*>(&Xs[buf][(tid + 256 * j) * 4]) = rx[j];
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+
+  const long long ntiles = (m_end - m_begin + MR - 1) / MR;
+  if (ntiles > 0) {
+    gload(m_begin);
+    sstore(0);
+  }
+  __syncthreads();
+  for (long long t = 0; t < ntiles; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < ntiles) gload(m_begin + (t + 1) * MR);
+    const float* ya = &Ys[cur][h * BN + wn * 32 + r];
+    const float* xa = &Xs[cur][h * BK + wk * 32 + r];
+#pragma unroll
+    for (int j = 0; j < MR / 2; ++j)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[2 * j * BN], xa[2 * j * BK], acc, 0, 0, 0);
+    if (t + 1 < ntiles) sstore(cur ^ 1);
+    __syncthreads();
+  }
+  // D[i = n][j = k]: lane holds column k = r, rows n = (v&3) + 8*(v>>2) + 4*h
+  float* out = p.partial + (long long)blockIdx.z * p.N * p.Kp;  // [batch][chunk][N][Kp]
+  const int k = k0 + wk * 32 + r;
+  if (k < p.Kp) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int n = n0 + wn * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+      if (n < p.N) out[(long long)n * p.Kp + k] = acc[v];
+    }
+  }
+}
+
+// sum over chunks (fp64) and scatter from the packed [N][Kp] (tap-major, channel-minor) order into the
+// parameter's own layout: OIHW for convs; element (n, k) -> dw[n*sn + k*sk] for dense problems.
+// accumulate != 0: grad += value.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           int chunks, int N, int K, int Kp, int Cin, int KH, int KW,
+                                                           int dense, long long sn, long long sk, long long dw_zs,
+                                                           int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)N * K) return;
+  const int zb = blockIdx.y;
+  const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+  const float* p = partial + (long long)zb * chunks * N * Kp;
+  double s = 0.0;
+  for (int c = 0; c < chunks; ++c) s += (double)p[((long long)c * N + n) * Kp + k];
+  long long dst;
+  if (dense) dst = n * sn + k * sk;
+  else {
+    const int tap = k / Cin, ch = k - tap * Cin;
+    const int ky = tap / KW, kx = tap - ky * KW;
+    dst = (((long long)n * Cin + ch) * KH + ky) * KW + kx;
+  }
+  dst += zb * dw_zs;
+  dw[dst] = accumulate ? dw[dst] + (float)s : (float)s;
+}
+
+// column sums of a rows x N matrix (bias gradients): stage 1 per row block, stage 2 over blocks.
+constexpr int CS_ROWS = 2048;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, double* __restrict__ partial,
+                                                             long long rows, int N, int ldx) {
+  const long long r0 = (long long)blockIdx.x * CS_ROWS;
+  const long long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+  for (int n = threadIdx.x; n < N; n += 256) {  // N <= 2048: a few columns per thread, coalesced across n
+    float s = 0.f;
+    double acc = 0.0;
+    int cnt = 0;
+    for (long long r = r0; r < r1; ++r) {
+      s += x[r * ldx + n];
+      if (++cnt == 64) {
+        acc += (double)s;
+        s = 0.f;
+        cnt = 0;
+      }
+    }
+    partial[(long long)blockIdx.x * N + n] = acc + (double)s;
+  }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ partial, float* __restrict__ out,
+                                                           int nblk, int N, int accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += partial[(long long)b * N + n];
+  out[n] = accumulate ? out[n] + (float)s : (float)s;
+}
+
+// dx = dy * f'(.) for the fused-epilogue activations.  `ref` is the activation OUTPUT for ReLU /
+// PReLU (sign test; PReLU needs slope > 0 for sign(out) == sign(pre)) and the PRE-activation for GELU.
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ref,
+                                                      float* __restrict__ dx, long long rows, int C, int ldy, int ldr,
+                                                      int ldx, int act, const float* __restrict__ slope_p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * C) return;
+  const long long row = i / C;
+  const int c = (int)(i - row * C);
+  const float g = dy[row * ldy + c], v = ref[row * ldr + c];
+  float o;
+  if (act == SEGMIF_ACT_RELU) o = v > 0.f ? g : 0.f;
+  else if (act == SEGMIF_ACT_PRELU) o = v >= 0.f ? g : g * *slope_p;
+  else if (act == SEGMIF_ACT_GELU) {
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+    o = g * (cdf + v * pdf);
+  } else o = g;
+  dx[row * ldx + c] = o;
+}
+
+}  // namespace
+}  // namespace segmif
+
+using namespace segmif;
+
+static long long pick_chunks(long long M, int N, int K) {
+  const int Kp = (K + 15) / 16 * 16;
+  const bool narrow = N <= 32;
+  const int BN = narrow ? 32 : 64, BK = narrow ? 128 : 64;
+  const long long tiles = (long long)((N + BN - 1) / BN) * ((Kp + BK - 1) / BK);
+  long long chunks = (2048 + tiles - 1) / tiles;  // aim for >= 2048 blocks
+  const long long max_chunks = (M + 1023) / 1024;  // at least 1024 rows per chunk
+  if (chunks > max_chunks) chunks = max_chunks;
+  return chunks < 1 ? 1 : chunks;
+}
+
+extern "C" int64_t segmif_wgrad_workspace_size(int64_t M, int N, int K) {
+  const int Kp = (K + 15) / 16 * 16;
+  return pick_chunks(M, N, K) * (int64_t)N * Kp;
+}
+
+extern "C" int segmif_wgrad_f32(const SegmifIgemm* d, const float* dy, int ldy, int64_t dy_zstride, float* dw,
+                                int64_t dw_sn, int64_t dw_sk, float* workspace, int accumulate, void* stream) {
+  if (!d || !d->in || !dy || !dw || !workspace || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->in2) return SEGMIF_EINVAL;
+  WgradK k;
+  k.dy = dy; k.in = d->in; k.partial = workspace; k.M = d->M; k.N = d->N; k.K = d->K; k.Kp = (d->K + 15) / 16 * 16;
+  k.ldy = ldy; k.lda = d->lda;
+  k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad;
+  k.dil = d->dil; k.OH = d->OH; k.OW = d->OW;
+  const int nz = d->nz > 0 ? d->nz : 1;
+  k.in_zs = d->in_zstride; k.dy_zs = dy_zstride;
+  const bool is_conv = !(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0);
+  if (!is_conv) {
+    if ((d->K % 4) || (d->lda % 4) || ((uintptr_t)d->in & 15) || (d->in_zstride % 4)) return SEGMIF_EINVAL;
+    k.conv = 0;
+    k.Cin = d->K; k.KH = k.KW = 1;
+  } else {
+    k.conv = (d->Cin % 4 == 0 && d->lda % 4 == 0 && !((uintptr_t)d->in & 15) && d->in_zstride % 4 == 0) ? 1 : 2;
+  }
+  k.yvec = (ldy % 4 == 0) && !((uintptr_t)dy & 15) && (dy_zstride % 4 == 0);
+  long long chunks = pick_chunks(d->M, d->N, d->K);
+  k.rows_per_chunk = ((d->M + chunks - 1) / chunks + MR - 1) / MR * MR;
+  chunks = (d->M + k.rows_per_chunk - 1) / k.rows_per_chunk;
+  k.chunks = (int)chunks;
+  const bool narrow = d->N <= 32;
+  const int BN = narrow ? 32 : 64, BK = narrow ? 128 : 64;
+  k.nnt = (d->N + BN - 1) / BN;
+  k.nkt = (k.Kp + BK - 1) / BK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)(k.nnt * k.nkt), 1, (unsigned)(chunks * nz));
+  if (narrow) hipLaunchKernelGGL((wgrad_kernel<1, 4>), grid, dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((wgrad_kernel<2, 2>), grid, dim3(256), 0, s, k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  const long long total = (long long)d->N * d->K;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)nz), dim3(256), 0, s,
+                     workspace, dw, (int)chunks, d->N, d->K, k.Kp, k.Cin, k.KH, k.KW, is_conv ? 0 : 1,
+                     (long long)dw_sn, (long long)dw_sk, (long long)d->out_zstride, accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_colsum_blocks(int64_t rows) { return (int)((rows + CS_ROWS - 1) / CS_ROWS); }
+
+extern "C" int segmif_colsum_f32(const float* x, float* out, double* workspace, int64_t rows, int N, int ldx,
+                                 int accumulate, void* stream) {
+  if (!x || !out || !workspace || rows <= 0 || N <= 0 || ldx < N) return SEGMIF_EINVAL;
+  const int nblk = segmif_colsum_blocks(rows);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, workspace, (long long)rows, N, ldx);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, workspace, out, nblk, N,
+                     accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_act_bwd_f32(const float* dy, const float* ref, float* dx, int64_t rows, int C, int ldy, int ldr,
+                                  int ldx, int act, const float* slope, void* stream) {
+  if (!dy || !ref || !dx || rows <= 0 || C <= 0) return SEGMIF_EINVAL;
+  if (act == SEGMIF_ACT_PRELU && !slope) return SEGMIF_EINVAL;
+  const long long total = (long long)rows * C;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, ref,
+                     dx, (long long)rows, C, ldy, ldr, ldx, act, slope);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,227 @@
+"""GPU parity tests for the training path: every backward kernel against torch-CPU fp64 autograd
+of the aten op the reference differentiates, the seg-training step's parameter gradients against
+the CPU oracle's autograd, and the fused AdamW against torch.optim.AdamW."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import detweights as dw
+import segmif_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+TOL = 5e-5
+
+
+@pytest.fixture(scope="module")
+def ag():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from segmif_amd import autograd as _ag
+    return _ag
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * (hi - lo) + lo).float()
+
+
+def err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def leaf(t, dev=None, double=False):
+    t = t.double() if double else t.clone()
+    if dev:
+        t = t.to(dev)
+    return t.requires_grad_(True)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1000, 64, 64, 0), (777, 128, 320, 1), (300, 9, 256, 0), (4100, 32, 224, 1),
+                                       (2500, 512, 128, 2)])
+def test_linear_backward(ag, M, N, K, act):
+    x, w, b, g = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    slope = torch.tensor([0.2])
+    xr, wr, br, sr = leaf(x, double=True), leaf(w, double=True), leaf(b, double=True), leaf(slope, double=True)
+    y = F.linear(xr, wr, br)
+    y = F.relu(y) if act == 1 else (F.prelu(y, sr) if act == 2 else y)
+    y.backward(g.double())
+    xg, wg, bg, sg = leaf(x, "cuda"), leaf(w, "cuda"), leaf(b, "cuda"), leaf(slope, "cuda")
+    yg = ag.linear(xg, wg, bg, act=act, slope=sg if act == 2 else None)
+    assert err(yg, y) < TOL
+    yg.backward(g.cuda())
+    assert err(xg.grad, xr.grad) < TOL and err(wg.grad, wr.grad) < TOL and err(bg.grad, br.grad) < TOL
+    if act == 2:
+        assert err(sg.grad, sr.grad) < 1e-4
+
+
+CONV_CASES = [
+    # B, H, W, Cin, N, k, stride, pad, dil, act
+    (2, 20, 28, 64, 32, 3, 1, 2, 2, 1),  # DRDB dilated conv + ReLU
+    (1, 17, 23, 64, 128, 3, 2, 1, 1, 0),  # overlap patch embed (strided, overlapping)
+    (1, 16, 24, 128, 128, 4, 4, 0, 1, 0),  # sr conv
+    (1, 9, 13, 32, 64, 2, 2, 0, 1, 0),  # sr conv dropping the remainder
+    (2, 21, 19, 3, 32, 7, 4, 3, 1, 0),  # stage-1 patch embed
+    (2, 12, 20, 32, 1, 3, 1, 1, 1, 2),  # conv22 + PReLU
+    (1, 14, 18, 128, 64, 3, 1, 1, 1, 2),  # conv2 + PReLU
+    (2, 10, 12, 1, 64, 3, 1, 1, 1, 2),  # conv1
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_backward(ag, case):
+    B, H, W, Cin, N, k, s, p, d, act = case
+    x, w, b = rnd(B, Cin, H, W, seed=5), rnd(N, Cin, k, k, seed=6), rnd(N, seed=7)
+    slope = torch.tensor([0.25])
+    xr, wr, br, sr = leaf(x, double=True), leaf(w, double=True), leaf(b, double=True), leaf(slope, double=True)
+    y = F.conv2d(xr, wr, br, stride=s, padding=p, dilation=d)
+    y = F.relu(y) if act == 1 else (F.prelu(y, sr) if act == 2 else y)
+    g = rnd(*y.shape, seed=8)
+    y.backward(g.double())
+    xg = leaf(x.permute(0, 2, 3, 1).contiguous(), "cuda")
+    wg, bg, sg = leaf(w, "cuda"), leaf(b, "cuda"), leaf(slope, "cuda")
+    yg = ag.conv2d(xg, wg, bg, k=k, stride=s, pad=p, dil=d, act=act, slope=sg if act == 2 else None)
+    assert err(yg, y.permute(0, 2, 3, 1)) < TOL
+    yg.backward(g.permute(0, 2, 3, 1).contiguous().cuda())
+    assert err(xg.grad, xr.grad.permute(0, 2, 3, 1)) < TOL
+    assert err(wg.grad, wr.grad) < TOL and err(bg.grad, br.grad) < TOL
+    if act == 2:
+        assert err(sg.grad, sr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("rows,C", [(1003, 64), (517, 320), (40, 512), (9000, 128), (333, 32)])
+def test_layernorm_backward(ag, rows, C):
+    x, gm, bt, g = rnd(rows, C, seed=9, lo=-3, hi=5), rnd(C, seed=10), rnd(C, seed=11), rnd(rows, C, seed=12)
+    xr, gr, br = leaf(x, double=True), leaf(gm, double=True), leaf(bt, double=True)
+    F.layer_norm(xr, (C,), gr, br, 1e-6).backward(g.double())
+    xg, gg, bg = leaf(x, "cuda"), leaf(gm, "cuda"), leaf(bt, "cuda")
+    ag.layernorm(xg, gg, bg, 1e-6).backward(g.cuda())
+    assert err(xg.grad, xr.grad) < TOL and err(gg.grad, gr.grad) < TOL and err(bg.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 13, 128), (1, 30, 40, 1280), (1, 5, 3, 256)])
+def test_dwconv_gelu_backward(ag, B, H, W, C):
+    h, w, b, g = rnd(B, H * W, C, seed=13, lo=-2, hi=2), rnd(C, 1, 3, 3, seed=14), rnd(C, seed=15), rnd(B, H * W, C, seed=16)
+    hr, wr, br = leaf(h, double=True), leaf(w, double=True), leaf(b, double=True)
+    img = hr.transpose(1, 2).reshape(B, C, H, W)
+    F.gelu(F.conv2d(img, wr, br, padding=1, groups=C)).flatten(2).transpose(1, 2).backward(g.double())
+    hg, wg, bg = leaf(h, "cuda"), leaf(w, "cuda"), leaf(b, "cuda")
+    ag.dwconv_gelu(hg, wg, bg, H, W).backward(g.cuda())
+    assert err(hg.grad, hr.grad) < TOL and err(wg.grad, wr.grad) < TOL and err(bg.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize("B,IH,IW,OH,OW,C", [(2, 16, 24, 64, 96, 64), (1, 15, 20, 120, 160, 256), (1, 5, 7, 18, 26, 32),
+                                             (2, 18, 26, 72, 104, 9), (1, 30, 40, 30, 40, 8), (1, 64, 48, 16, 12, 4)])
+def test_bilinear_backward(ag, B, IH, IW, OH, OW, C):
+    x, g = rnd(B, IH, IW, C, seed=17), rnd(B, OH, OW, C, seed=18)
+    xr = leaf(x.permute(0, 3, 1, 2), double=True)
+    F.interpolate(xr, size=[OH, OW], mode="bilinear", align_corners=False).backward(g.permute(0, 3, 1, 2).double())
+    xg = leaf(x, "cuda")
+    ag.bilinear(xg, OH, OW).backward(g.cuda())
+    assert err(xg.grad, xr.grad.permute(0, 2, 3, 1)) < TOL
+
+
+@pytest.mark.parametrize("B,heads,N,Nk,hd", [(2, 2, 96, 6, 64), (1, 1, 2000, 300, 64), (2, 5, 130, 35, 64),
+                                             (1, 8, 300, 300, 64), (1, 2, 256, 64, 32)])
+def test_sr_attention_backward(ag, B, heads, N, Nk, hd):
+    C = heads * hd
+    q, kv, g = rnd(B, N, C, seed=19, lo=-2, hi=2), rnd(B, Nk, 2 * C, seed=20, lo=-2, hi=2), rnd(B, N, C, seed=21)
+    qr, kvr = leaf(q, double=True), leaf(kv, double=True)
+    scale = hd ** -0.5
+    qh = qr.reshape(B, N, heads, hd).permute(0, 2, 1, 3)
+    kvh = kvr.reshape(B, Nk, 2, heads, hd)
+    k, v = kvh[:, :, 0].permute(0, 2, 1, 3), kvh[:, :, 1].permute(0, 2, 1, 3)
+    (torch.softmax(qh @ k.transpose(-2, -1) * scale, -1) @ v).transpose(1, 2).reshape(B, N, C).backward(g.double())
+    qg, kvg = leaf(q, "cuda"), leaf(kv, "cuda")
+    ag.sr_attention(qg, kvg, heads, scale).backward(g.cuda())
+    assert err(qg.grad, qr.grad) < TOL and err(kvg.grad, kvr.grad) < TOL
+
+
+def test_softmax_ce_with_ignore(ag):
+    B, H, W, C = 2, 17, 23, 9
+    x = rnd(B, H, W, C, seed=22, lo=-3, hi=3)
+    labels = dw.det_labels("ce", (B, H, W), 9)
+    labels[0, :3] = 255
+    xr = leaf(x.permute(0, 3, 1, 2), double=True)
+    lr = F.cross_entropy(xr, labels, ignore_index=255)
+    lr.backward()
+    xg = leaf(x, "cuda")
+    lg = ag.softmax_ce(xg, labels.cuda(), 255)
+    lg.backward()
+    assert abs(float(lg) - float(lr)) / abs(float(lr)) < 1e-5
+    assert err(xg.grad, xr.grad.permute(0, 2, 3, 1)) < TOL
+
+
+def test_seg_training_step_gradients_match_oracle_autograd(ag):
+    """Network3('mit_b1') in eval mode with grad (the deterministic regime of train_seg):
+    loss = CE(bilinear-up(seg), labels).  Every parameter gradient vs the oracle's autograd."""
+    from segmif_amd.core import Network3
+    B, H, W = 2, 64, 96
+    x = dw.det_input("tr_x", (B, 3, H, W))
+    labels = dw.det_labels("tr_y", (B, H, W), 9)
+    labels[0, 5:9, 7:30] = 255
+    sd = {k: (v.double().requires_grad_(True) if v.dtype.is_floating_point else v)
+          for k, v in dw.det_state_dict(so.network3_shapes("mit_b1", 9), seed=0).items()}
+    seg = so.network3_forward(sd, x.double(), "mit_b1")
+    ref_loss = F.cross_entropy(F.interpolate(seg, size=[H, W], mode="bilinear", align_corners=False), labels,
+                               ignore_index=255)
+    ref_loss.backward()
+    net = Network3("mit_b1", 9, pretrained=None)
+    dw.load_det_weights(net, seed=0)
+    net = net.cuda().eval()
+    loss = net._loss(x.cuda(), labels.cuda(), torch.nn.CrossEntropyLoss(ignore_index=255))
+    assert abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)) < 1e-4
+    loss.backward()
+    worst = ("", 0.0)
+    checked = 0
+    for name, p in net.named_parameters():
+        ref = sd[name].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name  # classifier.weight: no grad
+            continue
+        assert p.grad is not None, name
+        e = err(p.grad, ref)
+        checked += 1
+        if e > worst[1]:
+            worst = (name, e)
+    assert checked > 150
+    assert worst[1] < 1e-3, worst  # north-star tolerance; typically ~1e-5
+
+
+def test_fused_adamw_matches_torch(ag):
+    from segmif_amd.utils.optimizer import FusedAdamW, PolyWarmupAdamW_seg
+    torch.manual_seed(0)
+    shapes = [(64, 64), (128,), (32, 16, 3, 3), (1,), (100000,)]
+    ps = [torch.randn(s) for s in shapes]
+    a = [p.clone().cuda().requires_grad_(True) for p in ps]
+    b = [p.clone().cuda().requires_grad_(True) for p in ps]
+    oa = FusedAdamW([{"params": a[:2], "lr": 1e-3, "weight_decay": 0.01}, {"params": a[2:], "lr": 1e-2, "weight_decay": 0.0}],
+                    lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    ob = torch.optim.AdamW([{"params": b[:2], "lr": 1e-3, "weight_decay": 0.01}, {"params": b[2:], "lr": 1e-2, "weight_decay": 0.0}],
+                           lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for it in range(4):
+        for i, (pa, pb) in enumerate(zip(a, b)):
+            g = torch.randn(pa.shape, device="cuda")
+            if i == 3 and it < 2:
+                pa.grad = pb.grad = None  # a parameter without a gradient is skipped, not zero-filled
+            else:
+                pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for pa, pb in zip(a, b):
+        assert err(pa, pb.detach().cpu()) < 1e-6
+    # schedule mirror: linear warm-up for warmup_iter steps, then polynomial decay, written into param_groups
+    p = torch.zeros(4, device="cuda", requires_grad=True)
+    opt = PolyWarmupAdamW_seg([{"params": [p], "lr": 1e-2, "weight_decay": 0.0}], lr=1e-2, weight_decay=0.0,
+                              betas=(0.9, 0.999), iter_curr=0, warmup_iter=10, max_iter=100, warmup_ratio=0.1, power=1.0)
+    seen = []
+    for _ in range(12):
+        p.grad = torch.ones_like(p)
+        opt.step()
+        seen.append(opt.param_groups[0]["lr"])
+    assert abs(seen[0] - 1e-2 * 0.1) < 1e-12 and abs(seen[5] - 1e-2 * (1 - 0.5 * 0.9)) < 1e-12
+    assert abs(seen[11] - 1e-2 * (1 - 11 / 100)) < 1e-12
