@@ -352,6 +352,133 @@ class SoftmaxCEFn(torch.autograd.Function):
         return dlog * (g / cnt.float()), None, None
 
 
+class DRDBFn(torch.autograd.Function):
+    """Dense dilated block (core/model_fusion.py:134-157) as ONE autograd node.  Forward is the
+    inference path (five dilated convs writing in place into a 224-channel buffer, 1x1 conv + ReLU +
+    residual); only that buffer and the output are kept for backward (every intermediate concat of
+    the reference is a channel prefix of it)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):  # params = (w1, b1, ..., w5, b5, w6, b6)
+        B, H, W, C0 = x.shape
+        growth = params[0].shape[0]
+        total = C0 + 5 * growth
+        buf = torch.empty((B, H, W, total), device=x.device, dtype=torch.float32)
+        buf[..., :C0].copy_(x)
+        ch = C0
+        for i in range(5):
+            w, b = params[2 * i], params[2 * i + 1]
+            ops.conv2d(buf[..., :ch], ops.pack_weight(w), growth, 3, pad=2, dil=2, bias=b, act=ACT_RELU,
+                       out=buf[..., ch:ch + growth])
+            ch += growth
+        w6, b6 = params[10], params[11]
+        out = ops.linear(buf, ops.pack_weight(w6), C0, bias=b6, act=ACT_RELU, res=buf[..., :C0])
+        ctx.save_for_backward(buf, out, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        buf, out = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        dout = dout.contiguous()
+        B, H, W, total = buf.shape
+        C0 = out.shape[-1]
+        growth = params[0].shape[0]
+        grads = [None] * 12
+        w6 = params[10].reshape(C0, total)
+        y6 = out - buf[..., :C0]  # relu output of the 1x1 branch (mask source)
+        dz6 = act_bwd(dout, y6, ACT_RELU)
+        del y6
+        dbuf = torch.empty_like(buf)
+        w6t = w6.t().contiguous()  # (total, C0): input-gradient weights, rows = concat channels
+        ops.linear(dz6, w6t[:C0].contiguous(), C0, res=dout, out=dbuf[..., :C0])  # + residual path
+        ops.linear(dz6, w6t[C0:].contiguous(), total - C0, out=dbuf[..., C0:])
+        grads[10] = linear_wgrad(buf, dz6, C0).reshape(params[10].shape)
+        grads[11] = colsum(dz6)
+        del dz6
+        ch = total - growth
+        for i in range(4, -1, -1):
+            w = params[2 * i]
+            dy = act_bwd(dbuf[..., ch:ch + growth], buf[..., ch:ch + growth], ACT_RELU)
+            grads[2 * i] = conv_wgrad(buf[..., :ch], dy, w.shape, 3, 1, 2, 2)
+            grads[2 * i + 1] = colsum(dy)
+            wr = w.flip(2, 3).transpose(0, 1).contiguous()
+            ops.conv2d(dy, ops.pack_weight(wr), ch, 3, pad=2, dil=2, res=dbuf[..., :ch], out=dbuf[..., :ch])
+            ch -= growth
+        dx = dbuf[..., :C0].contiguous() if ctx.needs_input_grad[0] else None
+        return (dx, *grads)
+
+
+class BatchedLinearFn(torch.autograd.Function):
+    """y[b] = x[b] @ w[b]^T + bias with one weight matrix per image (the folded end_proj of CrossPath)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        B, n, K = x.shape
+        N = w.shape[1]
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return ops.linear(x, w.contiguous(), N, bias=bias, batched_weight=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, n, K = x.shape
+        N = w.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(dy, w.transpose(1, 2).contiguous(), K, batched_weight=True)
+        if ctx.needs_input_grad[1]:
+            d = _lib.SegmifIgemm()
+            d.in_ = x.data_ptr()
+            d.M, d.N, d.K, d.lda = n, N, K, x.stride(1)
+            d.H = d.W = d.OH = d.OW = 1
+            d.Cin = K
+            d.KH = d.KW = d.stride = d.dil = 1
+            d.nz = B
+            d.in_zstride = x.stride(0)
+            d.out_zstride = N * K
+            dw = torch.empty((B, N, K), device=x.device, dtype=torch.float32)
+            _wgrad(d, dy, N, dw, dy_zstride=n * N, sn=K, sk=1, nz=B)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy)
+        return dx, dw, db
+
+
+class KvContextFn(torch.autograd.Function):
+    """ctx_raw[b][h] = K^T V per head with [K | V] = y @ wkv^T (no bias): the N-reduction of the linear
+    cross attention (core/model_fusion.py:281, 316-318).  Forward = fused projection + reduction kernel
+    (kv never hits HBM); backward recomputes kv with one GEMM."""
+
+    @staticmethod
+    def forward(ctx, y, wkv):
+        ctx.save_for_backward(y, wkv)
+        part = ops.linattn_kvpartial(y, wkv.contiguous())
+        B = y.shape[0]
+        return part.sum(1).float().view(B, 8, 8, 8)
+
+    @staticmethod
+    def backward(ctx, dctx):
+        y, wkv = ctx.saved_tensors
+        B, n, C = y.shape
+        kv = ops.linear(y, wkv.contiguous(), 2 * C)  # (B, n, 128)
+        dctx = dctx.contiguous()
+        # dk = v @ D1^T-form, dv = k @ D2^T-form with block-diagonal (B, 64, 64) weights [out][in]
+        wk = torch.zeros((B, C, C), device=y.device, dtype=torch.float32)
+        wv = torch.zeros((B, C, C), device=y.device, dtype=torch.float32)
+        for h in range(8):
+            sl = slice(8 * h, 8 * h + 8)
+            wk[:, sl, sl] = dctx[:, h]  # dk[.., h8+i] = sum_j dctx[h][i][j] v[.., h8+j]
+            wv[:, sl, sl] = dctx[:, h].transpose(1, 2)  # dv[.., h8+j] = sum_i dctx[h][i][j] k[.., h8+i]
+        dkv = torch.empty_like(kv)
+        ops.linear(kv[..., C:], wk, C, out=dkv[..., :C], batched_weight=True)
+        ops.linear(kv[..., :C], wv, C, out=dkv[..., C:], batched_weight=True)
+        dy = ops.linear(dkv, wkv.t().contiguous(), C) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(y, dkv, 2 * C) if ctx.needs_input_grad[1] else None
+        return dy, dw
+
+
 # functional front-ends ------------------------------------------------------------------------------
 def linear(x, w, b=None, act=ACT_NONE, slope=None):
     return LinearFn.apply(x, w, b, act, slope)
@@ -379,3 +506,15 @@ def sr_attention(q, kv, heads, scale):
 
 def softmax_ce(logits_nhwc, labels, ignore_index=255):
     return SoftmaxCEFn.apply(logits_nhwc, labels, ignore_index)
+
+
+def drdb(x, params):
+    return DRDBFn.apply(x, *params)
+
+
+def batched_linear(x, w, bias=None):
+    return BatchedLinearFn.apply(x, w, bias)
+
+
+def kv_context(y, wkv):
+    return KvContextFn.apply(y, wkv)

@@ -185,34 +185,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   dw[dst] = accumulate ? dw[dst] + (float)s : (float)s;
 }
 
-// column sums of a rows x N matrix (bias gradients): stage 1 per row block, stage 2 over blocks.
-constexpr int CS_ROWS = 2048;
+// column sums of a rows x N matrix (bias gradients, LN / dwconv parameter partials):
+// stage 1: a block owns CS_ROWS rows; thread (c = tid & 63, slot = tid >> 6) walks 64-column chunks,
+// summing rows slot, slot+4, ... in fp32 (256-byte coalesced row segments), the 4 slots are combined in
+// LDS and written as one fp64 partial row; stage 2 sums the partial rows per column.
+constexpr int CS_ROWS = 256;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, double* __restrict__ partial,
                                                              long long rows, int N, int ldx) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, slot = threadIdx.x >> 6;
   const long long r0 = (long long)blockIdx.x * CS_ROWS;
   const long long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
-  for (int n = threadIdx.x; n < N; n += 256) {  // N <= 2048: a few columns per thread, coalesced across n
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int n = n0 + c;
     float s = 0.f;
-    double acc = 0.0;
-    int cnt = 0;
-    for (long long r = r0; r < r1; ++r) {
-      s += x[r * ldx + n];
-      if (++cnt == 64) {
-        acc += (double)s;
-        s = 0.f;
-        cnt = 0;
-      }
-    }
-    partial[(long long)blockIdx.x * N + n] = acc + (double)s;
+    if (n < N)
+      for (long long r = r0 + slot; r < r1; r += 4) s += x[r * ldx + n];
+    red[slot][c] = s;
+    __syncthreads();
+    if (slot == 0 && n < N)
+      partial[(long long)blockIdx.x * N + n] = ((double)red[0][c] + (double)red[1][c]) + ((double)red[2][c] + (double)red[3][c]);
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ partial, float* __restrict__ out,
                                                            int nblk, int N, int accumulate) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  // 64 columns per block, 4 row-slices combined in LDS (fixed order: deterministic)
+  __shared__ double red[4][64];
+  const int c = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += partial[(long long)b * N + n];
-  out[n] = accumulate ? out[n] + (float)s : (float)s;
+  if (n < N)
+    for (int b = slot; b < nblk; b += 4) s += partial[(long long)b * N + n];
+  red[slot][c] = s;
+  __syncthreads();
+  if (slot == 0 && n < N) {
+    const double t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    out[n] = accumulate ? out[n] + (float)t : (float)t;
+  }
 }
 
 // dx = dy * f'(.) for the fused-epilogue activations.  `ref` is the activation OUTPUT for ReLU /
@@ -305,7 +315,7 @@ extern "C" int segmif_colsum_f32(const float* x, float* out, double* workspace, 
   const int nblk = segmif_colsum_blocks(rows);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, workspace, (long long)rows, N, ldx);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, workspace, out, nblk, N,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, workspace, out, nblk, N,
                      accumulate);
   return (int)hipGetLastError();
 }

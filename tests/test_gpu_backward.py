@@ -227,3 +227,138 @@ def test_fused_adamw_matches_torch(ag):
         seen.append(opt.param_groups[0]["lr"])
     assert abs(seen[0] - 1e-2 * 0.1) < 1e-12 and abs(seen[5] - 1e-2 * (1 - 0.5 * 0.9)) < 1e-12
     assert abs(seen[11] - 1e-2 * (1 - 11 / 100)) < 1e-12
+
+
+def _oracle_params(shapes, seed=0):
+    sd = {}
+    for k, v in dw.det_state_dict(shapes, seed=seed).items():
+        is_param = v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))
+        sd[k] = v.double().requires_grad_(True) if is_param else (v.double() if v.dtype.is_floating_point else v)
+    return sd
+
+
+def _compare_param_grads(module, sd, tol=1e-3, skip_prefix=()):
+    worst, checked = ("", 0.0), 0
+    for name, p in module.named_parameters():
+        if name.startswith(skip_prefix):
+            continue
+        ref = sd[name].grad if sd[name].requires_grad else None
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        e = err(p.grad, ref)
+        checked += 1
+        if e > worst[1]:
+            worst = (name, e)
+    assert worst[1] < tol, worst
+    return checked
+
+
+def test_drdb_backward(ag):
+    from segmif_amd.core import Fusion_Network3_ac
+    fus = Fusion_Network3_ac()
+    dw.load_det_weights(fus, seed=0)
+    fus = fus.cuda()
+    sd = _oracle_params(so.fusion_shapes())
+    x = rnd(2, 64, 20, 28, seed=30)
+    g = rnd(2, 64, 20, 28, seed=31)
+    xr = leaf(x, double=True)
+    so.drdb(sd, "DRDB1", xr).backward(g.double())
+    xg = leaf(x, "cuda")
+    fus.DRDB1(xg).backward(g.cuda())
+    assert err(xg.grad, xr.grad) < TOL
+    for i in range(1, 6):
+        assert err(getattr(fus.DRDB1, f"Dcov{i}").weight.grad, sd[f"DRDB1.Dcov{i}.weight"].grad) < TOL, i
+        assert err(getattr(fus.DRDB1, f"Dcov{i}").bias.grad, sd[f"DRDB1.Dcov{i}.bias"].grad) < TOL, i
+    assert err(fus.DRDB1.conv.weight.grad, sd["DRDB1.conv.weight"].grad) < TOL
+    assert err(fus.DRDB1.conv.bias.grad, sd["DRDB1.conv.bias"].grad) < TOL
+
+
+def test_feature_fusion_module_backward(ag):
+    from segmif_amd.core import Fusion_Network3_ac
+    fus = Fusion_Network3_ac()
+    dw.load_det_weights(fus, seed=0)
+    fus = fus.cuda()
+    sd = _oracle_params(so.fusion_shapes())
+    xs = [rnd(2, 64, 12, 16, seed=32 + i) for i in range(3)]
+    g1, g2 = rnd(2, 64, 12, 16, seed=36), rnd(2, 64, 12, 16, seed=37)
+    xr = [leaf(t, double=True) for t in xs]
+    o1, o2 = so.feature_fusion_module(sd, "ffm", *xr)
+    (o1 * g1.double()).sum().add((o2 * g2.double()).sum()).backward()
+    xg = [leaf(t, "cuda") for t in xs]
+    p1, p2 = fus.ffm(*xg)
+    assert err(p1, o1) < TOL and err(p2, o2) < TOL
+    (p1 * g1.cuda()).sum().add((p2 * g2.cuda()).sum()).backward()
+    for a, b in zip(xg, xr):
+        assert err(a.grad, b.grad) < 2e-4
+    n = 0
+    for name, p in fus.ffm.named_parameters():
+        assert err(p.grad, sd["ffm." + name].grad) < 2e-4, name
+        n += 1
+    assert n == 17
+
+
+def test_fusion_network_gradients_match_oracle_autograd(ag):
+    """Fusion_Network3_ac parameter gradients (the tensors train_fusion's optimizer updates) vs the
+    oracle's autograd; ffm2.* must stay without gradient."""
+    from segmif_amd.core import Fusion_Network3_ac
+    B, H, W = 2, 24, 40
+    ir, vis = dw.det_input("g_ir", (B, 1, H, W)), dw.det_input("g_vis", (B, 3, H, W))
+    o1, o2 = rnd(B, 64, H, W, seed=40), rnd(B, 128, H, W, seed=41)
+    g = rnd(B, 1, H, W, seed=42)
+    sd = _oracle_params(so.fusion_shapes())
+    ref = so.fusion_network3_ac(sd, ir.double(), vis.double(), o1.double(), o2.double())
+    (ref * g.double()).sum().backward()
+    fus = Fusion_Network3_ac()
+    dw.load_det_weights(fus, seed=0)
+    fus = fus.cuda()
+    out = fus(ir.cuda(), vis.cuda(), o1.cuda(), o2.cuda())
+    assert err(out, ref) < 1e-4
+    (out * g.cuda()).sum().backward()
+    checked = _compare_param_grads(fus, sd, tol=1e-3)
+    assert checked == 97 - 34  # everything except the unused ffm2.* copy
+    assert all(p.grad is None for n, p in fus.named_parameters() if n.startswith("ffm2."))
+
+
+def test_fusion_training_loss_through_seg_net(ag):
+    """The round>=2 objective of train_fusion (train.py:363-374) without its host-side weighting:
+    CE(seg(YCrCb2RGB([fusion, Cr, Cb])), labels) + MSE(fusion, mask) back-propagated into the fusion
+    net through the (frozen-in-effect) segmentation net, vs the oracle's autograd."""
+    from segmif_amd.core import Fusion_Network3_ac, Network3, YCrCb2RGB
+    B, H, W = 1, 64, 96
+    ir, vis = dw.det_input("l_ir", (B, 1, H, W)), dw.det_input("l_vis", (B, 3, H, W))
+    mask = dw.det_input("l_mask", (B, 1, H, W))
+    labels = dw.det_labels("l_y", (B, H, W), 9)
+    sd_f = _oracle_params(so.fusion_shapes())
+    sd_s = {k: (v.double() if v.dtype.is_floating_point else v)
+            for k, v in dw.det_state_dict(so.network3_shapes("mit_b1", 9), seed=0).items()}
+    with torch.no_grad():
+        o0, o1 = so.mit_forward_fusion(sd_s, "denoise_net.encoder.", mask.repeat(1, 3, 1, 1).double(), "mit_b1")
+    ycc = so.rgb2ycrcb(vis.double())
+
+    def objective(fusion, seg_fn, rgb_fn):
+        rgb = rgb_fn(torch.cat((fusion, ycc_dev[:, 1:2], ycc_dev[:, 2:3]), dim=1))
+        return seg_fn(rgb) + ((fusion - mask_dev) ** 2).mean()
+
+    ycc_dev, mask_dev = ycc, mask.double()
+    f_ref = so.fusion_network3_ac(sd_f, ir.double(), ycc, o0, o1)
+    seg_ref = lambda rgb: F.cross_entropy(
+        F.interpolate(so.network3_forward(sd_s, rgb, "mit_b1"), size=[H, W], mode="bilinear", align_corners=False), labels)
+    l_ref = objective(f_ref, seg_ref, so.ycrcb2rgb)
+    l_ref.backward()
+
+    seg = Network3("mit_b1", 9, pretrained=None)
+    fus = Fusion_Network3_ac()
+    dw.load_det_weights(seg, seed=0)
+    dw.load_det_weights(fus, seed=0)
+    seg, fus = seg.cuda().eval(), fus.cuda()
+    ycc_dev, mask_dev = ycc.float().cuda(), mask.cuda()
+    with torch.no_grad():
+        g0, g1 = seg.denoise_net.encoder.forward_fusion(mask.repeat(1, 3, 1, 1).cuda())
+    f_hip = fus(ir.cuda(), ycc_dev, g0, g1)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+    l_hip = objective(f_hip, lambda rgb: seg._loss(rgb, labels.cuda(), crit), YCrCb2RGB)
+    assert abs(float(l_hip.detach()) - float(l_ref.detach())) / abs(float(l_ref.detach())) < 1e-4
+    l_hip.backward()
+    assert _compare_param_grads(fus, sd_f, tol=2e-3) == 63
