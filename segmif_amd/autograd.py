@@ -456,14 +456,14 @@ class KvContextFn(torch.autograd.Function):
         ctx.save_for_backward(y, wkv)
         part = ops.linattn_kvpartial(y, wkv.contiguous())
         B = y.shape[0]
-        return part.sum(1).float().view(B, 8, 8, 8)
+        return part.sum(1).view(B, 8, 8, 8)  # fp64: these logits feed a saturated softmax
 
     @staticmethod
     def backward(ctx, dctx):
         y, wkv = ctx.saved_tensors
         B, n, C = y.shape
         kv = ops.linear(y, wkv.contiguous(), 2 * C)  # (B, n, 128)
-        dctx = dctx.contiguous()
+        dctx = dctx.float().contiguous()
         # dk = v @ D1^T-form, dv = k @ D2^T-form with block-diagonal (B, 64, 64) weights [out][in]
         wk = torch.zeros((B, C, C), device=y.device, dtype=torch.float32)
         wv = torch.zeros((B, C, C), device=y.device, dtype=torch.float32)

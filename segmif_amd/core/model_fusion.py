@@ -234,11 +234,11 @@ class CrossPath(nn.Module):
         for i, (x, ui, ctx_i) in enumerate(((x1, u[0], ctx1), (x2, u[1], ctx2)), start=1):
             end = getattr(self, f"end_proj{i}")
             B = x.shape[0]
-            wz = end.weight[:, :C].reshape(C, heads, d)  # [n][h][j]
-            wv = end.weight[:, C:].reshape(C, heads, d)
+            wz = end.weight[:, :C].reshape(C, heads, d).double()  # [n][h][j]; contexts are fp64
+            wv = end.weight[:, C:].reshape(C, heads, d).double()
             # Weff[b][n][h*d+i] = sum_j ctx[b][h][i][j] * Wend[n][ofs + h*d + j]
             weff = torch.cat((torch.einsum("bhij,nhj->bnhi", ctx_i, wz).reshape(B, C, C),
-                              torch.einsum("bhij,nhj->bnhi", ctx3, wv).reshape(B, C, C)), dim=-1)
+                              torch.einsum("bhij,nhj->bnhi", ctx3, wv).reshape(B, C, C)), dim=-1).float()
             a = torch.cat((y[2], ui), dim=-1)
             t = x + ag.batched_linear(a, weff, end.bias)
             norm = getattr(self, f"norm{i}")

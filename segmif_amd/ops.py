@@ -323,6 +323,8 @@ def to_nhwc(x):
     p = x.permute(0, 2, 3, 1)
     if p.is_contiguous():
         return p
+    if torch.is_grad_enabled() and x.requires_grad:
+        return p.contiguous()  # keep the layout change inside the autograd graph
     x = x.contiguous()
     out = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
     _lib.check(_lib.load().segmif_nchw_to_nhwc_f32(x.data_ptr(), out.data_ptr(), B, C, H * W, C, _stream()),

@@ -58,3 +58,59 @@ def test_shard_partition_properties():
             parts = [list(shard(n, r, w)) for r in range(w)]
             assert sum(parts, []) == list(range(n))
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def _dp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from segmif_amd import dist as sdist
+    from segmif_amd.parallel import GradAllReducer, allreduce_scalar_mean
+    sdist.init(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    dead = torch.nn.Linear(4, 4)  # never used: its grads stay None on every rank (SURVEY F7 analogue)
+    params = list(net.parameters()) + list(dead.parameters())
+    red = GradAllReducer(params, bucket_mb=0.0002)  # tiny buckets: several collectives per step
+    full_x = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
+    full_y = torch.arange(8 * 3, dtype=torch.float32).reshape(8, 3) / 7.0
+    mine = slice(rank * 4, rank * 4 + 4)
+    out = []
+    for step in range(3):  # step 0 = discovery (no overlap), steps 1-2 = hook-driven overlapped buckets
+        for p in params:
+            p.grad = None
+        loss = ((net(full_x[mine]) - full_y[mine]) ** 2).mean()
+        loss.backward()
+        red.finish()
+        out.append([p.grad.clone() if p.grad is not None else None for p in params])
+    mean_loss = allreduce_scalar_mean(float(loss))
+    q.put((rank, out, mean_loss, len(red._buckets)))
+    sdist.shutdown()
+
+
+def test_data_parallel_gradient_allreduce_matches_full_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process reference on the full batch of 8
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    x = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
+    y = torch.arange(8 * 3, dtype=torch.float32).reshape(8, 3) / 7.0
+    ((net(x) - y) ** 2).mean().backward()
+    ref = [p.grad for p in net.parameters()]
+    assert res[0][3] > 1  # really bucketed
+    for rank in range(world):
+        for step in range(3):
+            grads = res[rank][1][step]
+            for g, r in zip(grads[:4], ref):
+                assert torch.allclose(g, r, atol=1e-6), (rank, step)
+            assert grads[4] is None and grads[5] is None  # unused parameters stay grad-less
+    assert abs(res[0][2] - res[1][2]) < 1e-12

@@ -237,11 +237,12 @@ def _oracle_params(shapes, seed=0):
     return sd
 
 
-def _compare_param_grads(module, sd, tol=1e-3, skip_prefix=()):
-    worst, checked = ("", 0.0), 0
+def _compare_param_grads(module, sd, tol=1e-3, sd32=None):
+    """Every parameter gradient vs the fp64 oracle.  A gradient may exceed `tol` only if the oracle
+    evaluated in the reference's own precision (fp32, `sd32`) deviates from fp64 comparably — i.e.
+    the quantity is ill-conditioned (gradients through the saturated 8x8 context softmax), not wrong."""
+    bad, checked = [], 0
     for name, p in module.named_parameters():
-        if name.startswith(skip_prefix):
-            continue
         ref = sd[name].grad if sd[name].requires_grad else None
         if ref is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
@@ -249,10 +250,20 @@ def _compare_param_grads(module, sd, tol=1e-3, skip_prefix=()):
         assert p.grad is not None, name
         e = err(p.grad, ref)
         checked += 1
-        if e > worst[1]:
-            worst = (name, e)
-    assert worst[1] < tol, worst
+        if e >= tol:
+            e32 = err(sd32[name].grad, ref) if sd32 is not None else 0.0
+            if e > 4 * e32:
+                bad.append((name, e, e32, float(ref.abs().max())))
+    assert not bad, bad
     return checked
+
+
+def _oracle_params32(shapes, seed=0):
+    sd = {}
+    for k, v in dw.det_state_dict(shapes, seed=seed).items():
+        is_param = v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))
+        sd[k] = v.clone().requires_grad_(True) if is_param else v
+    return sd
 
 
 def test_drdb_backward(ag):
@@ -317,7 +328,7 @@ def test_fusion_network_gradients_match_oracle_autograd(ag):
     assert err(out, ref) < 1e-4
     (out * g.cuda()).sum().backward()
     checked = _compare_param_grads(fus, sd, tol=1e-3)
-    assert checked == 97 - 34  # everything except the unused ffm2.* copy
+    assert checked == 97 - 17  # everything except the unused ffm2.* copy (17 tensors)
     assert all(p.grad is None for n, p in fus.named_parameters() if n.startswith("ffm2."))
 
 
@@ -347,6 +358,14 @@ def test_fusion_training_loss_through_seg_net(ag):
         F.interpolate(so.network3_forward(sd_s, rgb, "mit_b1"), size=[H, W], mode="bilinear", align_corners=False), labels)
     l_ref = objective(f_ref, seg_ref, so.ycrcb2rgb)
     l_ref.backward()
+    # the same objective in the reference's own precision (fp32) — the conditioning yardstick
+    sd_f32 = _oracle_params32(so.fusion_shapes())
+    sd_s32 = dw.det_state_dict(so.network3_shapes("mit_b1", 9), seed=0)
+    ycc_dev, mask_dev = ycc.float(), mask
+    f32 = so.fusion_network3_ac(sd_f32, ir, ycc.float(), o0.float(), o1.float())
+    seg32 = lambda rgb: F.cross_entropy(
+        F.interpolate(so.network3_forward(sd_s32, rgb, "mit_b1"), size=[H, W], mode="bilinear", align_corners=False), labels)
+    objective(f32, seg32, so.ycrcb2rgb).backward()
 
     seg = Network3("mit_b1", 9, pretrained=None)
     fus = Fusion_Network3_ac()
@@ -361,4 +380,4 @@ def test_fusion_training_loss_through_seg_net(ag):
     l_hip = objective(f_hip, lambda rgb: seg._loss(rgb, labels.cuda(), crit), YCrCb2RGB)
     assert abs(float(l_hip.detach()) - float(l_ref.detach())) / abs(float(l_ref.detach())) < 1e-4
     l_hip.backward()
-    assert _compare_param_grads(fus, sd_f, tol=2e-3) == 63
+    assert _compare_param_grads(fus, sd_f, tol=2e-3, sd32=sd_f32) == 80
