@@ -1,0 +1,49 @@
+"""Fusion losses used by the reference's train_fusion (core/loss.py:459-476 Fusionloss3, :506-517
+Fusionloss_grad3, :634-650 Sobelxy; pytorch_ssim/__init__.py:8-43).
+
+STATUS: these are SURVEY §8(f) N1 ("next"): they run on stock torch-ROCm ops, not on hand-written HIP
+kernels yet.  They act on (B,1,H,W) images only (a few MB), next to ~2.3 TFLOP per pair in the
+networks, and are kept here so that the full training step can be assembled and timed.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _gaussian_window(size=11, sigma=1.5, device=None, dtype=torch.float32):
+    g = torch.tensor([math.exp(-(x - size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(size)], dtype=dtype)
+    g = g / g.sum()
+    return (g[:, None] @ g[None, :]).to(device)[None, None]
+
+
+def ssim(img1, img2, window_size=11):
+    """Gaussian-window SSIM averaged over the image (single channel per group)."""
+    C = img1.shape[1]
+    w = _gaussian_window(window_size, 1.5, img1.device, img1.dtype).expand(C, 1, window_size, window_size).contiguous()
+    pad = window_size // 2
+    blur = lambda t: F.conv2d(t, w, padding=pad, groups=C)
+    mu1, mu2 = blur(img1), blur(img2)
+    s11 = blur(img1 * img1) - mu1 * mu1
+    s22 = blur(img2 * img2) - mu2 * mu2
+    s12 = blur(img1 * img2) - mu1 * mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2))).mean()
+
+
+def fusion_loss_grad3(generate_img, mask):
+    """MSE(mask_0, fused) + 1.1 * (1 - SSIM(fused, mask_0))  — the round >= 2 intensity term."""
+    m = mask[:, :1]
+    return F.mse_loss(m, generate_img) + 1.1 * (1 - ssim(generate_img, m))
+
+
+def sobel_xy(x):
+    kx = x.new_tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]])[None, None]
+    ky = x.new_tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]])[None, None]
+    return F.conv2d(x, kx, padding=1).abs() + F.conv2d(x, ky, padding=1).abs()
+
+
+def fusion_loss3(generate_img, mask):
+    """L1(mask_0, fused) + L1(Sobel(mask_0), Sobel(fused))  — the round-1 objective."""
+    m = mask[:, :1]
+    return F.l1_loss(m, generate_img) + F.l1_loss(sobel_xy(m), sobel_xy(generate_img))

@@ -1,0 +1,65 @@
+"""The two training steps of the reference's train.py as functions over the HIP modules.
+
+  seg_train_step     train.py:217-227   forward, x4 bilinear + CE(ignore 255), backward, PolyWarmupAdamW_seg
+  fusion_train_step  train.py:351-385   no-grad forward_fusion, fusion net, intensity loss + CE through the
+                                         segmentation net, backward, PolyWarmupAdamW on the fusion net only
+
+Data parallelism (one process per GPU): pass a segmif_amd.parallel.GradAllReducer; gradients are
+averaged over ranks in overlapped buckets before the optimizer step, and the two scalar losses that
+feed train.py:369-374's dynamic weights are averaged too so every rank applies identical weights.
+"""
+import torch
+
+from . import losses
+from .core.model_fusion import RGB2YCrCb, YCrCb2RGB
+from .parallel import allreduce_scalar_mean
+
+
+def seg_train_step(seg_net, optimizer, images, labels, criterion, reducer=None):
+    optimizer.zero_grad(set_to_none=True)
+    loss = seg_net._loss(images, labels, criterion)
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+    optimizer.step()
+    return loss.detach()
+
+
+class FusionTrainer:
+    """State of train_fusion's inner loop: the loss history behind its dynamic weights."""
+
+    def __init__(self, seg_net, fusion_net, optimizer, criterion, iter_=2, reducer=None):
+        self.seg, self.fus, self.opt, self.crit = seg_net, fusion_net, optimizer, criterion
+        self.iter_ = iter_
+        self.reducer = reducer
+        self.history = []  # (loss1, loss2) per step, rank-averaged
+
+    def step(self, ir3, vis3, mask3, labels, sync_loss_history=True):
+        ir = ir3[:, 0:1]
+        vis = RGB2YCrCb(vis3)
+        with torch.no_grad():
+            out0, out1 = self.seg.denoise_net.encoder.forward_fusion(mask3)
+        fusion = self.fus(ir, vis, out0, out1)
+        self.opt.zero_grad(set_to_none=True)
+        if self.iter_ > 1:
+            loss1 = losses.fusion_loss_grad3(fusion, mask3)
+            fused_rgb = YCrCb2RGB(torch.cat((fusion, vis[:, 1:2], vis[:, 2:3]), dim=1))
+            loss2 = self.seg._loss(fused_rgb, labels, self.crit)
+            w0 = w1 = 1.0
+            n = len(self.history)
+            if sync_loss_history:  # the reference's .item() host syncs (train.py:370-371, 377-378)
+                self.history.append((allreduce_scalar_mean(float(loss1.detach())),
+                                     allreduce_scalar_mean(float(loss2.detach()))))
+                if n > 10:
+                    r = torch.tensor([self.history[n - 1][0] / self.history[n - 2][0],
+                                      self.history[n - 1][1] / self.history[n - 2][1]])
+                    bw = 2 * torch.softmax(r / 1000.0, dim=-1)
+                    w0, w1 = float(bw[0]), float(bw[1])
+            loss = w0 * loss1 * (0.4 / self.iter_) + w1 * loss2 * 0.8
+        else:
+            loss = losses.fusion_loss3(fusion, mask3)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.opt.step()
+        return loss.detach()

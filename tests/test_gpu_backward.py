@@ -251,8 +251,11 @@ def _compare_param_grads(module, sd, tol=1e-3, sd32=None):
         e = err(p.grad, ref)
         checked += 1
         if e >= tol:
+            # ill-conditioned tensors: when the reference's own fp32 evaluation is already outside `tol`
+            # of fp64 (roundoff amplified ~1e5x by a softmax with 1-p ~ 1e-5), only the order of magnitude
+            # of the deviation is comparable between two fp32 implementations
             e32 = err(sd32[name].grad, ref) if sd32 is not None else 0.0
-            if e > 4 * e32:
+            if not (e32 >= tol and e <= 10 * e32):
                 bad.append((name, e, e32, float(ref.abs().max())))
     assert not bad, bad
     return checked
