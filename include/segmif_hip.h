@@ -233,6 +233,11 @@ int segmif_softmax_ce_f32(const float* logits, const int64_t* labels, float* dlo
 int segmif_conv_dgrad_strided_f32(const float* dy, const float* wd, float* dx, int B, int H, int W, int Cin, int N,
                                   int KH, int KW, int stride, int pad, int OH, int OW, int lddy, int lddx, void* stream);
 
+/* 11-tap separable Gaussian blur, zero padded, over (planes, H, W): the SSIM window of
+ * pytorch_ssim/__init__.py:8-43 (five of these per SSIM evaluation; self-adjoint, so also its backward).
+ * taps11 is a HOST pointer to the 11 window weights. */
+int segmif_gauss_blur11_f32(const float* x, float* y, int planes, int H, int W, const float* taps11, void* stream);
+
 /* multi-tensor AdamW (utils/optimizer.py:6 -> torch.optim.AdamW arithmetic). table: device array of
  * {float* p; const float* g; float* m; float* v; int64 n; float lr; float wd;} entries
  * (segmif_adamw_entry_bytes() each); chunk_entry / chunk_off map each block to (entry, offset). */

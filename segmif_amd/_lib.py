@@ -69,6 +69,7 @@ SIGNATURES = {
     "segmif_softmax_ce_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                       c_void_p]),
     "segmif_conv_dgrad_strided_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
+    "segmif_gauss_blur11_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p]),
     "segmif_adamw_entry_bytes": (c_int, []),
     "segmif_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]),
     "segmif_seg_normalize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -105,6 +106,21 @@ def load():
     return lib
 
 
+_SYNC_DEBUG = bool(os.environ.get("SEGMIF_SYNC_DEBUG"))
+_TRACE = bool(os.environ.get("SEGMIF_TRACE"))
+_trace_n = [0]
+
+
 def check(code, what):
     if code != 0:
         raise RuntimeError(f"{what} failed with code {code}")
+    if _TRACE:
+        import sys
+        _trace_n[0] += 1
+        print(f"[segmif {_trace_n[0]}] {what}", file=sys.stderr, flush=True)
+    if _SYNC_DEBUG:  # debugging aid: localise an asynchronous GPU fault to the launch that caused it
+        import sys
+        import torch
+        print(f"[segmif] {what} ...", end="", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        print(" ok", file=sys.stderr, flush=True)

@@ -479,6 +479,38 @@ class KvContextFn(torch.autograd.Function):
         return dy, dw
 
 
+class GaussBlurFn(torch.autograd.Function):
+    """11x11 Gaussian "same" blur (sigma 1.5) of (B, C, H, W) images; symmetric => backward = blur."""
+
+    _taps = None
+
+    @staticmethod
+    def taps():
+        if GaussBlurFn._taps is None:
+            import math
+            g = torch.tensor([math.exp(-(x - 5) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)])
+            g = (g / g.sum()).tolist()
+            GaussBlurFn._taps = (ctypes.c_float * 11)(*g)
+        return GaussBlurFn._taps
+
+    @staticmethod
+    def _run(x):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        _lib.check(_lib.load().segmif_gauss_blur11_f32(x.data_ptr(), y.data_ptr(), B * C, H, W, GaussBlurFn.taps(),
+                                                       _stream()), "segmif_gauss_blur11_f32")
+        return y
+
+    @staticmethod
+    def forward(ctx, x):
+        return GaussBlurFn._run(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return GaussBlurFn._run(g)
+
+
 # functional front-ends ------------------------------------------------------------------------------
 def linear(x, w, b=None, act=ACT_NONE, slope=None):
     return LinearFn.apply(x, w, b, act, slope)
@@ -518,3 +550,7 @@ def batched_linear(x, w, bias=None):
 
 def kv_context(y, wkv):
     return KvContextFn.apply(y, wkv)
+
+
+def gauss_blur11(x):
+    return GaussBlurFn.apply(x)

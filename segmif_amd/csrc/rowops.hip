@@ -232,6 +232,49 @@ __global__ __launch_bounds__(256) void fuse_ycrcb_kernel(const float* __restrict
   out[(b * 3 + 2) * HW + p] = fminf(fmaxf(bl, 0.f), 1.f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 11-tap separable Gaussian blur with zero padding over (planes, H, W) images: the window of
+// pytorch_ssim (pytorch_ssim/__init__.py:8-17; an outer product, so the 2-D "same" convolution
+// factorises exactly).  32x32 output tile, (32+10)^2 halo in LDS, row pass then column pass.
+// The operator is symmetric, so the same kernel is its own adjoint (SSIM backward).
+// ---------------------------------------------------------------------------------------------
+struct GaussTaps {
+  float g[11];
+};
+
+__global__ __launch_bounds__(256) void gauss_blur11_kernel(const float* __restrict__ x, float* __restrict__ y, int H,
+                                                           int W, GaussTaps taps) {
+  __shared__ float tile[42][43];
+  __shared__ float rowp[42][33];
+  const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+  const float* xp = x + (long long)blockIdx.z * H * W;
+  float* yp = y + (long long)blockIdx.z * H * W;
+  for (int i = threadIdx.x; i < 42 * 42; i += 256) {
+    const int r = i / 42, c = i - r * 42;
+    const int gy = ty0 - 5 + r, gx = tx0 - 5 + c;
+    tile[r][c] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? xp[(long long)gy * W + gx] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 42 * 32; i += 256) {
+    const int r = i >> 5, c = i & 31;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 11; ++t) s = fmaf(taps.g[t], tile[r][c + t], s);
+    rowp[r][c] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+    const int r = i >> 5, c = i & 31;
+    const int gy = ty0 + r, gx = tx0 + c;
+    if (gy < H && gx < W) {
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < 11; ++t) s = fmaf(taps.g[t], rowp[r + t][c], s);
+      yp[(long long)gy * W + gx] = s;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x, int32_t* __restrict__ labels,
                                                      long long rows, int C, int ldx) {
   const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -330,5 +373,15 @@ extern "C" int segmif_argmax_nhwc_i32(const float* x, int32_t* labels, int64_t r
   if (!x || !labels || rows <= 0 || C <= 0 || ldx < C) return SEGMIF_EINVAL;
   hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, labels,
                      (long long)rows, C, ldx);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_gauss_blur11_f32(const float* x, float* y, int planes, int H, int W, const float* taps11,
+                                       void* stream) {
+  if (!x || !y || !taps11 || planes <= 0 || H <= 0 || W <= 0) return SEGMIF_EINVAL;
+  GaussTaps t;
+  for (int i = 0; i < 11; ++i) t.g[i] = taps11[i];  // host pointer: 11 window weights
+  dim3 grid((unsigned)((W + 31) / 32), (unsigned)((H + 31) / 32), (unsigned)planes);
+  hipLaunchKernelGGL(gauss_blur11_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, H, W, t);
   return (int)hipGetLastError();
 }

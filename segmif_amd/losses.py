@@ -1,8 +1,9 @@
 """Fusion losses used by the reference's train_fusion (core/loss.py:459-476 Fusionloss3, :506-517
 Fusionloss_grad3, :634-650 Sobelxy; pytorch_ssim/__init__.py:8-43).
 
-STATUS: these are SURVEY §8(f) N1 ("next"): they run on stock torch-ROCm ops, not on hand-written HIP
-kernels yet.  They act on (B,1,H,W) images only (a few MB), next to ~2.3 TFLOP per pair in the
+STATUS: SURVEY §8(f) N1 ("next"), partly done: SSIM's five 11x11 Gaussian window convolutions and their
+backward run in a HIP kernel (csrc/rowops.hip: gauss_blur11); the remaining pointwise arithmetic and
+the Sobel loss are stock torch-ROCm ops.  They act on (B,1,H,W) images only (a few MB), next to ~2.3 TFLOP per pair in the
 networks, and are kept here so that the full training step can be assembled and timed.
 """
 import math
@@ -18,11 +19,16 @@ def _gaussian_window(size=11, sigma=1.5, device=None, dtype=torch.float32):
 
 
 def ssim(img1, img2, window_size=11):
-    """Gaussian-window SSIM averaged over the image (single channel per group)."""
+    """Gaussian-window SSIM averaged over the image (single channel per group).  On the GPU the five
+    window convolutions (and their backward) run in the separable HIP blur kernel."""
     C = img1.shape[1]
-    w = _gaussian_window(window_size, 1.5, img1.device, img1.dtype).expand(C, 1, window_size, window_size).contiguous()
-    pad = window_size // 2
-    blur = lambda t: F.conv2d(t, w, padding=pad, groups=C)
+    if img1.is_cuda and window_size == 11 and img1.dtype == torch.float32:
+        from . import autograd as ag
+        blur = ag.gauss_blur11
+    else:
+        w = _gaussian_window(window_size, 1.5, img1.device, img1.dtype).expand(C, 1, window_size, window_size).contiguous()
+        pad = window_size // 2
+        blur = lambda t: F.conv2d(t, w, padding=pad, groups=C)
     mu1, mu2 = blur(img1), blur(img2)
     s11 = blur(img1 * img1) - mu1 * mu1
     s22 = blur(img2 * img2) - mu2 * mu2

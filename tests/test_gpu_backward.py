@@ -384,3 +384,18 @@ def test_fusion_training_loss_through_seg_net(ag):
     assert abs(float(l_hip.detach()) - float(l_ref.detach())) / abs(float(l_ref.detach())) < 1e-4
     l_hip.backward()
     assert _compare_param_grads(fus, sd_f, tol=2e-3, sd32=sd_f32) == 80
+
+
+def test_ssim_loss_matches_reference_formula(ag):
+    """segmif_amd.losses.ssim (HIP separable blur, fwd + bwd) vs the reference's conv2d formulation
+    (pytorch_ssim/__init__.py:19-43) in fp64 on the CPU."""
+    from segmif_amd import losses
+    a, b = rnd(2, 1, 37, 53, seed=50, lo=0, hi=1), rnd(2, 1, 37, 53, seed=51, lo=0, hi=1)
+    ar = leaf(a, double=True)
+    ref = losses.ssim(ar, b.double())
+    ref.backward()
+    ag_ = leaf(a, "cuda")
+    got = losses.ssim(ag_, b.cuda())
+    got.backward()
+    assert abs(float(got.detach()) - float(ref.detach())) < 1e-5
+    assert err(ag_.grad, ar.grad) < 1e-4
