@@ -108,7 +108,8 @@ int segmif_pack_conv_weight(const float* src_oihw, float* dst, int N, int Cin, i
  */
 int64_t segmif_wgrad_workspace_size(int64_t M, int N, int K);
 int segmif_wgrad_f32(const SegmifIgemm* desc, const float* dy, int ldy, int64_t dy_zstride, float* dw,
-                     int64_t dw_sn, int64_t dw_sk, float* workspace, int accumulate, void* stream);
+                     int64_t dw_sn, int64_t dw_sk, float* dbias /* optional [N]: sum_m dY, fused */,
+                     float* workspace, int accumulate, void* stream);
 /* column sums of a rows x N matrix (bias gradients), two-pass, fp64 accumulation.
  * workspace: segmif_colsum_blocks(rows) * N doubles. */
 int segmif_colsum_blocks(int64_t rows);

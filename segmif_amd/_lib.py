@@ -39,7 +39,7 @@ SIGNATURES = {
     "segmif_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "segmif_wgrad_workspace_size": (c_int64, [c_int64, c_int, c_int]),
     "segmif_wgrad_f32": (c_int, [POINTER(SegmifIgemm), c_void_p, c_int, c_int64, c_void_p, c_int64, c_int64, c_void_p,
-                                 c_int, c_void_p]),
+                                 c_void_p, c_int, c_void_p]),
     "segmif_colsum_blocks": (c_int, [c_int64]),
     "segmif_colsum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "segmif_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,

@@ -40,17 +40,22 @@ def act_bwd(dy, ref, act, slope=None):
     return dx
 
 
-def _wgrad(desc, dy, ldy, dw, dy_zstride=0, sn=0, sk=1, nz=1):
+def _wgrad(desc, dy, ldy, dw, dy_zstride=0, sn=0, sk=1, nz=1, db=None):
     lib = _lib.load()
     ws = torch.empty((lib.segmif_wgrad_workspace_size(desc.M, desc.N, desc.K) * max(nz, 1),), device=dw.device,
                      dtype=torch.float32)
     _lib.check(lib.segmif_wgrad_f32(ctypes.byref(desc), dy.data_ptr(), ldy, dy_zstride, dw.data_ptr(), sn, sk,
-                                    ws.data_ptr(), 0, _stream()), "segmif_wgrad_f32")
+                                    db.data_ptr() if db is not None else None, ws.data_ptr(), 0, _stream()),
+               "segmif_wgrad_f32")
     return dw
 
 
-def linear_wgrad(x, dy, N):
-    """dW (N, K) = dy^T x.  x: rows view (..., K); dy: rows view (..., N)."""
+def _bias_out(want, N, like):
+    return torch.empty((N,), device=like.device, dtype=torch.float32) if want else None
+
+
+def linear_wgrad(x, dy, N, want_bias=False):
+    """dW (N, K) = dy^T x (and db = column sums of dy, fused).  x: rows view (..., K); dy: rows view (..., N)."""
     rows, K, lda = rows_view(x, "x")
     rows2, n2, ldy = rows_view(dy, "dy")
     assert rows == rows2 and n2 == N
@@ -61,11 +66,13 @@ def linear_wgrad(x, dy, N):
     d.Cin = K
     d.KH = d.KW = d.stride = d.dil = 1
     dw = torch.empty((N, K), device=x.device, dtype=torch.float32)
-    return _wgrad(d, dy, ldy, dw, sn=K, sk=1)
+    db = _bias_out(want_bias, N, x)
+    _wgrad(d, dy, ldy, dw, sn=K, sk=1, db=db)
+    return (dw, db) if want_bias else dw
 
 
-def conv_wgrad(x, dy, w_shape, k, stride, pad, dil):
-    """dW in OIHW. x: (B,H,W,Cin) rows view; dy: (B,OH,OW,N) rows view."""
+def conv_wgrad(x, dy, w_shape, k, stride, pad, dil, want_bias=False):
+    """dW in OIHW (and db, fused). x: (B,H,W,Cin) rows view; dy: (B,OH,OW,N) rows view."""
     N, cin = w_shape[0], w_shape[1]
     B, H, W, _ = x.shape
     _, _, lda = rows_view(x, "x")
@@ -76,7 +83,9 @@ def conv_wgrad(x, dy, w_shape, k, stride, pad, dil):
     d.H, d.W, d.Cin, d.KH, d.KW = H, W, cin, k, k
     d.stride, d.pad, d.dil, d.OH, d.OW = stride, pad, dil, dy.shape[1], dy.shape[2]
     dw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
-    return _wgrad(d, dy, ldy, dw)
+    db = _bias_out(want_bias, N, x)
+    _wgrad(d, dy, ldy, dw, db=db)
+    return (dw, db) if want_bias else dw
 
 
 def _slope_grad(dy, y, slope):
@@ -121,9 +130,12 @@ class LinearFn(torch.autograd.Function):
             wtT = w2.t().contiguous()  # (K, N): "weights" of the input-gradient GEMM
             wtT = wtT if N % 16 == 0 else ops.pack_weight(wtT)
             dx = ops.linear(dz, wtT, K)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = linear_wgrad(x, dz, N).reshape(w.shape)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            r = linear_wgrad(x, dz, N, want_bias=want_b)
+            dw, db = (r if want_b else (r, None))
+            dw = dw.reshape(w.shape)
+        elif want_b:
             db = colsum(dz)
         return dx, dw, db, None, dslope
 
@@ -166,9 +178,11 @@ class ConvFn(torch.autograd.Function):
                 _lib.check(_lib.load().segmif_conv_dgrad_strided_f32(
                     dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, H, W, cin, N, k, k, stride, pad, dz.shape[1],
                     dz.shape[2], N, cin, _stream()), "segmif_conv_dgrad_strided_f32")
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(x, dz, w.shape, k, stride, pad, dil)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            r = conv_wgrad(x, dz, w.shape, k, stride, pad, dil, want_bias=want_b)
+            dw, db = (r if want_b else (r, None))
+        elif want_b:
             db = colsum(dz)
         return dx, dw, db, None, None, None, None, None, dslope
 
@@ -325,7 +339,7 @@ class SrAttentionFn(torch.autograd.Function):
                 out = dkv.data_ptr() + 4 * (col0 + hh * hd)
                 # element (n = d, k = key) -> dkv[b][key][col0 + hh*hd + d]
                 _lib.check(lib.segmif_wgrad_f32(ctypes.byref(d), src.data_ptr() + 4 * hh * hd, C, N * C, out, 1,
-                                                2 * C, ws.data_ptr(), 0, _stream()), "segmif_wgrad_f32")
+                                                2 * C, None, ws.data_ptr(), 0, _stream()), "segmif_wgrad_f32")
         return dq, dkv[:, :Nk], None, None
 
 
@@ -393,15 +407,14 @@ class DRDBFn(torch.autograd.Function):
         w6t = w6.t().contiguous()  # (total, C0): input-gradient weights, rows = concat channels
         ops.linear(dz6, w6t[:C0].contiguous(), C0, res=dout, out=dbuf[..., :C0])  # + residual path
         ops.linear(dz6, w6t[C0:].contiguous(), total - C0, out=dbuf[..., C0:])
-        grads[10] = linear_wgrad(buf, dz6, C0).reshape(params[10].shape)
-        grads[11] = colsum(dz6)
+        g10, grads[11] = linear_wgrad(buf, dz6, C0, want_bias=True)
+        grads[10] = g10.reshape(params[10].shape)
         del dz6
         ch = total - growth
         for i in range(4, -1, -1):
             w = params[2 * i]
             dy = act_bwd(dbuf[..., ch:ch + growth], buf[..., ch:ch + growth], ACT_RELU)
-            grads[2 * i] = conv_wgrad(buf[..., :ch], dy, w.shape, 3, 1, 2, 2)
-            grads[2 * i + 1] = colsum(dy)
+            grads[2 * i], grads[2 * i + 1] = conv_wgrad(buf[..., :ch], dy, w.shape, 3, 1, 2, 2, want_bias=True)
             wr = w.flip(2, 3).transpose(0, 1).contiguous()
             ops.conv2d(dy, ops.pack_weight(wr), ch, 3, pad=2, dil=2, res=dbuf[..., :ch], out=dbuf[..., :ch])
             ch -= growth

@@ -37,6 +37,7 @@ struct WgradK {
   long long rows_per_chunk;
   int nkt, nnt, chunks;
   long long in_zs, dy_zs;  // batch strides (gridDim.z = batches * chunks)
+  float* bias_partial;  // optional [batch][chunk][N]: column sums of dY (bias gradient), k-tile 0 blocks only
 };
 
 template <int NT, int KT>
@@ -62,6 +63,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   // loaders: dY tile MR x BN, X tile MR x BK, 16 B per thread per unit
   constexpr int YUPR = BN / 4, XUPR = BK / 4;
   f32x4 ry[YU], rx[XU];
+  f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};  // this thread's column quad of sum_m dY (every tile is loaded once)
+  const bool want_bias = p.bias_partial != nullptr && kt == 0;
   auto gload = [&](long long m0) {
 #pragma unroll
     for (int j = 0; j < YU; ++j) {
@@ -78,6 +81,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
             if (n0 + q + e < p.N) ry[j][e] = src[e];
         }
       }
+      if (want_bias) bsum += ry[j];
     }
 #pragma unroll
     for (int j = 0; j < XU; ++j) {
@@ -148,6 +152,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     if (t + 1 < ntiles) sstore(cur ^ 1);
     __syncthreads();
   }
+  if (want_bias) {  // combine the 256 / YUPR threads that share a column quad (Ys is free now)
+    f32x4* red = reinterpret_cast<f32x4*>(&Ys[0][0]);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < YUPR) {
+      f32x4 sacc = red[tid];
+      for (int i = 1; i < 256 / YUPR; ++i) sacc += red[tid + i * YUPR];
+      float* bo = p.bias_partial + (long long)blockIdx.z * p.N;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n0 + tid * 4 + e < p.N) bo[n0 + tid * 4 + e] = sacc[e];
+    }
+  }
   // D[i = n][j = k]: lane holds column k = r, rows n = (v&3) + 8*(v>>2) + 4*h
   float* out = p.partial + (long long)blockIdx.z * p.N * p.Kp;  // [batch][chunk][N][Kp]
   const int k = k0 + wk * 32 + r;
@@ -183,6 +200,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
   dst += zb * dw_zs;
   dw[dst] = accumulate ? dw[dst] + (float)s : (float)s;
+}
+
+__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ db,
+                                                                int chunks, int nz, int N, int accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  double s = 0.0;
+  for (int c = 0; c < chunks * nz; ++c) s += (double)partial[(long long)c * N + n];
+  db[n] = accumulate ? db[n] + (float)s : (float)s;
 }
 
 // column sums of a rows x N matrix (bias gradients, LN / dwconv parameter partials):
@@ -264,11 +290,12 @@ static long long pick_chunks(long long M, int N, int K) {
 
 extern "C" int64_t segmif_wgrad_workspace_size(int64_t M, int N, int K) {
   const int Kp = (K + 15) / 16 * 16;
-  return pick_chunks(M, N, K) * (int64_t)N * Kp;
+  return pick_chunks(M, N, K) * ((int64_t)N * Kp + N);  // weight partials + bias partials
 }
 
 extern "C" int segmif_wgrad_f32(const SegmifIgemm* d, const float* dy, int ldy, int64_t dy_zstride, float* dw,
-                                int64_t dw_sn, int64_t dw_sk, float* workspace, int accumulate, void* stream) {
+                                int64_t dw_sn, int64_t dw_sk, float* dbias, float* workspace, int accumulate,
+                                void* stream) {
   if (!d || !d->in || !dy || !dw || !workspace || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->in2) return SEGMIF_EINVAL;
   WgradK k;
   k.dy = dy; k.in = d->in; k.partial = workspace; k.M = d->M; k.N = d->N; k.K = d->K; k.Kp = (d->K + 15) / 16 * 16;
@@ -290,6 +317,7 @@ extern "C" int segmif_wgrad_f32(const SegmifIgemm* d, const float* dy, int ldy, 
   k.rows_per_chunk = ((d->M + chunks - 1) / chunks + MR - 1) / MR * MR;
   chunks = (d->M + k.rows_per_chunk - 1) / k.rows_per_chunk;
   k.chunks = (int)chunks;
+  k.bias_partial = dbias ? workspace + (long long)chunks * nz * d->N * k.Kp : nullptr;
   const bool narrow = d->N <= 32;
   const int BN = narrow ? 32 : 64, BK = narrow ? 128 : 64;
   k.nnt = (d->N + BN - 1) / BN;
@@ -304,6 +332,9 @@ extern "C" int segmif_wgrad_f32(const SegmifIgemm* d, const float* dy, int ldy, 
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)nz), dim3(256), 0, s,
                      workspace, dw, (int)chunks, d->N, d->K, k.Kp, k.Cin, k.KH, k.KW, is_conv ? 0 : 1,
                      (long long)dw_sn, (long long)dw_sk, (long long)d->out_zstride, accumulate);
+  if (dbias)  // bias gradient: sum over every chunk of every batch slice
+    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->N + 255) / 256)), dim3(256), 0, s,
+                       k.bias_partial, dbias, (int)chunks, nz, d->N, accumulate);
   return (int)hipGetLastError();
 }
 
