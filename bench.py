@@ -148,10 +148,17 @@ def main():
         if timer is not None:
             n, ms, flops = timer.summary()
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant.json")
+            if os.path.exists(pmc) and B == 8 and (H, W) == (480, 640):
+                # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+                rec = json.load(open(pmc))
+                traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/r01_pmc_dominant.json"
             out["roofline"] = {
                 "kernel": "conv3x3_halo_kernel<32,8,2> (DRDB dilated 3x3 conv, fp32 MFMA)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": (1200.0 + 300.0) * 2 ** 20 * B / 8,
                 "launches_timed": n, "avg_launch_ms": ms, "avg_launch_gflop": flops / 1e9,
             }
         if world == 1 and not args.no_cpu_baseline:
