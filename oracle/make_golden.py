@@ -160,6 +160,47 @@ def main():
                         block=npy(full), pe_x=npy(pe_x), pe_tokens=npy(pe_t), pe_hw=np.array([pe_h, pe_w]),
                         tokens4=npy(t4), attn4=npy(att4))
 
+    # ---- 5b. gradients from the reference's own autograd (training path parity pin) -----------
+    def grad_record(module, prefix=""):
+        rec = {}
+        for name, p in module.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.detach()
+            rec[prefix + name + "|norm"] = np.float64(g.double().norm())
+            flat = g.reshape(-1)
+            rec[prefix + name + "|head"] = npy(flat[:2048])  # first 2048 entries (whole tensor when smaller)
+        return rec
+
+    torch.set_grad_enabled(True)
+    B, H, W = 2, 64, 96
+    xs = dw.det_input("tr_x", (B, 3, H, W))
+    ys = dw.det_labels("tr_y", (B, H, W), 9)
+    ys[0, 5:9, 7:30] = 255
+    net1.zero_grad()
+    net1.eval()
+    loss = net1._loss(xs.clone(), ys, torch.nn.CrossEntropyLoss(ignore_index=255))  # model_fusion.py:1090-1097
+    loss.backward()
+    rec = grad_record(net1)
+    rec["loss"] = np.float64(loss.detach())
+    np.savez_compressed(os.path.join(OUT, "grads_seg_b1_64x96.npz"), **rec)
+    net1.zero_grad()
+
+    Bf, Hf, Wf = 2, 24, 40
+    irf, visf = dw.det_input("g_ir", (Bf, 1, Hf, Wf)), dw.det_input("g_vis", (Bf, 3, Hf, Wf))
+    g = torch.Generator().manual_seed(4242)
+    o1f = torch.rand(Bf, 64, Hf, Wf, generator=g) * 2 - 1
+    o2f = torch.rand(Bf, 128, Hf, Wf, generator=g) * 2 - 1
+    cot = torch.rand(Bf, 1, Hf, Wf, generator=g) * 2 - 1
+    fus.zero_grad()
+    outf = fus(irf, visf, o1f, o2f)
+    (outf * cot).sum().backward()
+    rec = grad_record(fus)
+    rec.update(o1=npy(o1f), o2=npy(o2f), cot=npy(cot), out=npy(outf))
+    np.savez_compressed(os.path.join(OUT, "grads_fusion_24x40.npz"), **rec)
+    fus.zero_grad()
+    torch.set_grad_enabled(False)
+
     # ---- 6. full-size checksum record: mit_b3, 480x640, B=1 -----------------------------------
     if args.full:
         net3 = quiet(mf.Network3, "mit_b3", NUM_CLASSES, pretrained=None).eval()

@@ -399,3 +399,47 @@ def test_ssim_loss_matches_reference_formula(ag):
     got.backward()
     assert abs(float(got.detach()) - float(ref.detach())) < 1e-5
     assert err(ag_.grad, ar.grad) < 1e-4
+
+
+def _golden_grad_check(module, g, tol):
+    import numpy as np
+    names = sorted(k[:-5] for k in g if k.endswith("|norm"))
+    produced = {n for n, p in module.named_parameters() if p.grad is not None}
+    assert produced == set(names)
+    for n, p in module.named_parameters():
+        if p.grad is None:
+            continue
+        got = p.grad.detach().double().cpu().reshape(-1)
+        ref_head = torch.from_numpy(g[n + "|head"]).double()
+        rms = float(g[n + "|norm"]) / max(got.numel(), 1) ** 0.5 + 1e-30
+        assert abs(float(got.norm()) - float(g[n + "|norm"])) <= tol * float(g[n + "|norm"]) + 1e-12, n
+        e = float((got[:ref_head.numel()] - ref_head).abs().max()) / max(rms, float(ref_head.abs().max()))
+        assert e < tol, (n, e)
+
+
+def test_hip_gradients_match_reference_autograd_fixtures(ag, golden_dir):
+    """HIP training path vs gradients recorded from the REAL reference's autograd (tests/golden/grads_*)."""
+    import os
+    import numpy as np
+    from segmif_amd.core import Fusion_Network3_ac, Network3
+    g = dict(np.load(os.path.join(golden_dir, "grads_seg_b1_64x96.npz")))
+    net = Network3("mit_b1", 9, pretrained=None)
+    dw.load_det_weights(net, seed=0)
+    net = net.cuda().eval()
+    x = dw.det_input("tr_x", (2, 3, 64, 96)).cuda()
+    y = dw.det_labels("tr_y", (2, 64, 96), 9)
+    y[0, 5:9, 7:30] = 255
+    loss = net._loss(x, y.cuda(), torch.nn.CrossEntropyLoss(ignore_index=255))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
+    loss.backward()
+    _golden_grad_check(net, g, tol=2e-3)
+
+    g = dict(np.load(os.path.join(golden_dir, "grads_fusion_24x40.npz")))
+    fus = Fusion_Network3_ac()
+    dw.load_det_weights(fus, seed=0)
+    fus = fus.cuda()
+    ir, vis = dw.det_input("g_ir", (2, 1, 24, 40)).cuda(), dw.det_input("g_vis", (2, 3, 24, 40)).cuda()
+    out = fus(ir, vis, torch.from_numpy(g["o1"]).cuda(), torch.from_numpy(g["o2"]).cuda())
+    assert err(out, torch.from_numpy(g["out"])) < 1e-4
+    (out * torch.from_numpy(g["cot"]).cuda()).sum().backward()
+    _golden_grad_check(fus, g, tol=2e-3)

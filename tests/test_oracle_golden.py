@@ -128,3 +128,58 @@ def test_full_size_checksum_b3(golden_dir, sd_fus):
     stable = torch.from_numpy(g["margin_f16"].astype(np.float32)) > 1e-3
     assert torch.equal(r["labels"][stable], torch.from_numpy(g["labels"]).long()[stable])
     assert len(np.unique(g["labels"])) >= 5  # non-degenerate segmentation on synthetic input
+
+
+def _grad_fixture_check(named_grads, g, tol):
+    """named_grads: name -> tensor or None.  Fixture holds '<name>|norm' and '<name>|head' for every
+    parameter the reference's autograd produced a gradient for."""
+    names = sorted(k[:-5] for k in g if k.endswith("|norm"))
+    assert len(names) > 50
+    produced = {n for n, v in named_grads.items() if v is not None}
+    assert produced == set(names)  # same set of parameters receives gradients (SURVEY F7)
+    worst = 0.0
+    for n in names:
+        got = named_grads[n].detach().double().reshape(-1)
+        ref_head = torch.from_numpy(g[n + "|head"]).double()
+        scale = float(g[n + "|norm"]) / max(got.numel(), 1) ** 0.5 + 1e-30  # rms of the reference gradient
+        assert abs(float(got.norm()) - float(g[n + "|norm"])) <= tol * float(g[n + "|norm"]) + 1e-12, n
+        e = float((got[:ref_head.numel()] - ref_head).abs().max()) / max(scale, float(ref_head.abs().max()))
+        worst = max(worst, e)
+        assert e < tol, (n, e)
+    return worst
+
+
+def _leaf_sd(shapes):
+    sd = {}
+    for k, v in dw.det_state_dict(shapes, seed=0).items():
+        is_param = v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))
+        sd[k] = v.clone().requires_grad_(True) if is_param else v
+    return sd
+
+
+def test_oracle_autograd_matches_reference_gradients_seg(golden_dir):
+    """Pins the oracle's backward: CE(bilinear-up(Network3(x))) parameter gradients vs the reference's
+    own autograd (model_fusion.py:1090-1097 driven by make_golden.py)."""
+    import torch.nn.functional as F
+    g = load(golden_dir, "grads_seg_b1_64x96.npz")
+    sd = _leaf_sd(so.network3_shapes("mit_b1", 9))
+    x = dw.det_input("tr_x", (2, 3, 64, 96))
+    y = dw.det_labels("tr_y", (2, 64, 96), 9)
+    y[0, 5:9, 7:30] = 255
+    seg = so.network3_forward(sd, x, "mit_b1")
+    loss = F.cross_entropy(F.interpolate(seg, size=[64, 96], mode="bilinear", align_corners=False), y, ignore_index=255)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    loss.backward()
+    grads = {k: v.grad for k, v in sd.items() if isinstance(v, torch.Tensor) and v.requires_grad}
+    _grad_fixture_check(grads, g, tol=2e-3)
+
+
+def test_oracle_autograd_matches_reference_gradients_fusion(golden_dir):
+    g = load(golden_dir, "grads_fusion_24x40.npz")
+    sd = _leaf_sd(so.fusion_shapes())
+    ir, vis = dw.det_input("g_ir", (2, 1, 24, 40)), dw.det_input("g_vis", (2, 3, 24, 40))
+    out = so.fusion_network3_ac(sd, ir, vis, torch.from_numpy(g["o1"]), torch.from_numpy(g["o2"]))
+    assert rel_err(out, g["out"]) < TOL
+    (out * torch.from_numpy(g["cot"])).sum().backward()
+    grads = {k: v.grad for k, v in sd.items() if v.requires_grad}
+    _grad_fixture_check(grads, g, tol=2e-3)
