@@ -234,6 +234,17 @@ int segmif_softmax_ce_f32(const float* logits, const int64_t* labels, float* dlo
 int segmif_conv_dgrad_strided_f32(const float* dy, const float* wd, float* dx, int B, int H, int W, int Cin, int N,
                                   int KH, int KW, int stride, int pad, int OH, int OW, int lddy, int lddx, void* stream);
 
+/* Train-mode BatchNorm2d on NHWC rows (segformer_head.py:50-55: linear_fuse.bn with batch statistics).
+ * segmif_bn_colstats_f32: mode 0 -> out[C] = sum_rows (x - mu)^2 ; mode 1 -> out[2C] = [sum dz | sum dz*xhat]
+ * (fp64; partial holds ceil(rows/256) * (mode ? 2C : C) doubles).  segmif_bn_apply_f32: y = relu?(x*scale + shift).
+ * segmif_bn_bwd_apply_f32: dx = scale * (dz - a - xhat * b) with a = mean dz, b = mean dz*xhat. */
+int segmif_bn_colstats_f32(const float* x, const float* dz, const float* mu, const float* rstd, double* partial,
+                           double* out, int64_t rows, int C, int mode, void* stream);
+int segmif_bn_apply_f32(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C,
+                        int relu, void* stream);
+int segmif_bn_bwd_apply_f32(const float* x, const float* dz, const float* mu, const float* rstd, const float* scale,
+                            const float* a, const float* b, float* dx, int64_t rows, int C, void* stream);
+
 /* 11-tap separable Gaussian blur, zero padded, over (planes, H, W): the SSIM window of
  * pytorch_ssim/__init__.py:8-43 (five of these per SSIM evaluation; self-adjoint, so also its backward).
  * taps11 is a HOST pointer to the 11 window weights. */

@@ -121,8 +121,10 @@ def mit_forward_fusion(sd, pfx, x, variant):
 
 
 # --- SegFormer head -------------------------------------------------------------------------
-def segformer_head(sd, pfx, feats):
-    """core/segformer_head.py:59-82, eval mode (BatchNorm running stats, Dropout2d off).
+def segformer_head(sd, pfx, feats, bn_training=False):
+    """core/segformer_head.py:59-82.  Default: eval mode (BatchNorm running stats, Dropout2d off);
+    bn_training=True evaluates linear_fuse.bn with batch statistics as nn.BatchNorm2d does in train
+    mode (running statistics in `sd` are updated in place, momentum 0.1); Dropout2d stays off.
 
     linear_fuse is mmcv ConvModule = conv(no bias) -> BatchNorm2d(eps 1e-5) -> ReLU
     (semantics from mmcv 1.x, not verifiable offline).
@@ -141,12 +143,12 @@ def segformer_head(sd, pfx, feats):
     cat = torch.cat(embedded, dim=1)
     y = F.conv2d(cat, sd[pfx + "linear_fuse.conv.weight"])
     y = F.batch_norm(y, sd[pfx + "linear_fuse.bn.running_mean"], sd[pfx + "linear_fuse.bn.running_var"],
-                     sd[pfx + "linear_fuse.bn.weight"], sd[pfx + "linear_fuse.bn.bias"], False, 0.1, 1e-5)
+                     sd[pfx + "linear_fuse.bn.weight"], sd[pfx + "linear_fuse.bn.bias"], bn_training, 0.1, 1e-5)
     y = F.relu(y)
     return F.conv2d(y, sd[pfx + "linear_pred.weight"], sd[pfx + "linear_pred.bias"])
 
 
-def network3_forward(sd, x, backbone):
+def network3_forward(sd, x, backbone, bn_training=False):
     """core/model_fusion.py:1081-1088 + WeTr.forward :62-68 -> seg logits (B, K, H/4, W/4).
 
     The reference also evaluates `classifier(_x4)` and drops it (:66); it has no effect on
@@ -156,7 +158,7 @@ def network3_forward(sd, x, backbone):
     std = torch.tensor(SEG_STD, dtype=x.dtype).view(1, 3, 1, 1)
     xn = (x * 255 - mean) / std
     feats = mit_forward_features(sd, "denoise_net.encoder.", xn, backbone)
-    return segformer_head(sd, "denoise_net.decoder.", feats)
+    return segformer_head(sd, "denoise_net.decoder.", feats, bn_training=bn_training)
 
 
 # --- Fusion network -------------------------------------------------------------------------

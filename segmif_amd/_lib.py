@@ -69,6 +69,10 @@ SIGNATURES = {
     "segmif_softmax_ce_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                       c_void_p]),
     "segmif_conv_dgrad_strided_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
+    "segmif_bn_colstats_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                       c_void_p]),
+    "segmif_bn_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "segmif_bn_bwd_apply_f32": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_void_p]),
     "segmif_gauss_blur11_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p]),
     "segmif_adamw_entry_bytes": (c_int, []),
     "segmif_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]),

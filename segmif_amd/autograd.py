@@ -492,6 +492,56 @@ class KvContextFn(torch.autograd.Function):
         return dy, dw
 
 
+class BatchNormReluFn(torch.autograd.Function):
+    """Train-mode BatchNorm (batch statistics, biased variance) + ReLU over NHWC rows (rows, C).
+    Returns (y, batch_mean, batch_var_biased); the caller updates the running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        rows, C, _ = rows_view(x, "x")
+        lib = _lib.load()
+        mean = colsum(x.view(rows, C)) / rows
+        nblk = (rows + 255) // 256
+        part = torch.empty((nblk * C,), device=x.device, dtype=torch.float64)
+        ssq = torch.empty((C,), device=x.device, dtype=torch.float64)
+        _lib.check(lib.segmif_bn_colstats_f32(x.data_ptr(), None, mean.data_ptr(), None, part.data_ptr(), ssq.data_ptr(),
+                                              rows, C, 0, _stream()), "segmif_bn_colstats_f32")
+        var = (ssq / rows).float()
+        rstd = torch.rsqrt(var + eps)
+        scale = (gamma * rstd).contiguous()
+        shift = (beta - mean * scale).contiguous()
+        y = torch.empty_like(x)
+        _lib.check(lib.segmif_bn_apply_f32(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), rows, C, 1,
+                                           _stream()), "segmif_bn_apply_f32")
+        ctx.save_for_backward(x, y, mean, rstd, gamma)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, y, mean, rstd, gamma = ctx.saved_tensors
+        rows, C, _ = rows_view(x, "x")
+        lib = _lib.load()
+        dz = act_bwd(dy.contiguous(), y, ACT_RELU)
+        nblk = (rows + 255) // 256
+        part = torch.empty((nblk * 2 * C,), device=x.device, dtype=torch.float64)
+        sums = torch.empty((2 * C,), device=x.device, dtype=torch.float64)
+        _lib.check(lib.segmif_bn_colstats_f32(x.data_ptr(), dz.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                              part.data_ptr(), sums.data_ptr(), rows, C, 1, _stream()),
+                   "segmif_bn_colstats_f32")
+        dbeta = sums[:C].float()
+        dgamma = sums[C:].float()
+        a = (dbeta / rows).contiguous()
+        b = (dgamma / rows).contiguous()
+        scale = (gamma * rstd).contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(lib.segmif_bn_bwd_apply_f32(x.data_ptr(), dz.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               scale.data_ptr(), a.data_ptr(), b.data_ptr(), dx.data_ptr(), rows, C,
+                                               _stream()), "segmif_bn_bwd_apply_f32")
+        return dx, dgamma, dbeta, None
+
+
 class GaussBlurFn(torch.autograd.Function):
     """11x11 Gaussian "same" blur (sigma 1.5) of (B, C, H, W) images; symmetric => backward = blur."""
 
@@ -567,3 +617,7 @@ def kv_context(y, wkv):
 
 def gauss_blur11(x):
     return GaussBlurFn.apply(x)
+
+
+def batchnorm_relu_train(x, gamma, beta, eps):
+    return BatchNormReluFn.apply(x, gamma, beta, eps)

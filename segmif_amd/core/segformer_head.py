@@ -70,8 +70,8 @@ class ConvModule(nn.Module):
 
     def forward_nhwc(self, x_nhwc):
         if self.training and self.with_norm:
-            raise NotImplementedError(
-                "train-mode BatchNorm (batch statistics) is not implemented on the HIP path yet; call .eval()")
+            raise RuntimeError("ConvModule.forward_nhwc is the eval-mode (folded BatchNorm) path; train mode is "
+                               "handled by SegFormerHead.forward_train_nhwc")
         w, b = self._folded()
         return ops.linear(x_nhwc, w, self.conv.out_channels, bias=b, act=ops.ACT_RELU)
 
@@ -103,10 +103,6 @@ class SegFormerHead(nn.Module):
         c1, c2, c3, c4 = feats
         B, H1, W1, _ = c1.shape
         fuse = self.linear_fuse
-        if self.training and fuse.with_norm:
-            raise NotImplementedError("train-mode BatchNorm (batch statistics) has no HIP backward yet: use "
-                                      ".eval() (the reference's train_seg runs in eval mode after its first "
-                                      "validation, SURVEY F11)")
         parts = []
         for mlp, c in ((self.linear_c4, c4), (self.linear_c3, c3), (self.linear_c2, c2)):
             parts.append(ag.bilinear(ag.linear(c.contiguous(), mlp.proj.weight, mlp.proj.bias), H1, W1))
@@ -114,19 +110,33 @@ class SegFormerHead(nn.Module):
         cat = torch.cat(parts, dim=-1)
         w = fuse.conv.weight.flatten(1)
         b = fuse.conv.bias
-        if fuse.with_norm:  # fold eval-mode BN differentiably: grads reach conv.weight, bn.weight, bn.bias
-            s = fuse.bn.weight / torch.sqrt(fuse.bn.running_var + fuse.bn.eps)
-            w = w * s[:, None]
-            b = fuse.bn.bias - fuse.bn.running_mean * s
-        y = ag.linear(cat, w, b, act=ops.ACT_RELU)
+        if fuse.with_norm and self.training:
+            # train mode: batch statistics (biased variance for the normalisation, unbiased for the running
+            # estimate, momentum 0.1 — nn.BatchNorm2d defaults, as mmcv's ConvModule builds it)
+            bn = fuse.bn
+            pre = ag.linear(cat, w, None)
+            y, mean, var = ag.batchnorm_relu_train(pre, bn.weight, bn.bias, bn.eps)
+            if bn.track_running_stats:
+                with torch.no_grad():
+                    n = pre.numel() // pre.shape[-1]
+                    m = bn.momentum if bn.momentum is not None else 0.1
+                    bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                    bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+                    bn.num_batches_tracked += 1
+        else:
+            if fuse.with_norm:  # fold eval-mode BN differentiably: grads reach conv.weight, bn.weight, bn.bias
+                s = fuse.bn.weight / torch.sqrt(fuse.bn.running_var + fuse.bn.eps)
+                w = w * s[:, None]
+                b = fuse.bn.bias - fuse.bn.running_mean * s
+            y = ag.linear(cat, w, b, act=ops.ACT_RELU)
         if self.training:
             y = self.dropout(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
         return ag.linear(y, self.linear_pred.weight, self.linear_pred.bias)
 
     def forward_nhwc(self, feats):
         """feats: [c1..c4] NHWC -> logits NHWC (B, H/4, W/4, num_classes)."""
-        if wants_grad(self, *feats):
-            return self.forward_train_nhwc(feats)
+        if wants_grad(self, *feats) or (self.training and self.linear_fuse.with_norm):
+            return self.forward_train_nhwc(feats)  # also used under no_grad in train mode (batch-stat BN)
         c1, c2, c3, c4 = feats
         B, H1, W1, _ = c1.shape
         E = self.linear_c1.proj.out_features

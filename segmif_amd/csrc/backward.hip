@@ -470,6 +470,100 @@ __global__ __launch_bounds__(256) void conv_dgrad_strided_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------------------------------
+// BatchNorm2d on NHWC rows (the SegFormer head's linear_fuse.bn, segformer_head.py:50-55), train mode.
+//   bn_colstats<MODE>: per-column partial sums over 256-row blocks (fp64 partial rows, summed by
+//                      segmif_colsum-style final pass on the host side):
+//        MODE 0: sum (x - mu)^2            (mu = per-column mean, for the biased batch variance)
+//        MODE 1: [sum dz | sum dz * xhat]  (backward reductions; dz already masked by the ReLU)
+//   bn_apply:        y = relu(x * s[c] + t[c])
+//   bn_bwd_apply:    dx = s[c] * (dz - a[c] - xhat * b[c]),  a = mean dz, b = mean dz*xhat
+// ---------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                          const float* __restrict__ mu, const float* __restrict__ rstd,
+                                                          double* __restrict__ partial, long long rows, int C) {
+  __shared__ float red[2][4][64];
+  const int c = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.x * 256;
+  const long long r1 = r0 + 256 < rows ? r0 + 256 : rows;
+  const int W = MODE == 0 ? C : 2 * C;
+  for (int n0 = 0; n0 < C; n0 += 64) {
+    const int n = n0 + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (n < C) {
+      const float m = mu[n], rs = MODE == 1 ? rstd[n] : 0.f;
+      for (long long r = r0 + slot; r < r1; r += 4) {
+        const float xv = x[r * C + n];
+        if (MODE == 0) {
+          const float d = xv - m;
+          s0 += d * d;
+        } else {
+          const float g = dz[r * C + n];
+          s0 += g;
+          s1 += g * (xv - m) * rs;
+        }
+      }
+    }
+    red[0][slot][c] = s0;
+    red[1][slot][c] = s1;
+    __syncthreads();
+    if (slot == 0 && n < C) {
+      partial[(long long)blockIdx.x * W + n] = ((double)red[0][0][c] + red[0][1][c]) + ((double)red[0][2][c] + red[0][3][c]);
+      if (MODE == 1)
+        partial[(long long)blockIdx.x * W + C + n] = ((double)red[1][0][c] + red[1][1][c]) + ((double)red[1][2][c] + red[1][3][c]);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_f64_kernel(const double* __restrict__ partial, double* __restrict__ out,
+                                                         int nblk, int N) {
+  __shared__ double red[4][64];
+  const int c = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
+  double s = 0.0;
+  if (n < N)
+    for (int b = slot; b < nblk; b += 4) s += partial[(long long)b * N + n];
+  red[slot][c] = s;
+  __syncthreads();
+  if (slot == 0 && n < N) out[n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                       const float* __restrict__ t, float* __restrict__ y, long long total4,
+                                                       int C, int relu) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int c = (int)((i * 4) % C);
+  const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+  const f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), tv = *reinterpret_cast<const f32x4*>(t + c);
+  f32x4 o = xv * sv + tv;
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+  }
+  *reinterpret_cast<f32x4*>(y + i * 4) = o;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                           const float* __restrict__ mu, const float* __restrict__ rstd,
+                                                           const float* __restrict__ s, const float* __restrict__ a,
+                                                           const float* __restrict__ b, float* __restrict__ dx,
+                                                           long long total4, int C) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int c = (int)((i * 4) % C);
+  const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4), g = *reinterpret_cast<const f32x4*>(dz + i * 4);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float xh = (xv[e] - mu[c + e]) * rstd[c + e];
+    o[e] = s[c + e] * (g[e] - a[c + e] - xh * b[c + e]);
+  }
+  *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Multi-tensor AdamW (decoupled weight decay), torch.optim.AdamW arithmetic:
 //   p *= 1 - lr*wd ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
 //   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
@@ -622,5 +716,37 @@ extern "C" int segmif_adamw_f32(const void* table, const int32_t* chunk_entry, c
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)table,
                      (const int*)chunk_entry, (const long long*)chunk_off, beta1, beta2, eps, bc1, bc2s, chunk_elems);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_bn_colstats_f32(const float* x, const float* dz, const float* mu, const float* rstd, double* partial,
+                                      double* out, int64_t rows, int C, int mode, void* stream) {
+  // mode 0: out[C] = sum (x - mu)^2 ; mode 1: out[2C] = [sum dz | sum dz * xhat].  partial: ceil(rows/256) * (mode ? 2C : C) doubles
+  if (!x || !mu || !partial || !out || rows <= 0 || C <= 0 || (mode == 1 && (!dz || !rstd))) return SEGMIF_EINVAL;
+  const int nblk = (int)((rows + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  const int Wd = mode == 0 ? C : 2 * C;
+  if (mode == 0) hipLaunchKernelGGL(bn_colstats_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, s, x, dz, mu, rstd, partial, (long long)rows, C);
+  else hipLaunchKernelGGL(bn_colstats_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, x, dz, mu, rstd, partial, (long long)rows, C);
+  hipLaunchKernelGGL(colsum_f64_kernel, dim3((unsigned)((Wd + 63) / 64)), dim3(256), 0, s, partial, out, nblk, Wd);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_bn_apply_f32(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C,
+                                   int relu, void* stream) {
+  if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || (C & 3)) return SEGMIF_EINVAL;
+  const long long total4 = (long long)rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                     shift, y, total4, C, relu);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_bn_bwd_apply_f32(const float* x, const float* dz, const float* mu, const float* rstd,
+                                       const float* scale, const float* a, const float* b, float* dx, int64_t rows, int C,
+                                       void* stream) {
+  if (!x || !dz || !mu || !rstd || !scale || !a || !b || !dx || rows <= 0 || C <= 0 || (C & 3)) return SEGMIF_EINVAL;
+  const long long total4 = (long long)rows * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dz,
+                     mu, rstd, scale, a, b, dx, total4, C);
   return (int)hipGetLastError();
 }

@@ -443,3 +443,52 @@ def test_hip_gradients_match_reference_autograd_fixtures(ag, golden_dir):
     assert err(out, torch.from_numpy(g["out"])) < 1e-4
     (out * torch.from_numpy(g["cot"]).cuda()).sum().backward()
     _golden_grad_check(fus, g, tol=2e-3)
+
+
+def test_batchnorm_relu_train_mode(ag):
+    rows, C = 5000, 256
+    x, gm, bt, g = rnd(rows, C, seed=60, lo=-2, hi=3), rnd(C, seed=61, lo=0.5, hi=1.5), rnd(C, seed=62), rnd(rows, C, seed=63)
+    xr, gr, br = leaf(x, double=True), leaf(gm, double=True), leaf(bt, double=True)
+    yr = F.relu(F.batch_norm(xr.t()[None], None, None, gr, br, True, 0.1, 1e-5))[0].t()
+    yr.backward(g.double())
+    xg, gg, bg = leaf(x, "cuda"), leaf(gm, "cuda"), leaf(bt, "cuda")
+    y, mean, var = ag.batchnorm_relu_train(xg, gg, bg, 1e-5)
+    assert err(y, yr) < TOL
+    assert err(mean, x.double().mean(0)) < 1e-6 and err(var, x.double().var(0, unbiased=False)) < 1e-5
+    y.backward(g.cuda())
+    assert err(xg.grad, xr.grad) < TOL and err(gg.grad, gr.grad) < TOL and err(bg.grad, br.grad) < TOL
+
+
+def test_seg_net_train_mode_gradients_and_running_stats(ag):
+    """Network3 in train() mode (BatchNorm on batch statistics — the regime of train_fusion and of the
+    first 1000 iterations of train_seg) with the stochastic layers switched off
+    (DropPath rate 0, Dropout2d p 0) so the comparison is deterministic."""
+    from segmif_amd.core import Network3
+    B, H, W = 2, 64, 96
+    x = dw.det_input("tm_x", (B, 3, H, W))
+    labels = dw.det_labels("tm_y", (B, H, W), 9)
+    sd = _oracle_params(so.network3_shapes("mit_b1", 9))
+    seg = so.network3_forward(sd, x.double(), "mit_b1", bn_training=True)
+    ref_loss = F.cross_entropy(F.interpolate(seg, size=[H, W], mode="bilinear", align_corners=False), labels)
+    ref_loss.backward()
+    net = Network3("mit_b1", 9, pretrained=None)
+    dw.load_det_weights(net, seed=0)
+    net = net.cuda().train()
+    net.denoise_net.encoder.reset_drop_path(0.0)
+    net.denoise_net.decoder.dropout.p = 0.0
+    loss = net._loss(x.cuda(), labels.cuda(), torch.nn.CrossEntropyLoss(ignore_index=255))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) / abs(float(ref_loss.detach())) < 1e-4
+    loss.backward()
+    assert _compare_param_grads(net, sd, tol=1e-3) > 150
+    bn = net.denoise_net.decoder.linear_fuse.bn
+    assert err(bn.running_mean, sd["denoise_net.decoder.linear_fuse.bn.running_mean"]) < 1e-5
+    assert err(bn.running_var, sd["denoise_net.decoder.linear_fuse.bn.running_var"]) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
+    # stochastic layers: a DropPath'ed / Dropout2d'ed forward still runs and differs from the deterministic one
+    net.denoise_net.encoder.reset_drop_path(0.5)
+    net.denoise_net.decoder.dropout.p = 0.5
+    torch.manual_seed(0)
+    with torch.no_grad():
+        a = net(x.cuda())[2]
+        b = net(x.cuda())[2]
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
