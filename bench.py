@@ -27,7 +27,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 # algorithmic work, GFLOP per pair forward at 480x640 (torch FlopCounterMode, 2*MAC)
-GFLOP_PER_PAIR = {"mit_b1": 700.2, "mit_b3": 827.1}
+GFLOP_PER_PAIR = {("mit_b1", 480, 640): 700.2, ("mit_b3", 480, 640): 827.1,
+                  ("mit_b5", 1024, 1024): 2 * 798.47 + 38.8 + 2178.0}  # b5: BASELINE.md table, head / fusion scaled by pixels
 CPU_BASELINE_THREADS = 16  # fastest of {16,32,64,128,256} on the GPU box host (profiles/r01_cpu_threads.txt)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
 
@@ -142,8 +143,8 @@ def main():
                        "parallelism": f"replicas x{world} (independent pairs, no collective)",
                        "launch": "hipGraph replay" if args.graph else "eager"},
         }
-        gf = GFLOP_PER_PAIR.get(args.backbone)
-        if gf is not None and (H, W) == (480, 640):
+        gf = GFLOP_PER_PAIR.get((args.backbone, H, W))
+        if gf is not None:
             out["whole_path_tflops"] = value * gf / 1000.0 / world
         if timer is not None:
             n, ms, flops = timer.summary()

@@ -82,9 +82,14 @@ typedef struct SegmifIgemm {
   int32_t nz2;         /* 0 / 1 = unused */
   int32_t ldw;         /* weight row pitch in floats; 0 = Kp (packed). Lets K / V slices of a kv tensor act as weights */
   int64_t in_zstride2, wt_zstride2, out_zstride2, res_zstride2;
+  /* optional split-K scratch: segmif_igemm_workspace_floats(desc) floats (0 = none needed). Without it the
+   * same problem runs un-split. Partials are summed in a fixed order: results do not depend on the split. */
+  float* workspace;
+  int64_t workspace_floats;
 } SegmifIgemm;
 
 int segmif_igemm_f32(const SegmifIgemm* desc, void* stream);
+int64_t segmif_igemm_workspace_floats(const SegmifIgemm* desc);
 /* number of tile configurations and a printable name for each (bench / tests) */
 int segmif_igemm_num_tiles(void);
 const char* segmif_igemm_tile_name(int tile);

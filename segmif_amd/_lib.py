@@ -26,6 +26,7 @@ class SegmifIgemm(ctypes.Structure):
         ("out_zstride", c_int64), ("res_zstride", c_int64),
         ("tile", c_int32), ("nz2", c_int32), ("ldw", c_int32),
         ("in_zstride2", c_int64), ("wt_zstride2", c_int64), ("out_zstride2", c_int64), ("res_zstride2", c_int64),
+        ("workspace", c_void_p), ("workspace_floats", c_int64),
     ]
 
 
@@ -34,6 +35,7 @@ SIGNATURES = {
     "segmif_abi_version": (c_int, []),
     "segmif_device_name": (c_int, [c_char_p, c_int]),
     "segmif_igemm_f32": (c_int, [POINTER(SegmifIgemm), c_void_p]),
+    "segmif_igemm_workspace_floats": (c_int64, [POINTER(SegmifIgemm)]),
     "segmif_igemm_num_tiles": (c_int, []),
     "segmif_igemm_tile_name": (c_char_p, [c_int]),
     "segmif_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
   const int mt = bid / p.ntn, nt = bid - mt * p.ntn;
   const long long m0 = (long long)mt * BM;
   const int n0 = nt * BN;
-  const long long zb = blockIdx.z / p.nz2, z2 = blockIdx.z - zb * p.nz2;
+  const int zsplit = p.splitk > 1 ? (int)blockIdx.z : 0;  // split-K is only used with nz == 1
+  const long long zb = p.splitk > 1 ? 0 : blockIdx.z / p.nz2, z2 = p.splitk > 1 ? 0 : blockIdx.z - zb * p.nz2;
   const float* __restrict__ in = p.in + zb * p.in_zs + z2 * p.in_zs2;
   const float* __restrict__ in2 = (MODE == MODE_DENSE2) ? p.in2 + zb * p.in2_zs : nullptr;
   const float* __restrict__ wt = p.wt + zb * p.wt_zs + z2 * p.wt_zs2;
@@ -187,14 +188,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-  const int nk = p.Kp / BK;
-  gload(0);
+  int kc_begin = 0, nk = p.Kp / BK;
+  if (p.splitk > 1) {
+    kc_begin = zsplit * p.ksteps_per_split;
+    const int kc_end = kc_begin + p.ksteps_per_split;
+    nk = kc_end < nk ? kc_end : nk;
+    if (MODE == MODE_CONV) {  // position of this split's first K tile
+      const int k0 = kc_begin * BK;
+      const int tap = k0 / p.Cin;
+      tap_c0 = k0 - tap * p.Cin;
+      tap_ky = tap / p.KW;
+      tap_kx = tap - tap_ky * p.KW;
+    }
+  }
+  gload(kc_begin);
   sstore(0);
   __syncthreads();
 
   const int frag_off = (lane & 31) * BKP + (lane >> 5) * 4;
-  for (int kc = 0; kc < nk; ++kc) {
-    const int cur = kc & 1;
+  for (int kc = kc_begin; kc < nk; ++kc) {
+    const int cur = (kc - kc_begin) & 1;
     if (kc + 1 < nk) gload(kc + 1);
     const float* a_base = As + cur * (BM * BKP) + (wm * WM) * BKP + frag_off;
     const float* b_base = Bs + cur * (BN * BKP) + (wn * WN) * BKP + frag_off;
@@ -217,6 +230,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
     __syncthreads();
   }
 
+  if (p.splitk > 1) {  // raw partial sums; bias / activation / residual are applied by splitk_reduce_kernel
+    float* __restrict__ wsp = p.ws + (long long)zsplit * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const long long m = m0 + wm * WM + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+          if (m < p.M) wsp[m * p.N + n] = acc[i][j][v];
+        }
+      }
+    return;
+  }
   // ---- epilogue: bias + activation (+ residual), 128-byte row segments per half wave ----------
   float* __restrict__ out = p.out + zb * p.out_zs + z2 * p.out_zs2;
   const float* __restrict__ res = p.res ? p.res + zb * p.res_zs + z2 * p.res_zs2 : nullptr;
@@ -247,12 +276,12 @@ struct TileCfg {
   int BM, BN, BK;
   const char* name;
 };
-constexpr int kNumTiles = 11;  // 0-8: implicit-GEMM tiles; 9, 10: halo-tiled 3x3 (conv3x3.hip)
+constexpr int kNumTiles = 12;  // 0-8, 11: implicit-GEMM tiles; 9, 10: halo-tiled 3x3 (conv3x3.hip)
 const TileCfg kTiles[kNumTiles] = {
     {256, 32, 16, "256x32x16"}, {256, 32, 32, "256x32x32"}, {128, 64, 16, "128x64x16"},
     {128, 64, 32, "128x64x32"}, {128, 128, 16, "128x128x16"}, {128, 128, 32, "128x128x32"},
     {64, 64, 16, "64x64x16"},   {256, 64, 16, "256x64x16"},   {256, 64, 32, "256x64x32"},
-    {256, 64, 16, "halo8x32c16"}, {256, 64, 8, "halo8x32c8"},
+    {256, 64, 16, "halo8x32c16"}, {256, 64, 8, "halo8x32c8"}, {64, 64, 32, "64x64x32"},
 };
 constexpr int kHaloTile0 = 9;
 
@@ -285,6 +314,7 @@ int dispatch_tile(int tile, const IgemmK& k, int nz, hipStream_t s) {
     case 6: return launch<64, 64, 32, 32, 16, MODE>(k, nz, s);
     case 7: return launch<256, 64, 64, 64, 16, MODE>(k, nz, s);
     case 8: return launch<256, 64, 64, 64, 32, MODE>(k, nz, s);
+    case 11: return launch<64, 64, 32, 32, 32, MODE>(k, nz, s);
   }
   return SEGMIF_EINVAL;
 }
@@ -312,6 +342,32 @@ int pick_tile(long long M, int N, int K, int nz, bool generic) {
   if (N <= 64 && K >= 128 && blocks(7) >= 2048) return 7;
   if (blocks(6) >= 16384) return 2;
   return 6;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmK p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.M * p.N) return;
+  const long long m = i / p.N;
+  const int n = (int)(i - m * p.N);
+  float y = 0.f;
+  for (int s = 0; s < p.splitk; ++s) y += p.ws[(long long)s * p.M * p.N + i];  // fixed order: deterministic
+  if (p.bias) y += p.bias[n];
+  if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
+  else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : *p.prelu * y;
+  else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
+  if (p.res) y += p.res[m * p.ldr + n];
+  p.out[m * p.ldo + n] = y;
+}
+
+// split-K plan: only for single-slice dense / conv problems whose tile grid leaves most CUs idle
+int plan_splitk(long long M, int N, int Kp, int tile) {
+  const long long blocks = ((M + kTiles[tile].BM - 1) / kTiles[tile].BM) * ((N + kTiles[tile].BN - 1) / kTiles[tile].BN);
+  const int nk = Kp / kTiles[tile].BK;
+  if (blocks >= 512 || nk < 8) return 1;
+  long long s = (1024 + blocks - 1) / blocks;
+  if (s > nk / 4) s = nk / 4;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : (int)s;
 }
 
 __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int Cin, int KH,
@@ -342,9 +398,45 @@ extern "C" int segmif_pack_conv_weight(const float* src, float* dst, int N, int 
   return (int)hipGetLastError();
 }
 
-extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
-  if (!d || !d->in || !d->wt || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return SEGMIF_EINVAL;
+static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& tile_out, int& nz_out, bool& halo_out);
+
+extern "C" int64_t segmif_igemm_workspace_floats(const SegmifIgemm* d) {
   IgemmK k;
+  int mode, tile, nz;
+  bool halo;
+  if (igemm_resolve(d, k, mode, tile, nz, halo) != 0 || halo) return 0;
+  return k.splitk > 1 ? (int64_t)k.splitk * k.M * k.N : 0;
+}
+
+extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
+  IgemmK k;
+  int mode, tile, nz;
+  bool halo;
+  const int rc = igemm_resolve(d, k, mode, tile, nz, halo);
+  if (rc != 0) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (halo) return conv3x3_halo_launch(k, tile - kHaloTile0, s);
+  if (k.splitk > 1) {
+    if (!d->workspace || d->workspace_floats < (int64_t)k.splitk * k.M * k.N) k.splitk = 1;  // no room: plain launch
+    else k.ws = d->workspace;
+  }
+  int r;
+  const int gz = k.splitk > 1 ? k.splitk : nz;
+  switch (mode) {
+    case MODE_DENSE: r = dispatch_tile<MODE_DENSE>(tile, k, gz, s); break;
+    case MODE_CONV: r = dispatch_tile<MODE_CONV>(tile, k, gz, s); break;
+    case MODE_DENSE2: r = dispatch_tile<MODE_DENSE2>(tile, k, gz, s); break;
+    default: r = dispatch_generic(tile, k, gz, s);
+  }
+  if (r != 0 || k.splitk <= 1) return r;
+  const long long total = k.M * k.N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k);
+  return (int)hipGetLastError();
+}
+
+static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& tile_out, int& nz_out, bool& halo_out) {
+  if (!d || !d->in || !d->wt || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return SEGMIF_EINVAL;
+  halo_out = false;
   k.in = d->in; k.in2 = d->in2; k.wt = d->wt; k.bias = d->bias; k.res = d->res; k.prelu = d->prelu; k.out = d->out;
   k.M = d->M; k.N = d->N; k.K = d->K; k.Kp = (d->K + 15) / 16 * 16;
   k.lda = d->lda; k.lda2 = d->lda2; k.K1 = d->K1; k.ldo = d->ldo; k.ldr = d->ldr;
@@ -377,22 +469,36 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
   const bool bk32_ok = (k.Kp % 32 == 0) && (mode != MODE_CONV || d->Cin % 32 == 0) &&
                        (mode != MODE_DENSE2 || (d->K1 % 32 == 0));
   int tile = d->tile;
-  hipStream_t s = (hipStream_t)stream;
   const bool halo_ok = mode == MODE_CONV && nz == 1 && k.ldw == k.Kp && conv3x3_halo_eligible(k);
   if (tile < 0 && halo_ok) tile = kHaloTile0 + 1;  // 8-channel chunks: best on every shape (profiles/r01_kernel_bench_halo.txt)
-  if (tile >= kHaloTile0 && tile < kNumTiles) {
+  k.splitk = 1;
+  k.ksteps_per_split = 0;
+  k.ws = nullptr;
+  mode_out = mode;
+  nz_out = nz;
+  if (tile >= kHaloTile0 && tile < kHaloTile0 + 2) {
     if (!halo_ok) return SEGMIF_EINVAL;
-    return conv3x3_halo_launch(k, tile - kHaloTile0, s);
+    halo_out = true;
+    tile_out = tile;
+    return 0;
   }
+  const bool auto_tile = tile < 0;
   if (tile < 0) tile = pick_tile(d->M, d->N, d->K, nz, mode == MODE_GENERIC);
   if (tile >= kNumTiles) return SEGMIF_EINVAL;
   if (kTiles[tile].BK == 32 && !bk32_ok) return SEGMIF_EINVAL;
+  if (auto_tile && tile == 6 && bk32_ok && d->K >= 1024 &&
+      ((d->M + 63) / 64) * ((d->N + 63) / 64) * nz <= 1024)
+    tile = 11;  // few blocks, long K: half the barriers (profiles/r01_enc_gemm_tiles.txt)
   k.ntm = (int)((d->M + kTiles[tile].BM - 1) / kTiles[tile].BM);
   k.ntn = (d->N + kTiles[tile].BN - 1) / kTiles[tile].BN;
-  switch (mode) {
-    case MODE_DENSE: return dispatch_tile<MODE_DENSE>(tile, k, nz, s);
-    case MODE_CONV: return dispatch_tile<MODE_CONV>(tile, k, nz, s);
-    case MODE_DENSE2: return dispatch_tile<MODE_DENSE2>(tile, k, nz, s);
-    default: return dispatch_generic(tile, k, nz, s);
+  if (auto_tile && nz == 1 && (mode == MODE_DENSE || mode == MODE_CONV) && k.ldw == k.Kp) {
+    k.splitk = plan_splitk(d->M, d->N, k.Kp, tile);
+    if (k.splitk > 1) {
+      const int nk = k.Kp / kTiles[tile].BK;
+      k.ksteps_per_split = (nk + k.splitk - 1) / k.splitk;
+      k.splitk = (nk + k.ksteps_per_split - 1) / k.ksteps_per_split;
+    }
   }
+  tile_out = tile;
+  return 0;
 }

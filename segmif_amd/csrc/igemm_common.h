@@ -26,6 +26,9 @@ struct IgemmK {
   int nz2;  // z = zb * nz2 + z2; second-level strides below (0 when unused)
   long long in_zs2, wt_zs2, out_zs2, res_zs2;
   int ldw;  // weight row pitch (floats), normally Kp
+  int splitk;  // > 1: gridDim.z = splitk, raw partial sums go to ws[split][M][N] (reduce + epilogue in a 2nd kernel)
+  int ksteps_per_split;
+  float* ws;
   int ntm, ntn;
 };
 

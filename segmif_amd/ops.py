@@ -96,8 +96,15 @@ def launch_timer_active():
 
 
 def _igemm(desc, tag=None):
+    lib = _lib.load()
+    need = lib.segmif_igemm_workspace_floats(ctypes.byref(desc))
+    ws = None
+    if need > 0:  # split-K scratch for problems whose tile grid would leave most CUs idle
+        ws = torch.empty((need,), device="cuda", dtype=torch.float32)
+        desc.workspace, desc.workspace_floats = ws.data_ptr(), need
+
     def go():
-        _lib.check(_lib.load().segmif_igemm_f32(ctypes.byref(desc), _stream()), "segmif_igemm_f32")
+        _lib.check(lib.segmif_igemm_f32(ctypes.byref(desc), _stream()), "segmif_igemm_f32")
 
     if _timer is not None and tag is not None and tag == _timer.tag:
         _timer.bracket(go, 2.0 * desc.M * max(desc.nz, 1) * desc.N * desc.K)

@@ -44,7 +44,7 @@ def act_ref(y, act, slope=None):
     return y
 
 
-TILES_ALL = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8]
+TILES_ALL = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 11]
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 64, 64), (300, 512, 2048), (4099, 9, 256), (257, 128, 32), (77, 1, 64),
@@ -54,7 +54,7 @@ def test_igemm_dense_all_tiles(ops, M, N, K):
     ref_lin = x.double() @ w.double().t() + b.double()
     wt = ops.pack_weight(w.cuda())
     for tile in TILES_ALL:
-        if tile in (1, 3, 5, 8) and K % 32:
+        if tile in (1, 3, 5, 8, 11) and K % 32:
             continue
         for act, use_res in ((0, False), (1, True), (3, False)):
             ref = act_ref(ref_lin, act)
@@ -112,7 +112,7 @@ def test_igemm_conv(ops, case):
     if k == 3 and s == 1 and p == d and N <= 64 and Cin % 16 == 0:
         tiles += [9, 10]  # halo-tiled 3x3 variants (conv3x3.hip)
     for tile in tiles:
-        if tile in (1, 3, 5, 8) and Cin % 32:
+        if tile in (1, 3, 5, 8, 11) and Cin % 32:
             continue
         y = ops.conv2d(xh, wt, N, k, stride=s, pad=p, dil=d, bias=b.cuda(), tile=tile)
         assert err(y, ref) < TOL, tile
