@@ -453,8 +453,10 @@ class BatchedLinearFn(torch.autograd.Function):
             d.in_zstride = x.stride(0)
             d.out_zstride = N * K
             dw = torch.empty((B, N, K), device=x.device, dtype=torch.float32)
-            _wgrad(d, dy, N, dw, dy_zstride=n * N, sn=K, sk=1, nz=B)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            db = _bias_out(want_b, N, x)
+            _wgrad(d, dy, N, dw, dy_zstride=n * N, sn=K, sk=1, nz=B, db=db)
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)
         return dx, dw, db
 

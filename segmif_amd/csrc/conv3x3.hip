@@ -43,10 +43,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const IgemmK p, int t
   // vertically adjacent patches — which share 2*DIL halo rows — hit the same L2.
   int bid = blockIdx.x;
   {
-    const int nwg = gridDim.x;
+    const int nwg = gridDim.x;  // (gridDim.y = output-channel tiles)
     const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
   }
+  const int nbase = blockIdx.y * NOUT;  // output-channel tile (N > 64: the halo is re-read per tile, from L2)
   const int tx = bid % tiles_x;
   const int ty = (bid / tiles_x) % tiles_y;
   const int b = bid / (tiles_x * tiles_y);
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const IgemmK p, int t
       const int row = u / UPP, q4 = u - row * UPP;  // row = tap * NOUT + n
       const int tap = row / NOUT, n = row - tap * NOUT;
       b_dst[j] = row * CKP + q4 * 4;
-      if (n < p.N) b_src[j] = n * p.Kp + tap * p.Cin + q4 * 4;  // rows beyond N stay zero
+      if (nbase + n < p.N) b_src[j] = (nbase + n) * p.Kp + tap * p.Cin + q4 * 4;  // rows beyond N stay zero
     }
   }
   const int a_q4 = (tid % UPP) * 4;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const IgemmK p, int t
     if (oy >= p.H) continue;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = j * 32 + r;
+      const int n = nbase + j * 32 + r;
       if (n >= p.N) continue;
       const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
@@ -191,7 +192,7 @@ int launch(const IgemmK& k, hipStream_t stream) {
   }
   const int tiles_x = (k.W + TW - 1) / TW, tiles_y = (k.H + TH - 1) / TH;
   const long long B = k.M / ((long long)k.H * k.W);
-  dim3 grid((unsigned)(B * tiles_x * tiles_y));
+  dim3 grid((unsigned)(B * tiles_x * tiles_y), (unsigned)((k.N + NOUT - 1) / NOUT));
   hipLaunchKernelGGL(fn, grid, dim3(256), smem, stream, k, tiles_x, tiles_y);
   return (int)hipGetLastError();
 }
@@ -200,7 +201,7 @@ int launch(const IgemmK& k, hipStream_t stream) {
 
 bool conv3x3_halo_eligible(const IgemmK& k) {
   return k.KH == 3 && k.KW == 3 && k.stride == 1 && (k.dil == 1 || k.dil == 2) && k.pad == k.dil &&
-         k.OH == k.H && k.OW == k.W && k.Cin % 16 == 0 && (k.lda % 4) == 0 && (k.N <= 64) && !k.in2 &&
+         k.OH == k.H && k.OW == k.W && k.Cin % 16 == 0 && (k.lda % 4) == 0 && (k.N <= 256) && !k.in2 &&
          k.in_zs == 0 && k.wt_zs == 0 && k.M % ((long long)k.H * k.W) == 0 && (long long)k.H * k.W < (1ll << 31) &&
          !(((uintptr_t)k.in | (uintptr_t)k.wt) & 15);
 }

@@ -211,11 +211,50 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
   db[n] = accumulate ? db[n] + (float)s : (float)s;
 }
 
-// column sums of a rows x N matrix (bias gradients, LN / dwconv parameter partials):
-// stage 1: a block owns CS_ROWS rows; thread (c = tid & 63, slot = tid >> 6) walks 64-column chunks,
-// summing rows slot, slot+4, ... in fp32 (256-byte coalesced row segments), the 4 slots are combined in
-// LDS and written as one fp64 partial row; stage 2 sums the partial rows per column.
-constexpr int CS_ROWS = 256;
+// column sums of a rows x N matrix (bias gradients, LN / dwconv / BN parameter partials):
+// stage 1: a block owns CS_ROWS rows.  Vector path (N % 4 == 0, 16-byte aligned rows): QPR lanes cover the
+// column quads of a row (QPR = 8..64), 256/QPR row slots per block, four rows in flight per thread; scalar
+// path otherwise.  Slots are combined in LDS and written as one fp64 partial row; stage 2 sums the partial rows.
+constexpr int CS_ROWS = 1024;
+template <int QPR>
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* __restrict__ x, double* __restrict__ partial,
+                                                                 long long rows, int N, int ldx) {
+  constexpr int SLOTS = 256 / QPR;
+  __shared__ f32x4 red[256];
+  const int q = threadIdx.x % QPR, slot = threadIdx.x / QPR;
+  const long long r0 = (long long)blockIdx.x * CS_ROWS;
+  const long long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+  const int nq = N >> 2;
+  for (int q0 = 0; q0 < nq; q0 += QPR) {
+    const int qq = q0 + q;
+    f32x4 a0{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (qq < nq) {
+      const float* base = x + 4 * qq;
+      long long r = r0 + slot;
+      for (; r + 3 * SLOTS < r1; r += 4 * SLOTS) {
+        a0 += *reinterpret_cast<const f32x4*>(base + r * ldx);
+        a1 += *reinterpret_cast<const f32x4*>(base + (r + SLOTS) * ldx);
+        a2 += *reinterpret_cast<const f32x4*>(base + (r + 2 * SLOTS) * ldx);
+        a3 += *reinterpret_cast<const f32x4*>(base + (r + 3 * SLOTS) * ldx);
+      }
+      for (; r < r1; r += SLOTS) a0 += *reinterpret_cast<const f32x4*>(base + r * ldx);
+    }
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (slot == 0 && qq < nq) {
+      double s[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int sl = 0; sl < SLOTS; ++sl) {
+        const f32x4 v = red[sl * QPR + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += (double)v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) partial[(long long)blockIdx.x * N + 4 * qq + e] = s[e];
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, double* __restrict__ partial,
                                                              long long rows, int N, int ldx) {
   __shared__ float red[4][64];
@@ -345,7 +384,13 @@ extern "C" int segmif_colsum_f32(const float* x, float* out, double* workspace, 
   if (!x || !out || !workspace || rows <= 0 || N <= 0 || ldx < N) return SEGMIF_EINVAL;
   const int nblk = segmif_colsum_blocks(rows);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, workspace, (long long)rows, N, ldx);
+  const bool vec = !(N & 3) && !(ldx & 3) && !((uintptr_t)x & 15);
+  const int nq = N >> 2;
+  if (!vec) hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, workspace, (long long)rows, N, ldx);
+  else if (nq <= 8) hipLaunchKernelGGL(colsum_partial_vec_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, s, x, workspace, (long long)rows, N, ldx);
+  else if (nq <= 16) hipLaunchKernelGGL(colsum_partial_vec_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, s, x, workspace, (long long)rows, N, ldx);
+  else if (nq <= 32) hipLaunchKernelGGL(colsum_partial_vec_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, s, x, workspace, (long long)rows, N, ldx);
+  else hipLaunchKernelGGL(colsum_partial_vec_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, s, x, workspace, (long long)rows, N, ldx);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, workspace, out, nblk, N,
                      accumulate);
   return (int)hipGetLastError();

@@ -98,6 +98,8 @@ CONV_CASES = [
     (2, 16, 24, 32, 1, 3, 1, 1, 1),  # conv22
     (1, 33, 47, 128, 64, 3, 1, 1, 1),  # conv2
     (1, 8, 8, 320, 320, 2, 2, 0, 1),  # stage-3 sr conv
+    (2, 20, 28, 32, 160, 3, 1, 2, 2),  # DRDB input gradient shape (N > 64: halo kernel with output-channel tiles)
+    (1, 19, 37, 64, 96, 3, 1, 1, 1),
 ]
 
 
@@ -109,7 +111,7 @@ def test_igemm_conv(ops, case):
     xh = x.permute(0, 2, 3, 1).contiguous().cuda()
     wt = ops.pack_weight(w.cuda())
     tiles = [-1] if (Cin % 16) else list(TILES_ALL)
-    if k == 3 and s == 1 and p == d and N <= 64 and Cin % 16 == 0:
+    if k == 3 and s == 1 and p == d and N <= 256 and Cin % 16 == 0:
         tiles += [9, 10]  # halo-tiled 3x3 variants (conv3x3.hip)
     for tile in tiles:
         if tile in (1, 3, 5, 8, 11) and Cin % 32:
