@@ -177,6 +177,153 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Halo-tiled weight gradient of a 3x3 stride-1 convolution (dilation 1 or 2): the DRDB convs and the
+// other 3x3 convs of the fusion net.  The generic kernel above re-gathers the shifted input once per
+// tap and — with only 32 output channels — is bound by that gather (32 % of the MFMA peak measured).
+// Here a block owns a 32-channel slice of the input and walks a strip of 8x32 pixel tiles: per tile it
+// stages dY (256 px x 32 n) and the input halo ((8+2d) x (32+2d) px x 32 c) in LDS once; wave w takes
+// tile rows 2w, 2w+1 and accumulates ALL nine taps (nine 32x32 accumulators): A = dY^T read once per
+// pixel pair, B = the halo at nine shifted addresses.  After the strip the four waves' accumulators are
+// combined through LDS and written as one partial [N][9*Cin] slab (summed by wgrad_reduce_kernel).
+// ---------------------------------------------------------------------------------------------------
+struct Wg3K {
+  const float* dy;
+  const float* in;
+  float* partial;  // [strips][N][Kp]
+  float* bias_partial;  // [strips][N] or null (only channel-chunk 0 blocks write it)
+  int B, H, W, Cin, N, Kp, ldy, lda;
+  int tiles_x, tiles_y, tiles_total, tiles_per_strip, nchunks, yvec;
+};
+
+template <int DIL>
+__global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3K p) {
+  constexpr int TH = 8, TW = 32, HH = TH + 2 * DIL, HWD = TW + 2 * DIL, HP = HH * HWD;
+  constexpr int YJ = 8;  // dY float4 units per thread: 256 px * 8 / 256
+  constexpr int XJ = (HP * 8 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ys = smem;  // [256][32]
+  float* Xs = smem + 256 * 32;  // [HP][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int chunk = blockIdx.x % p.nchunks, strip = blockIdx.x / p.nchunks;
+  const int ntile = blockIdx.y;  // 32 output channels
+  const int c0 = chunk * 32, n0 = ntile * 32;
+  const int t_begin = strip * p.tiles_per_strip;
+  const int t_end = min(t_begin + p.tiles_per_strip, p.tiles_total);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+  f32x4 bsum{0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = p.bias_partial != nullptr && chunk == 0;
+
+  f32x4 ry[YJ], rx[XJ];
+  auto gload = [&](int tile) {
+    const int tx = tile % p.tiles_x;
+    const int ty = (tile / p.tiles_x) % p.tiles_y;
+    const int b = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = tx * TW, y0 = ty * TH;
+    const long long img = (long long)b * p.H * p.W;
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) {
+      const int u = tid + 256 * j;
+      const int px = u >> 3, q = (u & 7) * 4;
+      const int gy = y0 + (px >> 5), gx = x0 + (px & 31);
+      ry[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (gy < p.H && gx < p.W) {
+        const float* src = p.dy + (img + (long long)gy * p.W + gx) * p.ldy + n0 + q;
+        if (p.yvec && n0 + q + 3 < p.N) ry[j] = *reinterpret_cast<const f32x4*>(src);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n0 + q + e < p.N) ry[j][e] = src[e];
+        }
+      }
+      if (want_bias) bsum += ry[j];
+    }
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int u = tid + 256 * j;
+      rx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u < HP * 8) {
+        const int pp = u >> 3, q = (u & 7) * 4;
+        const int hy = pp / HWD, hx = pp - hy * HWD;
+        const int gy = y0 - DIL + hy, gx = x0 - DIL + hx;
+        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+          rx[j] = *reinterpret_cast<const f32x4*>(p.in + (img + (long long)gy * p.W + gx) * p.lda + c0 + q);
+      }
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) *reinterpret_cast<f32x4*>(Ys + (tid + 256 * j) * 4) = ry[j];
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int u = tid + 256 * j;
+      if (u < HP * 8) *reinterpret_cast<f32x4*>(Xs + u * 4) = rx[j];
+    }
+  };
+
+  if (t_begin < t_end) gload(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    sstore();
+    __syncthreads();
+    if (tile + 1 < t_end) gload(tile + 1);
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+      const int ry_ = 2 * wave + row;
+      const float* ya = Ys + (ry_ * 32 + h) * 32 + r;  // pixel (ry_, 2j + h), channel n = r
+      const float* xa = Xs + (ry_ * HWD + h) * 32 + r;  // halo pixel (ry_ + ky*DIL, 2j + h + kx*DIL), channel c = r
+#pragma unroll 4
+      for (int j = 0; j < 16; ++j) {
+        const float a = ya[2 * j * 32];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                a, xa[((ky * DIL) * HWD + 2 * j + kx * DIL) * 32], acc[ky * 3 + kx], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // combine the four waves (each holds 9 x [32 n][32 c]) tap by tap through LDS, write the partial slab
+  float* red = smem;  // [4][32][33]
+  float* out = p.partial + (long long)strip * p.N * p.Kp;
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int n = (v & 3) + 8 * (v >> 2) + 4 * h;
+      red[(wave * 32 + n) * 33 + r] = acc[t][v];
+    }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+      const int n = i >> 5, c = i & 31;
+      const float s4 = (red[(0 * 32 + n) * 33 + c] + red[(1 * 32 + n) * 33 + c]) +
+                       (red[(2 * 32 + n) * 33 + c] + red[(3 * 32 + n) * 33 + c]);
+      if (n0 + n < p.N) out[(long long)(n0 + n) * p.Kp + t * p.Cin + c0 + c] = s4;
+    }
+  }
+  if (want_bias) {
+    __syncthreads();
+    f32x4* rb = reinterpret_cast<f32x4*>(smem);
+    rb[tid] = bsum;
+    __syncthreads();
+    if (tid < 8) {
+      f32x4 sacc = rb[tid];
+      for (int i = 1; i < 32; ++i) sacc += rb[tid + 8 * i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n0 + tid * 4 + e < p.N) p.bias_partial[(long long)strip * p.N + n0 + tid * 4 + e] = sacc[e];
+    }
+  }
+}
+
 // sum over chunks (fp64) and scatter from the packed [N][Kp] (tap-major, channel-minor) order into the
 // parameter's own layout: OIHW for convs; element (n, k) -> dw[n*sn + k*sk] for dense problems.
 // accumulate != 0: grad += value.
@@ -352,6 +499,51 @@ extern "C" int segmif_wgrad_f32(const SegmifIgemm* d, const float* dy, int ldy, 
     k.conv = (d->Cin % 4 == 0 && d->lda % 4 == 0 && !((uintptr_t)d->in & 15) && d->in_zstride % 4 == 0) ? 1 : 2;
   }
   k.yvec = (ldy % 4 == 0) && !((uintptr_t)dy & 15) && (dy_zstride % 4 == 0);
+  {  // halo-tiled path for 3x3 stride-1 convs (DRDB and friends)
+    const bool halo = is_conv && d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) &&
+                      d->pad == d->dil && d->OH == d->H && d->OW == d->W && d->Cin % 32 == 0 && d->lda % 4 == 0 &&
+                      !((uintptr_t)d->in & 15) && nz == 1 && d->N <= 64 && d->M % ((long long)d->H * d->W) == 0;
+    if (halo) {
+      Wg3K w;
+      w.dy = dy; w.in = d->in; w.B = (int)(d->M / ((long long)d->H * d->W)); w.H = d->H; w.W = d->W; w.Cin = d->Cin;
+      w.N = d->N; w.Kp = k.Kp; w.ldy = ldy; w.lda = d->lda; w.yvec = k.yvec;
+      w.tiles_x = (d->W + 31) / 32; w.tiles_y = (d->H + 7) / 8; w.tiles_total = w.B * w.tiles_x * w.tiles_y;
+      w.nchunks = d->Cin / 32;
+      const int ntiles_n = (d->N + 31) / 32;
+      // strips: as many as the workspace sized by segmif_wgrad_workspace_size allows, aiming at ~1024 blocks
+      long long strips = pick_chunks(d->M, d->N, d->K);
+      const long long want = (1024 + (long long)w.nchunks * ntiles_n - 1) / ((long long)w.nchunks * ntiles_n);
+      if (strips > want) strips = want;
+      if (strips > w.tiles_total) strips = w.tiles_total;
+      if (strips < 1) strips = 1;
+      w.tiles_per_strip = (int)((w.tiles_total + strips - 1) / strips);
+      strips = (w.tiles_total + w.tiles_per_strip - 1) / w.tiles_per_strip;
+      w.partial = workspace;
+      w.bias_partial = dbias ? workspace + strips * d->N * k.Kp : nullptr;
+      hipStream_t s = (hipStream_t)stream;
+      dim3 grid((unsigned)(strips * w.nchunks), (unsigned)ntiles_n);
+      const int HPd = (8 + 2 * d->dil) * (32 + 2 * d->dil);
+      const size_t smem = (size_t)(256 * 32 + HPd * 32) * sizeof(float);
+      static bool raised1 = false, raised2 = false;
+      if (d->dil == 1) {
+        if (!raised1) { hipFuncSetAttribute((const void*)wgrad3x3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); raised1 = true; }
+        hipLaunchKernelGGL(wgrad3x3_halo_kernel<1>, grid, dim3(256), smem, s, w);
+      } else {
+        if (!raised2) { hipFuncSetAttribute((const void*)wgrad3x3_halo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); raised2 = true; }
+        hipLaunchKernelGGL(wgrad3x3_halo_kernel<2>, grid, dim3(256), smem, s, w);
+      }
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return (int)e;
+      const long long total = (long long)d->N * d->K;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1u), dim3(256), 0, s, workspace, dw,
+                         (int)strips, d->N, d->K, k.Kp, k.Cin, k.KH, k.KW, 0, (long long)dw_sn, (long long)dw_sk, 0LL,
+                         accumulate);
+      if (dbias)
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->N + 255) / 256)), dim3(256), 0, s,
+                           w.bias_partial, dbias, (int)strips, 1, d->N, accumulate);
+      return (int)hipGetLastError();
+    }
+  }
   long long chunks = pick_chunks(d->M, d->N, d->K);
   k.rows_per_chunk = ((d->M + chunks - 1) / chunks + MR - 1) / MR * MR;
   chunks = (d->M + k.rows_per_chunk - 1) / k.rows_per_chunk;
