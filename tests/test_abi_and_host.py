@@ -117,3 +117,42 @@ def test_oracle_is_not_imported_by_the_product():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "segmif_oracle" not in text and "detweights" not in text and "oracle" not in text.lower().replace(
                     "cpu oracle", "").replace("the oracle", ""), os.path.join(dirpath, fn)
+
+
+def test_reference_import_lines_resolve():
+    """train.py:18,111-112 / test_fusion.py:9 import lines work against the mirror package."""
+    import importlib
+    import segmif_amd.core as core
+    for name in ("core", "core.model_fusion", "core.mix_transformer", "core.segformer_head", "core.loss"):
+        sys.modules.pop(name, None)
+    sys.modules["core"] = core
+    sys.modules["core.model_fusion"] = core.model_fusion
+    try:
+        ns = {}
+        exec("from core.model_fusion import Fusion_Network3_ac, Network3, Mean\n"
+             "from core import Total_fusion_loss, Total_fusion_loss2, RGB2YCrCb, Fusionloss, Fusionloss_add, "
+             "Fusionloss2, Fusionloss3, Fusionloss4, Fusionloss_grad3\n"
+             "from core import SegFormerHead, WeTr, mit_b3", ns)
+        assert ns["Network3"] is core.Network3 and callable(ns["Fusionloss_grad3"])
+        with pytest.raises(NotImplementedError):
+            ns["Fusionloss4"]()(None)
+    finally:
+        sys.modules.pop("core", None)
+        sys.modules.pop("core.model_fusion", None)
+
+
+def test_losses_match_reference_formulas_on_cpu():
+    """Fusionloss3 / Fusionloss_grad3 restated (segmif_amd/losses.py) vs the reference formulas written
+    with library convolutions (core/loss.py:459-476, 506-517, 634-650; pytorch_ssim/__init__.py:19-43)."""
+    import torch.nn.functional as F
+    from segmif_amd import losses
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(2, 1, 21, 33, generator=g, dtype=torch.float64)
+    m = torch.rand(2, 3, 21, 33, generator=g, dtype=torch.float64)
+    kx = torch.tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]], dtype=torch.float64)[None, None]
+    ky = torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]], dtype=torch.float64)[None, None]
+    sob = lambda t: F.conv2d(t, kx, padding=1).abs() + F.conv2d(t, ky, padding=1).abs()
+    assert torch.allclose(losses.sobel_xy(a), sob(a), atol=1e-12)
+    ref3 = F.l1_loss(m[:, :1], a) + F.l1_loss(sob(m[:, :1]), sob(a))
+    assert abs(float(losses.fusion_loss3(a, m)) - float(ref3)) < 1e-12
+    assert 0.0 < float(losses.ssim(a, m[:, :1])) < 1.0 and abs(float(losses.ssim(a, a)) - 1.0) < 1e-9
