@@ -86,6 +86,11 @@ typedef struct SegmifIgemm {
    * same problem runs un-split. Partials are summed in a fixed order: results do not depend on the split. */
   float* workspace;
   int64_t workspace_floats;
+  /* optional fused LayerNorm over the output row (N must be 64, act NONE): out = LN(res + A.W^T + bias)
+   * — CrossPath's norm(x + end_proj(...)) (core/model_fusion.py:359-360) in the GEMM epilogue */
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
 } SegmifIgemm;
 
 int segmif_igemm_f32(const SegmifIgemm* desc, void* stream);

@@ -27,6 +27,7 @@ class SegmifIgemm(ctypes.Structure):
         ("tile", c_int32), ("nz2", c_int32), ("ldw", c_int32),
         ("in_zstride2", c_int64), ("wt_zstride2", c_int64), ("out_zstride2", c_int64), ("res_zstride2", c_int64),
         ("workspace", c_void_p), ("workspace_floats", c_int64),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
     ]
 
 

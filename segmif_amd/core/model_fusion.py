@@ -213,9 +213,10 @@ class CrossPath(nn.Module):
             # cat(z_i, v_i) @ Wend^T  ==  [y3 | u_i] @ Weff^T with the contexts folded in (ref :357-360)
             ops.linattn_fold(part, end.weight, weff, wofs=0, kofs=0, scale=self.cross_attn2.scale)
             ops.linattn_fold(part3, end.weight, weff, wofs=C, kofs=C, scale=self.cross_attn.scale)
-            y = ops.linear(p3[..., :C], weff, C, bias=end.bias, res=x, x2=p[..., C:], batched_weight=True)
             norm = getattr(self, f"norm{i}")
-            outs.append(ops.layernorm(y, norm.weight, norm.bias, norm.eps, out=o if o is not None else y))
+            # LN(x + [y3 | u_i] @ Weff^T + b): GEMM, residual and LayerNorm in one kernel
+            outs.append(ops.linear(p3[..., :C], weff, C, bias=end.bias, res=x, x2=p[..., C:], batched_weight=True,
+                                   ln=(norm.weight, norm.bias, norm.eps), out=o))
         return outs[0], outs[1]
 
     def forward_tokens_train(self, x1, x2, seg):

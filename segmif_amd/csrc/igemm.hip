@@ -249,6 +249,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
   // ---- epilogue: bias + activation (+ residual), 128-byte row segments per half wave ----------
   float* __restrict__ out = p.out + zb * p.out_zs + z2 * p.out_zs2;
   const float* __restrict__ res = p.res ? p.res + zb * p.res_zs + z2 * p.res_zs2 : nullptr;
+  if constexpr (WN == 64 && BN == 64) {
+    if (p.ln_gamma) {  // out = LayerNorm_64(res + acc + bias): a row lives in the 32 lanes of a half wave x 2 sub-tiles
+      const int nl = lane & 31;
+      const float b0 = p.bias ? p.bias[nl] : 0.f, b1 = p.bias ? p.bias[32 + nl] : 0.f;
+      const float g0 = p.ln_gamma[nl], g1 = p.ln_gamma[32 + nl], t0 = p.ln_beta[nl], t1 = p.ln_beta[32 + nl];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const long long m = m0 + wm * WM + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+          const bool ok = m < p.M;
+          float y0 = acc[i][0][v] + b0, y1 = acc[i][1][v] + b1;
+          if (res && ok) {
+            y0 += res[m * p.ldr + nl];
+            y1 += res[m * p.ldr + 32 + nl];
+          }
+          float s1 = y0 + y1;
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) s1 += __shfl_xor(s1, off);
+          const float mean = s1 * (1.0f / 64.0f);
+          const float d0 = y0 - mean, d1 = y1 - mean;
+          float s2 = d0 * d0 + d1 * d1;
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+          const float rstd = 1.0f / sqrtf(s2 * (1.0f / 64.0f) + p.ln_eps);
+          if (ok) {
+            out[m * p.ldo + nl] = d0 * rstd * g0 + t0;
+            out[m * p.ldo + 32 + nl] = d1 * rstd * g1 + t1;
+          }
+        }
+      }
+      return;
+    }
+  }
   const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -446,6 +480,8 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   k.res_zs = d->res_zstride;
   k.nz2 = d->nz2 > 0 ? d->nz2 : 1;
   k.in_zs2 = d->in_zstride2; k.wt_zs2 = d->wt_zstride2; k.out_zs2 = d->out_zstride2; k.res_zs2 = d->res_zstride2;
+  k.ln_gamma = d->ln_gamma; k.ln_beta = d->ln_beta; k.ln_eps = d->ln_eps;
+  if (k.ln_gamma && (!k.ln_beta || d->N != 64 || d->act != SEGMIF_ACT_NONE)) return SEGMIF_EINVAL;
   k.ldw = d->ldw > 0 ? d->ldw : k.Kp;
   if (k.ldw % 4) return SEGMIF_EINVAL;
   const int nz = (d->nz > 0 ? d->nz : 1) * k.nz2;
@@ -469,7 +505,11 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   const bool bk32_ok = (k.Kp % 32 == 0) && (mode != MODE_CONV || d->Cin % 32 == 0) &&
                        (mode != MODE_DENSE2 || (d->K1 % 32 == 0));
   int tile = d->tile;
-  const bool halo_ok = mode == MODE_CONV && nz == 1 && k.ldw == k.Kp && conv3x3_halo_eligible(k);
+  const bool halo_ok = mode == MODE_CONV && nz == 1 && k.ldw == k.Kp && !k.ln_gamma && conv3x3_halo_eligible(k);
+  if (k.ln_gamma) {
+    if (mode == MODE_GENERIC || (tile >= 0 && tile != 7 && tile != 8)) return SEGMIF_EINVAL;
+    if (tile < 0) tile = 7;  // the fused LayerNorm needs a wave tile spanning all 64 columns
+  }
   if (tile < 0 && halo_ok) tile = kHaloTile0 + 1;  // 8-channel chunks: best on every shape (profiles/r01_kernel_bench_halo.txt)
   k.splitk = 1;
   k.ksteps_per_split = 0;
@@ -491,7 +531,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
     tile = 11;  // few blocks, long K: half the barriers (profiles/r01_enc_gemm_tiles.txt)
   k.ntm = (int)((d->M + kTiles[tile].BM - 1) / kTiles[tile].BM);
   k.ntn = (d->N + kTiles[tile].BN - 1) / kTiles[tile].BN;
-  if (auto_tile && nz == 1 && (mode == MODE_DENSE || mode == MODE_CONV) && k.ldw == k.Kp) {
+  if (auto_tile && nz == 1 && (mode == MODE_DENSE || mode == MODE_CONV) && k.ldw == k.Kp && !k.ln_gamma) {
     k.splitk = plan_splitk(d->M, d->N, k.Kp, tile);
     if (k.splitk > 1) {
       const int nk = k.Kp / kTiles[tile].BK;

@@ -29,6 +29,9 @@ struct IgemmK {
   int splitk;  // > 1: gridDim.z = splitk, raw partial sums go to ws[split][M][N] (reduce + epilogue in a 2nd kernel)
   int ksteps_per_split;
   float* ws;
+  const float* ln_gamma;  // fused LayerNorm over the N = 64 output columns (tiles whose wave tile spans 64 columns)
+  const float* ln_beta;
+  float ln_eps;
   int ntm, ntn;
 };
 

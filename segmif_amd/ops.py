@@ -113,7 +113,7 @@ def _igemm(desc, tag=None):
 
 
 def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None, x2=None, tile=-1,
-           batched_weight=False):
+           batched_weight=False, ln=None):
     """out = res + act(x @ wt^T + bias).  x: rows view (..., K); wt: packed (N, Kp).
     x2: optional second source (..., K2): A = [x | x2] along K (no concat materialised).
     batched_weight: wt is (B, N, Kp) with one weight per leading batch index of x (x.dim() == 3)."""
@@ -166,6 +166,8 @@ def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
     d.KH = d.KW = d.stride = d.dil = 1
     d.pad = 0
     d.act, d.nz, d.tile = act, nz, tile
+    if ln is not None:  # (gamma, beta, eps): LayerNorm over the N = 64 outputs fused into the epilogue
+        d.ln_gamma, d.ln_beta, d.ln_eps = _req(ln[0]).data_ptr(), _req(ln[1]).data_ptr(), float(ln[2])
     _igemm(d)
     return out
 

@@ -87,6 +87,26 @@ def test_igemm_two_source_batched_weight(ops):
     assert err(y, ref) < TOL
 
 
+def test_igemm_fused_layernorm_epilogue(ops):
+    """out = LN_64(res + [a | b] @ W[z]^T + bias) in one launch (CrossPath end_proj + norm)."""
+    B, n, C = 2, 1500, 64
+    p3, p1, x = rnd(B, n, 128, seed=50), rnd(B, n, 128, seed=51), rnd(B, n, C, seed=52)
+    weff, bias, gm, bt = rnd(B, C, 128, seed=53), rnd(C, seed=54), rnd(C, seed=55, lo=0.5, hi=1.5), rnd(C, seed=56)
+    wide = torch.zeros(B, n, 224, device="cuda")
+    ops.linear(p3.cuda()[..., :C], weff.cuda(), C, bias=bias.cuda(), res=x.cuda(), x2=p1.cuda()[..., C:],
+               batched_weight=True, ln=(gm.cuda(), bt.cuda(), 1e-5), out=wide[..., :C])
+    a = torch.cat((p3[..., :C], p1[..., C:]), dim=-1).double()
+    pre = x.double() + torch.einsum("bnk,bok->bno", a, weff.double()) + bias.double()
+    ref = F.layer_norm(pre, (C,), gm.double(), bt.double(), 1e-5)
+    assert err(wide[..., :C], ref) < TOL
+    assert float(wide[..., C:].abs().max()) == 0.0
+    # plain dense with LN, rows not a multiple of the tile
+    xx, w = rnd(777, 224, seed=57), rnd(64, 224, seed=58)
+    y = ops.linear(xx.cuda(), ops.pack_weight(w.cuda()), 64, bias=bias.cuda(), ln=(gm.cuda(), bt.cuda(), 1e-6))
+    ref = F.layer_norm(xx.double() @ w.double().t() + bias.double(), (64,), gm.double(), bt.double(), 1e-6)
+    assert err(y, ref) < TOL
+
+
 CONV_CASES = [
     # B, H, W, Cin, N, k, stride, pad, dil
     (2, 20, 28, 64, 32, 3, 1, 2, 2),  # DRDB dilated conv
