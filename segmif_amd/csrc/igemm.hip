@@ -33,7 +33,7 @@ namespace {
 
 enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_GENERIC = 2, MODE_DENSE2 = 3 };
 
-template <int BM, int BN, int WM, int WN, int BK, int MODE>
+template <int BM, int BN, int WM, int WN, int BK, int MODE, int PF = 1>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
   constexpr int BKP = BK + 4;
   constexpr int UPR = BK / 4;  // float4 units per tile row
@@ -103,10 +103,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
     b_ptr[j] = wt + (long long)(n0 + nrow) * p.ldw + kq * 4;
   }
 
-  f32x4 ra[AU], rb[BU];
+  f32x4 ra0[AU], rb0[BU], ra1[PF == 2 ? AU : 1], rb1[PF == 2 ? BU : 1];
   int tap_ky = 0, tap_kx = 0, tap_c0 = 0;  // CONV mode: wave-uniform position of the next K tile
 
-  auto gload = [&](int kc) {
+  auto gload = [&](int kc, f32x4* ra, f32x4* rb) {
     const int k0 = kc * BK;
 #pragma unroll
     for (int j = 0; j < BU; ++j) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
     }
   };
 
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const f32x4* ra, const f32x4* rb) {
     float* a_dst = As + buf * (BM * BKP) + row_t * BKP + kq * 4;
 #pragma unroll
     for (int j = 0; j < AU; ++j) *reinterpret_cast<f32x4*>(a_dst + j * RPP * BKP) = ra[j];
@@ -201,14 +201,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
       tap_kx = tap - tap_ky * p.KW;
     }
   }
-  gload(kc_begin);
-  sstore(0);
-  __syncthreads();
-
   const int frag_off = (lane & 31) * BKP + (lane >> 5) * 4;
-  for (int kc = kc_begin; kc < nk; ++kc) {
-    const int cur = (kc - kc_begin) & 1;
-    if (kc + 1 < nk) gload(kc + 1);
+  auto compute = [&](int cur) {
     const float* a_base = As + cur * (BM * BKP) + (wm * WM) * BKP + frag_off;
     const float* b_base = Bs + cur * (BN * BKP) + (wn * WN) * BKP + frag_off;
 #pragma unroll
@@ -226,8 +220,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
-    if (kc + 1 < nk) sstore(cur ^ 1);
+  };
+
+  if constexpr (PF == 1) {
+    gload(kc_begin, ra0, rb0);
+    sstore(0, ra0, rb0);
     __syncthreads();
+    for (int kc = kc_begin; kc < nk; ++kc) {
+      const int cur = (kc - kc_begin) & 1;
+      if (kc + 1 < nk) gload(kc + 1, ra0, rb0);
+      compute(cur);
+      if (kc + 1 < nk) sstore(cur ^ 1, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    // prefetch distance 2: a tile's global loads are issued two K steps before its LDS store, so ~2 x the MFMA
+    // work of a step covers the L2 / HBM latency (latency-bound grids of a few blocks per CU)
+    gload(kc_begin, ra0, rb0);
+    sstore(0, ra0, rb0);
+    if (kc_begin + 1 < nk) gload(kc_begin + 1, ra1, rb1);
+    if (kc_begin + 2 < nk) gload(kc_begin + 2, ra0, rb0);
+    __syncthreads();
+    for (int kc = kc_begin; kc < nk; kc += 2) {
+      compute(0);  // tile kc
+      if (kc + 1 < nk) sstore(1, ra1, rb1);
+      if (kc + 3 < nk) gload(kc + 3, ra1, rb1);
+      __syncthreads();
+      if (kc + 1 < nk) {
+        compute(1);  // tile kc + 1
+        if (kc + 2 < nk) sstore(0, ra0, rb0);
+        if (kc + 4 < nk) gload(kc + 4, ra0, rb0);
+        __syncthreads();
+      }
+    }
   }
 
   if (p.splitk > 1) {  // raw partial sums; bias / activation / residual are applied by splitk_reduce_kernel
@@ -310,19 +335,20 @@ struct TileCfg {
   int BM, BN, BK;
   const char* name;
 };
-constexpr int kNumTiles = 12;  // 0-8, 11: implicit-GEMM tiles; 9, 10: halo-tiled 3x3 (conv3x3.hip)
+constexpr int kNumTiles = 14;  // 0-8, 11-13: implicit-GEMM tiles; 9, 10: halo-tiled 3x3 (conv3x3.hip)
 const TileCfg kTiles[kNumTiles] = {
     {256, 32, 16, "256x32x16"}, {256, 32, 32, "256x32x32"}, {128, 64, 16, "128x64x16"},
     {128, 64, 32, "128x64x32"}, {128, 128, 16, "128x128x16"}, {128, 128, 32, "128x128x32"},
     {64, 64, 16, "64x64x16"},   {256, 64, 16, "256x64x16"},   {256, 64, 32, "256x64x32"},
     {256, 64, 16, "halo8x32c16"}, {256, 64, 8, "halo8x32c8"}, {64, 64, 32, "64x64x32"},
+    {64, 64, 16, "64x64x16p2"}, {128, 64, 16, "128x64x16p2"},
 };
 constexpr int kHaloTile0 = 9;
 
-template <int BM, int BN, int WM, int WN, int BK, int MODE>
+template <int BM, int BN, int WM, int WN, int BK, int MODE, int PF = 1>
 int launch(const IgemmK& k, int nz, hipStream_t stream) {
   constexpr size_t smem = 2ull * (BM + BN) * (BK + 4) * sizeof(float);
-  auto fn = igemm_kernel<BM, BN, WM, WN, BK, MODE>;
+  auto fn = igemm_kernel<BM, BN, WM, WN, BK, MODE, PF>;
   if (smem > 64 * 1024) {
     static bool raised = false;  // idempotent attribute; benign race
     if (!raised) {
@@ -349,6 +375,8 @@ int dispatch_tile(int tile, const IgemmK& k, int nz, hipStream_t s) {
     case 7: return launch<256, 64, 64, 64, 16, MODE>(k, nz, s);
     case 8: return launch<256, 64, 64, 64, 32, MODE>(k, nz, s);
     case 11: return launch<64, 64, 32, 32, 32, MODE>(k, nz, s);
+    case 12: return launch<64, 64, 32, 32, 16, MODE, 2>(k, nz, s);
+    case 13: return launch<128, 64, 64, 32, 16, MODE, 2>(k, nz, s);
   }
   return SEGMIF_EINVAL;
 }
@@ -526,9 +554,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   if (tile < 0) tile = pick_tile(d->M, d->N, d->K, nz, mode == MODE_GENERIC);
   if (tile >= kNumTiles) return SEGMIF_EINVAL;
   if (kTiles[tile].BK == 32 && !bk32_ok) return SEGMIF_EINVAL;
-  if (auto_tile && tile == 6 && bk32_ok && d->K >= 1024 &&
-      ((d->M + 63) / 64) * ((d->N + 63) / 64) * nz <= 1024)
-    tile = 11;  // few blocks, long K: half the barriers (profiles/r01_enc_gemm_tiles.txt)
+  if (auto_tile && tile == 6 && d->K >= 128) tile = 12;  // prefetch distance 2: +3..9 % (profiles/r01_enc_gemm_tiles.txt)
   k.ntm = (int)((d->M + kTiles[tile].BM - 1) / kTiles[tile].BM);
   k.ntn = (d->N + kTiles[tile].BN - 1) / kTiles[tile].BN;
   if (auto_tile && nz == 1 && (mode == MODE_DENSE || mode == MODE_CONV) && k.ldw == k.Kp && !k.ln_gamma) {

@@ -44,7 +44,7 @@ def act_ref(y, act, slope=None):
     return y
 
 
-TILES_ALL = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 11]
+TILES_ALL = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13]
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 64, 64), (300, 512, 2048), (4099, 9, 256), (257, 128, 32), (77, 1, 64),

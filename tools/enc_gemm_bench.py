@@ -5,6 +5,6 @@ from kernel_bench import bench_dense, bench_conv, tile_names
 names = tile_names()
 for (m, n, k) in ((153600, 64, 64), (153600, 256, 64), (153600, 64, 256), (38400, 128, 128), (38400, 512, 128), (38400, 128, 512),
                   (9600, 320, 320), (9600, 640, 320), (9600, 1280, 320), (9600, 320, 1280), (2400, 512, 512), (2400, 2048, 512), (2400, 512, 2048)):
-    bench_dense(m, n, k, [6, 11, 2], names, iters=20)
-bench_conv(8, 30, 40, 320, 320, 2, 0, 1, [6, 11], names, stride=2)
-bench_conv(8, 120, 160, 64, 64, 8, 0, 1, [6, 11], names, stride=8)
+    bench_dense(m, n, k, [6, 12, 2, 13], names, iters=20)
+bench_conv(8, 30, 40, 320, 320, 2, 0, 1, [6, 12], names, stride=2)
+bench_conv(8, 120, 160, 64, 64, 8, 0, 1, [6, 12], names, stride=8)
