@@ -82,8 +82,8 @@ def _dp_worker(rank, world, port, q):
         loss = ((net(full_x[mine]) - full_y[mine]) ** 2).mean()
         loss.backward()
         red.finish()
-        out.append([p.grad.clone() if p.grad is not None else None for p in params])
-    mean_loss = allreduce_scalar_mean(float(loss))
+        out.append([p.grad.tolist() if p.grad is not None else None for p in params])  # plain lists: no shared-memory handles
+    mean_loss = allreduce_scalar_mean(float(loss.detach()))
     q.put((rank, out, mean_loss, len(red._buckets)))
     sdist.shutdown()
 
@@ -111,6 +111,6 @@ def test_data_parallel_gradient_allreduce_matches_full_batch():
         for step in range(3):
             grads = res[rank][1][step]
             for g, r in zip(grads[:4], ref):
-                assert torch.allclose(g, r, atol=1e-6), (rank, step)
+                assert torch.allclose(torch.tensor(g), r, atol=1e-6), (rank, step)
             assert grads[4] is None and grads[5] is None  # unused parameters stay grad-less
     assert abs(res[0][2] - res[1][2]) < 1e-12
