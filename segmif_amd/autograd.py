@@ -172,6 +172,19 @@ class ConvFn(torch.autograd.Function):
                 # full correlation with the 180-degree rotated, in/out-swapped kernel
                 wr = w.flip(2, 3).transpose(0, 1).contiguous()
                 dx = ops.conv2d(dz, ops.pack_weight(wr), cin, k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
+            elif stride == k and pad == 0 and dil == 1:
+                # non-overlapping patches (sr conv): every input pixel belongs to exactly one patch, so
+                # dX is one dense GEMM dY (M', N) @ W (N, k*k*Cin) followed by a patch -> image permutation
+                OH, OW = dz.shape[1], dz.shape[2]
+                wt = w.permute(2, 3, 1, 0).reshape(k * k * cin, N).contiguous()  # [(ky,kx,c)][n]
+                wt = wt if N % 16 == 0 else ops.pack_weight(wt)
+                cols = ops.linear(dz.view(B, OH * OW, N), wt, k * k * cin)
+                cols = cols.view(B, OH, OW, k, k, cin).permute(0, 1, 3, 2, 4, 5).reshape(B, OH * k, OW * k, cin)
+                if OH * k == H and OW * k == W:
+                    dx = cols.contiguous()
+                else:  # rows / columns the forward conv dropped receive no gradient
+                    dx = torch.zeros((B, H, W, cin), device=x.device, dtype=torch.float32)
+                    dx[:, :OH * k, :OW * k] = cols
             else:
                 wd = w.permute(2, 3, 0, 1).contiguous()  # [ky][kx][n][c]
                 dx = torch.empty((B, H, W, cin), device=x.device, dtype=torch.float32)
