@@ -554,7 +554,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   if (tile < 0) tile = pick_tile(d->M, d->N, d->K, nz, mode == MODE_GENERIC);
   if (tile >= kNumTiles) return SEGMIF_EINVAL;
   if (kTiles[tile].BK == 32 && !bk32_ok) return SEGMIF_EINVAL;
-  if (auto_tile && tile == 6 && d->K >= 128) tile = 12;  // prefetch distance 2: +3..9 % (profiles/r01_enc_gemm_tiles.txt)
+  if (auto_tile && tile == 6 && d->K >= 128 && mode != MODE_GENERIC) tile = 12;  // prefetch distance 2: +3..9 % (profiles/r01_enc_gemm_tiles.txt)
   k.ntm = (int)((d->M + kTiles[tile].BM - 1) / kTiles[tile].BM);
   k.ntn = (d->N + kTiles[tile].BN - 1) / kTiles[tile].BN;
   if (auto_tile && nz == 1 && (mode == MODE_DENSE || mode == MODE_CONV) && k.ldw == k.Kp && !k.ln_gamma) {
