@@ -1,5 +1,5 @@
-"""How many host threads should the CPU baseline (oracle) use on the GPU box?  Times one
-mit_b1 64x96 ... no: one quarter-size mit_b3 pair per thread count, bounded."""
+"""How many host threads should the CPU baseline (oracle) use on the GPU box?  Times one quarter-size
+(240x320) mit_b3 pair forward per thread count; bench.py's CPU_BASELINE_THREADS is the fastest setting."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
