@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step")
     ap.add_argument("--backbone", default="mit_b3")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
@@ -150,11 +150,11 @@ def main():
             n, ms, flops = timer.summary()
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant.json")
-            if os.path.exists(pmc) and B == 8 and (H, W) == (480, 640):
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant.json" if B == 8 else f"r01_pmc_dominant_b{B}.json")
+            if os.path.exists(pmc) and (H, W) == (480, 640):
                 # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
                 rec = json.load(open(pmc))
-                traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/r01_pmc_dominant.json"
+                traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(pmc)
             out["roofline"] = {
                 "kernel": "conv3x3_halo_kernel<32,8,2> (DRDB dilated 3x3 conv, fp32 MFMA)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
