@@ -31,6 +31,10 @@ GFLOP_PER_PAIR = {("mit_b1", 480, 640): 700.2, ("mit_b3", 480, 640): 827.1,
                   ("mit_b5", 1024, 1024): 2 * 798.47 + 38.8 + 2178.0}  # b5: BASELINE.md table, head / fusion scaled by pixels
 CPU_BASELINE_THREADS = 16  # fastest of {16,32,64,128,256} on the GPU box host (profiles/r01_cpu_threads.txt)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
+# bf16x6 (csrc/conv3x3_split.hip): six bf16 MFMA products per fp32-equivalent multiply-add, so the
+# ceiling in algorithmic (fp32) flops is the dense BF16 MFMA peak / 6
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def parse():
@@ -135,7 +139,9 @@ def main():
             "metric": "IR+visible image-pairs/sec fwd", "value": value, "unit": "img-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if ops.conv3x3_mode() == "fp32" else "f32 (3x3 convs: fp32-equivalent 3-way bf16 split, 6 MFMA products)",
+            "data": "synthetic",
             "config": {"workload": f"{args.backbone} pair forward (forward_fusion + Fusion_Network3_ac + Network3 "
                                    f"+ x4 bilinear + argmax), {H}x{W}, {B} pairs per GPU per step, eval mode, "
                                    "seeded deterministic weights",
@@ -150,15 +156,21 @@ def main():
             n, ms, flops = timer.summary()
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant.json" if B == 8 else f"r01_pmc_dominant_b{B}.json")
+            split = ops.conv3x3_mode() == "bf16x6"
+            peak = PEAK_BF16X6_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+            pmc = os.path.join(ROOT, "profiles", (f"r01_pmc_dominant_b{B}_bf16x6.json" if split else
+                                                  "r01_pmc_dominant.json" if B == 8 else f"r01_pmc_dominant_b{B}.json"))
             if os.path.exists(pmc) and (H, W) == (480, 640):
                 # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
                 rec = json.load(open(pmc))
                 traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(pmc)
             out["roofline"] = {
-                "kernel": "conv3x3_halo_kernel<32,8,2> (DRDB dilated 3x3 conv, fp32 MFMA)",
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                "kernel": ("conv3x3_split_kernel<32,2,8> (DRDB dilated 3x3 conv, bf16 MFMA x 6 split products, fp32-class)"
+                           if split else "conv3x3_halo_kernel<32,8,2> (DRDB dilated 3x3 conv, fp32 MFMA)"),
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "peak_basis": ("dense BF16 MFMA 2500 TFLOP/s / 6 products per fp32-equivalent MAC; achieved counts "
+                               "algorithmic fp32 flops" if split else "dense fp32 MFMA"),
+                "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": (1200.0 + 300.0) * 2 ** 20 * B / 8,
                 "launches_timed": n, "avg_launch_ms": ms, "avg_launch_gflop": flops / 1e9,
             }

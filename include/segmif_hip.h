@@ -107,6 +107,20 @@ const char* segmif_igemm_tile_name(int tile);
 int segmif_pack_conv_weight(const float* src_oihw, float* dst, int N, int Cin, int KH, int KW, void* stream);
 
 /*
+ * Split-bf16 ("bf16x6") form of a packed 3x3 weight, for tile 14 of segmif_igemm_f32: every fp32
+ * weight becomes three bf16 planes (w = w0 + w1 + w2, 24 significand bits), laid out
+ * [n-tile][16-channel chunk][tap][n][plane][16] so a workgroup streams one chunk's nine taps as one
+ * contiguous block.  The kernel splits the activations the same way on the fly and sums the six
+ * products >= 2^-16 on v_mfma_f32_32x32x16_bf16: fp32-class accuracy at 2.7x the fp32 MFMA rate
+ * (DRDB convs, core/model_fusion.py:121-157).  `packed` is the segmif_pack_conv_weight image
+ * (row pitch ldw floats); `out` holds segmif_conv3x3_split_weight_bytes(N, Cin) bytes.  Cin % 16 == 0.
+ * With tile = 14 the descriptor's `wt` points at this image; geometry limits are those of the halo
+ * tiles (3x3, stride 1, dilation 1|2, pad = dilation, N <= 256), anything else returns SEGMIF_EINVAL.
+ */
+int64_t segmif_conv3x3_split_weight_bytes(int N, int Cin);
+int segmif_conv3x3_split_pack(const float* packed, int N, int Cin, int ldw, void* out, void* stream);
+
+/*
  * Weight gradient of the same problem: dW[n][k] = sum_m dY[m][n] * A(m,k), contraction over rows on
  * fp32 MFMA, deterministic two-pass reduction (per-chunk partials, then an fp64 sum) written in the
  * parameter's own layout: dw[n*dw_sn + k'*...] — OIHW for convs, (N, K) for linears; for dense

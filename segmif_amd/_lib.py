@@ -40,6 +40,8 @@ SIGNATURES = {
     "segmif_igemm_num_tiles": (c_int, []),
     "segmif_igemm_tile_name": (c_char_p, [c_int]),
     "segmif_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "segmif_conv3x3_split_weight_bytes": (c_int64, [c_int, c_int]),
+    "segmif_conv3x3_split_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "segmif_wgrad_workspace_size": (c_int64, [c_int64, c_int, c_int]),
     "segmif_wgrad_f32": (c_int, [POINTER(SegmifIgemm), c_void_p, c_int, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                  c_void_p, c_int, c_void_p]),
@@ -98,11 +100,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SEGMIF_HIP_LIB", LIB_PATH)  # override: kernel-tuning builds of the same ABI
+    if not os.path.exists(path):
         raise HipLibraryMissing(
-            f"{LIB_PATH} not found: build it with `python -m segmif_amd.build` "
+            f"{path} not found: build it with `python -m segmif_amd.build` "
             "(hipcc --offload-arch=gfx950). segmif_amd has no CPU or torch fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.restype = res

@@ -107,7 +107,7 @@ class DRDB(nn.Module):
         ch = self.in_ch
         for i in range(1, 6):
             conv = getattr(self, f"Dcov{i}")
-            ops.conv2d(buf[..., :ch], self._pk.get(f"d{i}", conv.weight, ops.pack_weight), self.growth, 3,
+            ops.conv2d(buf[..., :ch], self._pk.get(f"d{i}:{ops.conv3x3_mode()}", conv.weight, ops.pack_conv3x3), self.growth, 3,
                        pad=2, dil=2, bias=conv.bias, act=ops.ACT_RELU, out=buf[..., ch:ch + self.growth], tag="drdb_dcov")
             ch += self.growth
         return ops.linear(buf, self._pk.get("conv", self.conv.weight, ops.pack_weight), self.in_ch,
@@ -298,6 +298,9 @@ class Fusion_Network3_ac(nn.Module):
     def _w(self, name):
         return self._pk.get(name, getattr(self, name).weight, ops.pack_weight)
 
+    def _w3(self, name):  # stride-1 "same" 3x3 convs: split-bf16 image when ops.conv3x3_mode() allows
+        return self._pk.get(f"{name}:{ops.conv3x3_mode()}", getattr(self, name).weight, ops.pack_conv3x3)
+
     @staticmethod
     def _first_channel_nhwc(x):
         """x[:, 0:1] of an NCHW image as an NHWC (B,H,W,1) tensor (identical memory for C == 1)."""
@@ -358,8 +361,8 @@ class Fusion_Network3_ac(nn.Module):
         seg = ops.linear(ops.to_nhwc(out2), self._w("conv4"), 64, bias=self.conv4.bias)
         cat = torch.empty((B, H, W, 128), device=dev, dtype=torch.float32)
         self.ffm.forward_nhwc(x1, x2, seg, out1=cat[..., :64], out2=cat[..., 64:])
-        f = ops.conv2d(cat, self._w("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)
-        f = ops.conv2d(f, self._w("conv21"), 32, 3, pad=1, bias=self.conv21.bias, act=PRELU, prelu=slope)
+        f = ops.conv2d(cat, self._w3("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)
+        f = ops.conv2d(f, self._w3("conv21"), 32, 3, pad=1, bias=self.conv21.bias, act=PRELU, prelu=slope)
         f = ops.conv2d(f, self._w("conv22"), 1, 3, pad=1, bias=self.conv22.bias, act=PRELU, prelu=slope)
         return f.view(B, 1, H, W)
 

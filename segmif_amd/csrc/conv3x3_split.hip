@@ -1,0 +1,330 @@
+// Halo-tiled 3x3 stride-1 convolution on the bf16 matrix pipe with a 3-way operand split
+// ("bf16x6"): fp32-class results at 2.7x the fp32-MFMA rate.  Same role as conv3x3.hip — the DRDB
+// dilated convs of core/model_fusion.py:121-157 — selected with tile id 14.
+//
+// Numerics.  Every fp32 operand is written as x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0),
+// x2 = bf16(x - x0 - x1) (round to nearest, the two subtractions are exact in fp32), i.e. 3 x 8 = 24
+// significand bits.  A product a*w is evaluated as the six terms of weight >= 2^-16
+//     a0 w0 + (a0 w1 + a1 w0) + (a0 w2 + a1 w1 + a2 w0)
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16; the dropped
+// terms (a1 w2, a2 w1, a2 w2) are <= 2^-23 |a w| with random sign — the size of one fp32 rounding.
+// The result is therefore as accurate as the exact-fp32 MFMA path (tests: both against fp64), at
+// 6 x 32 = 192 matrix-pipe cycles per 32x32x16 block instead of 8 x 64 = 512.  Inf inputs turn
+// into NaN (inf - inf in the split); finite inputs of any magnitude are safe (bf16 has the fp32
+// exponent range).
+//
+// Layout.  A workgroup owns an STH x 32 patch of output pixels (STH = 8: 4 waves, 79 KB of LDS, two
+// workgroups per CU — the NOUT = 32 DRDB case; STH = 16: 8 waves, one workgroup per CU, when 64 output
+// channels fill the LDS).  Per 16-channel chunk it stages the (STH+2d) x (32+2d) input halo in LDS as
+// three bf16 planes per pixel ([pixel][plane][16 ch], 96 B + 16 B pad = 112 B pitch: conflict-free
+// ds_read_b128 across 16 consecutive pixels) — the split happens in registers between the global fp32
+// load and the LDS write, HBM still holds plain fp32 NHWC — and the nine taps' pre-split weights
+// ([tap][n][plane][16], packed once per parameter by segmif_conv3x3_split_pack).  A wave computes
+// two patch rows R0 and R0 + d: tap ky of the second reads the halo row tap ky + 1 of the first reads,
+// so 4 x 3 fragment sets (not 2 x 9) cover both.  Fragments of step s + 1 are requested before the
+// MFMAs of step s (double-buffered A set, 3-deep weight ring, sched_barrier-pinned), chunk c + 1
+// streams into registers under chunk c's MFMAs and is split between its last steps.
+//
+// Where the time goes (round 1, 128 -> 32 DRDB conv at 8 x 480 x 640, tools/split_ablate.sh and
+// tools/micro/mfma_chain.hip): the matrix pipe alone needs 0.53 ms (16.4 ns per MFMA per SIMD at the
+// ~1.95 GHz the chip holds under bf16 MFMA load; one accumulation chain per wave already issues
+// back-to-back), staging alone 0.45 ms, the kernel 1.03 ms: the two co-resident workgroups of a CU
+// run in lock-step, so load/split/store segments meet load/split/store segments instead of MFMA
+// segments.  Tried and measured no better: 16-row patches, a ping-pong workgroup (two halves held in
+// anti-phase by a barrier per phase, 1.10 ms), static wave priority by LDS slot, 4 accumulation
+// chains.  Still 1.45x the exact-fp32 halo kernel (1.49 ms) at equal accuracy.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "igemm_common.h"
+#include "segmif_hip.h"
+
+#ifndef SPLIT_DBG
+#define SPLIT_DBG 0  // tuning aid: compile-time ablation mask (tools/split_ablate.sh)
+#endif
+
+namespace segmif {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int STW = 32;
+constexpr int ROWB = 112;  // LDS bytes per pixel / weight row
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: a -> low half
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+  p1 = pk_bf16(r0, r1);
+  r0 -= __uint_as_float(p1 << 16);
+  r1 -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = pk_bf16(r0, r1);
+}
+
+inline int split_nout(int N) { return N <= 32 ? 32 : 64; }
+
+// STH = patch height: 8 (4 waves, 79 KB LDS with NOUT = 32 -> two workgroups per CU, one loading while
+// the other multiplies) or 16 (8 waves, one workgroup per CU; needed when NOUT = 64 fills the LDS).
+template <int NOUT, int DIL, int STH>
+__global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_kernel(const IgemmK p, int tiles_x, int tiles_y) {
+  constexpr int NT = STH * 32;
+  constexpr int HH = STH + 2 * DIL, HW = STW + 2 * DIL, HP = HH * HW;
+  constexpr int A_UNITS = HP * 4;         // float4 units: 16 channels = 4 per pixel
+  constexpr int B_UNITS = 9 * NOUT * 6;   // 16-byte units of split weights per chunk
+  constexpr int AJ = (A_UNITS + NT - 1) / NT, BJ = (B_UNITS + NT - 1) / NT;
+  constexpr int TN = NOUT / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  unsigned char* As = smem_b;              // [HP][ROWB]
+  unsigned char* Bs = smem_b + HP * ROWB;  // [9 * NOUT][ROWB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  int bid = blockIdx.x;
+  {  // XCD-aware remap: each XCD owns a contiguous run of patches (shared halo rows stay in one L2)
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int ntile = blockIdx.y, nbase = ntile * NOUT;
+  const int tx = bid % tiles_x;
+  const int ty = (bid / tiles_x) % tiles_y;
+  const int b = bid / (tiles_x * tiles_y);
+  const int x0 = tx * STW, y0 = ty * STH;
+  const float* __restrict__ in = p.in + (long long)b * p.H * p.W * p.lda;
+  const int nchunks = p.Cin / 16;
+  const u32x4* __restrict__ wsp = reinterpret_cast<const u32x4*>(p.wt) + (long long)ntile * nchunks * B_UNITS;
+
+  // per-thread staging slots, fixed across chunks.  Loads are unconditional (out-of-image and
+  // surplus slots read pixel 0 / the last weight unit and are zeroed / dropped later) so that the
+  // compiler can count them: s_waitcnt vmcnt(n) on the oldest slot while the rest are in flight.
+  int a_off[AJ], a_dst[AJ];
+  bool a_ok[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int u = tid + NT * j;
+    const int pp = u >> 2, q4 = u & 3;
+    const int hy = pp / HW, hx = pp - hy * HW;
+    const int gy = y0 - DIL + hy, gx = x0 - DIL + hx;
+    a_dst[j] = u < A_UNITS ? pp * ROWB + q4 * 8 : -1;
+    a_ok[j] = u < A_UNITS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    a_off[j] = (a_ok[j] ? (gy * p.W + gx) * p.lda : 0) + q4 * 4;
+  }
+  int b_src[BJ], b_dst[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int u = tid + NT * j;
+    const int row = u / 6, s6 = u - row * 6;
+    b_dst[j] = u < B_UNITS ? row * ROWB + s6 * 16 : -1;
+    b_src[j] = u < B_UNITS ? u : B_UNITS - 1;
+  }
+
+  f32x4 ra[AJ];
+  u32x2 pa[AJ][3];  // the same units after the split: [plane] = 4 bf16
+  u32x4 rb[BJ];
+  auto gload = [&](int c) {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(in + a_off[j] + c * 16);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) rb[j] = wsp[(long long)c * B_UNITS + b_src[j]];
+  };
+  auto split_unit = [&](int j) {  // registers only: interleaved with the tail of the previous chunk's MFMAs
+    uint32_t p0a, p1a, p2a, p0b, p1b, p2b;
+    const f32x4 x = a_ok[j] ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    split3(x[0], x[1], p0a, p1a, p2a);
+    split3(x[2], x[3], p0b, p1b, p2b);
+    pa[j][0] = u32x2{p0a, p0b};
+    pa[j][1] = u32x2{p1a, p1b};
+    pa[j][2] = u32x2{p2a, p2b};
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j)
+      if (a_dst[j] >= 0) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(As + a_dst[j] + pl * 32) = pa[j][pl];
+      }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j)
+      if (b_dst[j] >= 0) *reinterpret_cast<u32x4*>(Bs + b_dst[j]) = rb[j];
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  // The wave's two sub-tiles are patch rows R0 and R0 + DIL: tap ky of the second reads the halo row
+  // tap ky + 1 of the first reads, so 4 x 3 fragment sets (not 2 x 9) cover both.  A chunk is 12
+  // steps (kx, m): halo row R0 + m * DIL at column offset kx * DIL feeds sub-tile 0 with tap ky = m
+  // (m < 3) and sub-tile 1 with tap ky = m - 1 (m > 0).  The fragments of step s + 1 are requested
+  // before the MFMAs of step s are issued (double-buffered A set, 3-deep weight ring), so the LDS
+  // latency hides under 6-12 MFMAs instead of stalling the wave once per fragment.
+  const int R0 = (DIL == 2) ? ((wave >> 1) * 4 + (wave & 1)) : 2 * wave;
+  const unsigned char* a_lane = As + (R0 * HW + r) * ROWB + h * 16;
+  const unsigned char* b_lane = Bs + r * ROWB + h * 16;
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first
+  constexpr int PW[6] = {0, 1, 2, 0, 1, 0};
+  constexpr int SPLIT_FROM = 12 - AJ;
+
+  constexpr bool W_AHEAD = TN == 1;  // two output-channel tiles: the 3-deep weight ring would spill
+  bf16x8 F[2][3], Wr[W_AHEAD ? 3 : 2][TN][3];
+  auto load_f = [&](int st) {
+    const int kx = st >> 2, m = st & 3;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      F[st & 1][pl] = *reinterpret_cast<const bf16x8*>(a_lane + (m * DIL * HW + kx * DIL) * ROWB + pl * 32);
+  };
+  auto load_w = [&](int st) {
+    const int kx = st >> 2, m = st & 3;
+    if (m < 3) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          Wr[W_AHEAD ? m : (m & 1)][j][pl] =
+              *reinterpret_cast<const bf16x8*>(b_lane + ((m * 3 + kx) * NOUT + j * 32) * ROWB + pl * 32);
+    }
+  };
+
+  gload(0);
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) split_unit(j);
+  for (int c = 0; c < nchunks; ++c) {
+    if (!(SPLIT_DBG & 16) || c == 0) sstore();
+    __syncthreads();
+    const bool more = c + 1 < nchunks;
+    if (more && !(SPLIT_DBG & 8)) gload(c + 1);
+    load_f(0);
+    if (W_AHEAD) load_w(0);
+#pragma unroll
+    for (int st = 0; st < 12; ++st) {
+      const int m = st & 3;
+      const int wc = W_AHEAD ? m : (m & 1), wp = W_AHEAD ? m - 1 : ((m - 1) & 1);
+      if (!(SPLIT_DBG & 2)) {
+        if (!W_AHEAD) load_w(st);
+        if (st + 1 < 12) {
+          load_f(st + 1);
+          if (W_AHEAD) load_w(st + 1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (SPLIT_DBG & 1) continue;
+          if (m < 3)
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[st & 1][PA[t]], Wr[wc][j][PW[t]], acc[0][j], 0, 0, 0);
+          if (m > 0)
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[st & 1][PA[t]], Wr[wp][j][PW[t]], acc[1][j], 0, 0, 0);
+        }
+      if (st >= SPLIT_FROM && more && !(SPLIT_DBG & 4)) split_unit(st - SPLIT_FROM);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (same contract as the fp32 halo kernel) ----------------------------------------
+  const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
+  const long long img = (long long)b * p.H * p.W;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oy = y0 + R0 + i * DIL;
+    if (oy >= p.H) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nbase + j * 32 + r;
+      if (n >= p.N) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int ox = x0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (ox >= p.W) continue;
+        const long long m = img + (long long)oy * p.W + ox;
+        float y = acc[i][j][v] + bv;
+        if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
+        else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
+        else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
+        if (p.res) y += p.res[m * p.ldr + n];
+        p.out[m * p.ldo + n] = y;
+      }
+    }
+  }
+}
+
+template <int NOUT, int DIL, int STH>
+int launch(const IgemmK& k, hipStream_t stream) {
+  constexpr int HP = (STH + 2 * DIL) * (STW + 2 * DIL);
+  constexpr size_t smem = (size_t)(HP + 9 * NOUT) * ROWB;
+  auto fn = conv3x3_split_kernel<NOUT, DIL, STH>;
+  static bool raised = false;  // idempotent attribute; benign race
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  const int tiles_x = (k.W + STW - 1) / STW, tiles_y = (k.H + STH - 1) / STH;
+  const long long B = k.M / ((long long)k.H * k.W);
+  dim3 grid((unsigned)(B * tiles_x * tiles_y), (unsigned)((k.N + NOUT - 1) / NOUT));
+  hipLaunchKernelGGL(fn, grid, dim3(STH * 32), smem, stream, k, tiles_x, tiles_y);
+  return (int)hipGetLastError();
+}
+
+// packed fp32 [N][ldw] (k = tap * Cin + c)  ->  [n-tile][chunk][tap][n][plane][16] bf16
+__global__ void split_pack_kernel(const float* __restrict__ w, int N, int Cin, int ldw, int NOUT, long long total,
+                                  uint16_t* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int nchunks = Cin / 16;
+  const int c16 = (int)(idx & 15);
+  long long t = idx >> 4;
+  const int n = (int)(t % NOUT); t /= NOUT;
+  const int tap = (int)(t % 9); t /= 9;
+  const int chunk = (int)(t % nchunks);
+  const int nt = (int)(t / nchunks);
+  const int gn = nt * NOUT + n;
+  const float x = gn < N ? w[(long long)gn * ldw + tap * Cin + chunk * 16 + c16] : 0.f;
+  uint32_t p0, p1, p2;
+  split3(x, 0.f, p0, p1, p2);
+  const long long row = (((long long)nt * nchunks + chunk) * 9 + tap) * NOUT + n;
+  out[row * 48 + c16] = (uint16_t)(p0 & 0xffffu);
+  out[row * 48 + 16 + c16] = (uint16_t)(p1 & 0xffffu);
+  out[row * 48 + 32 + c16] = (uint16_t)(p2 & 0xffffu);
+}
+
+}  // namespace
+
+int conv3x3_split_launch(const IgemmK& k, hipStream_t s) {
+  const bool wide = split_nout(k.N) == 64;
+  if (wide) return k.dil == 2 ? launch<64, 2, 16>(k, s) : launch<64, 1, 16>(k, s);
+  return k.dil == 2 ? launch<32, 2, 8>(k, s) : launch<32, 1, 8>(k, s);
+}
+
+}  // namespace segmif
+
+extern "C" int64_t segmif_conv3x3_split_weight_bytes(int N, int Cin) {
+  if (N <= 0 || Cin <= 0 || Cin % 16) return 0;
+  const int nout = segmif::split_nout(N);
+  return (int64_t)((N + nout - 1) / nout) * nout * 9 * Cin * 6;
+}
+
+extern "C" int segmif_conv3x3_split_pack(const float* packed, int N, int Cin, int ldw, void* out, void* stream) {
+  if (!packed || !out || N <= 0 || Cin <= 0 || Cin % 16 || ldw < 9 * Cin) return SEGMIF_EINVAL;
+  const int nout = segmif::split_nout(N);
+  const long long total = (long long)((N + nout - 1) / nout) * nout * 9 * Cin;
+  hipLaunchKernelGGL(segmif::split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     packed, N, Cin, ldw, nout, total, (uint16_t*)out);
+  return (int)hipGetLastError();
+}

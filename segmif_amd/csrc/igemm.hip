@@ -335,15 +335,16 @@ struct TileCfg {
   int BM, BN, BK;
   const char* name;
 };
-constexpr int kNumTiles = 14;  // 0-8, 11-13: implicit-GEMM tiles; 9, 10: halo-tiled 3x3 (conv3x3.hip)
+constexpr int kNumTiles = 15;  // 0-8, 11-13: implicit-GEMM tiles; 9, 10: halo-tiled 3x3 (conv3x3.hip); 14: split-bf16 halo 3x3
 const TileCfg kTiles[kNumTiles] = {
     {256, 32, 16, "256x32x16"}, {256, 32, 32, "256x32x32"}, {128, 64, 16, "128x64x16"},
     {128, 64, 32, "128x64x32"}, {128, 128, 16, "128x128x16"}, {128, 128, 32, "128x128x32"},
     {64, 64, 16, "64x64x16"},   {256, 64, 16, "256x64x16"},   {256, 64, 32, "256x64x32"},
     {256, 64, 16, "halo8x32c16"}, {256, 64, 8, "halo8x32c8"}, {64, 64, 32, "64x64x32"},
-    {64, 64, 16, "64x64x16p2"}, {128, 64, 16, "128x64x16p2"},
+    {64, 64, 16, "64x64x16p2"}, {128, 64, 16, "128x64x16p2"}, {512, 64, 16, "halo16x32c16_bf16x6"},
 };
 constexpr int kHaloTile0 = 9;
+constexpr int kSplitTile = 14;  // desc.wt = segmif_conv3x3_split_pack() image, not the fp32 packing
 
 template <int BM, int BN, int WM, int WN, int BK, int MODE, int PF = 1>
 int launch(const IgemmK& k, int nz, hipStream_t stream) {
@@ -477,7 +478,7 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
   const int rc = igemm_resolve(d, k, mode, tile, nz, halo);
   if (rc != 0) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (halo) return conv3x3_halo_launch(k, tile - kHaloTile0, s);
+  if (halo) return tile == kSplitTile ? conv3x3_split_launch(k, s) : conv3x3_halo_launch(k, tile - kHaloTile0, s);
   if (k.splitk > 1) {
     if (!d->workspace || d->workspace_floats < (int64_t)k.splitk * k.M * k.N) k.splitk = 1;  // no room: plain launch
     else k.ws = d->workspace;
@@ -544,7 +545,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   k.ws = nullptr;
   mode_out = mode;
   nz_out = nz;
-  if (tile >= kHaloTile0 && tile < kHaloTile0 + 2) {
+  if ((tile >= kHaloTile0 && tile < kHaloTile0 + 2) || tile == kSplitTile) {
     if (!halo_ok) return SEGMIF_EINVAL;
     halo_out = true;
     tile_out = tile;

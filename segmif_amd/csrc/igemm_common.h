@@ -43,5 +43,7 @@ __device__ __forceinline__ float gelu_exact(float x) {
 // halo-tiled 3x3 stride-1 convolution (conv3x3.hip); variant 0: 16-channel chunks, 1: 8-channel chunks
 bool conv3x3_halo_eligible(const IgemmK& k);
 int conv3x3_halo_launch(const IgemmK& k, int variant, hipStream_t stream);
+// same geometry on the bf16 matrix pipe with 3-way split operands (conv3x3_split.hip); k.wt = split-packed weights
+int conv3x3_split_launch(const IgemmK& k, hipStream_t stream);
 
 }  // namespace segmif

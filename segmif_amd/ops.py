@@ -6,6 +6,7 @@ dimension is dense (stride 1) and whose leading dimensions collapse to `rows` wi
 convs read from and write into concat buffers without copies.
 """
 import ctypes
+import os
 
 import torch
 
@@ -58,6 +59,58 @@ def pack_weight(w):
     _lib.check(_lib.load().segmif_pack_conv_weight(w.data_ptr(), out.data_ptr(), N, cin, kh, kw, _stream()),
                "segmif_pack_conv_weight")
     return out
+
+
+class SplitWeight:
+    """bf16x6 image of a packed 3x3 conv weight (segmif_conv3x3_split_pack): three bf16 planes per fp32
+    weight in the streaming order of tile 14 (csrc/conv3x3_split.hip)."""
+    __slots__ = ("data", "N", "cin")
+
+    def __init__(self, data, N, cin):
+        self.data, self.N, self.cin = data, N, cin
+
+
+_CONV3X3_MODES = ("bf16x6", "fp32")
+_conv3x3_mode = os.environ.get("SEGMIF_CONV3X3", "bf16x6")
+if _conv3x3_mode not in _CONV3X3_MODES:
+    raise RuntimeError(f"SEGMIF_CONV3X3 must be one of {_CONV3X3_MODES}, got {_conv3x3_mode!r}")
+
+
+def conv3x3_mode():
+    return _conv3x3_mode
+
+
+def set_conv3x3_mode(mode):
+    """'bf16x6': 3x3 stride-1 convs with Cin % 16 == 0 run on the bf16 matrix pipe with 3-way split
+    operands (fp32-class accuracy, 2.7x the fp32 MFMA rate); 'fp32': exact-fp32 MFMA everywhere."""
+    global _conv3x3_mode
+    if mode not in _CONV3X3_MODES:
+        raise ValueError(f"mode must be one of {_CONV3X3_MODES}")
+    prev, _conv3x3_mode = _conv3x3_mode, mode
+    return prev
+
+
+def pack_weight_split(w):
+    """OIHW 3x3 weight -> SplitWeight (the geometry limits of tile 14 are checked at launch)."""
+    N, cin = w.shape[0], w.shape[1]
+    packed = pack_weight(w)
+    lib = _lib.load()
+    nbytes = lib.segmif_conv3x3_split_weight_bytes(N, cin)
+    if nbytes <= 0:
+        raise RuntimeError(f"split packing needs Cin % 16 == 0, got Cin={cin}")
+    out = torch.empty((nbytes,), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.segmif_conv3x3_split_pack(packed.data_ptr(), N, cin, packed.shape[1], out.data_ptr(), _stream()),
+               "segmif_conv3x3_split_pack")
+    return SplitWeight(out, N, cin)
+
+
+def pack_conv3x3(w):
+    """Packing for a stride-1 'same' 3x3 conv (dilation 1 or 2): the split image when the mode and the
+    shape allow it, the fp32 packing otherwise.  Cache entries must be keyed on conv3x3_mode()."""
+    if _conv3x3_mode == "bf16x6" and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and w.shape[1] % 16 == 0 \
+            and 16 <= w.shape[0] <= 256:
+        return pack_weight_split(w)
+    return pack_weight(w)
 
 
 class LaunchTimer:
@@ -189,10 +242,18 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
         raise RuntimeError(f"out shape {tuple(out.shape)} != {(B, OH, OW, N)}")
     K = k * k * cin
     kp = (K + 15) // 16 * 16
-    if tuple(_req(wt, "wt").shape) != (N, kp) or not wt.is_contiguous():
-        raise RuntimeError(f"packed weight must be contiguous ({N}, {kp}), got {tuple(wt.shape)}")
+    if isinstance(wt, SplitWeight):
+        if (wt.N, wt.cin) != (N, cin) or k != 3 or tile not in (-1, 14):
+            raise RuntimeError(f"split weight ({wt.N}, {wt.cin}) does not fit conv N={N} Cin={cin} k={k} tile={tile}")
+        if not wt.data.is_cuda or wt.data.dtype != torch.uint8:
+            raise RuntimeError("segmif_amd: split weight image must be a uint8 tensor on the MI355X device")
+        wt_ptr, tile = wt.data.data_ptr(), 14
+    else:
+        if tuple(_req(wt, "wt").shape) != (N, kp) or not wt.is_contiguous():
+            raise RuntimeError(f"packed weight must be contiguous ({N}, {kp}), got {tuple(wt.shape)}")
+        wt_ptr = wt.data_ptr()
     d = _lib.SegmifIgemm()
-    d.in_, d.wt, d.out = x.data_ptr(), wt.data_ptr(), out.data_ptr()
+    d.in_, d.wt, d.out = x.data_ptr(), wt_ptr, out.data_ptr()
     d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
     d.prelu = _req(prelu, "prelu").data_ptr() if prelu is not None else None
     if res is not None:

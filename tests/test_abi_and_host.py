@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == syms
     assert lib.segmif_abi_version() == 1
-    assert lib.segmif_igemm_num_tiles() == 14
+    assert lib.segmif_igemm_num_tiles() == 15
     assert lib.segmif_linattn_num_blocks(307200) == 300
 
 

@@ -140,6 +140,57 @@ def test_igemm_conv(ops, case):
         assert err(y, ref) < TOL, tile
 
 
+SPLIT_CASES = [c for c in CONV_CASES if c[5] == 3 and c[6] == 1 and c[3] % 16 == 0 and c[4] >= 16]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv3x3_split_bf16x6(ops, case):
+    """Tile 14 (csrc/conv3x3_split.hip): bf16 MFMA with 3-way split operands must be as accurate as the
+    exact-fp32 MFMA kernel — same fp64 reference, same tolerance, and an error within 2x of tile 10's."""
+    B, H, W, Cin, N, k, s, p, d = case
+    x, w, b = rnd(B, Cin, H, W, seed=13), rnd(N, Cin, k, k, seed=14), rnd(N, seed=15)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p, dilation=d).permute(0, 2, 3, 1)
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y32 = ops.conv2d(xh, ops.pack_weight(w.cuda()), N, k, pad=p, dil=d, bias=b.cuda(), tile=10)
+    y = ops.conv2d(xh, ops.pack_weight_split(w.cuda()), N, k, pad=p, dil=d, bias=b.cuda())
+    e, e32 = err(y, ref), err(y32, ref)
+    assert e < TOL and e <= 2.0 * e32 + 1e-7, (e, e32)
+
+
+def test_conv3x3_split_epilogue_range_and_views(ops):
+    """PReLU + residual + pitched in/out views on the split kernel, with operands spanning 1e-6..1e3
+    (bf16 keeps the fp32 exponent range, so tiny and large values must both survive the split)."""
+    B, H, W, Cin, N = 2, 21, 45, 96, 32
+    g = torch.Generator().manual_seed(5)
+    mag = 10.0 ** (torch.rand(B, H, W, Cin, generator=g) * 9 - 6)
+    x = (torch.rand(B, H, W, Cin, generator=g) * 2 - 1) * mag
+    w, b, res = rnd(N, Cin, 3, 3, seed=21) * 0.05, rnd(N, seed=22), rnd(B, H, W, N, seed=23)
+    slope = torch.tensor([0.2])
+    buf = torch.zeros(B, H, W, 224)
+    buf[..., :Cin] = x
+    buf = buf.cuda()
+    ops.conv2d(buf[..., :Cin], ops.pack_weight_split(w.cuda()), N, 3, pad=2, dil=2, bias=b.cuda(), act=2,
+               prelu=slope.cuda(), res=res.cuda(), out=buf[..., Cin:Cin + N])
+    pre = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=2, dilation=2).permute(0, 2, 3, 1)
+    ref = torch.where(pre >= 0, pre, 0.2 * pre) + res.double()
+    assert err(buf[..., Cin:Cin + N], ref) < TOL
+    assert float(buf[..., Cin + N:].abs().max()) == 0.0
+    # elementwise: relative to the sum of |products| (the conditioning of each output), not the tensor max
+    cond = F.conv2d(x.double().abs().permute(0, 3, 1, 2), w.double().abs(), padding=2, dilation=2).permute(0, 2, 3, 1)
+    rel = ((buf[..., Cin:Cin + N].double().cpu() - ref).abs() / (cond + 1e-30)).max()
+    assert float(rel) < 1e-6, float(rel)
+
+
+def test_conv3x3_split_rejects_bad_geometry(ops):
+    x = rnd(1, 8, 8, 32, seed=3).cuda()
+    w = rnd(32, 32, 3, 3, seed=4).cuda()
+    sw = ops.pack_weight_split(w)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x, sw, 32, 3, stride=2, pad=1)  # tile 14 is stride-1 only
+    with pytest.raises(RuntimeError):
+        ops.pack_weight_split(rnd(32, 24, 3, 3, seed=5).cuda())  # Cin % 16
+
+
 def test_drdb_concat_in_place(ops):
     """A conv reading the first Cin channels of a 224-wide buffer and writing its 32 channels in place."""
     B, H, W = 2, 14, 18

@@ -36,7 +36,9 @@ def tile_names():
 def bench_conv(B, H, W, Cin, N, k, pad, dil, tiles, names, cbuf=None, stride=1, iters=10):
     cbuf = cbuf or Cin
     x = torch.randn(B, H, W, cbuf, device="cuda")
-    w = ops.pack_weight(torch.randn(N, Cin, k, k, device="cuda") * 0.05)
+    wraw = torch.randn(N, Cin, k, k, device="cuda") * 0.05
+    w = ops.pack_weight(wraw)
+    wsplit = ops.pack_weight_split(wraw) if 14 in tiles else None
     b = torch.randn(N, device="cuda")
     OH = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
     OW = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
@@ -46,8 +48,8 @@ def bench_conv(B, H, W, Cin, N, k, pad, dil, tiles, names, cbuf=None, stride=1, 
         if t >= 0 and names[t].endswith("x32") and Cin % 32:
             continue
         try:
-            ms = timeit(lambda: ops.conv2d(x[..., :Cin], w, N, k, stride=stride, pad=pad, dil=dil, bias=b, act=1,
-                                           out=out, tile=t), iters)
+            ms = timeit(lambda: ops.conv2d(x[..., :Cin], wsplit if t == 14 else w, N, k, stride=stride, pad=pad, dil=dil,
+                                           bias=b, act=1, out=out, tile=t), iters)
         except RuntimeError as ex:
             print(f"  conv {Cin}->{N} k{k} tile {t}: {ex}")
             continue
@@ -76,6 +78,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--convs-only", action="store_true")
+    ap.add_argument("--drdb-only", type=int, default=0, metavar="CIN", help="one DRDB conv shape, tiles 10 and 14 (PMC passes)")
     args = ap.parse_args()
     lib = _lib.load()
     import ctypes
@@ -84,12 +87,15 @@ def main():
     print("device:", buf.value.decode())
     names = tile_names()
     B, H, W = args.batch, 480, 640
+    if args.drdb_only:
+        bench_conv(B, H, W, args.drdb_only, 32, 3, 2, 2, [10, 14], names, cbuf=224)
+        return
     print("== DRDB dilated 3x3 (reads a 224-pitch concat buffer)")
     for cin in ((64, 192) if args.quick else (64, 96, 128, 160, 192)):
-        bench_conv(B, H, W, cin, 32, 3, 2, 2, [0, 9, 10], names, cbuf=224)
+        bench_conv(B, H, W, cin, 32, 3, 2, 2, [10, 14] if args.convs_only else [0, 9, 10, 14], names, cbuf=224)
     print("== fusion-net plain convs")
-    bench_conv(B, H, W, 128, 64, 3, 1, 1, [7, 9, 10], names)
-    bench_conv(B, H, W, 64, 32, 3, 1, 1, [0, 9, 10], names)
+    bench_conv(B, H, W, 128, 64, 3, 1, 1, [7, 9, 10, 14], names)
+    bench_conv(B, H, W, 64, 32, 3, 1, 1, [0, 9, 10, 14], names)
     bench_conv(B, H, W, 32, 1, 3, 1, 1, [0, 9, 10], names)
     bench_conv(B, H, W, 1, 64, 3, 1, 1, [-1], names)
     if args.convs_only:
