@@ -140,13 +140,22 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None, dslope
 
 
+def _pack_conv(w, k, stride, pad, dil):
+    """Kernel-layout weights for a conv: the split-bf16 image for stride-1 'same' 3x3 convs when
+    ops.conv3x3_mode() allows it (csrc/conv3x3_split.hip), the fp32 packing otherwise."""
+    if k == 3 and stride == 1 and pad == dil and dil in (1, 2):
+        return ops.pack_conv3x3(w)
+    return ops.pack_weight(w)
+
+
 class ConvFn(torch.autograd.Function):
     """NHWC convolution y = act(conv(x, w) + b), w in OIHW."""
 
     @staticmethod
     def forward(ctx, x, w, b, k, stride, pad, dil, act, slope):
         N = w.shape[0]
-        y = ops.conv2d(x, ops.pack_weight(w), N, k, stride=stride, pad=pad, dil=dil, bias=b, act=act, prelu=slope)
+        y = ops.conv2d(x, _pack_conv(w, k, stride, pad, dil), N, k, stride=stride, pad=pad, dil=dil, bias=b, act=act,
+                       prelu=slope)
         ctx.geom = (k, stride, pad, dil, act)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, y if act in (ACT_RELU, ACT_PRELU) else None, slope)
@@ -171,7 +180,8 @@ class ConvFn(torch.autograd.Function):
             if stride == 1:
                 # full correlation with the 180-degree rotated, in/out-swapped kernel
                 wr = w.flip(2, 3).transpose(0, 1).contiguous()
-                dx = ops.conv2d(dz, ops.pack_weight(wr), cin, k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
+                dx = ops.conv2d(dz, _pack_conv(wr, k, 1, dil * (k - 1) - pad, dil), cin, k, stride=1,
+                                pad=dil * (k - 1) - pad, dil=dil)
             elif stride == k and pad == 0 and dil == 1:
                 # non-overlapping patches (sr conv): every input pixel belongs to exactly one patch, so
                 # dX is one dense GEMM dY (M', N) @ W (N, k*k*Cin) followed by a patch -> image permutation
@@ -395,7 +405,7 @@ class DRDBFn(torch.autograd.Function):
         ch = C0
         for i in range(5):
             w, b = params[2 * i], params[2 * i + 1]
-            ops.conv2d(buf[..., :ch], ops.pack_weight(w), growth, 3, pad=2, dil=2, bias=b, act=ACT_RELU,
+            ops.conv2d(buf[..., :ch], ops.pack_conv3x3(w), growth, 3, pad=2, dil=2, bias=b, act=ACT_RELU,
                        out=buf[..., ch:ch + growth])
             ch += growth
         w6, b6 = params[10], params[11]
@@ -429,7 +439,7 @@ class DRDBFn(torch.autograd.Function):
             dy = act_bwd(dbuf[..., ch:ch + growth], buf[..., ch:ch + growth], ACT_RELU)
             grads[2 * i], grads[2 * i + 1] = conv_wgrad(buf[..., :ch], dy, w.shape, 3, 1, 2, 2, want_bias=True)
             wr = w.flip(2, 3).transpose(0, 1).contiguous()
-            ops.conv2d(dy, ops.pack_weight(wr), ch, 3, pad=2, dil=2, res=dbuf[..., :ch], out=dbuf[..., :ch])
+            ops.conv2d(dy, ops.pack_conv3x3(wr), ch, 3, pad=2, dil=2, res=dbuf[..., :ch], out=dbuf[..., :ch])
             ch -= growth
         dx = dbuf[..., :C0].contiguous() if ctx.needs_input_grad[0] else None
         return (dx, *grads)
