@@ -43,6 +43,19 @@
 #define SPLIT_DBG 0  // tuning aid: compile-time ablation mask (tools/split_ablate.sh)
 #endif
 
+#if SPLIT_DBG & 32  // timeline probe: s_memtime at the phase boundaries of wave 0 of the first blocks
+#define SPLIT_TL_BLOCKS 2048
+#define SPLIT_TL_CHUNKS 12
+__device__ unsigned long long split_timeline[SPLIT_TL_BLOCKS][SPLIT_TL_CHUNKS + 1][8];
+#define TL(slot)                                                                                      \
+  do {                                                                                                \
+    if (tid == 0 && blockIdx.x < SPLIT_TL_BLOCKS && c < SPLIT_TL_CHUNKS)                              \
+      split_timeline[blockIdx.x][c][slot] = __builtin_amdgcn_s_memtime();                             \
+  } while (0)
+#else
+#define TL(slot) do {} while (0)
+#endif
+
 namespace segmif {
 namespace {
 
@@ -130,12 +143,8 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
   f32x4 ra[AJ];
   u32x2 pa[AJ][3];  // the same units after the split: [plane] = 4 bf16
   u32x4 rb[BJ];
-  auto gload = [&](int c) {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(in + a_off[j] + c * 16);
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) rb[j] = wsp[(long long)c * B_UNITS + b_src[j]];
-  };
+  auto gload_a = [&](int j, int c) { ra[j] = *reinterpret_cast<const f32x4*>(in + a_off[j] + c * 16); };
+  auto gload_b = [&](int j, int c) { rb[j] = wsp[(long long)c * B_UNITS + b_src[j]]; };
   auto split_unit = [&](int j) {  // registers only: interleaved with the tail of the previous chunk's MFMAs
     uint32_t p0a, p1a, p2a, p0b, p1b, p2b;
     const f32x4 x = a_ok[j] ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -198,16 +207,23 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   };
 
-  gload(0);
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) gload_a(j, 0);
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) gload_b(j, 0);
 #pragma unroll
   for (int j = 0; j < AJ; ++j) split_unit(j);
+  static_assert(AJ <= 7 && BJ <= 12, "staging slots are issued one per MFMA step");
   for (int c = 0; c < nchunks; ++c) {
+    TL(0);
     if (!(SPLIT_DBG & 16) || c == 0) sstore();
+    TL(1);
     __syncthreads();
-    const bool more = c + 1 < nchunks;
-    if (more && !(SPLIT_DBG & 8)) gload(c + 1);
+    TL(2);
+    const int cnext = c + 1 < nchunks ? c + 1 : c;
     load_f(0);
     if (W_AHEAD) load_w(0);
+    TL(3);
 #pragma unroll
     for (int st = 0; st < 12; ++st) {
       const int m = st & 3;
@@ -218,6 +234,14 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
           load_f(st + 1);
           if (W_AHEAD) load_w(st + 1);
         }
+      }
+      // next chunk's global loads, one slot of each kind per step: a burst at the chunk start queues
+      // all eight waves of the CU on the 64 B/clk vector-memory issue path (1700 of 8750 cycles per chunk)
+      // (unconditional — the last chunk re-reads itself — so the loop body stays one basic block and the
+      // compiler keeps exact vmcnt counts instead of draining the queue before every load)
+      if (!(SPLIT_DBG & 8)) {
+        if (st < AJ) gload_a(st, cnext);                        // halo slots early: split from step 12 - AJ on
+        if (st >= 12 - BJ) gload_b(st - (12 - BJ), cnext);     // weight slots late: only the LDS store needs them
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -230,11 +254,21 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
           if (m > 0)
             acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[st & 1][PA[t]], Wr[wp][j][PW[t]], acc[1][j], 0, 0, 0);
         }
-      if (st >= SPLIT_FROM && more && !(SPLIT_DBG & 4)) split_unit(st - SPLIT_FROM);
+      if (st >= SPLIT_FROM && !(SPLIT_DBG & 4)) split_unit(st - SPLIT_FROM);
       __builtin_amdgcn_sched_barrier(0);
+      if (st == SPLIT_FROM - 1) TL(4);
     }
+    TL(5);
     __syncthreads();
+    TL(6);
   }
+#if SPLIT_DBG & 32
+  if (tid == 0 && blockIdx.x < SPLIT_TL_BLOCKS) {
+    split_timeline[blockIdx.x][SPLIT_TL_CHUNKS][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    split_timeline[blockIdx.x][SPLIT_TL_CHUNKS][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    split_timeline[blockIdx.x][SPLIT_TL_CHUNKS][2] = __builtin_amdgcn_s_getreg((31 << 11) | 6);   // LDS_ALLOC
+  }
+#endif
 
   // ---- epilogue (same contract as the fp32 halo kernel) ----------------------------------------
   const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
@@ -267,7 +301,7 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
 template <int NOUT, int DIL, int STH>
 int launch(const IgemmK& k, hipStream_t stream) {
   constexpr int HP = (STH + 2 * DIL) * (STW + 2 * DIL);
-  constexpr size_t smem = (size_t)(HP + 9 * NOUT) * ROWB;
+  constexpr size_t smem = (size_t)(HP + 9 * NOUT) * ROWB + ((SPLIT_DBG & 64) && STH == 8 ? 40960 : 0);  // 64: one workgroup per CU
   auto fn = conv3x3_split_kernel<NOUT, DIL, STH>;
   static bool raised = false;  // idempotent attribute; benign race
   if (!raised) {
@@ -309,6 +343,9 @@ __global__ void split_pack_kernel(const float* __restrict__ w, int N, int Cin, i
 int conv3x3_split_launch(const IgemmK& k, hipStream_t s) {
   const bool wide = split_nout(k.N) == 64;
   if (wide) return k.dil == 2 ? launch<64, 2, 16>(k, s) : launch<64, 1, 16>(k, s);
+#if SPLIT_DBG & 128  // 16-row patches for NOUT = 32 too (one workgroup per CU)
+  return k.dil == 2 ? launch<32, 2, 16>(k, s) : launch<32, 1, 16>(k, s);
+#endif
   return k.dil == 2 ? launch<32, 2, 8>(k, s) : launch<32, 1, 8>(k, s);
 }
 
@@ -328,3 +365,9 @@ extern "C" int segmif_conv3x3_split_pack(const float* packed, int N, int Cin, in
                      packed, N, Cin, ldw, nout, total, (uint16_t*)out);
   return (int)hipGetLastError();
 }
+
+#if SPLIT_DBG & 32
+extern "C" int segmif_debug_split_timeline(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(split_timeline), bytes < sizeof(split_timeline) ? bytes : sizeof(split_timeline));
+}
+#endif

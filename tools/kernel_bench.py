@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--convs-only", action="store_true")
+    ap.add_argument("--pointwise-only", action="store_true", help="full-resolution 1x1 convs / CrossPath linears")
     ap.add_argument("--drdb-only", type=int, default=0, metavar="CIN", help="one DRDB conv shape, tiles 10 and 14 (PMC passes)")
     args = ap.parse_args()
     lib = _lib.load()
@@ -89,6 +90,13 @@ def main():
     B, H, W = args.batch, 480, 640
     if args.drdb_only:
         bench_conv(B, H, W, args.drdb_only, 32, 3, 2, 2, [10, 14], names, cbuf=224)
+        return
+    if args.pointwise_only:
+        M = B * H * W
+        bench_dense(M, 64, 224, [-1, 2, 7, 13], names)
+        bench_dense(M, 128, 64, [-1, 2, 4, 7, 13], names, act=1)
+        bench_dense(M, 64, 128, [-1, 2, 7, 13], names)
+        bench_dense(M, 64, 64, [-1, 2, 7, 13], names)
         return
     print("== DRDB dilated 3x3 (reads a 224-pitch concat buffer)")
     for cin in ((64, 192) if args.quick else (64, 96, 128, 160, 192)):
