@@ -25,14 +25,19 @@
 // MFMAs of step s (double-buffered A set, 3-deep weight ring, sched_barrier-pinned), chunk c + 1
 // streams into registers under chunk c's MFMAs and is split between its last steps.
 //
-// Where the time goes (round 1, 128 -> 32 DRDB conv at 8 x 480 x 640, tools/split_ablate.sh and
-// tools/micro/mfma_chain.hip): the matrix pipe alone needs 0.53 ms (16.4 ns per MFMA per SIMD at the
-// ~1.95 GHz the chip holds under bf16 MFMA load; one accumulation chain per wave already issues
-// back-to-back), staging alone 0.45 ms, the kernel 1.03 ms: the two co-resident workgroups of a CU
-// run in lock-step, so load/split/store segments meet load/split/store segments instead of MFMA
-// segments.  Tried and measured no better: 16-row patches, a ping-pong workgroup (two halves held in
-// anti-phase by a barrier per phase, 1.10 ms), static wave priority by LDS slot, 4 accumulation
-// chains.  Still 1.45x the exact-fp32 halo kernel (1.49 ms) at equal accuracy.
+// Where the time goes (round 1, 128 -> 32 DRDB conv at 8 x 480 x 640: 0.95 ms against 1.49 ms for the
+// exact-fp32 halo kernel; tools/split_ablate.sh, tools/split_timeline.py, tools/micro/mfma_chain.hip).
+// The matrix pipe alone needs 0.53 ms (16.4 ns per MFMA per SIMD at the ~1.95 GHz the chip holds under
+// bf16 MFMA load; one accumulation chain per wave already issues back-to-back).  The s_memtime timeline
+// of a wave splits a chunk into: LDS stores 18 % (the VGPR -> LDS store path moves ~1.3 B per cycle per
+// wave and all eight waves of the CU use it at once), MFMA steps that also issue the next halo's global
+// loads 40 % (78 ticks per MFMA: a vector-memory issue stalls the in-order wave), MFMA steps that also
+// split 32 % (41 ticks per MFMA: the pipe is saturated there), barriers 4 %.  What helped: issuing the
+// next chunk's loads one slot per step instead of as a burst (and unconditionally — behind a branch the
+// compiler drains vmcnt to 0 before every load), weights late / halo early.  Tried and measured no
+// better: 16-row patches at one workgroup per CU, a ping-pong workgroup (two halves held in anti-phase
+// by a barrier per phase), static wave priority by LDS slot, four accumulation chains, contiguous
+// instead of 64-byte halo reads.  Next (round 2): a persistent, LDS-double-buffered schedule.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
