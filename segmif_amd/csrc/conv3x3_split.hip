@@ -44,6 +44,9 @@
 #include "igemm_common.h"
 #include "segmif_hip.h"
 
+#ifndef SPLIT_INTERLEAVE
+#define SPLIT_INTERLEAVE 1
+#endif
 #ifndef SPLIT_DBG
 #define SPLIT_DBG 0  // tuning aid: compile-time ablation mask (tools/split_ablate.sh)
 #endif
@@ -248,7 +251,9 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (st < AJ) gload_a(st, cnext);                        // halo slots early: split from step 12 - AJ on
         if (st >= 12 - BJ) gload_b(st - (12 - BJ), cnext);     // weight slots late: only the LDS store needs them
       }
+#if !SPLIT_INTERLEAVE
       __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -260,6 +265,18 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
             acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[st & 1][PA[t]], Wr[wp][j][PW[t]], acc[1][j], 0, 0, 0);
         }
       if (st >= SPLIT_FROM && !(SPLIT_DBG & 4)) split_unit(st - SPLIT_FROM);
+#if SPLIT_INTERLEAVE
+      // one scheduling region per step: every MFMA is followed by one of the next step's fragment reads,
+      // a staging load and a few of the split's VALU ops, so that a wave alone on its SIMD (its partner
+      // storing to LDS or parked at a barrier) still feeds the matrix pipe back-to-back
+#pragma unroll
+      for (int t = 0; t < 12 * TN; ++t) {  // (6-MFMA steps leave the tail groups without an MFMA)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
+        if (t < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);             // VALU
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       if (st == SPLIT_FROM - 1) TL(4);
     }
