@@ -105,6 +105,32 @@ def test_fusion_blocks_vs_reference(fus, golden_dir):
         assert rel(o1, g["ffm_o1"]) < TIGHT and rel(o2, g["ffm_o2"]) < TIGHT
 
 
+def test_fusion_net_in_both_conv3x3_modes(net_b1, fus, golden_dir):
+    """The 3x3 convs have two arithmetic modes (bf16x6 split operands on the bf16 matrix pipe, default;
+    exact-fp32 MFMA): both must meet the same reference fixtures, and agree with each other far inside
+    the parity tolerance."""
+    from segmif_amd import ops
+    g = load(golden_dir, "fusion_blocks.npz")
+    gp = load(golden_dir, "pair_b1_64x96.npz")
+    ir, vis, mask = (torch.from_numpy(gp[k]).cuda() for k in ("ir", "vis", "mask"))
+    outs = {}
+    prev = ops.conv3x3_mode()
+    try:
+        with torch.no_grad():
+            out0, out1 = net_b1.denoise_net.encoder.forward_fusion(mask)
+            for mode in ("bf16x6", "fp32"):
+                ops.set_conv3x3_mode(mode)
+                y = fus.DRDB1(torch.from_numpy(g["drdb_x"]).cuda())
+                assert rel(y, g["drdb_y"]) < TIGHT, mode
+                yf = fus(ir, vis, out0, out1)
+                assert rel(yf, gp["y_fused"]) < 5 * TIGHT, mode
+                outs[mode] = (y, yf)
+    finally:
+        ops.set_conv3x3_mode(prev)
+    assert rel(outs["bf16x6"][0], outs["fp32"][0].cpu()) < 2e-6
+    assert rel(outs["bf16x6"][1], outs["fp32"][1].cpu()) < 5e-6
+
+
 def assert_miou_parity(ref_labels, hip_labels, gt_name):
     """North star: seg mIoU within +-0.1 of the reference on fixed synthetic inputs.  mIoU is taken
     against seeded synthetic ground truth with the reference's own formula (util/util.py:31-55)."""
