@@ -30,11 +30,14 @@ def colsum(x2d, out=None, accumulate=False):
     return out
 
 
-def act_bwd(dy, ref, act, slope=None):
+def act_bwd(dy, ref, act, slope=None, out=None):
     rows, C, ldy = rows_view(dy, "dy")
     _, _, ldr = rows_view(ref, "ref")
-    dx = torch.empty(dy.shape, device=dy.device, dtype=torch.float32)
-    _lib.check(_lib.load().segmif_act_bwd_f32(dy.data_ptr(), ref.data_ptr(), dx.data_ptr(), rows, C, ldy, ldr, C, act,
+    dx = torch.empty(dy.shape, device=dy.device, dtype=torch.float32) if out is None else out
+    orow, oc, ldx = rows_view(dx, "dx")
+    if (orow, oc) != (rows, C):
+        raise RuntimeError("act_bwd out shape mismatch")
+    _lib.check(_lib.load().segmif_act_bwd_f32(dy.data_ptr(), ref.data_ptr(), dx.data_ptr(), rows, C, ldy, ldr, ldx, act,
                                               slope.data_ptr() if slope is not None else None, _stream()),
                "segmif_act_bwd_f32")
     return dx
@@ -433,13 +436,23 @@ class DRDBFn(torch.autograd.Function):
         g10, grads[11] = linear_wgrad(buf, dz6, C0, want_bias=True)
         grads[10] = g10.reshape(params[10].shape)
         del dz6
+        # Input gradients in GATHER form.  Conv i scatters into every channel below its own block
+        # (N = 64..192 outputs from 32 inputs: two-chunk workgroups, the halo re-read per output tile);
+        # instead, once dy_5 .. dy_{i+1} are known, the block just below conv i+1's outputs receives all
+        # of its contributions in ONE conv over their concatenation — Cin = 32 * (5 - i) inputs, 32 (64
+        # for the x block) outputs: the shape of the forward convs, same total FLOPs.
+        dz = torch.empty((B, H, W, 5 * growth), device=buf.device, dtype=torch.float32)  # [dy5 | dy4 | .. | dy1]
         ch = total - growth
         for i in range(4, -1, -1):
-            w = params[2 * i]
-            dy = act_bwd(dbuf[..., ch:ch + growth], buf[..., ch:ch + growth], ACT_RELU)
-            grads[2 * i], grads[2 * i + 1] = conv_wgrad(buf[..., :ch], dy, w.shape, 3, 1, 2, 2, want_bias=True)
-            wr = w.flip(2, 3).transpose(0, 1).contiguous()
-            ops.conv2d(dy, ops.pack_conv3x3(wr), ch, 3, pad=2, dil=2, res=dbuf[..., :ch], out=dbuf[..., :ch])
+            k = 4 - i
+            dy = act_bwd(dbuf[..., ch:ch + growth], buf[..., ch:ch + growth], ACT_RELU,
+                         out=dz[..., k * growth:(k + 1) * growth])
+            grads[2 * i], grads[2 * i + 1] = conv_wgrad(buf[..., :ch], dy, params[2 * i].shape, 3, 1, 2, 2, want_bias=True)
+            lo = ch - growth if i > 0 else 0
+            # rows = the channels of the receiving block, columns = (tap rotated by 180 deg, dz channel)
+            wcat = torch.cat([params[2 * q][:, lo:ch].flip(2, 3).transpose(0, 1) for q in range(4, i - 1, -1)], dim=1)
+            ops.conv2d(dz[..., :(k + 1) * growth], ops.pack_conv3x3(wcat.contiguous()), ch - lo, 3, pad=2, dil=2,
+                       res=dbuf[..., lo:ch], out=dbuf[..., lo:ch])
             ch -= growth
         dx = dbuf[..., :C0].contiguous() if ctx.needs_input_grad[0] else None
         return (dx, *grads)
