@@ -144,7 +144,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.backbone} pair forward (forward_fusion + Fusion_Network3_ac + Network3 "
                                    f"+ x4 bilinear + argmax), {H}x{W}, {B} pairs per GPU per step, eval mode, "
-                                   "seeded deterministic weights",
+                                   "seeded deterministic weights; conv3/conv4 (1x1) applied before the "
+                                   "bilinear resize of forward_fusion (same function, SURVEY 8(f) N4)",
                        "backbone": args.backbone, "height": H, "width": W, "pairs_per_gpu": B,
                        "parallelism": f"replicas x{world} (independent pairs, no collective)",
                        "launch": "hipGraph replay" if args.graph else "eager"},

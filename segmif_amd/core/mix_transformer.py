@@ -277,6 +277,13 @@ class MixVisionTransformer(nn.Module):
     def forward(self, x):
         return self.forward_features(x)
 
+    def forward_fusion_features(self, x):
+        """The two feature maps forward_fusion() up-samples, still at their own resolution and NHWC:
+        (B, H/4, W/4, C1), (B, H/8, W/8, C2).  For consumers that apply a 1x1 conv next and can do it
+        BEFORE the bilinear resize (Fusion_Network3_ac.forward_from_features)."""
+        feats = self.forward_features_nhwc(x)
+        return feats[0], feats[1]
+
     def forward_fusion(self, x):
         """Stage-1 / stage-2 features bilinearly resized to the input resolution (ref :358-375)."""
         H, W = x.shape[2], x.shape[3]

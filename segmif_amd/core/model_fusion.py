@@ -340,6 +340,29 @@ class Fusion_Network3_ac(nn.Module):
             # same failure the reference hits inside conv3/conv4 (mit_b0 features do not fit)
             raise RuntimeError(f"Fusion_Network3_ac expects 64/128-channel segmentation features, got "
                                f"{out1.shape[1]}/{out2.shape[1]} channels")
+        return self._forward_eval(
+            ir, vis,
+            lambda: ops.linear(ops.to_nhwc(out1), self._w("conv3"), 64, bias=self.conv3.bias),
+            lambda: ops.linear(ops.to_nhwc(out2), self._w("conv4"), 64, bias=self.conv4.bias))
+
+    def forward_from_features(self, ir, vis, f1, f2):
+        """Same result as forward(ir, vis, up(f1), up(f2)) for the NHWC feature maps of
+        MixVisionTransformer.forward_fusion_features(): conv3 / conv4 are 1x1 convs with bias, and a
+        bilinear resize is a per-channel convex combination (weights sum to 1), so the two commute
+        exactly in real arithmetic (to rounding in fp32; tests/test_gpu_modules.py).  Running the convs
+        at H/4 x W/4 and H/8 x W/8 removes the 64- and 128-channel full-resolution tensors (236 MB per
+        image) and 16x / 64x of the two GEMMs.  Inference only."""
+        require_device(ir, "Fusion_Network3_ac input")
+        if f1.shape[-1] != 64 or f2.shape[-1] != 128:
+            raise RuntimeError(f"Fusion_Network3_ac expects 64/128-channel segmentation features, got "
+                               f"{f1.shape[-1]}/{f2.shape[-1]} channels")
+        H, W = ir.shape[2], ir.shape[3]
+        return self._forward_eval(
+            ir, vis,
+            lambda: ops.bilinear(ops.linear(f1, self._w("conv3"), 64, bias=self.conv3.bias), H, W),
+            lambda: ops.bilinear(ops.linear(f2, self._w("conv4"), 64, bias=self.conv4.bias), H, W))
+
+    def _forward_eval(self, ir, vis, seg1_fn, seg2_fn):
         B, _, H, W = ir.shape
         dev, slope = ir.device, self.relu.weight
         PRELU = ops.ACT_PRELU
@@ -352,13 +375,13 @@ class Fusion_Network3_ac(nn.Module):
             bufs.append(buf)
         x1 = self.DRDB1.forward_buffer(bufs[0])
         x2 = self.DRDB2.forward_buffer(bufs[1])
-        seg = ops.linear(ops.to_nhwc(out1), self._w("conv3"), 64, bias=self.conv3.bias)
+        seg = seg1_fn()
         # first interaction writes straight into the DRDB3 / DRDB4 concat buffers (reused storage)
         x1, x2 = self.ffm.forward_nhwc(x1, x2, seg, out1=bufs[0][..., :64], out2=bufs[1][..., :64])
         x1 = self.DRDB3.forward_buffer(bufs[0])
         x2 = self.DRDB4.forward_buffer(bufs[1])
         del bufs
-        seg = ops.linear(ops.to_nhwc(out2), self._w("conv4"), 64, bias=self.conv4.bias)
+        seg = seg2_fn()
         cat = torch.empty((B, H, W, 128), device=dev, dtype=torch.float32)
         self.ffm.forward_nhwc(x1, x2, seg, out1=cat[..., :64], out2=cat[..., 64:])
         f = ops.conv2d(cat, self._w3("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)

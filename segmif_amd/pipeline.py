@@ -9,15 +9,20 @@ from .core.model_fusion import fuse_to_rgb
 
 
 class PairForward:
-    def __init__(self, seg_net, fusion_net):
+    def __init__(self, seg_net, fusion_net, commute_resize=True):
         self.seg, self.fus = seg_net, fusion_net
+        self.commute_resize = commute_resize
         self._graph = None
         self._static = None
 
     def eager(self, ir, vis, mask3):
         """-> (fused RGB (B,3,H,W), labels int32 (B,H,W))."""
-        out0, out1 = self.seg.denoise_net.encoder.forward_fusion(mask3)
-        y_f = self.fus(ir, vis, out0, out1)
+        enc = self.seg.denoise_net.encoder
+        if self.commute_resize:  # conv3 / conv4 (1x1) before the bilinear resize: same function (SURVEY §8(f) N4)
+            y_f = self.fus.forward_from_features(ir, vis, *enc.forward_fusion_features(mask3))
+        else:
+            out0, out1 = enc.forward_fusion(mask3)
+            y_f = self.fus(ir, vis, out0, out1)
         fused = fuse_to_rgb(vis, y_f)
         return fused, self.seg.predict_labels(fused, vis.shape[2:])
 

@@ -131,6 +131,30 @@ def test_fusion_net_in_both_conv3x3_modes(net_b1, fus, golden_dir):
     assert rel(outs["bf16x6"][1], outs["fp32"][1].cpu()) < 5e-6
 
 
+def test_conv3_conv4_commute_with_the_resize(net_b1, fus, golden_dir):
+    """forward_from_features (1x1 conv3 / conv4 at feature resolution, then bilinear)
+    is the same function as forward on the up-sampled features — checked against the reference fixture
+    and against the textbook order, through the pair pipeline too."""
+    from segmif_amd.pipeline import PairForward
+    gp = load(golden_dir, "pair_b1_64x96.npz")
+    ir, vis, mask = (torch.from_numpy(gp[k]).cuda() for k in ("ir", "vis", "mask"))
+    enc = net_b1.denoise_net.encoder
+    with torch.no_grad():
+        a = fus(ir, vis, *enc.forward_fusion(mask))
+        b = fus.forward_from_features(ir, vis, *enc.forward_fusion_features(mask))
+        assert rel(b, gp["y_fused"]) < 5 * TIGHT
+        assert rel(b, a.cpu()) < 1e-5
+        fused_c, labels_c = PairForward(net_b1, fus, commute_resize=True)(ir, vis, mask)
+        fused_t, labels_t = PairForward(net_b1, fus, commute_resize=False)(ir, vis, mask)
+    assert rel(fused_c, gp["fused"]) < 5 * TIGHT and rel(fused_c, fused_t.cpu()) < 1e-5
+    stable = torch.from_numpy(gp["margin"]) > 1e-3
+    ref = torch.from_numpy(gp["labels"]).long()
+    assert torch.equal(labels_c.cpu().long()[stable], ref[stable])
+    assert torch.equal(labels_t.cpu().long()[stable], ref[stable])
+    with pytest.raises(RuntimeError):
+        fus.forward_from_features(ir, vis, torch.zeros(1, 16, 24, 32).cuda(), torch.zeros(1, 8, 12, 64).cuda())
+
+
 def assert_miou_parity(ref_labels, hip_labels, gt_name):
     """North star: seg mIoU within +-0.1 of the reference on fixed synthetic inputs.  mIoU is taken
     against seeded synthetic ground truth with the reference's own formula (util/util.py:31-55)."""
@@ -234,6 +258,15 @@ def test_full_size_b3_vs_reference_checksum(core, fus, golden_dir):
     mismatches = int((labels != ref_labels).sum())
     assert mismatches <= int((~stable).sum())
     assert_miou_parity(ref_labels.numpy(), labels.numpy(), "b3_gt")
+    # the measured pipeline (segmif_amd.pipeline.PairForward: conv3 / conv4 before the resize) on the same record
+    from segmif_amd.pipeline import PairForward
+    fused_p, labels_p = PairForward(net, fus)(ir, vis, mask)
+    got = fused_p.contiguous().reshape(-1)[torch.from_numpy(g["fused_idx"]).cuda()].cpu()
+    scale = max(abs(g["fused_stats"][2]), abs(g["fused_stats"][3]))
+    assert float((got - torch.from_numpy(g["fused_val"])).abs().max()) / scale < 5 * TIGHT
+    labels_p = labels_p.cpu().long().reshape(ref_labels.shape)
+    assert torch.equal(labels_p[stable], ref_labels[stable])
+    assert_miou_parity(ref_labels.numpy(), labels_p.numpy(), "b3_gt")
 
 
 def test_batch_consistency_full_size(core, fus):
