@@ -217,6 +217,14 @@ int segmif_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int64_t HW, 
 int segmif_fuse_ycrcb_f32(const float* vis_nchw, const float* yf, float* out_nchw, int B, int64_t HW, void* stream);
 /* argmax over C of NHWC logits -> int32 labels (test_segmentation.py:174); ties -> lowest index */
 int segmif_argmax_nhwc_i32(const float* x, int32_t* labels, int64_t rows, int C, int ldx, void* stream);
+/* conf[t*K + p] += #{i : label[i] == t, pred[i] == p}, both inside [0, K) (K <= 32) — the accumulation of
+ * test_segmentation.py:176-177 (sklearn confusion_matrix with labels=[0..K-1]: rows = ground truth,
+ * columns = prediction, samples outside the label set ignored); conf is NOT cleared */
+int segmif_confusion_i32(const int32_t* pred, const int64_t* label, int64_t* conf, int64_t n, int K, void* stream);
+/* test_fusion.py:112-120 on device: a = uint8(255 x), min / max of a over the WHOLE batch, then
+ * uint8(255.0 * ((a - min) / (max - min))) in float64, written NHWC (the reference's transpose(0,2,3,1));
+ * x is (B, C, HW) fp32 already clamped to [0, 1]; minmax: 2 int32 of scratch (returns {min, max}) */
+int segmif_quantize_u8(const float* x_nchw, uint8_t* out_nhwc, int32_t* minmax, int B, int C, int64_t HW, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Training path (backward of the ops above; autograd in the reference: loss.backward() at

@@ -302,6 +302,33 @@ def miou(conf):
     return float(np.mean(np.nan_to_num(iou))), iou
 
 
+def compute_results(conf_total):
+    """util/util.py:31-55 with consider_unlabeled=True: per class cid, precision = conf[cid,cid] / column
+    sum, recall = conf[cid,cid] / row sum, IoU = conf[cid,cid] / (row + column - diagonal); NaN when the
+    denominator is 0.  Loop form, as the reference writes it."""
+    conf = np.asarray(conf_total)
+    n = conf.shape[0]
+    prec, rec, iou = np.zeros(n), np.zeros(n), np.zeros(n)
+    for cid in range(n):
+        col, row, tp = conf[:, cid].sum(), conf[cid, :].sum(), conf[cid, cid]
+        prec[cid] = np.nan if col == 0 else float(tp) / float(col)
+        rec[cid] = np.nan if row == 0 else float(tp) / float(row)
+        iou[cid] = np.nan if (row + col - tp) == 0 else float(tp) / float(row + col - tp)
+    return prec, rec, iou
+
+
+def quantize_fused_u8(fused):
+    """test_fusion.py:112-120 on the clamped fused image (B,3,H,W) float32: np.uint8(255.0 * x), NHWC
+    transpose, (a - min) / (max - min) with the GLOBAL min / max of the batch (uint8 - uint8, then a true
+    division -> float64), np.uint8(255.0 * .).  max == min divides 0 by 0; the write-out is then 0."""
+    x = np.asarray(fused, dtype=np.float32)
+    a = np.uint8(255.0 * x).transpose((0, 2, 3, 1))
+    lo, hi = np.min(a), np.max(a)
+    if hi == lo:
+        return np.zeros_like(a)
+    return np.uint8(255.0 * ((a - lo) / (hi - lo)))
+
+
 def top2_margin(logits):
     """Gap between the best and second-best class logit per pixel (argmax stability gate)."""
     top = torch.topk(logits, 2, dim=1).values

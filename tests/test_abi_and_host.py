@@ -156,3 +156,19 @@ def test_losses_match_reference_formulas_on_cpu():
     ref3 = F.l1_loss(m[:, :1], a) + F.l1_loss(sob(m[:, :1]), sob(a))
     assert abs(float(losses.fusion_loss3(a, m)) - float(ref3)) < 1e-12
     assert 0.0 < float(losses.ssim(a, m[:, :1])) < 1.0 and abs(float(losses.ssim(a, a)) - 1.0) < 1e-9
+
+
+def test_compute_results_host_port_matches_reference(golden_dir):
+    """segmif_amd.utils.metrics.compute_results (host arithmetic on the K x K matrix) against the
+    values util/util.py:31-55 produced, NaN pattern included; device entry points refuse CPU tensors."""
+    import numpy as np
+    from segmif_amd.utils import metrics
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    for conf in (g["conf"], torch.from_numpy(g["conf"])):
+        for got, name in zip(metrics.compute_results(conf), ("precision", "recall", "iou")):
+            assert np.array_equal(np.isnan(got), np.isnan(g[name])), name
+            assert np.allclose(np.nan_to_num(got), np.nan_to_num(g[name]), rtol=0, atol=1e-15), name
+    with pytest.raises(RuntimeError):
+        metrics.confusion_matrix(torch.zeros(4, dtype=torch.int32), torch.zeros(4, dtype=torch.int64))
+    with pytest.raises(RuntimeError):
+        metrics.quantize_fused(torch.zeros(1, 3, 4, 4))

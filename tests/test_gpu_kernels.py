@@ -327,3 +327,37 @@ def test_bad_arguments_fail_loudly(ops):
         ops.linear(torch.zeros(4, 64).cuda(), torch.zeros(8, 48).cuda(), 8)  # wrong packed shape
     with pytest.raises(RuntimeError):
         ops.layernorm(torch.zeros(4, 30).cuda(), torch.ones(30).cuda(), torch.zeros(30).cuda(), 1e-5)  # C % 4
+
+
+def test_confusion_matrix_and_quantize_on_device(ops):
+    """SURVEY §8(f) N3 kernels against the fixture recorded from sklearn + the reference's util.py, and
+    against the oracle's restatement of the uint8 write-out."""
+    import os
+
+    import numpy as np
+
+    import detweights as dw
+    import segmif_oracle as so
+    from segmif_amd.utils import metrics
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics.npz"))
+    pred, label = torch.from_numpy(g["pred"]).cuda(), torch.from_numpy(g["label"]).cuda()
+    conf = metrics.confusion_matrix(pred, label, 9)
+    assert np.array_equal(conf.cpu().numpy(), g["conf"])
+    metrics.confusion_matrix(pred, label, 9, out=conf)  # accumulates like conf_total += conf
+    assert np.array_equal(conf.cpu().numpy(), 2 * g["conf"])
+    lab2 = label.clone()
+    lab2.view(-1)[:100] = 255  # outside the label set: ignored, as sklearn does with labels=[0..8]
+    ref = so.confusion(lab2.cpu().numpy(), g["pred"], 9)
+    assert np.array_equal(metrics.confusion_matrix(pred, lab2, 9).cpu().numpy(), ref)
+    _, _, iou = metrics.compute_results(metrics.confusion_matrix(pred, label, 9))
+    assert np.allclose(np.nan_to_num(iou), np.nan_to_num(g["iou"]), atol=1e-15)
+    # large, ragged count
+    big_p = dw.det_labels("cm_p", (1000003,), 9).to(torch.int32).cuda()
+    big_l = dw.det_labels("cm_l", (1000003,), 9).cuda()
+    assert np.array_equal(metrics.confusion_matrix(big_p, big_l, 9).cpu().numpy(),
+                          so.confusion(big_l.cpu().numpy(), big_p.cpu().numpy(), 9))
+    # uint8 write-out
+    x = (dw.det_input("quant_gpu", (2, 3, 37, 53)) * 0.7 + 0.1)
+    q = metrics.quantize_fused(x.cuda())
+    assert q.dtype == torch.uint8 and np.array_equal(q.cpu().numpy(), so.quantize_fused_u8(x.numpy()))
+    assert not metrics.quantize_fused(torch.full((1, 3, 5, 7), 0.5).cuda()).any()

@@ -183,3 +183,30 @@ def test_oracle_autograd_matches_reference_gradients_fusion(golden_dir):
     (out * torch.from_numpy(g["cot"])).sum().backward()
     grads = {k: v.grad for k, v in sd.items() if v.requires_grad}
     _grad_fixture_check(grads, g, tol=2e-3)
+
+
+def test_metrics_match_the_reference_metric_code(golden_dir):
+    """confusion matrix / compute_results restatements against what sklearn's
+    confusion_matrix and the reference's util/util.py returned (oracle/make_golden_metrics.py)."""
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    conf = so.confusion(g["label"], g["pred"], 9)
+    assert np.array_equal(conf, g["conf"])
+    prec, rec, iou = so.compute_results(conf)
+    for got, name in ((prec, "precision"), (rec, "recall"), (iou, "iou")):
+        assert np.array_equal(np.isnan(got), np.isnan(g[name])), name
+        assert np.allclose(np.nan_to_num(got), np.nan_to_num(g[name]), rtol=0, atol=1e-15), name
+    assert np.isnan(iou[8]) and np.isnan(prec[5]) and np.isnan(rec[7])  # the three empty-class cases
+    m, per_class = so.miou(conf)
+    assert abs(m - float(np.mean(np.nan_to_num(g["iou"])))) < 1e-15
+
+
+def test_quantize_restatement_properties():
+    """test_fusion.py:112-120 restated (inline script code, so no callable to record from): uint8 range is
+    stretched to the batch's global min / max, truncation not rounding, constant image -> zeros."""
+    x = dw.det_input("quant", (2, 3, 8, 12)).numpy() * 0.6 + 0.2
+    q = so.quantize_fused_u8(x)
+    assert q.dtype == np.uint8 and q.shape == (2, 8, 12, 3) and q.min() == 0 and q.max() == 255
+    a = np.uint8(255.0 * x.astype(np.float32)).transpose(0, 2, 3, 1).astype(np.float64)
+    expect = np.floor(255.0 * (a - a.min()) / (a.max() - a.min()))
+    assert np.array_equal(q.astype(np.float64), expect)
+    assert not so.quantize_fused_u8(np.full((1, 3, 4, 4), 0.5, np.float32)).any()
