@@ -27,13 +27,13 @@ template <int CHAINS>
 void run(int threads, float* d) {
   const int iters = 4000, blocks = 256;
   hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   hipLaunchKernelGGL(k<CHAINS>, dim3(blocks), dim3(threads), 0, 0, d, 10);
-  hipEventRecord(e0);
+  (void)hipEventRecord(e0);
   hipLaunchKernelGGL(k<CHAINS>, dim3(blocks), dim3(threads), 0, 0, d, iters);
-  hipEventRecord(e1);
-  hipEventSynchronize(e1);
-  float ms; hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   const double mfma_per_simd = (double)iters * 16 * (threads / 256);  // waves per SIMD x MFMAs per wave
   const double tf = (double)blocks * (threads / 64) * iters * 16 * 32768.0 / (ms * 1e-3) / 1e12;
   printf("chains %d, %d wave(s)/SIMD: %.3f ms, %.0f TF/s, %.1f ns per MFMA per SIMD (= %.1f cycles at 2.4 GHz)\n", CHAINS,
@@ -41,7 +41,7 @@ void run(int threads, float* d) {
 }
 
 int main() {
-  float* d; hipMalloc(&d, 256 * 512 * 4);
+  float* d; (void)hipMalloc(&d, 256 * 512 * 4);
   run<1>(256, d); run<2>(256, d); run<3>(256, d); run<4>(256, d); run<8>(256, d);
   run<1>(512, d); run<2>(512, d); run<4>(512, d);
   return 0;
