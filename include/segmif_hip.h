@@ -169,6 +169,13 @@ int segmif_dwconv3x3_gelu_f32(const float* x, const float* w9, const float* bias
  */
 int segmif_bilinear_nhwc_f32(const float* x, float* y, int B, int IH, int IW, int OH, int OW, int C,
                              int ldx, int ldo, void* stream);
+/* out = act(base + bias + sum of up to three bilinear resizes (align_corners=False) to OH x OW), all NHWC with C
+ * channels (C % 4 == 0; the sources are dense, base / out may be pitched); act NONE or RELU; NULL base / bias /
+ * x_i are skipped.  The SegFormer head with linear_fuse applied per scale before the resize
+ * (segformer_head.py:67-77 commuted: a 1x1 conv commutes with a bilinear resize) ends in this kernel. */
+int segmif_upsum_act_nhwc_f32(const float* base, int ldb, const float* x0, int ih0, int iw0, const float* x1, int ih1,
+                              int iw1, const float* x2, int ih2, int iw2, const float* bias, float* out, int ldo, int B,
+                              int OH, int OW, int C, int act, void* stream);
 
 /*
  * Fused spatial-reduction attention: O = softmax(Q K^T * scale) V per (batch, head), never

@@ -42,6 +42,8 @@ SIGNATURES = {
     "segmif_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "segmif_conv3x3_split_weight_bytes": (c_int64, [c_int, c_int]),
     "segmif_conv3x3_split_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "segmif_upsum_act_nhwc_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                          c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "segmif_confusion_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "segmif_quantize_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "segmif_wgrad_workspace_size": (c_int64, [c_int64, c_int, c_int]),

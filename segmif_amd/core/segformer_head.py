@@ -96,7 +96,30 @@ class SegFormerHead(nn.Module):
         self.linear_fuse = ConvModule(in_channels=embedding_dim * 4, out_channels=embedding_dim, kernel_size=1,
                                       norm_cfg=dict(type='BN', requires_grad=True))
         self.linear_pred = nn.Conv2d(embedding_dim, self.num_classes, kernel_size=1)
+        self.commute_resize = True  # eval: apply linear_fuse per scale before the bilinear resize (same function)
         self._pk = PackedCache()
+
+    def _per_scale_fused(self):
+        """Packed (E, C_s) matrices fuse_slot_s @ proj_s for s = c4, c3, c2, c1 (eval-mode BatchNorm folded into
+        fuse) and the total shift  bn_shift + sum_s fuse_slot_s @ proj_s.bias ; composed in float64."""
+        fuse, bn = self.linear_fuse, self.linear_fuse.bn
+        mlps = (self.linear_c4, self.linear_c3, self.linear_c2, self.linear_c1)
+        srcs = (fuse.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var) + tuple(
+            p for m in mlps for p in (m.proj.weight, m.proj.bias))
+
+        def build():
+            E = fuse.conv.out_channels
+            s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            wf = fuse.conv.weight.double().flatten(1) * s[:, None]  # (E, 4E), columns in cat order [c4 c3 c2 c1]
+            shift = bn.bias.double() - bn.running_mean.double() * s
+            ws = []
+            for slot, m in enumerate(mlps):
+                blk = wf[:, slot * E:(slot + 1) * E]
+                ws.append(ops.pack_weight((blk @ m.proj.weight.double()).float().contiguous()))
+                shift = shift + blk @ m.proj.bias.double()
+            return ws, shift.float().contiguous()
+
+        return self._pk.get_multi("per_scale_fused", srcs, build)
 
     def forward_train_nhwc(self, feats):
         """autograd path (BatchNorm on running statistics; batch-statistics mode is not built yet)."""
@@ -140,6 +163,17 @@ class SegFormerHead(nn.Module):
         c1, c2, c3, c4 = feats
         B, H1, W1, _ = c1.shape
         E = self.linear_c1.proj.out_features
+        if self.commute_resize and not self.training and self.linear_fuse.with_norm:
+            # linear_fuse is a 1x1 conv over the concatenation, i.e. a sum over scales of 1x1 convs of resized maps,
+            # and a 1x1 conv commutes with a bilinear resize: fuse at each scale's own resolution (composed
+            # with the scale's Linear into one C_s -> E matrix), then resize, sum, shift, ReLU in one pass.
+            # No (B, H/4, W/4, 4E) buffer, 3x fewer FLOPs.
+            ws, b_total = self._per_scale_fused()
+            low = [ops.linear(c.contiguous(), w, E) for w, c in zip(ws[:3], (c4, c3, c2))]
+            p1 = ops.linear(c1, ws[3], E)
+            y = ops.upsum_act(p1, low, H1, W1, bias=b_total, act=ops.ACT_RELU)
+            return ops.linear(y, self._pk.get("pred", self.linear_pred.weight, ops.pack_weight), self.num_classes,
+                              bias=self.linear_pred.bias)
         cat = torch.empty((B, H1, W1, 4 * E), device=c1.device, dtype=torch.float32)
         for slot, (mlp, c) in enumerate(((self.linear_c4, c4), (self.linear_c3, c3), (self.linear_c2, c2))):
             ops.bilinear(mlp.forward_nhwc(c), H1, W1, out=cat[..., slot * E:(slot + 1) * E])

@@ -292,6 +292,75 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x
   labels[r] = bi;
 }
 
+// out = act(base + bias + sum_s bilinear(x_s -> OH x OW)): the SegFormer head with linear_fuse applied per
+// scale BEFORE the resize (segformer_head.py:67-77 commuted) needs the sum of three
+// up-sampled maps, the full-resolution term, the folded BatchNorm shift and the ReLU in one pass.
+struct UpSrc {
+  const float* x;
+  int ih, iw;
+  float sy, sx;
+};
+
+__device__ __forceinline__ f32x4 bilinear_tap4(const UpSrc& s, long long b, int oy, int ox, int c, int C) {
+  const float fy = fmaxf(s.sy * ((float)oy + 0.5f) - 0.5f, 0.f);
+  const float fx = fmaxf(s.sx * ((float)ox + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = min(y0 + 1, s.ih - 1), x1 = min(x0 + 1, s.iw - 1);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float* base = s.x + b * s.ih * s.iw * C + c;
+  const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((long long)y0 * s.iw + x0) * C);
+  const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((long long)y0 * s.iw + x1) * C);
+  const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * s.iw + x0) * C);
+  const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * s.iw + x1) * C);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+  return o;
+}
+
+__global__ __launch_bounds__(256) void upsum_act_kernel(const float* __restrict__ basep, int ldb, UpSrc s0, UpSrc s1, UpSrc s2,
+                                                        int nsrc, const float* __restrict__ bias, float* __restrict__ out,
+                                                        int ldo, int OH, int OW, int C, int act, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c4n = C / 4;
+  const int c = (int)(idx % c4n) * 4;
+  long long pix = idx / c4n;
+  const int ox = (int)(pix % OW);
+  const long long row = pix;  // (b * OH + oy) * OW + ox
+  pix /= OW;
+  const int oy = (int)(pix % OH);
+  const long long b = pix / OH;
+  f32x4 y = {0.f, 0.f, 0.f, 0.f};
+  if (basep) y = *reinterpret_cast<const f32x4*>(basep + row * ldb + c);
+  if (bias) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] += bv[e];
+  }
+  if (nsrc > 0) {
+    const f32x4 t = bilinear_tap4(s0, b, oy, ox, c, C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] += t[e];
+  }
+  if (nsrc > 1) {
+    const f32x4 t = bilinear_tap4(s1, b, oy, ox, c, C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] += t[e];
+  }
+  if (nsrc > 2) {
+    const f32x4 t = bilinear_tap4(s2, b, oy, ox, c, C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] += t[e];
+  }
+  if (act == SEGMIF_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+  }
+  *reinterpret_cast<f32x4*>(out + row * ldo + c) = y;
+}
+
 }  // namespace
 
 extern "C" int segmif_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
@@ -383,5 +452,27 @@ extern "C" int segmif_gauss_blur11_f32(const float* x, float* y, int planes, int
   for (int i = 0; i < 11; ++i) t.g[i] = taps11[i];  // host pointer: 11 window weights
   dim3 grid((unsigned)((W + 31) / 32), (unsigned)((H + 31) / 32), (unsigned)planes);
   hipLaunchKernelGGL(gauss_blur11_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, H, W, t);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_upsum_act_nhwc_f32(const float* base, int ldb, const float* x0, int ih0, int iw0, const float* x1,
+                                         int ih1, int iw1, const float* x2, int ih2, int iw2, const float* bias, float* out,
+                                         int ldo, int B, int OH, int OW, int C, int act, void* stream) {
+  if (!out || B <= 0 || OH <= 0 || OW <= 0 || C <= 0 || (C & 3) || ldo < C || (ldo & 3) || (base && (ldb < C || (ldb & 3))))
+    return SEGMIF_EINVAL;
+  if (act != SEGMIF_ACT_NONE && act != SEGMIF_ACT_RELU) return SEGMIF_EINVAL;
+  const float* xs[3] = {x0, x1, x2};
+  const int ihs[3] = {ih0, ih1, ih2}, iws[3] = {iw0, iw1, iw2};
+  UpSrc src[3] = {};
+  int n = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (!xs[i]) continue;
+    if (ihs[i] <= 0 || iws[i] <= 0 || ((uintptr_t)xs[i] & 15)) return SEGMIF_EINVAL;
+    src[n++] = UpSrc{xs[i], ihs[i], iws[i], (float)ihs[i] / (float)OH, (float)iws[i] / (float)OW};
+  }
+  if ((((uintptr_t)out | (uintptr_t)(base ? base : out) | (uintptr_t)(bias ? bias : out)) & 15)) return SEGMIF_EINVAL;
+  const long long total = (long long)B * OH * OW * (C / 4);
+  hipLaunchKernelGGL(upsum_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, ldb,
+                     src[0], src[1], src[2], n, bias, out, ldo, OH, OW, C, act, total);
   return (int)hipGetLastError();
 }

@@ -317,6 +317,38 @@ def bilinear(x, OH, OW, out=None):
     return out
 
 
+def upsum_act(base, srcs, OH, OW, bias=None, act=ACT_NONE, out=None):
+    """out = act(base + bias + sum_i bilinear(srcs[i] -> OH x OW)); base (B,OH,OW,C) rows view or None, srcs: up
+    to three contiguous (B, ih, iw, C) maps."""
+    if not 1 <= len(srcs) <= 3:
+        raise RuntimeError("upsum_act takes one to three sources")
+    B, C = srcs[0].shape[0], srcs[0].shape[-1]
+    for s in srcs:
+        if _req(s, "src").dim() != 4 or not s.is_contiguous() or s.shape[0] != B or s.shape[-1] != C:
+            raise RuntimeError("upsum_act sources must be contiguous (B, ih, iw, C) with a common B and C")
+    if out is None:
+        out = torch.empty((B, OH, OW, C), device=srcs[0].device, dtype=torch.float32)
+    _, oc, ldo = rows_view(out, "out")
+    ldb = 0
+    if base is not None:
+        _, bc, ldb = rows_view(_req(base, "base"), "base")
+        if tuple(base.shape) != (B, OH, OW, C):
+            raise RuntimeError("upsum_act base shape mismatch")
+    if tuple(out.shape) != (B, OH, OW, C):
+        raise RuntimeError("upsum_act out shape mismatch")
+    args = []
+    for i in range(3):
+        if i < len(srcs):
+            args += [srcs[i].data_ptr(), srcs[i].shape[1], srcs[i].shape[2]]
+        else:
+            args += [None, 0, 0]
+    _lib.check(_lib.load().segmif_upsum_act_nhwc_f32(base.data_ptr() if base is not None else None, ldb, *args,
+                                                     _req(bias, "bias").data_ptr() if bias is not None else None,
+                                                     out.data_ptr(), ldo, B, OH, OW, C, act, _stream()),
+               "segmif_upsum_act_nhwc_f32")
+    return out
+
+
 def sr_attention(q, kv, heads, scale):
     """q: (B, N, C) contiguous; kv: (B, Nk, 2C) contiguous (k | v) -> (B, N, C)."""
     _req(q, "q"), _req(kv, "kv")

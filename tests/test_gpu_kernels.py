@@ -361,3 +361,30 @@ def test_confusion_matrix_and_quantize_on_device(ops):
     q = metrics.quantize_fused(x.cuda())
     assert q.dtype == torch.uint8 and np.array_equal(q.cpu().numpy(), so.quantize_fused_u8(x.numpy()))
     assert not metrics.quantize_fused(torch.full((1, 3, 5, 7), 0.5).cuda()).any()
+
+
+def test_upsample_sum_act(ops):
+    """segmif_upsum_act_nhwc_f32: act(base + bias + sum of bilinear resizes) against F.interpolate, pitched
+    base / out, one to three sources, odd sizes."""
+    B, OH, OW, C = 2, 30, 41, 64
+    srcs = [rnd(B, 15, 21, C, seed=81), rnd(B, 8, 10, C, seed=82), rnd(B, 4, 5, C, seed=83)]
+    base, bias = rnd(B, OH, OW, C, seed=84), rnd(C, seed=85)
+
+    def up(t):
+        return F.interpolate(t.double().permute(0, 3, 1, 2), size=(OH, OW), mode="bilinear",
+                             align_corners=False).permute(0, 2, 3, 1)
+
+    for n in (1, 2, 3):
+        ref = F.relu(base.double() + bias.double() + sum(up(t) for t in srcs[:n]))
+        wide_b = torch.zeros(B, OH, OW, 96)
+        wide_b[..., 16:16 + C] = base
+        wide_b = wide_b.cuda()
+        out = torch.full((B, OH, OW, 80), 3.0, device="cuda")
+        ops.upsum_act(wide_b[..., 16:16 + C], [t.cuda() for t in srcs[:n]], OH, OW, bias=bias.cuda(), act=1,
+                      out=out[..., :C])
+        assert err(out[..., :C], ref) < TOL, n
+        assert float((out[..., C:] - 3).abs().max()) == 0
+    y = ops.upsum_act(None, [srcs[0].cuda()], OH, OW)
+    assert err(y, up(srcs[0])) < TOL
+    with pytest.raises(RuntimeError):
+        ops.upsum_act(None, [], OH, OW)

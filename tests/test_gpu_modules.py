@@ -155,6 +155,29 @@ def test_conv3_conv4_commute_with_the_resize(net_b1, fus, golden_dir):
         fus.forward_from_features(ir, vis, torch.zeros(1, 16, 24, 32).cuda(), torch.zeros(1, 8, 12, 64).cuda())
 
 
+def test_head_fuse_commutes_with_the_resize(net_b1, golden_dir):
+    """SURVEY §8(f) N4, second half: SegFormerHead in eval mode applies linear_fuse per scale before the
+    bilinear resize (composed with the scale's Linear, BatchNorm folded); same function as the textbook
+    order (concat -> fuse), and both meet the reference fixture through Network3."""
+    gp = load(golden_dir, "pair_b1_64x96.npz")
+    mask = torch.from_numpy(gp["mask"]).cuda()
+    head = net_b1.denoise_net.decoder
+    assert head.commute_resize
+    with torch.no_grad():
+        feats = net_b1.denoise_net.encoder.forward_features_nhwc(mask)
+        a = head.forward_nhwc(feats)
+        head.commute_resize = False
+        try:
+            b = head.forward_nhwc(feats)
+        finally:
+            head.commute_resize = True
+    assert rel(a, b.cpu()) < 1e-5
+    fused = torch.from_numpy(gp["fused"]).cuda()
+    with torch.no_grad():
+        _, _, seg = net_b1(fused)
+    assert rel(seg, gp["seg"]) < 5 * TIGHT
+
+
 def assert_miou_parity(ref_labels, hip_labels, gt_name):
     """North star: seg mIoU within +-0.1 of the reference on fixed synthetic inputs.  mIoU is taken
     against seeded synthetic ground truth with the reference's own formula (util/util.py:31-55)."""
