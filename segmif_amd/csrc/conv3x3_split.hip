@@ -127,7 +127,8 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
   // per-thread staging slots, fixed across chunks.  Loads are unconditional (out-of-image and
   // surplus slots read pixel 0 / the last weight unit and are zeroed / dropped later) so that the
   // compiler can count them: s_waitcnt vmcnt(n) on the oldest slot while the rest are in flight.
-  int a_off[AJ], a_dst[AJ];
+  long long a_off[AJ];  // float offset inside the image: H * W * lda can pass 2^31 (e.g. 3100 x 3100 x 224)
+  int a_dst[AJ];
   bool a_ok[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int gy = y0 - DIL + hy, gx = x0 - DIL + hx;
     a_dst[j] = u < A_UNITS ? pp * ROWB + q4 * 8 : -1;
     a_ok[j] = u < A_UNITS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    a_off[j] = (a_ok[j] ? (gy * p.W + gx) * p.lda : 0) + q4 * 4;
+    a_off[j] = (a_ok[j] ? ((long long)gy * p.W + gx) * p.lda : 0) + q4 * 4;
   }
   int b_src[BJ], b_dst[BJ];
 #pragma unroll
