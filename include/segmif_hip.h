@@ -121,6 +121,57 @@ int64_t segmif_conv3x3_split_weight_bytes(int N, int Cin);
 int segmif_conv3x3_split_pack(const float* packed, int N, int Cin, int ldw, void* out, void* stream);
 
 /*
+ * "Planes" activations: the bf16x6 operand split done ONCE by the producer instead of in every
+ * consumer (csrc/conv3x3_planes.hip).  A planes buffer holds `chunks` 16-channel chunk images per batch
+ * element, [b][chunk][Hp][Wp][plane 0..2][16] bf16 (x = p0 + p1 + p2, 24 significand bits), with
+ * Hp = ceil(H/8)*8 + 4, Wp = ceil(W/32)*32 + 4 (segmif_planes_dims): a zero border of 2 pixels plus the
+ * round-up to whole 8 x 32 patches, which segmif_planes_zero_border clears once per buffer (kernels only
+ * ever write the H x W interior).  Position j of a chunk holds channel 16*chunk + (j&3) + 4*(j>>3) +
+ * 8*((j>>2)&1) (the MFMA accumulator's hand-out order).  segmif_planes_from_f32 converts `nconv` chunks
+ * (16*nconv leading channels of the fp32 rows x, pixel pitch ldx floats, 16-byte aligned) into chunks
+ * [chunk0, chunk0 + nconv).  segmif_planes_pack_weight turns a segmif_pack_conv_weight image (row pitch
+ * ldw floats; taps = 9 for a 3x3 conv, 1 for a 1x1 conv / Linear; N % 32 == 0, Cin % 16 == 0) into the
+ * matching split weight image of segmif_planes_weight_bytes(N, Cin, taps) bytes.
+ *
+ * segmif_conv3x3_planes_bf16x6: 3x3 stride-1 "same" convolution (dilation 1 | 2) with 32 output channels
+ * over the first `cin` channels of a planes buffer: bias + act (NONE | RELU | PRELU), written as two more
+ * planes chunks (planes_out / out_chunk0; may be the input buffer, chunks >= cin/16) and / or as fp32 rows
+ * (out, pitch ldo).  Six bf16 MFMA products per fp32-equivalent MAC: fp32-class accuracy.  With w1 != NULL
+ * the kernel also evaluates   out1 = res + act1( W1 . [in(cin) | act(conv)(32)] + bias1 )   — a 1x1 conv with
+ * 64 outputs over the input channels and the conv's own result (w1: segmif_planes_pack_weight(N = 64,
+ * Cin = cin + 32, taps = 1)) — i.e. a whole DRDB tail (core/model_fusion.py:153-157: Dcov5, torch.cat,
+ * conv 224 -> 64, ReLU, residual) in one launch, the concat never reaching HBM.
+ * Replaces core/model_fusion.py:135-157 in inference.
+ */
+typedef struct SegmifConvPlanes {
+  const void* planes_in;
+  void* planes_out;    /* or NULL */
+  const void* wt;      /* segmif_planes_pack_weight(N = 32, Cin = cin, taps = 9) */
+  const float* bias;   /* [32] or NULL, 16-byte aligned */
+  const float* prelu;
+  float* out;          /* optional fp32 rows [B*H*W][ldo] */
+  int32_t ldo;
+  int32_t B, H, W, cin, dil;
+  int32_t in_chunks;   /* chunk images per batch element in planes_in */
+  int32_t out_chunks, out_chunk0;
+  int32_t act;
+  const void* w1;      /* fused 1x1 tail (NULL = off) */
+  const float* bias1;  /* [64] or NULL */
+  const float* res;    /* [B*H*W][ldr] or NULL */
+  float* out1;         /* [B*H*W][ldo1], 64 channels */
+  int32_t ldr, ldo1, act1;
+} SegmifConvPlanes;
+
+int segmif_planes_dims(int H, int W, int* Hp, int* Wp);
+int64_t segmif_planes_bytes(int B, int H, int W, int chunks);
+int segmif_planes_zero_border(void* planes, int B, int H, int W, int chunks, void* stream);
+int segmif_planes_from_f32(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0, int nconv,
+                           void* stream);
+int64_t segmif_planes_weight_bytes(int N, int Cin, int taps);
+int segmif_planes_pack_weight(const float* packed, int N, int Cin, int taps, int ldw, void* out, void* stream);
+int segmif_conv3x3_planes_bf16x6(const SegmifConvPlanes* desc, void* stream);
+
+/*
  * Weight gradient of the same problem: dW[n][k] = sum_m dY[m][n] * A(m,k), contraction over rows on
  * fp32 MFMA, deterministic two-pass reduction (per-chunk partials, then an fp64 sum) written in the
  * parameter's own layout: dw[n*dw_sn + k'*...] — OIHW for convs, (N, K) for linears; for dense

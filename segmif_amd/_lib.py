@@ -31,6 +31,17 @@ class SegmifIgemm(ctypes.Structure):
     ]
 
 
+class SegmifConvPlanes(ctypes.Structure):
+    _fields_ = [
+        ("planes_in", c_void_p), ("planes_out", c_void_p), ("wt", c_void_p), ("bias", c_void_p), ("prelu", c_void_p),
+        ("out", c_void_p), ("ldo", c_int32),
+        ("B", c_int32), ("H", c_int32), ("W", c_int32), ("cin", c_int32), ("dil", c_int32),
+        ("in_chunks", c_int32), ("out_chunks", c_int32), ("out_chunk0", c_int32), ("act", c_int32),
+        ("w1", c_void_p), ("bias1", c_void_p), ("res", c_void_p), ("out1", c_void_p),
+        ("ldr", c_int32), ("ldo1", c_int32), ("act1", c_int32),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol include/segmif_hip.h declares
 SIGNATURES = {
     "segmif_abi_version": (c_int, []),
@@ -42,6 +53,13 @@ SIGNATURES = {
     "segmif_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "segmif_conv3x3_split_weight_bytes": (c_int64, [c_int, c_int]),
     "segmif_conv3x3_split_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "segmif_planes_dims": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "segmif_planes_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "segmif_planes_zero_border": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "segmif_planes_from_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "segmif_planes_weight_bytes": (c_int64, [c_int, c_int, c_int]),
+    "segmif_planes_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "segmif_conv3x3_planes_bf16x6": (c_int, [POINTER(SegmifConvPlanes), c_void_p]),
     "segmif_upsum_act_nhwc_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                           c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "segmif_confusion_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

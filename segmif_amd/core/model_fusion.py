@@ -113,6 +113,33 @@ class DRDB(nn.Module):
         return ops.linear(buf, self._pk.get("conv", self.conv.weight, ops.pack_weight), self.in_ch,
                           bias=self.conv.bias, act=ops.ACT_RELU, res=buf[..., :self.in_ch], out=out)
 
+    PLANES_CHUNKS = 12  # 64 input + 4 x 32 grown channels; the fifth conv's result never leaves the kernel
+
+    def forward_planes(self, x, planes, out=None):
+        """Inference on pre-split activations (csrc/conv3x3_planes.hip): x (B,H,W,64) fp32 rows view, planes a
+        12-chunk ops.Planes scratch buffer.  Dcov1-4 read / append chunk images, Dcov5 also carries the closing
+        1x1 conv + ReLU + residual (ref :153-157), so the 224-channel concat is never materialised in fp32."""
+        B, H, W, _ = x.shape
+        if out is None:
+            out = torch.empty((B, H, W, self.in_ch), device=x.device, dtype=torch.float32)
+        planes.load_f32(x, 0)
+        ch = self.in_ch
+        for i in range(1, 6):
+            conv = getattr(self, f"Dcov{i}")
+            wt = self._pk.get(f"p{i}", conv.weight, ops.pack_weight_planes)
+            if i < 5:
+                ops.conv3x3_planes(planes, ch, wt, dil=2, bias=conv.bias, act=ops.ACT_RELU, out_chunk0=ch // 16,
+                                   tag="drdb_dcov")
+            else:
+                w1 = self._pk.get("p1x1", self.conv.weight, ops.pack_weight_planes)
+                ops.conv3x3_planes(planes, ch, wt, dil=2, bias=conv.bias, act=ops.ACT_RELU,
+                                   tail=(w1, self.conv.bias, x, out, ops.ACT_RELU), tag="drdb_tail")
+            ch += self.growth
+        return out
+
+    def planes_ok(self):
+        return ops.conv3x3_mode() == "planes" and self.in_ch == 64 and self.growth == 32
+
     def _params(self):
         ps = []
         for i in range(1, 6):
@@ -128,6 +155,8 @@ class DRDB(nn.Module):
         if wants_grad(self, x):
             return self.forward_train_nhwc(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
         B, _, H, W = x.shape
+        if self.planes_ok():
+            return ops.as_nchw(self.forward_planes(ops.to_nhwc(x), ops.Planes(B, H, W, self.PLANES_CHUNKS, x.device)))
         buf = self.new_buffer(B, H, W, x.device)
         buf[..., :self.in_ch].copy_(x.permute(0, 2, 3, 1))
         return ops.as_nchw(self.forward_buffer(buf))
@@ -366,6 +395,8 @@ class Fusion_Network3_ac(nn.Module):
         B, _, H, W = ir.shape
         dev, slope = ir.device, self.relu.weight
         PRELU = ops.ACT_PRELU
+        if self.DRDB1.planes_ok():
+            return self._forward_eval_planes(ir, vis, seg1_fn, seg2_fn)
         bufs = []
         for x, conv, drdb in ((ir, self.conv1_ir, self.DRDB1), (vis, self.conv1_vis, self.DRDB2)):
             buf = drdb.new_buffer(B, H, W, dev)
@@ -384,6 +415,33 @@ class Fusion_Network3_ac(nn.Module):
         seg = seg2_fn()
         cat = torch.empty((B, H, W, 128), device=dev, dtype=torch.float32)
         self.ffm.forward_nhwc(x1, x2, seg, out1=cat[..., :64], out2=cat[..., 64:])
+        f = ops.conv2d(cat, self._w3("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)
+        f = ops.conv2d(f, self._w3("conv21"), 32, 3, pad=1, bias=self.conv21.bias, act=PRELU, prelu=slope)
+        f = ops.conv2d(f, self._w("conv22"), 1, 3, pad=1, bias=self.conv22.bias, act=PRELU, prelu=slope)
+        return f.view(B, 1, H, W)
+
+
+    def _forward_eval_planes(self, ir, vis, seg1_fn, seg2_fn):
+        """_forward_eval with the four DRDBs on pre-split activations: two planes scratch buffers (one per
+        modality, reused by DRDB1 -> DRDB3 and DRDB2 -> DRDB4), 64-channel fp32 tensors between the blocks."""
+        B, _, H, W = ir.shape
+        dev, slope = ir.device, self.relu.weight
+        PRELU = ops.ACT_PRELU
+        xs, pls = [], []
+        for x, conv, name in ((ir, self.conv1_ir, "conv1_ir"), (vis, self.conv1_vis, "conv1_vis")):
+            xs.append(ops.conv2d(self._first_channel_nhwc(x), self._w(name), 64, 3, pad=1, bias=conv.bias, act=PRELU,
+                                 prelu=slope))
+            pls.append(ops.Planes(B, H, W, DRDB.PLANES_CHUNKS, dev))
+        y1 = self.DRDB1.forward_planes(xs[0], pls[0])
+        y2 = self.DRDB2.forward_planes(xs[1], pls[1])
+        seg = seg1_fn()
+        x1, x2 = self.ffm.forward_nhwc(y1, y2, seg, out1=xs[0], out2=xs[1])
+        y1 = self.DRDB3.forward_planes(x1, pls[0], out=y1)
+        y2 = self.DRDB4.forward_planes(x2, pls[1], out=y2)
+        del pls, xs, x1, x2
+        seg = seg2_fn()
+        cat = torch.empty((B, H, W, 128), device=dev, dtype=torch.float32)
+        self.ffm.forward_nhwc(y1, y2, seg, out1=cat[..., :64], out2=cat[..., 64:])
         f = ops.conv2d(cat, self._w3("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)
         f = ops.conv2d(f, self._w3("conv21"), 32, 3, pad=1, bias=self.conv21.bias, act=PRELU, prelu=slope)
         f = ops.conv2d(f, self._w("conv22"), 1, 3, pad=1, bias=self.conv22.bias, act=PRELU, prelu=slope)

@@ -1,0 +1,639 @@
+// DRDB dilated 3x3 convs (core/model_fusion.py:121-157) on the bf16 matrix pipe with 3-way split
+// operands ("bf16x6", numerics as in conv3x3_split.hip), reading activations that are ALREADY split.
+//
+// Why a second kernel.  conv3x3_split.hip keeps fp32 activations in HBM and splits them on their way to
+// LDS: a DRDB re-reads channels [0, 64 + 32 i) in conv i, so every element is split ~3 times over,
+// times the 1.69x halo overlap, and the split + VGPR -> LDS store phase is what kept the matrix pipe at
+// 61 % (profiles/r01_pmc_sq_counters_bf16x6.txt).  Here the producer writes the three bf16 planes once
+// ("planes" image, below) and a conv does no vector arithmetic at all on its input: the halo and the
+// weights go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write), the
+// waves only issue ds_read_b128 + MFMA (schedule: see the kernel).
+//
+// Planes image (include/segmif_hip.h, segmif_planes_*):  [b][chunk][Hp][Wp][plane 0..2][16] bf16, one
+// 16-channel chunk per image, Hp = ceil(H/8)*8 + 4, Wp = ceil(W/32)*32 + 4: a zero border of 2 pixels plus
+// the round-up to whole 8 x 32 patches, so a halo row is one contiguous run of (32 + 2d) * 96 bytes
+// and needs no bounds logic.  Position j of a chunk holds channel 16*chunk + sigma(j),
+// sigma(j) = (j & 3) + 4 (j >> 3) + 8 ((j >> 2) & 1): the order in which the 32x32 MFMA accumulator
+// hands a lane its 8 values of a 16-row block, so an epilogue writes 16 contiguous bytes per plane and —
+// in the fused tail — re-uses its accumulators as the next MFMA's B operand without any data movement.
+//
+// LDS image: [pixel][96 B] with NO padding (41.5 + 27 KB per workgroup; the padded 112-byte pitch of
+// conv3x3_split.hip cannot be written by a lane-linear DMA).  A 96-byte pitch alone is a 2-way
+// ds_read_b128 bank conflict; the image is therefore built with the two 16-byte halves of every plane
+// swapped in halo columns with bit 3 set (weights: rows with bit 4 set) — the DMA's per-lane SOURCE
+// address does that for free — and a lane reads half h ^ f.  For every 16-lane service group of
+// ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) and every tap offset this puts the 16 lanes
+// on 16 distinct 16-byte slots of the 256-byte bank row.
+//
+// Fused tail (FUSE): the DRDB's closing 1x1 conv 224 -> 64 + ReLU + residual (ref :155-157) rides on the
+// fifth dilated conv: its input at a pixel is that conv's centre-tap fragment (chunks 0..11, already in
+// LDS) plus the 32 channels the conv itself produces (in the accumulators), so 12 + 24 extra MFMAs per
+// sub-tile replace a separate HBM-bound pass over the 224-channel buffer.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "igemm_common.h"
+#include "segmif_hip.h"
+
+#ifndef PLANES_DBG
+#define PLANES_DBG 0  // tuning aid: 32 = s_memtime timeline probe (tools/planes_timeline.py), 64 = no planes stores, 128 = s_setprio 1 around the MFMA block
+#endif
+#if PLANES_DBG & 32
+#define PLANES_TL_ITEMS 64
+__device__ unsigned long long planes_timeline[256][2][PLANES_TL_ITEMS][8];
+#define TL(slot)                                                                                   \
+  do {                                                                                             \
+    if (wave == 0 && lane == 0 && blockIdx.x < 256 && i < PLANES_TL_ITEMS)                         \
+      planes_timeline[blockIdx.x][team][i][slot] = __builtin_amdgcn_s_memtime();                  \
+  } while (0)
+#else
+#define TL(slot) do {} while (0)
+#endif
+
+namespace segmif {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PB = 2;            // zero border of a planes image (pixels) = the largest dilation served
+constexpr int TH = 8, TW = 32;   // output patch of a workgroup
+constexpr int PXB = 96;          // bytes per pixel per chunk: 3 planes x 16 bf16
+constexpr int W3_BYTES = 9 * 32 * PXB;   // one chunk of 3x3 weights, 32 output channels
+constexpr int W1_BYTES = 64 * PXB;       // one chunk of the fused 1x1 weights, 64 output channels
+
+inline int planes_hp(int H) { return (H + TH - 1) / TH * TH + 2 * PB; }
+inline int planes_wp(int W) { return (W + TW - 1) / TW * TW + 2 * PB; }
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: a -> low half
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+  p1 = pk_bf16(r0, r1);
+  r0 -= __uint_as_float(p1 << 16);
+  r1 -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = pk_bf16(r0, r1);
+}
+
+// 8 fp32 values (positions 8h .. 8h+7 of a chunk) -> one 16-byte piece per plane
+__device__ __forceinline__ void split8(const float* y, u32x4& p0, u32x4& p1, u32x4& p2) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    uint32_t a, b, c;
+    split3(y[2 * e], y[2 * e + 1], a, b, c);
+    p0[e] = a;
+    p1[e] = b;
+    p2[e] = c;
+  }
+}
+
+__host__ __device__ inline int sigma16(int j) { return (j & 3) + 4 * (j >> 3) + 8 * ((j >> 2) & 1); }
+
+struct PlanesConvK {
+  const unsigned char* pin;   // planes input  [B][in_total][Hp][Wp][96]
+  unsigned char* pout;        // planes output [B][out_total][Hp][Wp][96] (may be the same buffer) or null
+  const unsigned char* wt;    // [chunk][tap][32][96] split, half-swapped
+  const float* bias;
+  const float* prelu;
+  float* out;                 // optional fp32 copy of the 32 outputs, pitch ldo
+  int ldo;
+  int B, H, W, Hp, Wp;
+  int nchunks, in_total, out_total, out_chunk0;
+  int act;
+  const unsigned char* w1;    // fused 1x1: [nchunks + 2][64][96]
+  const float* bias1;
+  const float* res;
+  float* out1;
+  int ldr, ldo1, act1;
+  int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// One persistent workgroup per CU, 8 waves = two TEAMS of four (one wave per SIMD each).  A team owns one 8 x 32
+// patch at a time and alternates between two roles, the teams in anti-phase, one workgroup barrier per phase:
+//   LOAD     issue the LDS-DMA of its next (patch, chunk) item — team 0 also the chunk's weights, which both teams
+//            use —, run the epilogue of a patch it has just finished, wait for its DMA;
+//   COMPUTE  12 steps of ds_read_b128 + MFMA on the item loaded in its previous phase.
+// While one team waits on memory (a wave blocked in vector-memory issue cannot feed the matrix pipe) the other has
+// every SIMD to itself.  Two independent workgroups per CU drift through all relative phases instead (measured: mean
+// |lag| 0.28 of a period, both in their MFMA segment 68 % of the time, both issuing DMA into the 64 B/clk L1 path at
+// once the rest — profiles/r02_planes_timeline.txt); the barrier pins the phase.  Item i of team 0 is loaded in phase
+// 2i and multiplied in phase 2i + 1; team 1 runs one phase later and finds the weights of item i still in W[i & 1].
+template <int DIL, bool FUSE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_planes_kernel(const PlanesConvK p) {
+  constexpr int HH = TH + 2 * DIL, HW = TW + 2 * DIL;
+  constexpr int UR = HW * 6;                      // 16-byte units per halo row
+  constexpr int A_UNITS = HH * UR;
+  constexpr int A_INSTR = (A_UNITS + 63) / 64;    // wave-level DMA instructions (64 units each)
+  constexpr int AJ = (A_INSTR + 3) / 4;
+  constexpr int A_BYTES = A_INSTR * 1024;
+  constexpr int W_INSTR = W3_BYTES / 1024;        // 27
+  constexpr int WJ = (W_INSTR + 3) / 4;
+  constexpr int W1_INSTR = W1_BYTES / 1024;       // 6
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = wave8 >> 2, wave = wave8 & 3;
+  const int r = lane & 31, h = lane >> 5;
+  unsigned char* As = smem_b + team * A_BYTES;                    // this team's halo
+  unsigned char* Wsb = smem_b + 2 * A_BYTES;                      // [2][W3_BYTES], shared by the teams
+  unsigned char* W1sb = Wsb + 2 * W3_BYTES;                       // [2][W1_BYTES] (FUSE)
+  unsigned char* Cst = W1sb + (FUSE ? 2 * W1_BYTES : 0);          // 512 B: bias[32], bias1[64], act slopes
+
+  // patch pairs of this workgroup: XCD x (= blockIdx % 8 under round-robin dispatch) owns a contiguous range of
+  // pairs and its workgroups stride through it together, so vertically adjacent patches meet in one L2
+  const int npatch = p.B * p.tiles_x * p.tiles_y, npairs = (npatch + 1) >> 1;
+  const int G = gridDim.x, nx = G < 8 ? G : 8;
+  const int xcd = blockIdx.x % nx, jx = blockIdx.x / nx, GX = (G - xcd + nx - 1) / nx;
+  const int q_lo = (int)((long long)npairs * xcd / nx), q_hi = (int)((long long)npairs * (xcd + 1) / nx);
+  const int n_my = q_lo + jx < q_hi ? (q_hi - q_lo - jx + GX - 1) / GX : 0;
+  const int n_items = n_my * p.nchunks;
+  const long long chunk_bytes = (long long)p.Hp * p.Wp * PXB;
+
+  // DMA slots of this lane relative to the patch origin.  LDS unit U (16 bytes, lane-linear) = halo pixel U / 6,
+  // sub-unit U % 6 = 2 * plane + half; it receives the source's half ^ f(halo column).  Kept in registers: a vector
+  // instruction of the loading team waits ~16 cycles for an issue slot beside the other team's MFMA stream.
+  uint32_t a_rel[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int u = (j * 4 + wave) * 64 + lane;
+    const int hy = u / UR, rem = u - hy * UR;
+    const int hx = rem / 6, sub = rem - hx * 6;
+    const int f = (hx >> 3) & 1;
+    a_rel[j] = (uint32_t)((hy * p.Wp + hx) * PXB + (sub >> 1) * 32 + (((sub & 1) ^ f) * 16));
+  }
+
+  struct Patch {
+    int b, x0, y0;
+    bool valid;
+  };
+  auto patch_of = [&](int k) {  // k-th pair of this workgroup -> this team's patch
+    const int pt = 2 * (q_lo + jx + k * GX) + team;
+    Patch t;
+    t.valid = pt < npatch;
+    const int pc = t.valid ? pt : npatch - 1;
+    t.x0 = (pc % p.tiles_x) * TW;
+    t.y0 = ((pc / p.tiles_x) % p.tiles_y) * TH;
+    t.b = pc / (p.tiles_x * p.tiles_y);
+    return t;
+  };
+
+  auto stage = [&](const Patch& pt, int c) {
+    {
+      const unsigned char* __restrict__ ab = p.pin + ((long long)pt.b * p.in_total + c) * chunk_bytes +
+                                             ((long long)(pt.y0 + (PB - DIL)) * p.Wp + pt.x0 + (PB - DIL)) * PXB;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int i = j * 4 + wave;
+        if (j < AJ - 1 || i * 64 + lane < A_UNITS) dma16(ab + a_rel[j], As + i * 1024);
+      }
+    }
+  };
+  // Weights of chunk c into slot: instructions [0, W_SPLIT) by team 0 together with the item's halo, the rest (and the
+  // fused 1x1 chunk) by team 1 one item ahead — 55 KB of DMA per team per phase instead of 69 + 41.
+  constexpr int W_SPLIT = 14;
+  auto stage_w = [&](int c, int slot) {
+    const unsigned char* __restrict__ wb = p.wt + (long long)c * W3_BYTES + lane * 16;
+    unsigned char* wd = Wsb + slot * W3_BYTES;
+    const int lo = team == 0 ? 0 : W_SPLIT, hi = team == 0 ? W_SPLIT : W_INSTR;
+#pragma unroll
+    for (int j = 0; j < (W_SPLIT + 3) / 4; ++j) {
+      const int i = lo + j * 4 + wave;
+      if (i < hi) dma16(wb + i * 1024, wd + i * 1024);
+    }
+    if (FUSE && team == 1) {
+      const unsigned char* __restrict__ w1b = p.w1 + (long long)c * W1_BYTES + lane * 16;
+      unsigned char* w1d = W1sb + slot * W1_BYTES;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = j * 4 + wave;
+        if (i < W1_INSTR) dma16(w1b + i * 1024, w1d + i * 1024);
+      }
+    }
+  };
+
+  if (tid < 98) {  // epilogue constants -> LDS (first read is after at least one workgroup barrier)
+    float v;
+    if (tid < 32) v = p.bias[tid];
+    else if (tid < 96) v = FUSE ? p.bias1[tid - 32] : 0.f;
+    else if (tid == 96) v = p.act == SEGMIF_ACT_RELU ? 0.f : (p.act == SEGMIF_ACT_PRELU ? *p.prelu : 1.f);
+    else v = p.act1 == SEGMIF_ACT_RELU ? 0.f : 1.f;
+    reinterpret_cast<float*>(Cst)[tid] = v;
+  }
+
+  f32x16 acc[2], acc1[FUSE ? 2 : 1][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (FUSE ? 2 : 1); ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc1[i][j][v] = 0.f;
+  };
+  zero_acc();
+
+  // The wave's two sub-tiles are patch rows R0 and R0 + DIL (tap ky of the second reads the halo row tap
+  // ky + 1 of the first reads): a chunk is 12 steps (kx, m), halo row R0 + m * DIL at column offset kx * DIL
+  // feeds sub-tile 0 with tap ky = m (m < 3) and sub-tile 1 with tap ky = m - 1 (m > 0).
+  const int R0 = (DIL == 2) ? ((wave >> 1) * 4 + (wave & 1)) : 2 * wave;
+  const unsigned char* a_lane[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int col = kx * DIL + r;
+    a_lane[kx] = As + (R0 * HW + col) * PXB + ((h ^ ((col >> 3) & 1)) * 16);
+  }
+  const int wsw = (h ^ (r >> 4)) * 16;
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first (activation plane)
+  constexpr int PW[6] = {0, 1, 2, 0, 1, 0};  // (weight plane)
+
+  auto compute = [&](int slot) {
+    const unsigned char* w_lane = Wsb + slot * W3_BYTES + r * PXB + wsw;
+    const unsigned char* w1_lane = W1sb + slot * W1_BYTES + r * PXB + wsw;
+    bf16x8 F[3][3], Wr[3][3];  // fragments are requested two steps ahead: one wave per SIMD has no partner to cover LDS latency
+    auto load_f = [&](int st) {
+      const int kx = st >> 2, m = st & 3;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        F[st % 3][pl] = *reinterpret_cast<const bf16x8*>(a_lane[kx] + (m * DIL * HW) * PXB + pl * 32);
+    };
+    auto load_w = [&](int st) {
+      const int kx = st >> 2, m = st & 3;
+      if (m < 3) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          Wr[m][pl] = *reinterpret_cast<const bf16x8*>(w_lane + ((m * 3 + kx) * 32) * PXB + pl * 32);
+      }
+    };
+    load_f(0);
+    load_w(0);
+    load_f(1);
+    load_w(1);
+#pragma unroll
+    for (int st = 0; st < 12; ++st) {
+      const int m = st & 3;
+      if (st + 2 < 12) {
+        load_f(st + 2);
+        load_w(st + 2);
+      }
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        if (m < 3) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[m][PW[t]], F[st % 3][PA[t]], acc[0], 0, 0, 0);
+        if (m > 0) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[m - 1][PW[t]], F[st % 3][PA[t]], acc[1], 0, 0, 0);
+      }
+      if (FUSE && (st == 5 || st == 6)) {  // centre tap of sub-tile st - 5: the 1x1 conv's input at this pixel
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          bf16x8 W1f[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) W1f[pl] = *reinterpret_cast<const bf16x8*>(w1_lane + (nt * 32) * PXB + pl * 32);
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+            acc1[st - 5][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1f[PW[t]], F[st % 3][PA[t]], acc1[st - 5][nt], 0, 0, 0);
+        }
+      }
+      // one scheduling region per step: every MFMA is followed by one of the next step's fragment reads
+#pragma unroll
+      for (int t = 0; t < (FUSE && (st == 5 || st == 6) ? 24 : 12); ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // accumulator register v of lane (r, h): output channel (v & 3) + 8 (v >> 2) + 4 h of pixel x0 + r
+  auto epilogue = [&](const Patch& pt, int item) {
+    int z = 0;  // opaque zero added to the weight pointer below: keeps loop-invariant loads of the epilogue from being
+    asm volatile("" : "+s"(z));  // hoisted out of the phase loop
+    // branch-free: act(t) = t >= 0 ? t : nslope * t with nslope = 0 (ReLU), the PReLU slope, or 1 (none).  Biases and
+    // slope were parked in LDS at kernel start: a global load here costs a loaded-memory-system round trip (2 000+
+    // cycles measured) in a phase the other team is waiting on, and per-element "pointer ? load : 0" code cost 5 000.
+    const float* cst = reinterpret_cast<const float*>(Cst);
+    const float nslope = cst[96];
+    float bv[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(cst + 8 * g + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[4 * g + e] = t[e];
+    }
+    const int ox = pt.x0 + r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oy = pt.y0 + R0 + i * DIL;
+      const bool ok = pt.valid && oy < p.H && ox < p.W;
+      float y[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const float t = acc[i][v] + bv[v];
+        y[v] = t >= 0.f ? t : nslope * t;
+      }
+#if PLANES_DBG & 32
+      if (i == 0 && wave == 0 && lane == 0 && blockIdx.x < 256 && item < PLANES_TL_ITEMS) {
+        asm volatile("" ::"v"(y[0]), "v"(y[15]));
+        planes_timeline[blockIdx.x][team][item][7] = __builtin_amdgcn_s_memtime();
+      }
+#endif
+      const long long m = ((long long)pt.b * p.H + oy) * p.W + ox;
+      if (p.out && ok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(p.out + m * p.ldo + 8 * g + 4 * h) = f32x4{y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]};
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        u32x4 pl[3];
+        split8(y + 8 * q, pl[0], pl[1], pl[2]);
+        if (PLANES_DBG & 64) asm volatile("" ::"v"(pl[0]), "v"(pl[1]), "v"(pl[2]));
+        if (p.pout && ok && !(PLANES_DBG & 64)) {
+          unsigned char* dst = p.pout + ((long long)pt.b * p.out_total + p.out_chunk0 + q) * chunk_bytes +
+                               ((long long)(oy + PB) * p.Wp + ox + PB) * PXB + h * 16;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(dst + k * 32) = pl[k];
+        }
+        if (FUSE) {  // 1x1 weights of the 16 channels just produced: chunk nchunks + q (re-read per sub-tile: L2 hits, keeps registers free)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            bf16x8 W1g[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              W1g[k] = *reinterpret_cast<const bf16x8*>(p.w1 + z + ((long long)(p.nchunks + q) * 64 + nt * 32 + r) * PXB + k * 32 + wsw);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+              acc1[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1g[PW[t]], __builtin_bit_cast(bf16x8, pl[PA[t]]), acc1[i][nt], 0, 0, 0);
+          }
+        }
+      }
+      if (FUSE && ok) {
+        const float nslope1 = cst[97];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n0 = nt * 32 + 8 * g + 4 * h;
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(cst + 32 + n0);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = acc1[i][nt][4 * g + e] + b1[e];
+              o[e] = t >= 0.f ? t : nslope1 * t;
+            }
+            if (p.res) {
+              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n0);
+              o += rv;
+            }
+            *reinterpret_cast<f32x4*>(p.out1 + m * p.ldo1 + n0) = o;
+          }
+        }
+      }
+    }
+  };
+
+  // ---- phase loop -----------------------------------------------------------------------------------
+  // Straight-line per item (LOAD, barrier, COMPUTE, barrier) with team 1 skewed by one barrier: no branch around the
+  // MFMA block and the accumulators are cleared by a select, so they stay in one set of registers (a conditional
+  // compute / clear made hipcc keep two copies and spill in the fused kernel).
+  if (n_items > 0) {
+    if (team == 1) {  // skewed by one phase; uses it to fetch its share of the first chunk's weights
+      stage_w(0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    Patch cur = patch_of(0);
+    int k = 0, c = 0;
+    for (int i = 0; i < n_items; ++i) {
+      // LOAD phase: this item's DMA and nothing else (a vector instruction issued here competes with the other team's
+      // MFMA stream for the SIMD's issue port and gets a slot every ~16 cycles: the epilogue took 5 500 cycles here)
+      TL(0);
+      stage(cur, c);
+      if (team == 0) stage_w(c, i & 1);
+      else if (i + 1 < n_items) stage_w(c + 1 == p.nchunks ? 0 : c + 1, (i + 1) & 1);
+      TL(2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TL(3);
+      __syncthreads();
+      TL(4);
+      // COMPUTE phase (an invalid tail patch multiplies the clamped patch's data; its stores are masked).  A patch's
+      // epilogue closes the phase of its last chunk: by then the other team's DMA burst has been issued and mostly
+      // landed, so the stores do not queue behind it in the CU's vector-memory path, and the SIMDs are otherwise idle.
+      if (PLANES_DBG & 128) __builtin_amdgcn_s_setprio(1);
+      compute(i & 1);
+      if (PLANES_DBG & 128) __builtin_amdgcn_s_setprio(0);
+      TL(1);
+      if (c + 1 == p.nchunks) {
+        epilogue(cur, i);
+        zero_acc();
+      }
+      TL(5);
+      __syncthreads();
+      TL(6);
+      if (++c == p.nchunks) {
+        c = 0;
+        if (++k < n_my) cur = patch_of(k);
+      }
+    }
+    if (team == 0) __syncthreads();
+  }
+}
+
+template <int DIL, bool FUSE>
+int launch(const PlanesConvK& k, hipStream_t stream) {
+  constexpr int A_UNITS = (TH + 2 * DIL) * (TW + 2 * DIL) * 6;
+  constexpr size_t smem = 2 * ((size_t)((A_UNITS + 63) / 64) * 1024 + W3_BYTES + (FUSE ? W1_BYTES : 0)) + 512;
+  auto fn = conv3x3_planes_kernel<DIL, FUSE>;
+  static bool raised = false;  // idempotent attribute; benign race
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SEGMIF_EINVAL;
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const long long npairs = ((long long)k.B * k.tiles_x * k.tiles_y + 1) / 2;
+  dim3 grid((unsigned)(npairs < ncu ? npairs : ncu));  // one persistent workgroup (two teams) per CU
+  hipLaunchKernelGGL(fn, grid, dim3(512), smem, stream, k);
+  return (int)hipGetLastError();
+}
+
+__device__ float planes_zero_bias[64];  // stands in for a NULL bias (static storage: zero-initialised)
+
+// ---- producers of the planes format ---------------------------------------------------------------
+
+// fp32 rows (pixel pitch ldx) -> planes chunks [chunk0, chunk0 + nconv).  One thread = (pixel, chunk, half).
+__global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, unsigned char* __restrict__ planes, int B,
+                                       int H, int W, int Hp, int Wp, int total, int chunk0, int nconv) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long npix = (long long)B * H * W;
+  if (idx >= npix * nconv * 2) return;
+  const int hf = (int)(idx & 1);
+  const int ch = (int)((idx >> 1) % nconv);
+  const long long pix = (idx >> 1) / nconv;
+  const int xx = (int)(pix % W);
+  const int yy = (int)((pix / W) % H);
+  const int b = (int)(pix / ((long long)W * H));
+  const float* src = x + pix * ldx + ch * 16 + 4 * hf;  // positions 8 hf + e <-> channels 4 hf + (e & 3) + 8 (e >> 2)
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 8);
+  const float y[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  u32x4 p0, p1, p2;
+  split8(y, p0, p1, p2);
+  unsigned char* dst = planes + (((long long)b * total + chunk0 + ch) * Hp + yy + PB) * (long long)Wp * PXB + (long long)(xx + PB) * PXB + hf * 16;
+  *reinterpret_cast<u32x4*>(dst) = p0;
+  *reinterpret_cast<u32x4*>(dst + 32) = p1;
+  *reinterpret_cast<u32x4*>(dst + 64) = p2;
+}
+
+// zero the border / round-up region of every chunk image: one block per padded row
+__global__ void planes_zero_border_kernel(unsigned char* __restrict__ planes, int H, int W, int Hp, int Wp) {
+  const int row = blockIdx.x;
+  u32x4* line = reinterpret_cast<u32x4*>(planes + ((long long)blockIdx.y * Hp + row) * (long long)Wp * PXB);
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  if (row < PB || row >= PB + H) {
+    for (int u = threadIdx.x; u < Wp * 6; u += blockDim.x) line[u] = z;
+  } else {
+    const int right = Wp - (PB + W);
+    for (int u = threadIdx.x; u < (PB + right) * 6; u += blockDim.x) line[u < PB * 6 ? u : (PB + W) * 6 + (u - PB * 6)] = z;
+  }
+}
+
+// fp32 [N][ldw] (k = tap * Cin + c, taps = 9 | 1) -> [chunk][tap][n][96 B]: plane-major, half-swapped rows
+__global__ void planes_pack_weight_kernel(const float* __restrict__ w, int N, int Cin, int taps, int ldw, long long total,
+                                          uint16_t* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx & 15);
+  long long t = idx >> 4;
+  const int n = (int)(t % N); t /= N;
+  const int tap = (int)(t % taps);
+  const int chunk = (int)(t / taps);
+  const float x = w[(long long)n * ldw + tap * Cin + chunk * 16 + sigma16(j)];
+  uint32_t p0, p1, p2;
+  split3(x, 0.f, p0, p1, p2);
+  const int f = (n >> 4) & 1;
+  const long long row = ((long long)chunk * taps + tap) * N + n;
+  uint16_t* dst = out + row * 48 + (((j >> 3) ^ f) * 8) + (j & 7);
+  dst[0] = (uint16_t)(p0 & 0xffffu);
+  dst[16] = (uint16_t)(p1 & 0xffffu);
+  dst[32] = (uint16_t)(p2 & 0xffffu);
+}
+
+}  // namespace
+}  // namespace segmif
+
+using namespace segmif;
+
+#if PLANES_DBG & 32
+extern "C" int segmif_debug_planes_timeline(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(planes_timeline), bytes < sizeof(planes_timeline) ? bytes : sizeof(planes_timeline));
+}
+#endif
+
+extern "C" int segmif_planes_dims(int H, int W, int* Hp, int* Wp) {
+  if (H <= 0 || W <= 0 || !Hp || !Wp) return SEGMIF_EINVAL;
+  *Hp = planes_hp(H);
+  *Wp = planes_wp(W);
+  return 0;
+}
+
+extern "C" int64_t segmif_planes_bytes(int B, int H, int W, int chunks) {
+  if (B <= 0 || H <= 0 || W <= 0 || chunks <= 0) return 0;
+  return (int64_t)B * chunks * planes_hp(H) * planes_wp(W) * PXB;
+}
+
+extern "C" int segmif_planes_zero_border(void* planes, int B, int H, int W, int chunks, void* stream) {
+  if (!planes || B <= 0 || H <= 0 || W <= 0 || chunks <= 0) return SEGMIF_EINVAL;
+  const int Hp = planes_hp(H), Wp = planes_wp(W);
+  hipLaunchKernelGGL(planes_zero_border_kernel, dim3((unsigned)Hp, (unsigned)(B * chunks)), dim3(256), 0, (hipStream_t)stream,
+                     (unsigned char*)planes, H, W, Hp, Wp);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_planes_from_f32(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0,
+                                      int nconv, void* stream) {
+  if (!x || !planes || B <= 0 || H <= 0 || W <= 0 || nconv <= 0 || chunk0 < 0 || chunk0 + nconv > chunks || ldx % 4 ||
+      ((uintptr_t)x & 15) || ldx < 16 * nconv)
+    return SEGMIF_EINVAL;
+  const long long n = (long long)B * H * W * nconv * 2;
+  hipLaunchKernelGGL(planes_from_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     (unsigned char*)planes, B, H, W, planes_hp(H), planes_wp(W), chunks, chunk0, nconv);
+  return (int)hipGetLastError();
+}
+
+extern "C" int64_t segmif_planes_weight_bytes(int N, int Cin, int taps) {
+  if (N <= 0 || N % 32 || Cin <= 0 || Cin % 16 || (taps != 9 && taps != 1)) return 0;
+  return (int64_t)N * Cin * taps * 6;
+}
+
+extern "C" int segmif_planes_pack_weight(const float* packed, int N, int Cin, int taps, int ldw, void* out, void* stream) {
+  if (!packed || !out || segmif_planes_weight_bytes(N, Cin, taps) == 0 || ldw < taps * Cin) return SEGMIF_EINVAL;
+  const long long total = (long long)N * Cin * taps;
+  hipLaunchKernelGGL(planes_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     packed, N, Cin, taps, ldw, total, (uint16_t*)out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_conv3x3_planes_bf16x6(const SegmifConvPlanes* d, void* stream) {
+  if (!d || !d->planes_in || !d->wt || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cin <= 0 || d->cin % 16) return SEGMIF_EINVAL;
+  if (d->dil != 1 && d->dil != 2) return SEGMIF_EINVAL;
+  if (d->act != SEGMIF_ACT_NONE && d->act != SEGMIF_ACT_RELU && d->act != SEGMIF_ACT_PRELU) return SEGMIF_EINVAL;
+  if (d->act == SEGMIF_ACT_PRELU && !d->prelu) return SEGMIF_EINVAL;
+  const bool fuse = d->w1 != nullptr;
+  if (!fuse && !d->out && !d->planes_out) return SEGMIF_EINVAL;
+  if (d->out && (d->ldo % 4 || ((uintptr_t)d->out & 15))) return SEGMIF_EINVAL;
+  if (d->bias && ((uintptr_t)d->bias & 15)) return SEGMIF_EINVAL;
+  PlanesConvK k;
+  k.pin = (const unsigned char*)d->planes_in;
+  k.pout = (unsigned char*)d->planes_out;
+  k.wt = (const unsigned char*)d->wt;
+  static const float* zero_bias = nullptr;  // benign race: every thread resolves the same symbol
+  if (!zero_bias && hipGetSymbolAddress((void**)&zero_bias, HIP_SYMBOL(planes_zero_bias)) != hipSuccess) return SEGMIF_EINVAL;
+  k.bias = d->bias ? d->bias : zero_bias;
+  k.prelu = d->prelu;
+  k.out = d->out;
+  k.ldo = d->ldo;
+  k.B = d->B; k.H = d->H; k.W = d->W;
+  k.Hp = planes_hp(d->H); k.Wp = planes_wp(d->W);
+  k.nchunks = d->cin / 16;
+  k.in_total = d->in_chunks;
+  k.out_total = d->out_chunks;
+  k.out_chunk0 = d->out_chunk0;
+  k.act = d->act;
+  if (k.nchunks > k.in_total) return SEGMIF_EINVAL;
+  if (k.pout && (k.out_chunk0 < 0 || k.out_chunk0 + 2 > k.out_total)) return SEGMIF_EINVAL;
+  if (k.pout && k.pout == k.pin && k.out_chunk0 < k.nchunks) return SEGMIF_EINVAL;  // would overwrite its own input
+  if ((long long)k.Hp * k.Wp * PXB >= (1ll << 32)) return SEGMIF_EINVAL;
+  k.w1 = (const unsigned char*)d->w1;
+  k.bias1 = d->bias1 ? d->bias1 : zero_bias;
+  k.res = d->res;
+  k.out1 = d->out1;
+  k.ldr = d->ldr; k.ldo1 = d->ldo1; k.act1 = d->act1;
+  if (fuse) {
+    if (!d->out1 || d->ldo1 % 4 || ((uintptr_t)d->out1 & 15) || (d->res && (d->ldr % 4 || ((uintptr_t)d->res & 15))) ||
+        (d->bias1 && ((uintptr_t)d->bias1 & 15)) || (d->act1 != SEGMIF_ACT_NONE && d->act1 != SEGMIF_ACT_RELU))
+      return SEGMIF_EINVAL;
+  }
+  k.tiles_x = (d->W + TW - 1) / TW;
+  k.tiles_y = (d->H + TH - 1) / TH;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dil == 2) return fuse ? launch<2, true>(k, s) : launch<2, false>(k, s);
+  return fuse ? launch<1, true>(k, s) : launch<1, false>(k, s);
+}

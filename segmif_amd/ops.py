@@ -70,8 +70,8 @@ class SplitWeight:
         self.data, self.N, self.cin = data, N, cin
 
 
-_CONV3X3_MODES = ("bf16x6", "fp32")
-_conv3x3_mode = os.environ.get("SEGMIF_CONV3X3", "bf16x6")
+_CONV3X3_MODES = ("planes", "bf16x6", "fp32")
+_conv3x3_mode = os.environ.get("SEGMIF_CONV3X3", "planes")
 if _conv3x3_mode not in _CONV3X3_MODES:
     raise RuntimeError(f"SEGMIF_CONV3X3 must be one of {_CONV3X3_MODES}, got {_conv3x3_mode!r}")
 
@@ -82,7 +82,9 @@ def conv3x3_mode():
 
 def set_conv3x3_mode(mode):
     """'bf16x6': 3x3 stride-1 convs with Cin % 16 == 0 run on the bf16 matrix pipe with 3-way split
-    operands (fp32-class accuracy, 2.7x the fp32 MFMA rate); 'fp32': exact-fp32 MFMA everywhere."""
+    operands (fp32-class accuracy, 2.7x the fp32 MFMA rate); 'planes' (default): the same, and a DRDB in
+    inference keeps its activations pre-split in a planes buffer (csrc/conv3x3_planes.hip); 'fp32':
+    exact-fp32 MFMA everywhere."""
     global _conv3x3_mode
     if mode not in _CONV3X3_MODES:
         raise ValueError(f"mode must be one of {_CONV3X3_MODES}")
@@ -107,10 +109,102 @@ def pack_weight_split(w):
 def pack_conv3x3(w):
     """Packing for a stride-1 'same' 3x3 conv (dilation 1 or 2): the split image when the mode and the
     shape allow it, the fp32 packing otherwise.  Cache entries must be keyed on conv3x3_mode()."""
-    if _conv3x3_mode == "bf16x6" and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and w.shape[1] % 16 == 0 \
+    if _conv3x3_mode in ("bf16x6", "planes") and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and w.shape[1] % 16 == 0 \
             and 16 <= w.shape[0] <= 256:
         return pack_weight_split(w)
     return pack_weight(w)
+
+
+class Planes:
+    """A planes buffer (include/segmif_hip.h, segmif_planes_*): `chunks` 16-channel chunk images per batch
+    element, each activation stored as three bf16 planes, zero border already cleared."""
+    __slots__ = ("data", "B", "H", "W", "chunks")
+
+    def __init__(self, B, H, W, chunks, device):
+        lib = _lib.load()
+        self.B, self.H, self.W, self.chunks = B, H, W, chunks
+        self.data = torch.empty((lib.segmif_planes_bytes(B, H, W, chunks),), device=device, dtype=torch.uint8)
+        _lib.check(lib.segmif_planes_zero_border(self.data.data_ptr(), B, H, W, chunks, _stream()),
+                   "segmif_planes_zero_border")
+
+    def load_f32(self, x, chunk0=0):
+        """x: (B, H, W, C) rows view, C % 16 == 0 -> chunks [chunk0, chunk0 + C/16)."""
+        _, C, ldx = rows_view(x, "x")
+        if tuple(x.shape[:3]) != (self.B, self.H, self.W) or C % 16:
+            raise RuntimeError(f"planes: x shape {tuple(x.shape)} does not fit ({self.B}, {self.H}, {self.W}, 16k)")
+        _lib.check(_lib.load().segmif_planes_from_f32(x.data_ptr(), ldx, self.data.data_ptr(), self.B, self.H, self.W,
+                                                      self.chunks, chunk0, C // 16, _stream()), "segmif_planes_from_f32")
+        return self
+
+
+class PlanesWeight:
+    """segmif_planes_pack_weight image of a 3x3 (taps = 9, N = 32) or 1x1 (taps = 1, N = 64) weight."""
+    __slots__ = ("data", "N", "cin", "taps")
+
+    def __init__(self, data, N, cin, taps):
+        self.data, self.N, self.cin, self.taps = data, N, cin, taps
+
+
+def pack_weight_planes(w):
+    """OIHW 3x3 / 1x1 conv weight (or a Linear weight) -> PlanesWeight."""
+    N, cin = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
+    packed = pack_weight(w)
+    lib = _lib.load()
+    nbytes = lib.segmif_planes_weight_bytes(N, cin, taps)
+    if nbytes <= 0:
+        raise RuntimeError(f"planes packing needs N % 32 == 0, Cin % 16 == 0, 3x3 or 1x1; got {tuple(w.shape)}")
+    out = torch.empty((nbytes,), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.segmif_planes_pack_weight(packed.data_ptr(), N, cin, taps, packed.shape[1], out.data_ptr(), _stream()),
+               "segmif_planes_pack_weight")
+    return PlanesWeight(out, N, cin, taps)
+
+
+def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None, out_chunk0=None, out=None, tail=None,
+                   tag=None):
+    """3x3 'same' conv (dilation 1 | 2, 32 outputs) over the first `cin` channels of a Planes buffer.
+    out_chunk0: write the result as chunks [out_chunk0, out_chunk0 + 2) of the same buffer; out: optional fp32
+    (B, H, W, 32) rows view; tail = (w1 PlanesWeight(64, cin + 32, 1), bias1, res, out1, act1): the fused 1x1 conv
+    out1 = res + act1(W1 . [input | result] + bias1)."""
+    if not isinstance(wt, PlanesWeight) or (wt.N, wt.cin, wt.taps) != (32, cin, 9):
+        raise RuntimeError("conv3x3_planes: weight image does not fit")
+    d = _lib.SegmifConvPlanes()
+    d.planes_in, d.wt = planes.data.data_ptr(), wt.data.data_ptr()
+    d.B, d.H, d.W, d.cin, d.dil = planes.B, planes.H, planes.W, cin, dil
+    d.in_chunks = d.out_chunks = planes.chunks
+    d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
+    d.prelu = _req(prelu, "prelu").data_ptr() if prelu is not None else None
+    d.act = act
+    if out_chunk0 is not None:
+        d.planes_out, d.out_chunk0 = planes.data.data_ptr(), out_chunk0
+    if out is not None:
+        rows, oc, ldo = rows_view(out, "out")
+        if tuple(out.shape) != (planes.B, planes.H, planes.W, 32):
+            raise RuntimeError("conv3x3_planes: out shape mismatch")
+        d.out, d.ldo = out.data_ptr(), ldo
+    if tail is not None:
+        w1, bias1, res, out1, act1 = tail
+        if not isinstance(w1, PlanesWeight) or (w1.N, w1.cin, w1.taps) != (64, cin + 32, 1):
+            raise RuntimeError("conv3x3_planes: tail weight image does not fit")
+        _, c1, ldo1 = rows_view(out1, "out1")
+        if tuple(out1.shape) != (planes.B, planes.H, planes.W, 64):
+            raise RuntimeError("conv3x3_planes: out1 shape mismatch")
+        d.w1, d.out1, d.ldo1, d.act1 = w1.data.data_ptr(), out1.data_ptr(), ldo1, act1
+        d.bias1 = _req(bias1, "bias1").data_ptr() if bias1 is not None else None
+        if res is not None:
+            _, rc, ldr = rows_view(res, "res")
+            if tuple(res.shape) != (planes.B, planes.H, planes.W, 64):
+                raise RuntimeError("conv3x3_planes: res shape mismatch")
+            d.res, d.ldr = res.data_ptr(), ldr
+    lib = _lib.load()
+
+    def go():
+        _lib.check(lib.segmif_conv3x3_planes_bf16x6(ctypes.byref(d), _stream()), "segmif_conv3x3_planes_bf16x6")
+
+    if _timer is not None and tag is not None and tag == _timer.tag:
+        _timer.bracket(go, 2.0 * planes.B * planes.H * planes.W * 32 * 9 * cin)
+    else:
+        go()
 
 
 class LaunchTimer:

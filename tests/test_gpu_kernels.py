@@ -191,6 +191,108 @@ def test_conv3x3_split_rejects_bad_geometry(ops):
         ops.pack_weight_split(rnd(32, 24, 3, 3, seed=5).cuda())  # Cin % 16
 
 
+def _sigma16():
+    return torch.tensor([(j & 3) + 4 * (j >> 3) + 8 * ((j >> 2) & 1) for j in range(16)])
+
+
+def _planes_decode(pl, chunk0, nch):
+    """Planes buffer -> (B, H, W, 16 * nch) float64 plus the raw padded array (B, chunks, Hp, Wp, 3, 16)."""
+    lib_hp = (pl.H + 7) // 8 * 8 + 4
+    lib_wp = (pl.W + 31) // 32 * 32 + 4
+    raw = pl.data.view(torch.bfloat16).view(pl.B, pl.chunks, lib_hp, lib_wp, 3, 16).double().cpu()
+    val = raw.sum(dim=4)[:, chunk0:chunk0 + nch, 2:2 + pl.H, 2:2 + pl.W]  # (B, nch, H, W, 16 positions)
+    out = torch.empty(pl.B, pl.H, pl.W, nch, 16, dtype=torch.float64)
+    out[..., _sigma16()] = val.permute(0, 2, 3, 1, 4)  # position j holds channel sigma(j)
+    return out.reshape(pl.B, pl.H, pl.W, nch * 16), raw
+
+
+def test_planes_roundtrip_and_border(ops):
+    """segmif_planes_from_f32: x = p0 + p1 + p2 to fp32 rounding for magnitudes 1e-6 .. 1e3, channel order
+    sigma, zero border / round-up region untouched."""
+    B, H, W, C = 2, 13, 45, 64
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand(B, H, W, 224, generator=g) * 2 - 1) * 10.0 ** (torch.rand(B, H, W, 224, generator=g) * 9 - 6)
+    pl = ops.Planes(B, H, W, 6, "cuda")
+    pl.data.fill_(0x7f)  # poison, then clear the border the way the constructor does
+    from segmif_amd import _lib
+    _lib.check(_lib.load().segmif_planes_zero_border(pl.data.data_ptr(), B, H, W, 6, None), "zero_border")
+    pl.load_f32(x.cuda()[..., :C], chunk0=1)
+    torch.cuda.synchronize()
+    got, raw = _planes_decode(pl, 1, C // 16)
+    ref = x[..., :C].double()
+    assert float(((got - ref).abs() / ref.abs()).max()) < 2.0 ** -23
+    mask = torch.ones_like(raw, dtype=torch.bool)
+    mask[:, :, 2:2 + H, 2:2 + W] = False
+    assert float(raw[mask].abs().max()) == 0.0
+
+
+PLANES_CASES = [  # B, H, W, Cin, dil
+    (2, 20, 28, 64, 2), (1, 17, 45, 192, 2), (2, 8, 32, 96, 2), (1, 33, 70, 64, 1), (1, 9, 31, 128, 1),
+]
+
+
+@pytest.mark.parametrize("case", PLANES_CASES)
+def test_conv3x3_planes_bf16x6(ops, case):
+    """csrc/conv3x3_planes.hip against the fp64 conv and the exact-fp32 MFMA kernel (tile 10): fp32-class accuracy
+    from pre-split operands, result delivered both as fp32 rows and as two more planes chunks."""
+    B, H, W, Cin, d = case
+    x, w, b = rnd(B, Cin, H, W, seed=13), rnd(32, Cin, 3, 3, seed=14), rnd(32, seed=15)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=d, dilation=d)).permute(0, 2, 3, 1)
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y32 = ops.conv2d(xh, ops.pack_weight(w.cuda()), 32, 3, pad=d, dil=d, bias=b.cuda(), act=1, tile=10)
+    chunks = Cin // 16 + 2
+    pl = ops.Planes(B, H, W, chunks, "cuda").load_f32(xh)
+    out = torch.full((B, H, W, 40), 7.0, device="cuda")
+    ops.conv3x3_planes(pl, Cin, ops.pack_weight_planes(w.cuda()), dil=d, bias=b.cuda(), act=1, out_chunk0=Cin // 16,
+                       out=out[..., :32])
+    e, e32 = err(out[..., :32], ref), err(y32, ref)
+    assert e < TOL and e <= 2.0 * e32 + 1e-7, (e, e32)
+    assert float((out[..., 32:] - 7).abs().max()) == 0
+    got, raw = _planes_decode(pl, Cin // 16, 2)
+    assert float((got - ref).abs().max() / ref.abs().max()) < TOL
+    mask = torch.ones_like(raw, dtype=torch.bool)
+    mask[:, :, 2:2 + H, 2:2 + W] = False
+    assert float(raw[mask].abs().max()) == 0.0  # nothing written outside the H x W interior
+
+
+def test_conv3x3_planes_fused_tail_is_a_drdb(ops):
+    """The fused tail: x + relu(W1 . [in | relu(conv(in))] + b1) — Dcov5 + cat + 1x1 + ReLU + residual of
+    core/model_fusion.py:153-157 in one launch — with wide-range operands, elementwise against its conditioning."""
+    B, H, W, Cin = 2, 19, 37, 192
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(B, H, W, Cin, generator=g) * 2 - 1) * 10.0 ** (torch.rand(B, H, W, Cin, generator=g) * 6 - 4)
+    w, b = rnd(32, Cin, 3, 3, seed=31) * 0.05, rnd(32, seed=32)
+    w1, b1 = rnd(64, Cin + 32, seed=33) * 0.1, rnd(64, seed=34)
+    xd = x.double().permute(0, 3, 1, 2)
+    mid = F.relu(F.conv2d(xd, w.double(), b.double(), padding=2, dilation=2))
+    cat = torch.cat((xd, mid), dim=1)
+    pre = F.conv2d(cat, w1.double()[:, :, None, None], b1.double())
+    ref = (xd[:, :64] + F.relu(pre)).permute(0, 2, 3, 1)
+    xc = x.cuda()
+    pl = ops.Planes(B, H, W, Cin // 16, "cuda").load_f32(xc)
+    out = torch.empty(B, H, W, 64, device="cuda")
+    ops.conv3x3_planes(pl, Cin, ops.pack_weight_planes(w.cuda()), dil=2, bias=b.cuda(), act=1,
+                       tail=(ops.pack_weight_planes(w1.cuda()), b1.cuda(), xc[..., :64], out, 1))
+    assert err(out, ref) < TOL
+    cond = F.conv2d(torch.cat((xd.abs(), mid.abs()), dim=1), w1.double().abs()[:, :, None, None]).permute(0, 2, 3, 1) \
+        + x[..., :64].double().abs()
+    rel = ((out.double().cpu() - ref).abs() / (cond + 1e-30)).max()
+    assert float(rel) < 2e-6, float(rel)
+
+
+def test_conv3x3_planes_rejects_bad_arguments(ops):
+    pl = ops.Planes(1, 8, 32, 6, "cuda")
+    w = ops.pack_weight_planes(rnd(32, 64, 3, 3, seed=4).cuda())
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_planes(pl, 64, w, dil=3, out_chunk0=4)  # dilation 1 | 2 only
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_planes(pl, 64, w, dil=2, out_chunk0=3)  # would overwrite its own input chunks
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_planes(pl, 64, w, dil=2, out_chunk0=5)  # two output chunks do not fit
+    with pytest.raises(RuntimeError):
+        ops.pack_weight_planes(rnd(48, 64, 3, 3, seed=5).cuda())  # N % 32
+
+
 def test_drdb_concat_in_place(ops):
     """A conv reading the first Cin channels of a 224-wide buffer and writing its 32 channels in place."""
     B, H, W = 2, 14, 18

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Phase timeline of csrc/conv3x3_planes.hip built with -DPLANES_DBG=32 (tools/planes_ablate.sh): s_memtime stamps of wave 0
+of each team of every workgroup, per item:  0 LOAD start | 2 DMA issued | 3 own DMA landed | 4 past barrier 1 | 1 epilogue done |
+5 MFMA steps done | 6 past barrier 2.   Prints mean / p10 / p90 segment lengths per team.
+
+    SEGMIF_HIP_LIB=segmif_amd/lib/variants/lib_dbg32.so python tools/planes_timeline.py [Cin]
+"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+import numpy as np
+import torch
+
+from segmif_amd import ops
+
+cin = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+B, H, W = 8, 480, 640
+x = torch.randn(B, H, W, 192, device="cuda")
+pl = ops.Planes(B, H, W, 14, "cuda").load_f32(x)
+wpl = ops.pack_weight_planes(torch.randn(32, cin, 3, 3, device="cuda") * 0.05)
+for _ in range(3):
+    ops.conv3x3_planes(pl, cin, wpl, dil=2, act=1, out_chunk0=12)
+torch.cuda.synchronize()
+lib = ctypes.CDLL(os.environ["SEGMIF_HIP_LIB"])
+NI = 64
+buf = np.zeros((256, 2, NI, 8), dtype=np.uint64)
+rc = lib.segmif_debug_planes_timeline(ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(buf.nbytes))
+assert rc == 0, rc
+t = buf[:, :, 8:56, :7].astype(np.int64)  # steady-state items
+t7 = buf[:, :, 8:56, 7].astype(np.int64)
+fresh = (np.arange(8, 56) % (cin // 16)) == cin // 16 - 1
+d = (t7 - t[..., 4])[:, :, fresh]  # t is re-ordered: index 4 = stamp 1 (MFMA steps done)
+print(f"epilogue items only: start -> first sub-tile's activations computed: mean {d.mean():.0f}, whole epilogue {(t[..., 5] - t[..., 4])[:, :, fresh].mean():.0f}")
+names = ["DMA issue (0-2)", "own DMA wait (2-3)", "barrier 1 wait (3-4)", "MFMA steps (4-1)", "epilogue (1-5)",
+         "barrier 2 wait (5-6)"]
+t = t[..., [0, 2, 3, 4, 1, 5, 6]]
+seg = np.diff(t, axis=3)
+print(f"Cin={cin}: per-item segment ticks (wave 0 of a team; mean / p10 / p90 over 256 workgroups x items 8..55)")
+for team in (0, 1):
+    print(f" team {team}")
+    for i, n in enumerate(names):
+        v = seg[:, team, :, i].ravel()
+        print(f"  {n:26s} {v.mean():8.0f} {np.percentile(v, 10):8.0f} {np.percentile(v, 90):8.0f}")
+    per = (t[:, team, 1:, 0] - t[:, team, :-1, 0]).ravel()
+    print(f"  {'item period (2 phases)':26s} {per.mean():8.0f} {np.percentile(per, 10):8.0f} {np.percentile(per, 90):8.0f}   (MFMA alone: 2 x 108 x 32 = 6912)")
