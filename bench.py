@@ -8,7 +8,8 @@ One "step" = one pass of the hot path over one batch of synthetic pairs already 
   logits    = seg(fused) -> bilinear x4 -> argmax              (Network3 = MiT encoder + SegFormer head)
 exactly the in-memory chain of test_fusion.py:100-111 + test_segmentation.py:169-174.
 
-Launch: `python bench.py --gpus 1` or, for N > 1,
+Launch: `python bench.py --gpus N` (for N > 1 without a launcher it re-executes itself under
+torch.distributed.run on 127.0.0.1) or, explicitly,
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 One process per GPU; the path shards over independent pairs, so there is no data-path collective
@@ -17,6 +18,8 @@ One process per GPU; the path shards over independent pairs, so there is no data
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +32,19 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 # algorithmic work, GFLOP per pair forward at 480x640 (torch FlopCounterMode, 2*MAC)
 GFLOP_PER_PAIR = {("mit_b1", 480, 640): 700.2, ("mit_b3", 480, 640): 827.1,
                   ("mit_b5", 1024, 1024): 2 * 798.47 + 38.8 + 2178.0}  # b5: BASELINE.md table, head / fusion scaled by pixels
+
+
+def gflop_removed_by_n4(H, W):
+    """FLOPs of the textbook order that the measured pipeline does not execute (exact in real
+    arithmetic): conv3 / conv4 run at H/4 x W/4 and H/8 x W/8 instead of H x W, and the head's 1024 -> 256 fuse conv is
+    composed with the four per-scale Linears (once per weight version) instead of running on the concatenation."""
+    px = H * W
+    conv3 = 2.0 * px * 64 * 64 * (1 - 1 / 16)
+    conv4 = 2.0 * px * 128 * 64 * (1 - 1 / 64)
+    fuse = 2.0 * (px / 16) * 1024 * 256
+    return (conv3 + conv4 + fuse) / 1e9
+
+
 CPU_BASELINE_THREADS = 16  # fastest of {16,32,64,128,256} on the GPU box host (profiles/r01_cpu_threads.txt)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
 # bf16x6 (csrc/conv3x3_split.hip): six bf16 MFMA products per fp32-equivalent multiply-add, so the
@@ -52,42 +68,74 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(backbone, H, W):
-    """The oracle (CPU port of the reference path) timed on this host's cores on a bounded sample."""
+    """The oracle (CPU port of the reference path) timed on this host's cores on a bounded sample: one warm-up pair,
+    then the best of three timed pairs (batch 1: SURVEY §8(d) — larger batches are slower per pair on CPU)."""
     import detweights as dw
     import segmif_oracle as so
-    # one thread per physical core up to 32: beyond that torch-CPU/oneDNN goes backwards on this
-    # path (256 threads on the GPU box's host: 284 s per pair, measured in round 1)
-    torch.set_num_threads(max(1, min(CPU_BASELINE_THREADS, os.cpu_count() or 1)))
+    # one thread per core up to 16: beyond that torch-CPU / oneDNN goes backwards on this path (measured in round 1
+    # on the GPU box's host: 16 threads fastest of {16..256}; 256 threads: 284 s per pair)
+    host_cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(CPU_BASELINE_THREADS, host_cores)))
     sd_seg = dw.det_state_dict(so.network3_shapes(backbone, 9), seed=0)
     sd_fus = dw.det_state_dict(so.fusion_shapes(), seed=0)
     ir = dw.det_input("cpu_ir", (1, 1, H, W))
     vis = dw.det_input("cpu_vis", (1, 3, H, W))
     mask = dw.det_input("cpu_mask", (1, 1, H, W)).repeat(1, 3, 1, 1)
-    n = 0
-    t0 = time.perf_counter()
+    times = []
+    t_all = time.perf_counter()
     with torch.no_grad():
-        while True:
+        so.pair_forward(sd_seg, sd_fus, ir, vis, mask, backbone)  # warm-up (allocator, oneDNN primitive cache)
+        for _ in range(3):
+            t0 = time.perf_counter()
             so.pair_forward(sd_seg, sd_fus, ir, vis, mask, backbone)
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt > 10.0 or n >= 3:
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > 40.0:
                 break
-    return {"value": n / dt, "unit": "img-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} pair(s) of {backbone} {H}x{W} at batch 1 through oracle/segmif_oracle.py "
-                      f"(torch-CPU fp32), {dt:.1f} s, no warm-up"}
+    best = min(times)
+    return {"value": 1.0 / best, "unit": "img-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cores": host_cores, "cpu_model": cpu_model_name(),
+            "sample": f"{backbone} {H}x{W} pairs at batch 1 through oracle/segmif_oracle.py (torch-CPU fp32): 1 warm-up "
+                      f"pair, best of {len(times)} timed pairs ({', '.join(f'{t:.2f}' for t in times)} s)"}
+
+
+def self_launch(args, script=None, argv=None):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU
+    (script / argv: what to run, for the CPU test of this entry; default: this file with the same arguments)."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)]
+    cmd += sys.argv[1:] if argv is None else list(argv)
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
     from segmif_amd import dist
     rank, local_rank, world = dist.env_world()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist.init()  # RCCL process group when WORLD_SIZE > 1; replicas only, no data-path collective
+    torch.manual_seed(1234 + rank)  # per-rank RNG stream (nothing on the eval path draws from it; train-mode masks would)
 
     import detweights as dw
     from segmif_amd import ops
@@ -141,6 +189,7 @@ def main():
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if ops.conv3x3_mode() == "fp32" else "f32 (3x3 convs: fp32-equivalent 3-way bf16 split, 6 MFMA products)",
+            "conv3x3_mode": ops.conv3x3_mode(),
             "data": "synthetic",
             "config": {"workload": f"{args.backbone} pair forward (forward_fusion + Fusion_Network3_ac + Network3 "
                                    f"+ x4 bilinear + argmax), {H}x{W}, {B} pairs per GPU per step, eval mode, "
@@ -152,27 +201,36 @@ def main():
         }
         gf = GFLOP_PER_PAIR.get((args.backbone, H, W))
         if gf is not None:
-            out["whole_path_tflops"] = value * gf / 1000.0 / world
+            # per GPU: executed FLOPs (N4 removes part of the textbook count) and, beside it, the textbook figure
+            out["whole_path_tflops"] = value * (gf - gflop_removed_by_n4(H, W)) / 1000.0 / world
+            out["whole_path_tflops_textbook_order"] = value * gf / 1000.0 / world
+            out["gflop_per_pair"] = {"executed": gf - gflop_removed_by_n4(H, W), "textbook_order": gf}
         if timer is not None:
             n, ms, flops = timer.summary()
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_src = None, None
-            split = ops.conv3x3_mode() == "bf16x6"
-            peak = PEAK_BF16X6_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
-            pmc = os.path.join(ROOT, "profiles", (f"r01_pmc_dominant_b{B}_bf16x6.json" if split else
-                                                  "r01_pmc_dominant.json" if B == 8 else f"r01_pmc_dominant_b{B}.json"))
+            mode = ops.conv3x3_mode()
+            peak = PEAK_FP32_MFMA_TFLOPS if mode == "fp32" else PEAK_BF16X6_TFLOPS
+            pmc_name = {"planes": f"r02_pmc_dominant_b{B}_planes.json", "bf16x6": f"r01_pmc_dominant_b{B}_bf16x6.json",
+                        "fp32": "r01_pmc_dominant.json" if B == 8 else f"r01_pmc_dominant_b{B}.json"}[mode]
+            pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and (H, W) == (480, 640):
                 # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
                 rec = json.load(open(pmc))
                 traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(pmc)
+            kernel = {"planes": "conv3x3_planes_kernel<2,false> (DRDB dilated 3x3 convs 1-4 on pre-split activations, bf16 MFMA x 6 "
+                                "split products, fp32-class; the fifth conv carries the DRDB's 1x1 tail and is a separate kernel)",
+                      "bf16x6": "conv3x3_split_kernel<32,2,8> (DRDB dilated 3x3 conv, bf16 MFMA x 6 split products, fp32-class)",
+                      "fp32": "conv3x3_halo_kernel<32,8,2> (DRDB dilated 3x3 conv, fp32 MFMA)"}[mode]
+            # algorithmic bytes per pixel of an average timed launch: planes mode reads Cin x 6 B (three bf16 planes) and
+            # writes 32 x 6 B, Cin averaging 112 over Dcov1-4; the fp32 layouts read Cin x 4 B (average 128) + write 128 B
+            alg_bytes = (112 * 6 + 32 * 6 if mode == "planes" else 128 * 4 + 32 * 4) * float(B) * H * W
             out["roofline"] = {
-                "kernel": ("conv3x3_split_kernel<32,2,8> (DRDB dilated 3x3 conv, bf16 MFMA x 6 split products, fp32-class)"
-                           if split else "conv3x3_halo_kernel<32,8,2> (DRDB dilated 3x3 conv, fp32 MFMA)"),
-                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "peak_basis": ("dense BF16 MFMA 2500 TFLOP/s / 6 products per fp32-equivalent MAC; achieved counts "
-                               "algorithmic fp32 flops" if split else "dense fp32 MFMA"),
+                "kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "peak_basis": ("dense fp32 MFMA" if mode == "fp32" else "dense BF16 MFMA 2500 TFLOP/s / 6 products per "
+                               "fp32-equivalent MAC; achieved counts algorithmic fp32 flops"),
                 "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": (1200.0 + 300.0) * 2 ** 20 * B / 8,
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                 "launches_timed": n, "avg_launch_ms": ms, "avg_launch_gflop": flops / 1e9,
             }
         if world == 1 and not args.no_cpu_baseline:

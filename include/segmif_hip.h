@@ -342,10 +342,12 @@ int segmif_gauss_blur11_f32(const float* x, float* y, int planes, int H, int W, 
 
 /* multi-tensor AdamW (utils/optimizer.py:6 -> torch.optim.AdamW arithmetic). table: device array of
  * {float* p; const float* g; float* m; float* v; int64 n; float lr; float wd;} entries
- * (segmif_adamw_entry_bytes() each); chunk_entry / chunk_off map each block to (entry, offset). */
+ * (segmif_adamw_entry_bytes() each); chunk_entry / chunk_off map each block to (entry, offset).
+ * bias_corr1 = 1 - beta1^step and bias_corr2_sqrt = sqrt(1 - beta2^step) are evaluated by the caller in double. */
 int segmif_adamw_entry_bytes(void);
 int segmif_adamw_f32(const void* table, const int32_t* chunk_entry, const int64_t* chunk_off, int nchunks,
-                     int chunk_elems, float beta1, float beta2, float eps, int step, void* stream);
+                     int chunk_elems, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2_sqrt,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,10 @@ suite read the fixtures, never the reference.
     PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--full]
 
 --full additionally records the full-size (mit_b3, 480x640) pair-forward checksum
-record (about one minute of CPU time).
+record (about one minute of CPU time) and a direct segmentation forward on a U[0,1) image whose
+labels populate all nine classes (the mIoU gate's fixture).
+--full5 records the BASELINE config[4] checksums: mit_b5 at 1024x1024, batch 1 — Network3 forward on a
+U[0,1) image and the whole pair forward (several minutes of CPU time, ~20 GB of RSS).
 """
 import argparse
 import contextlib
@@ -76,6 +79,7 @@ def ref_pair_forward(seg, fus, ir, vis, mask3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--full5", action="store_true")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -85,7 +89,7 @@ def main():
 
     # ---- 1. state_dict keys / shapes (checkpoint compatibility) ---------------
     keys = {}
-    for bb in ("mit_b0", "mit_b1", "mit_b3"):
+    for bb in ("mit_b0", "mit_b1", "mit_b2", "mit_b3", "mit_b4", "mit_b5"):
         net = quiet(mf.Network3, bb, NUM_CLASSES, pretrained=None)
         keys["Network3:" + bb] = {k: list(v.shape) for k, v in net.state_dict().items()}
     fus = quiet(mf.Fusion_Network3_ac)
@@ -226,6 +230,66 @@ def main():
         np.savez_compressed(os.path.join(OUT, "pair_b3_480x640_checksum.npz"), **rec)
         meta["full_label_hist"] = rec["label_hist"].tolist()
         meta["full_margin_min"] = float(margin.min())
+
+    def checksum_record(r, names, seed):
+        g = np.random.Generator(np.random.PCG64(seed))
+        margin = torch.topk(r["logits"], 2, dim=1).values
+        margin = margin[:, 0] - margin[:, 1]
+        rec = {"labels": npy(r["labels"]).astype(np.uint8), "margin_f16": npy(margin).astype(np.float16)}
+        for name in names:
+            t = r[name].double()
+            flat = r[name].reshape(-1)
+            idx = g.integers(0, flat.numel(), size=4096)
+            rec[name + "_idx"] = idx
+            rec[name + "_val"] = npy(flat[torch.from_numpy(idx)])
+            rec[name + "_stats"] = np.array([t.mean().item(), t.abs().mean().item(), t.min().item(), t.max().item()])
+        rec["label_hist"] = np.bincount(rec["labels"].reshape(-1), minlength=NUM_CLASSES)
+        return rec, float(margin.min())
+
+    def seg_direct(net, x):
+        """test_segmentation.py:169-174 on a given RGB image: logits -> x4 bilinear -> argmax.  With the seeded weights
+        one or two classes win everywhere, which would make an mIoU comparison vacuous: linear_pred.bias (a parameter
+        like any other) is first re-centred by the per-class mean logit of this very image, so that all nine classes
+        are predicted; the bias actually used is part of the fixture."""
+        pred = net.denoise_net.decoder.linear_pred
+        _, _, seg0 = net.forward(x.clone())
+        saved = pred.bias.detach().clone()
+        pred.bias.copy_(saved - seg0.mean(dim=(0, 2, 3)))
+        _, _, seg1 = net.forward(x.clone())
+        logits = F.interpolate(seg1, size=x.shape[2:], mode="bilinear", align_corners=False)
+        out = dict(seg=seg1, logits=logits, labels=logits.argmax(1), pred_bias=pred.bias.detach().clone())
+        pred.bias.copy_(saved)
+        return out
+
+    # ---- 7. direct segmentation forward, mit_b3 480x640: all nine classes predicted (mIoU gate) ----
+    if args.full:
+        x = dw.det_input("b3_direct", (1, 3, 480, 640))
+        r = seg_direct(net3, x)
+        rec, mmin = checksum_record(r, ("seg", "logits"), 4321)
+        rec["pred_bias"] = npy(r["pred_bias"])
+        np.savez_compressed(os.path.join(OUT, "seg_b3_480x640_direct.npz"), **rec)
+        meta["direct_b3_label_hist"] = rec["label_hist"].tolist()
+        del net3
+
+    # ---- 8. BASELINE config[4]: mit_b5, 1024x1024, batch 1 ----------------------------------------
+    if args.full5:
+        net5 = quiet(mf.Network3, "mit_b5", NUM_CLASSES, pretrained=None).eval()
+        dw.load_det_weights(net5, seed=0)
+        H = W = 1024
+        x = dw.det_input("b5_direct", (1, 3, H, W))
+        r = seg_direct(net5, x)
+        rec, _ = checksum_record(r, ("seg", "logits"), 555)
+        rec["pred_bias"] = npy(r["pred_bias"])
+        np.savez_compressed(os.path.join(OUT, "seg_b5_1024_direct.npz"), **rec)
+        meta["direct_b5_label_hist"] = rec["label_hist"].tolist()
+        ir = dw.det_input("b5_ir", (1, 1, H, W))
+        vis = dw.det_input("b5_vis", (1, 3, H, W))
+        mask = dw.det_input("b5_mask", (1, 1, H, W)).repeat(1, 3, 1, 1)
+        r = ref_pair_forward(net5, fus, ir, vis, mask)
+        rec, mmin = checksum_record(r, ("out0", "out1", "y_fused", "fused", "seg", "logits"), 556)
+        np.savez_compressed(os.path.join(OUT, "pair_b5_1024_checksum.npz"), **rec)
+        meta["full5_label_hist"] = rec["label_hist"].tolist()
+        meta["full5_margin_min"] = mmin
 
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -102,7 +102,8 @@ SIGNATURES = {
     "segmif_bn_bwd_apply_f32": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_void_p]),
     "segmif_gauss_blur11_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p]),
     "segmif_adamw_entry_bytes": (c_int, []),
-    "segmif_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]),
+    "segmif_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
+                               c_void_p]),
     "segmif_seg_normalize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "segmif_nchw_to_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
     "segmif_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),

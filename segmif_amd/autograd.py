@@ -91,6 +91,21 @@ def conv_wgrad(x, dy, w_shape, k, stride, pad, dil, want_bias=False):
     return (dw, db) if want_bias else dw
 
 
+_slope_checked = {}
+
+
+def _require_positive_slope(slope):
+    """The PReLU backward reads the negative branch off the sign of the activation OUTPUT and divides by the slope
+    (act_bwd kernel, _slope_grad): both need slope > 0.  The reference initialises it to 0.25 and AdamW keeps it
+    there in practice, but nothing forces that; check once per parameter version (one host sync per optimizer step)."""
+    key = (slope.data_ptr(), slope._version)
+    if _slope_checked.get("key") != key:
+        v = float(slope.detach().reshape(-1)[0])
+        if not v > 0.0:
+            raise RuntimeError(f"segmif_amd: the shared PReLU slope is {v}; the HIP backward needs slope > 0")
+        _slope_checked["key"] = key
+
+
 def _slope_grad(dy, y, slope):
     """d(loss)/d(slope) of the shared scalar PReLU: sum over y < 0 of dy * pre, pre = y / slope."""
     # TODO(next): fold into act_bwd's kernel; parameter-scalar reduction, negligible next to the convs
@@ -123,6 +138,8 @@ class LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         dslope = None
         if ctx.act in (ACT_RELU, ACT_PRELU):
+            if ctx.act == ACT_PRELU:
+                _require_positive_slope(slope)
             if ctx.act == ACT_PRELU and ctx.needs_input_grad[4]:
                 dslope = _slope_grad(dy, y, slope)
             dz = act_bwd(dy, y, ctx.act, slope)
@@ -172,6 +189,8 @@ class ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         dslope = None
         if act in (ACT_RELU, ACT_PRELU):
+            if act == ACT_PRELU:
+                _require_positive_slope(slope)
             if act == ACT_PRELU and ctx.needs_input_grad[8]:
                 dslope = _slope_grad(dy, y, slope)
             dz = act_bwd(dy, y, act, slope)

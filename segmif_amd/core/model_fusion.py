@@ -483,8 +483,10 @@ class Network3(nn.Module):
         whole chain (x4 bilinear, softmax-CE with ignore_index, their backward) runs in HIP kernels."""
         seg = self._segment_nhwc(fused_seg1)
         H, W = label.shape[1:]
+        # the HIP CE kernel holds a row's logits in 32 registers; labels outside [0, C) other than ignore_index are
+        # treated as ignored there (torch raises), so the data pipeline must already guarantee the range (train.py's does)
         if isinstance(criterion, nn.CrossEntropyLoss) and criterion.weight is None and criterion.reduction == "mean" \
-                and getattr(criterion, "label_smoothing", 0.0) == 0.0:
+                and getattr(criterion, "label_smoothing", 0.0) == 0.0 and seg.shape[-1] <= 32:
             up = ag.bilinear(seg, H, W) if seg.requires_grad else ops.bilinear(seg, H, W)
             return ag.softmax_ce(up, label.type(torch.long), criterion.ignore_index)
         outputs = F.interpolate(ops.as_nchw(seg), size=label.shape[1:], mode='bilinear', align_corners=False)

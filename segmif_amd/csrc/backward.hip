@@ -710,10 +710,8 @@ extern "C" int segmif_conv_dgrad_strided_f32(const float* dy, const float* wd, f
 extern "C" int segmif_adamw_entry_bytes(void) { return (int)sizeof(AdamEntry); }
 
 extern "C" int segmif_adamw_f32(const void* table, const int32_t* chunk_entry, const int64_t* chunk_off, int nchunks,
-                                int chunk_elems, float beta1, float beta2, float eps, int step, void* stream) {
-  if (!table || !chunk_entry || !chunk_off || nchunks <= 0 || chunk_elems <= 0 || step <= 0) return SEGMIF_EINVAL;
-  const float bc1 = 1.0f - powf(beta1, (float)step);
-  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+                                int chunk_elems, float beta1, float beta2, float eps, float bc1, float bc2s, void* stream) {
+  if (!table || !chunk_entry || !chunk_off || nchunks <= 0 || chunk_elems <= 0 || !(bc1 > 0.f) || !(bc2s > 0.f)) return SEGMIF_EINVAL;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)table,
                      (const int*)chunk_entry, (const long long*)chunk_off, beta1, beta2, eps, bc1, bc2s, chunk_elems);
   return (int)hipGetLastError();

@@ -23,18 +23,12 @@ def init(backend=None):
         use_gpu = torch.cuda.is_available() and backend != "gloo"
         if use_gpu:
             torch.cuda.set_device(local_rank)
-            try:
-                torch.distributed.init_process_group(backend or "nccl", device_id=torch.device("cuda", local_rank))
-                probe = torch.zeros(1, device="cuda")
-                torch.distributed.all_reduce(probe)  # surfaces RCCL / xGMI bootstrap problems here, not mid-bench
-                torch.cuda.synchronize()
-            except Exception as exc:  # forward replicas exchange no data: fall back to a CPU rendezvous for
-                import sys            # the barrier / max-time reduction rather than lose the measurement
-                print(f"[segmif_amd.dist] RCCL init failed on rank {rank} ({exc!r}); using gloo for the timing sync",
-                      file=sys.stderr)
-                if torch.distributed.is_initialized():
-                    torch.distributed.destroy_process_group()
-                torch.distributed.init_process_group("gloo")
+            # RCCL must come up on every rank or on none: a per-rank fallback to another backend would leave the
+            # ranks in different process groups and deadlock the first collective, so a failure here is fatal.
+            torch.distributed.init_process_group(backend or "nccl", device_id=torch.device("cuda", local_rank))
+            probe = torch.zeros(1, device="cuda")
+            torch.distributed.all_reduce(probe)  # surfaces RCCL / xGMI bootstrap problems here, not mid-bench
+            torch.cuda.synchronize()
         else:
             torch.distributed.init_process_group(backend or "gloo")
     return rank, local_rank, world

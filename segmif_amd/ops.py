@@ -242,12 +242,12 @@ def launch_timer_active():
     return _timer is not None
 
 
-def _igemm(desc, tag=None):
+def _igemm(desc, tag=None, dev="cuda"):
     lib = _lib.load()
     need = lib.segmif_igemm_workspace_floats(ctypes.byref(desc))
     ws = None
     if need > 0:  # split-K scratch for problems whose tile grid would leave most CUs idle
-        ws = torch.empty((need,), device="cuda", dtype=torch.float32)
+        ws = torch.empty((need,), device=dev, dtype=torch.float32)
         desc.workspace, desc.workspace_floats = ws.data_ptr(), need
 
     def go():
@@ -315,7 +315,7 @@ def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
     d.act, d.nz, d.tile = act, nz, tile
     if ln is not None:  # (gamma, beta, eps): LayerNorm over the N = 64 outputs fused into the epilogue
         d.ln_gamma, d.ln_beta, d.ln_eps = _req(ln[0]).data_ptr(), _req(ln[1]).data_ptr(), float(ln[2])
-    _igemm(d)
+    _igemm(d, dev=x.device)
     return out
 
 
@@ -360,7 +360,7 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
     d.H, d.W, d.Cin, d.KH, d.KW = H, W, cin, k, k
     d.stride, d.pad, d.dil, d.OH, d.OW = stride, pad, dil, OH, OW
     d.act, d.nz, d.tile = act, 1, tile
-    _igemm(d, tag)
+    _igemm(d, tag, dev=x.device)
     return out
 
 

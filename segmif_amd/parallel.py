@@ -59,6 +59,11 @@ class GradAllReducer:
     # ---- hook: gradient of `p` is final ----------------------------------------------------------
     def _on_grad(self, p):
         bi, off = self._where[p]
+        if self._pending[bi] <= 0:
+            # a second backward before finish() (gradient accumulation, an extra loss.backward()) would overwrite a
+            # bucket whose all-reduce is already in flight: not supported, say so instead of corrupting gradients
+            raise RuntimeError("GradAllReducer: a parameter received a second gradient before finish(); call "
+                               "finish() after every backward (gradient accumulation is not supported)")
         self._flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
@@ -66,7 +71,7 @@ class GradAllReducer:
 
     def _launch(self, bi):
         flat = self._flat[bi]
-        if self.world > 1:
+        if dist.is_initialized():  # also with one rank: the collective path is then exercised end to end
             self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     # ---- call after loss.backward() ---------------------------------------------------------------

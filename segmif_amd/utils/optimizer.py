@@ -16,6 +16,22 @@ from .. import _lib
 _CHUNK = 65536
 
 
+def _bump_versions(params):
+    """The kernel writes parameters through raw pointers, which autograd's version counters do not see; every cache
+    keyed on `tensor._version` (core/_util.PackedCache: packed weights, folded BatchNorm, fused head matrices) would
+    keep serving pre-step copies to the next eval / no_grad forward.  Bump the counters without touching the data."""
+    if not params:
+        return
+    setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+    if setter is not None:
+        try:
+            setter(params, [p._version + 1 for p in params])
+            return
+        except (TypeError, RuntimeError):
+            pass
+    torch._foreach_add_(params, 0.0)
+
+
 class _AdamEntry(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
                 ("n", ctypes.c_int64), ("lr", ctypes.c_float), ("wd", ctypes.c_float)]
@@ -46,7 +62,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
+                st["step"] = int(st["step"]) + 1  # a torch.optim.AdamW checkpoint stores `step` as a tensor
                 key = (st["step"], group["betas"], group["eps"], p.device)
                 by_hyper.setdefault(key, []).append((p, p.grad.contiguous(), st, group["lr"], group["weight_decay"]))
         for (step, betas, eps, dev), items in by_hyper.items():
@@ -65,9 +81,13 @@ class FusedAdamW(torch.optim.Optimizer):
             ce = torch.tensor(chunk_entry, dtype=torch.int32, device=dev)
             co = torch.tensor(chunk_off, dtype=torch.int64, device=dev)
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            # bias corrections in double on the host, like torch.optim.AdamW (fp32 powf is ~3e-5 off in early steps)
+            bc1 = 1.0 - float(betas[0]) ** step
+            bc2_sqrt = (1.0 - float(betas[1]) ** step) ** 0.5
             _lib.check(lib.segmif_adamw_f32(table.data_ptr(), ce.data_ptr(), co.data_ptr(), len(chunk_entry), _CHUNK,
-                                            betas[0], betas[1], eps, step, stream), "segmif_adamw_f32")
+                                            betas[0], betas[1], eps, bc1, bc2_sqrt, stream), "segmif_adamw_f32")
             self._keepalive = (table, ce, co, keep)
+            _bump_versions([p for p, *_ in items])
         return loss
 
 

@@ -114,3 +114,31 @@ def test_data_parallel_gradient_allreduce_matches_full_batch():
                 assert torch.allclose(torch.tensor(g), r, atol=1e-6), (rank, step)
             assert grads[4] is None and grads[5] is None  # unused parameters stay grad-less
     assert abs(res[0][2] - res[1][2]) < 1e-12
+
+
+def test_bench_self_launch_entry_spawns_one_rank_per_gpu(tmp_path):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (the form the driver
+    uses): the same function drives a GPU-less stand-in script here, world size 2 on gloo."""
+    import json
+    import subprocess
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import argparse, bench; "
+            f"bench.self_launch(argparse.Namespace(gpus=2), script={os.path.join(ROOT, 'tests', '_dist_probe.py')!r}, argv=['--steps', '7'])")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    assert lines == [{"n_gpus": 2, "pairs": 6.0, "elapsed": 2.0, "argv": ["--steps", "7"]}]
+
+
+def test_bench_main_self_launches_when_no_launcher_set_world_size(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    called = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "2"])
+    monkeypatch.setattr(bench, "self_launch", lambda args, **k: (called.update(gpus=args.gpus), (_ for _ in ()).throw(SystemExit(0)))[1])
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    assert called == {"gpus": 8}

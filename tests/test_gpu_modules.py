@@ -57,8 +57,9 @@ def net_b1(core):
 
 def test_state_dict_keys(core, golden_dir):
     keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
-    n = core.Network3("mit_b3", 9, pretrained=None)
-    assert {k: list(v.shape) for k, v in n.state_dict().items()} == keys["Network3:mit_b3"]
+    for bb in ("mit_b0", "mit_b1", "mit_b2", "mit_b3", "mit_b4", "mit_b5"):
+        n = core.Network3(bb, 9, pretrained=None)
+        assert {k: list(v.shape) for k, v in n.state_dict().items()} == keys["Network3:" + bb], bb
     f = core.Fusion_Network3_ac()
     assert {k: list(v.shape) for k, v in f.state_dict().items()} == keys["Fusion_Network3_ac"]
 
@@ -291,6 +292,71 @@ def test_full_size_b3_vs_reference_checksum(core, fus, golden_dir):
     labels_p = labels_p.cpu().long().reshape(ref_labels.shape)
     assert torch.equal(labels_p[stable], ref_labels[stable])
     assert_miou_parity(ref_labels.numpy(), labels_p.numpy(), "b3_gt")
+
+
+def _check_samples(r, g, names):
+    for name in names:
+        got = r[name].contiguous().reshape(-1)[torch.from_numpy(g[name + "_idx"]).cuda()].cpu()
+        scale = max(abs(g[name + "_stats"][2]), abs(g[name + "_stats"][3]))
+        e = float((got - torch.from_numpy(g[name + "_val"])).abs().max()) / scale
+        assert e < TOL and e < 5 * TIGHT, (name, e)
+    labels = r["labels"].cpu().long().reshape(g["labels"].shape)
+    ref_labels = torch.from_numpy(g["labels"]).long()
+    stable = torch.from_numpy(g["margin_f16"].astype(np.float32)) > 1e-3
+    assert torch.equal(labels[stable], ref_labels[stable])
+    assert int((labels != ref_labels).sum()) <= int((~stable).sum())
+    return labels, ref_labels
+
+
+def _direct_hip(net, x, g):
+    """test_segmentation.py:169-174 on the HIP path with the fixture's re-centred linear_pred.bias."""
+    from segmif_amd import ops
+    with torch.no_grad():
+        net.denoise_net.decoder.linear_pred.bias.copy_(torch.from_numpy(g["pred_bias"]).cuda())
+        _, _, seg = net(x)
+        logits = ops.bilinear(ops.to_nhwc(seg), x.shape[2], x.shape[3])
+        return dict(seg=seg, logits=ops.as_nchw(logits), labels=ops.argmax_nhwc(logits))
+
+
+def test_direct_segmentation_b3_all_nine_classes_and_miou(core, golden_dir):
+    """The mIoU gate on a record in which the reference predicts all nine classes (>= 24 000 pixels each): sampled
+    logits, exact labels above the margin, mIoU within 1e-4 of the reference's (north star: +-0.1)."""
+    g = load(golden_dir, "seg_b3_480x640_direct.npz")
+    assert int((g["label_hist"] >= 20000).sum()) == 9
+    net = build(core, core.Network3, "mit_b3", 9, pretrained=None)
+    r = _direct_hip(net, dw.det_input("b3_direct", (1, 3, 480, 640)).cuda(), g)
+    labels, ref_labels = _check_samples(r, g, ("seg", "logits"))
+    assert_miou_parity(ref_labels.numpy(), labels.numpy(), "b3_direct_gt")
+
+
+def test_config4_mit_b5_1024_vs_reference_checksums(core, fus, golden_dir):
+    """BASELINE config[4]: mit_b5 at 1024x1024 — Network3 forward and the whole pair forward against the records of
+    the real reference (Nk = 1024 keys per attention block, 65 536 stage-1 tokens), plus the config's batch of 2 as a
+    batch-consistency property (batch 2 == two batches of 1 to fp32 rounding)."""
+    net = build(core, core.Network3, "mit_b5", 9, pretrained=None)
+    H = W = 1024
+    g = load(golden_dir, "seg_b5_1024_direct.npz")
+    saved = net.denoise_net.decoder.linear_pred.bias.detach().clone()
+    x = dw.det_input("b5_direct", (1, 3, H, W)).cuda()
+    labels, ref_labels = _check_samples(_direct_hip(net, x, g), g, ("seg", "logits"))
+    assert_miou_parity(ref_labels.numpy(), labels.numpy(), "b5_direct_gt")
+    with torch.no_grad():
+        x2 = torch.cat((x, dw.det_input("b5_second", (1, 3, H, W)).cuda()))
+        both = net(x2)[2]
+        # (not bitwise: small grids run split-K, whose split — hence summation order — depends on the row count)
+        for i in range(2):
+            assert rel(both[i:i + 1], net(x2[i:i + 1])[2].cpu()) < TIGHT, i
+        net.denoise_net.decoder.linear_pred.bias.copy_(saved)
+    g = load(golden_dir, "pair_b5_1024_checksum.npz")
+    ir = dw.det_input("b5_ir", (1, 1, H, W)).cuda()
+    vis = dw.det_input("b5_vis", (1, 3, H, W)).cuda()
+    mask = dw.det_input("b5_mask", (1, 1, H, W)).repeat(1, 3, 1, 1).cuda()
+    with torch.no_grad():
+        r = pair_forward_hip(core, net, fus, ir, vis, mask)
+    _check_samples(r, g, ("out0", "out1", "y_fused", "fused", "seg", "logits"))
+    from segmif_amd.pipeline import PairForward
+    fused_p, labels_p = PairForward(net, fus)(ir, vis, mask)
+    _check_samples(dict(fused=fused_p, labels=labels_p), g, ("fused",))
 
 
 def test_batch_consistency_full_size(core, fus):

@@ -30,7 +30,7 @@ def sd_fus():
 
 def test_state_dict_keys_match_reference(golden_dir):
     keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
-    for bb in ("mit_b0", "mit_b1", "mit_b3"):
+    for bb in ("mit_b0", "mit_b1", "mit_b2", "mit_b3", "mit_b4", "mit_b5"):
         ours = {k: list(v) for k, v in so.network3_shapes(bb, 9).items()}
         assert ours == keys["Network3:" + bb]
     assert {k: list(v) for k, v in so.fusion_shapes().items()} == keys["Fusion_Network3_ac"]
@@ -128,6 +128,56 @@ def test_full_size_checksum_b3(golden_dir, sd_fus):
     stable = torch.from_numpy(g["margin_f16"].astype(np.float32)) > 1e-3
     assert torch.equal(r["labels"][stable], torch.from_numpy(g["labels"]).long()[stable])
     assert len(np.unique(g["labels"])) >= 5  # non-degenerate segmentation on synthetic input
+
+
+def _check_samples(r, g, names, tol=5e-5):
+    for name in names:
+        got = r[name].reshape(-1)[torch.from_numpy(g[name + "_idx"])]
+        scale = max(abs(g[name + "_stats"][2]), abs(g[name + "_stats"][3]))
+        assert float((got - torch.from_numpy(g[name + "_val"])).abs().max()) / scale < tol, name
+    stable = torch.from_numpy(g["margin_f16"].astype(np.float32)) > 1e-3
+    assert torch.equal(r["labels"][stable], torch.from_numpy(g["labels"]).long()[stable])
+
+
+def _direct(sd, x, backbone, g):
+    """test_segmentation.py:169-174 on an RGB image with the fixture's re-centred linear_pred.bias."""
+    sd = dict(sd)
+    sd["denoise_net.decoder.linear_pred.bias"] = torch.from_numpy(g["pred_bias"])
+    with torch.no_grad():
+        seg = so.network3_forward(sd, x, backbone)
+        logits = torch.nn.functional.interpolate(seg, size=x.shape[2:], mode="bilinear", align_corners=False)
+    return dict(seg=seg, logits=logits, labels=logits.argmax(1))
+
+
+def test_direct_segmentation_b3_all_nine_classes(golden_dir):
+    """Network3('mit_b3') on a U[0,1) 480x640 image with a class-balanced prediction bias: the reference predicts all
+    nine classes (>= 24 000 pixels each), so label / mIoU agreement on this record is not vacuous."""
+    g = load(golden_dir, "seg_b3_480x640_direct.npz")
+    assert int((g["label_hist"] >= 20000).sum()) == 9
+    sd = dw.det_state_dict(so.network3_shapes("mit_b3", 9), seed=0)
+    r = _direct(sd, dw.det_input("b3_direct", (1, 3, 480, 640)), "mit_b3", g)
+    _check_samples(r, g, ("seg", "logits"))
+    gt = dw.det_labels("b3_direct_gt", g["labels"].shape, 9).numpy()
+    m_ref, _ = so.miou(so.confusion(gt, g["labels"]))
+    m_orc, _ = so.miou(so.confusion(gt, r["labels"].numpy()))
+    assert abs(m_ref - m_orc) < 1e-4
+
+
+def test_config4_mit_b5_1024_checksums(golden_dir, sd_fus):
+    """BASELINE config[4] (mit_b5, 1024x1024, batch 1): oracle vs the reference's records of the direct segmentation
+    forward and of the whole pair forward (Nk = 1024 keys per attention block, 40 stage-3 blocks)."""
+    sd = dw.det_state_dict(so.network3_shapes("mit_b5", 9), seed=0)
+    H = W = 1024
+    g = load(golden_dir, "seg_b5_1024_direct.npz")
+    assert int((g["label_hist"] >= 50000).sum()) == 9
+    _check_samples(_direct(sd, dw.det_input("b5_direct", (1, 3, H, W)), "mit_b5", g), g, ("seg", "logits"))
+    g = load(golden_dir, "pair_b5_1024_checksum.npz")
+    ir = dw.det_input("b5_ir", (1, 1, H, W))
+    vis = dw.det_input("b5_vis", (1, 3, H, W))
+    mask = dw.det_input("b5_mask", (1, 1, H, W)).repeat(1, 3, 1, 1)
+    with torch.no_grad():
+        r = so.pair_forward(sd, sd_fus, ir, vis, mask, "mit_b5", return_all=True)
+    _check_samples(r, g, ("out0", "out1", "y_fused", "fused", "seg", "logits"))
 
 
 def _grad_fixture_check(named_grads, g, tol):

@@ -1,0 +1,271 @@
+"""Training path against fixtures recorded from the REAL reference (oracle/make_golden_train.py):
+utils/optimizer.py, pytorch_ssim / core/loss.py, and three iterations of each loop of train.py.
+CPU part: host logic (LR schedules) and the loss formulas; GPU part: the HIP steps."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+TINY = 1e-30
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+SEG_KW = dict(lr=8e-5, weight_decay=0.01, betas=[0.9, 0.999], warmup_iter=3000, max_iter=160000, warmup_ratio=1e-6, power=1.0)
+
+
+def seg_groups(ps):
+    return [{"params": ps[:2], "lr": 8e-5, "weight_decay": 0.01}, {"params": ps[2:3], "lr": 8e-5, "weight_decay": 0.0},
+            {"params": ps[3:], "lr": 8e-4, "weight_decay": 0.01}]
+
+
+def fus_kw(iter_):
+    return dict(lr=3e-4 / iter_, weight_decay=0.01, betas=[0.9, 0.999], warmup_iter=3e-5 / iter_, max_iter=160000,
+                warmup_ratio=1e-6, power=1.0)
+
+
+def test_lr_schedules_match_the_reference_optimizer():
+    """PolyWarmupAdamW(_seg)._apply_schedule (host logic) against the learning rates utils/optimizer.py:16-31 /
+    :49-64 wrote into param_groups, incl. the warm-up branch, the polynomial branch, the last iteration before
+    max_iter and the fusion loop's warmup_iter = 3e-5 / iter_ (train.py:328: warm-up never taken)."""
+    from segmif_amd.utils.optimizer import PolyWarmupAdamW, PolyWarmupAdamW_seg
+    g = load("optim_steps.npz")
+    for it_start in (0, 10000, 159999):
+        ps = [torch.nn.Parameter(torch.zeros(2)) for _ in range(5)]
+        opt = PolyWarmupAdamW_seg(seg_groups(ps), iter_curr=it_start, **SEG_KW)
+        for st in range(3):
+            opt._apply_schedule()
+            opt.global_step += 1
+            np.testing.assert_allclose([gr["lr"] for gr in opt.param_groups], g[f"seg{it_start}|lr|{st}"], rtol=1e-12)
+    for iter_ in (1, 2):
+        ps = [torch.nn.Parameter(torch.zeros(2)) for _ in range(5)]
+        opt = PolyWarmupAdamW([{"params": ps, "lr": 8e-5 / iter_, "weight_decay": 0.01}], **fus_kw(iter_))
+        for st in range(3):
+            opt._apply_schedule()
+            opt.global_step += 1
+            np.testing.assert_allclose([gr["lr"] for gr in opt.param_groups], g[f"fus{iter_}|lr|{st}"], rtol=1e-12)
+
+
+def test_loss_formulas_match_the_reference_on_cpu():
+    """segmif_amd.losses (torch formulation used off-GPU) against pytorch_ssim.ssim and core/loss.py
+    Fusionloss_grad3 / Fusionloss3 / Sobelxy: values and gradients."""
+    from segmif_amd import losses
+    g = load("losses.npz")
+    gen = torch.from_numpy(g["gen"]).requires_grad_(True)
+    mask = torch.from_numpy(g["mask"])
+    s = losses.ssim(gen, mask[:, :1])
+    (gs,) = torch.autograd.grad(s, gen)
+    assert abs(float(s) - float(g["ssim"])) < 1e-6
+    assert float((gs - torch.from_numpy(g["ssim_grad"])).abs().max()) < 1e-7
+    for name, fn in (("grad3", losses.fusion_loss_grad3), ("loss3", losses.fusion_loss3)):
+        v = fn(gen, mask)
+        (gv,) = torch.autograd.grad(v, gen)
+        assert abs(float(v) - float(g[name])) < 2e-6 * max(1.0, abs(float(g[name]))), name
+        ref = torch.from_numpy(g[name + "_grad"])
+        assert float((gv - ref).abs().max()) < 1e-6 * max(1.0, float(ref.abs().max())), name
+    assert float((losses.sobel_xy(gen.detach()) - torch.from_numpy(g["sobel"])).abs().max()) < 1e-5
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+
+
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+@gpu
+def test_fused_adamw_steps_match_the_reference_optimizer():
+    """Three steps of the fused multi-tensor AdamW under both schedules against parameters recorded from
+    utils/optimizer.py (= torch.optim.AdamW arithmetic); the parameter without a gradient is left untouched."""
+    need_gpu()
+    import detweights as dw
+    from segmif_amd.utils.optimizer import PolyWarmupAdamW, PolyWarmupAdamW_seg
+    g = load("optim_steps.npz")
+    shapes = [(7, 5), (33,), (4, 3, 3, 3), (1,), (6,)]
+
+    def run(tag, make):
+        ps = [torch.nn.Parameter(dw.det_input(f"opt_{tag}_p{i}", s, lo=-1.0, hi=1.0).cuda()) for i, s in enumerate(shapes)]
+        opt = make(ps)
+        for st in range(3):
+            for i, p in enumerate(ps):
+                p.grad = None if i == 4 else dw.det_input(f"opt_{tag}_g{i}_s{st}", p.shape, lo=-1.0, hi=1.0).cuda()
+            v0 = [p._version for p in ps]
+            opt.step()
+            for i, p in enumerate(ps):
+                ref = g[f"{tag}|p{i}|{st}"]
+                assert float(np.abs(p.detach().cpu().numpy() - ref).max()) < 2e-7 * max(1.0, float(np.abs(ref).max())), (tag, i, st)
+                if i != 4:
+                    assert p._version > v0[i]  # caches keyed on _version must see the raw-pointer update
+
+    for it_start in (0, 10000, 159999):
+        run(f"seg{it_start}", lambda ps: PolyWarmupAdamW_seg(seg_groups(ps), iter_curr=it_start, **SEG_KW))
+    for iter_ in (1, 2):
+        run(f"fus{iter_}", lambda ps: PolyWarmupAdamW([{"params": ps, "lr": 8e-5 / iter_, "weight_decay": 0.01}], **fus_kw(iter_)))
+
+
+@gpu
+def test_losses_on_the_hip_path_match_the_reference():
+    need_gpu()
+    from segmif_amd import losses
+    g = load("losses.npz")
+    gen = torch.from_numpy(g["gen"]).cuda().requires_grad_(True)
+    mask = torch.from_numpy(g["mask"]).cuda()
+    for name, fn in (("grad3", losses.fusion_loss_grad3), ("loss3", losses.fusion_loss3)):
+        v = fn(gen, mask)
+        (gv,) = torch.autograd.grad(v, gen)
+        assert abs(float(v) - float(g[name])) < 5e-6 * max(1.0, abs(float(g[name]))), name
+        ref = torch.from_numpy(g[name + "_grad"])
+        assert float((gv.cpu() - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max())), name
+    s = losses.ssim(gen, mask[:, :1])
+    assert abs(float(s) - float(g["ssim"])) < 2e-6
+
+
+def _check_params(module, g, lr_scale):
+    """Updated parameters against the reference's.  An AdamW step moves an element by ~lr whatever the gradient's
+    size, so an element whose gradient is within rounding of zero may legitimately differ by a few lr: nothing may be
+    further off than the three steps can explain, norms must agree, and elementwise all but a sliver must agree to
+    fp32 rounding.  The key half of every attention kv.bias has an exactly-zero true gradient (softmax is shift
+    invariant): both sides step on pure rounding noise there, so it only gets the "few lr" bound."""
+    bad, total = 0, 0
+    for name, p in module.named_parameters():
+        t = p.detach().double().cpu()
+        head = torch.from_numpy(g[name + "|head"]).double()
+        d = (t.reshape(-1)[:head.numel()] - head).abs()
+        assert float(d.max()) <= 4 * lr_scale, name
+        ref_norm = float(g[name + "|norm"])
+        noise_only = name.endswith("attn.kv.bias")
+        assert abs(float(t.norm()) - ref_norm) <= (1e-3 if noise_only else 1e-4) * max(ref_norm, 1e-3), name
+        if not noise_only:
+            bad += int((d > 2e-6 * (1.0 + head.abs())).sum())
+            total += head.numel()
+    assert bad <= 0.02 * total, (bad, total)
+
+
+@gpu
+def test_seg_train_step_three_iterations_vs_reference():
+    """train.py:217-227 assembled: segmif_amd.train.seg_train_step on the HIP Network3('mit_b1') with
+    PolyWarmupAdamW_seg over get_param_groups(), three iterations: losses and every updated parameter against the
+    reference's own run; classifier.weight stays gradient-less; the eval forward after the steps uses
+    the updated weights (version-keyed caches see the fused optimizer's writes)."""
+    need_gpu()
+    import detweights as dw
+    from segmif_amd.core import Network3
+    from segmif_amd.train import seg_train_step
+    from segmif_amd.utils.optimizer import PolyWarmupAdamW_seg
+    g = load("train_seg_b1.npz")
+    net = Network3("mit_b1", 9, pretrained=None)
+    dw.load_det_weights(net, seed=0)
+    net = net.cuda().eval()
+    groups = net.denoise_net.get_param_groups()
+    opt = PolyWarmupAdamW_seg([{"params": groups[0], "lr": 8e-5, "weight_decay": 0.01},
+                               {"params": groups[1], "lr": 8e-5, "weight_decay": 0.0},
+                               {"params": groups[2], "lr": 8e-4, "weight_decay": 0.01}], iter_curr=10000, **SEG_KW)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+    B, H, W = 2, 64, 96
+    probe = dw.det_input("trs_x0", (B, 3, H, W)).cuda()
+    with torch.no_grad():
+        before = net(probe)[2].clone()  # fills the eval-path weight caches
+    for st in range(3):
+        x = dw.det_input(f"trs_x{st}", (B, 3, H, W)).cuda()
+        y = dw.det_labels(f"trs_y{st}", (B, H, W), 9)
+        y[0, 3:9, 5:40] = 255
+        loss = seg_train_step(net, opt, x, y.cuda(), crit)
+        assert abs(float(loss) - float(g["losses"][st])) < 2e-5 * abs(float(g["losses"][st])), st
+    assert sorted(n for n, p in net.named_parameters() if p.grad is None) == sorted(g["no_grad_params"].tolist())
+    _check_params(net, g, 8e-4)
+    with torch.no_grad():
+        after = net(probe)[2]
+        net2 = Network3("mit_b1", 9, pretrained=None).cuda().eval()
+        net2.load_state_dict(net.state_dict())
+        fresh = net2(probe)[2]  # a module that has never cached anything
+    assert float((after - before).abs().max()) > 1e-4  # the step changed the function ...
+    assert float((after - fresh).abs().max()) <= 1e-6 * float(fresh.abs().max())  # ... and the cached path follows
+
+
+@gpu
+def test_fusion_train_step_three_iterations_vs_reference():
+    """train.py:351-385 (iter_ = 2) assembled: FusionTrainer.step — no-grad forward_fusion, fusion net, Fusionloss_grad3,
+    CE through the segmentation net, fixed weights 0.4 / iter_ and 0.8 while n_iter <= 10, PolyWarmupAdamW on the
+    fusion net — three iterations against the reference's losses and updated parameters (ffm2.* gradient-less)."""
+    need_gpu()
+    import detweights as dw
+    from segmif_amd.core import Fusion_Network3_ac, Network3
+    from segmif_amd.train import FusionTrainer
+    from segmif_amd.utils.optimizer import PolyWarmupAdamW
+    g = load("train_fusion_b1.npz")
+    iter_ = 2
+    net = Network3("mit_b1", 9, pretrained=None)
+    fus = Fusion_Network3_ac()
+    dw.load_det_weights(net, seed=0)
+    dw.load_det_weights(fus, seed=0)
+    net, fus = net.cuda().eval(), fus.cuda().eval()
+    opt = PolyWarmupAdamW([{"params": fus.parameters(), "lr": 8e-5 / iter_, "weight_decay": 0.01}], **fus_kw(iter_))
+    tr = FusionTrainer(net, fus, opt, torch.nn.CrossEntropyLoss(ignore_index=255), iter_=iter_)
+    B, H, W = 2, 32, 48
+    for st in range(3):
+        ir3 = dw.det_input(f"trf_ir{st}", (B, 1, H, W)).repeat(1, 3, 1, 1).cuda()
+        vis3 = dw.det_input(f"trf_vis{st}", (B, 3, H, W)).cuda()
+        mask3 = dw.det_input(f"trf_mask{st}", (B, 1, H, W)).repeat(1, 3, 1, 1).cuda()
+        labels = dw.det_labels(f"trf_y{st}", (B, H, W), 9).cuda()
+        loss = tr.step(ir3, vis3, mask3, labels)
+        assert abs(float(loss) - float(g["total"][st])) < 5e-5 * abs(float(g["total"][st])), st
+        assert abs(tr.history[st][0] - float(g["loss1"][st])) < 5e-5 * abs(float(g["loss1"][st]))
+        assert abs(tr.history[st][1] - float(g["loss2"][st])) < 5e-5 * abs(float(g["loss2"][st]))
+    assert sorted(n for n, p in fus.named_parameters() if p.grad is None) == sorted(g["no_grad_params"].tolist())
+    _check_params(fus, g, 4e-5)
+
+
+@gpu
+def test_grad_allreducer_over_the_hip_backward_on_rccl():
+    """GradAllReducer driven by the HIP autograd Functions of Network3('mit_b1') inside a one-rank RCCL ("nccl") group:
+    post-accumulate-grad hooks fire for every parameter that receives a gradient, every bucket's all-reduce is launched
+    from backward and completes, and the gradients equal those of a plain backward; a second backward before finish()
+    is refused instead of racing the in-flight collective."""
+    need_gpu()
+    import socket
+    import torch.distributed as tdist
+    import detweights as dw
+    from segmif_amd.core import Network3
+    from segmif_amd.parallel import GradAllReducer
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                             device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        net = Network3("mit_b1", 9, pretrained=None)
+        dw.load_det_weights(net, seed=0)
+        net = net.cuda().eval()
+        crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+        x = dw.det_input("dp_x", (2, 3, 64, 96)).cuda()
+        y = dw.det_labels("dp_y", (2, 64, 96), 9).cuda()
+        net._loss(x, y, crit).backward()
+        ref = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        red = GradAllReducer(net.parameters(), bucket_mb=4.0)
+        for step in range(3):  # step 0 discovers the active set; steps 1-2 run hook-driven, overlapped with backward
+            for p in net.parameters():
+                p.grad = None
+            net._loss(x, y, crit).backward()
+            if step > 0:
+                assert all(n == 0 for n in red._pending) and len(red._handles) == len(red._buckets)
+            red.finish()
+            got = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+            assert got.keys() == ref.keys()
+            for n in ref:
+                assert torch.equal(got[n], ref[n]), (step, n)
+        assert len(red._buckets) >= 10 and red.gradient_bytes() == sum(g.numel() * 4 for g in ref.values())
+        for p in net.parameters():
+            p.grad = None
+        net._loss(x, y, crit).backward()
+        with pytest.raises(RuntimeError, match="second gradient"):
+            net._loss(x, y, crit).backward()
+    finally:
+        tdist.destroy_process_group()
