@@ -122,7 +122,8 @@ class SegFormerHead(nn.Module):
         return self._pk.get_multi("per_scale_fused", srcs, build)
 
     def forward_train_nhwc(self, feats):
-        """autograd path (BatchNorm on running statistics; batch-statistics mode is not built yet)."""
+        """autograd path: BatchNorm on batch statistics in train() mode (bn_colstats / bn_apply kernels, running statistics
+        updated like nn.BatchNorm2d), on running statistics in eval() mode."""
         c1, c2, c3, c4 = feats
         B, H1, W1, _ = c1.shape
         fuse = self.linear_fuse
