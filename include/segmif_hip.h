@@ -262,6 +262,38 @@ int segmif_linattn_fold_f32(const double* partial, const float* wend, float* wef
                             float scale, void* stream);
 
 /*
+ * CrossPath in inference without its 128-wide intermediates (csrc/crosspath.hip; core/model_fusion.py:329-361).
+ *  - segmif_crosspath_gram_f32: per-image Gram matrix G = sum_n y_n y_n^T of y_n = ReLU(W x_n + bias), W: 64 rows x 64
+ *    (row-major, the needed half of a channel_proj weight), x: (B, N, 64) rows with pixel pitch ldx.  Written as
+ *    segmif_crosspath_gram_blocks(N) partial matrices per image, 3072 doubles each (tiles (0,0), (0,1), (1,1) of the
+ *    symmetric 64 x 64 matrix, 32 x 32 row-major); fp32 inside a 32-pixel run, fp64 across runs.
+ *  - segmif_crosspath_fold_f32: K^T V = Wk G Wv^T per head from the Gram partials ([Wk; Wv] = the raw (128, 64) kv
+ *    weight), softmax over the k index of (K^T V) * scale, folded into end_proj exactly like segmif_linattn_fold_f32.
+ *  - segmif_crosspath_tail_f32: out = LayerNorm_64(x_i + Weff_b . [ReLU(W3 x_3 + b3) | ReLU(Wi x_i + bi)] + bend):
+ *    channel_proj halves, the context-folded end_proj (Weff: (B, 64, 128)), residual and norm in one pass over the
+ *    tokens; optionally also emits out as planes chunks 0..3 (conv3x3_planes format, H * W == N) for the next DRDB.
+ * Replaces core/model_fusion.py:351-360 together with :281-286 / :316-326 (the three kv Linears and K^T V).
+ */
+typedef struct SegmifCrossTail {
+  const float* x3; const float* xi;     /* (B, N, 64) rows, pitches ld3 / ldi */
+  const float* w3; const float* b3;     /* 64 x 64 rows of channel_proj3 (y half) and their bias (or NULL) */
+  const float* wi; const float* bi;     /* 64 x 64 rows of channel_proj_i (u half) and their bias (or NULL) */
+  const float* weff;                    /* (B, 64, 128) */
+  const float* bend;                    /* end_proj bias [64] or NULL */
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  float* out; int32_t ld3, ldi, ldo;
+  int32_t B; int64_t N;
+  void* planes_out; int32_t H, W, planes_chunks;   /* optional planes copy of out (NULL = off) */
+} SegmifCrossTail;
+
+int segmif_crosspath_gram_blocks(int64_t N);
+int segmif_crosspath_gram_f32(const float* x, int ldx, const float* w, const float* bias, double* partial, int B, int64_t N,
+                              void* stream);
+int segmif_crosspath_fold_f32(const double* partial, int nblk, const float* wkv, const float* wend, float* weff, int B,
+                              int Nout, int ldw, int wofs, int ldweff, int kofs, float scale, void* stream);
+int segmif_crosspath_tail_f32(const SegmifCrossTail* desc, void* stream);
+
+/*
  * Pointwise helpers (bandwidth-bound, NCHW <-> NHWC at the module boundary).
  *  - segmif_seg_normalize: (x*255 - mean_c)/std_c on a (B,3,H,W) NCHW image -> NHWC (B,H,W,3)
  *    (core/model_fusion.py:1083-1085).

@@ -42,6 +42,16 @@ class SegmifConvPlanes(ctypes.Structure):
     ]
 
 
+class SegmifCrossTail(ctypes.Structure):
+    _fields_ = [
+        ("x3", c_void_p), ("xi", c_void_p), ("w3", c_void_p), ("b3", c_void_p), ("wi", c_void_p), ("bi", c_void_p),
+        ("weff", c_void_p), ("bend", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
+        ("out", c_void_p), ("ld3", c_int32), ("ldi", c_int32), ("ldo", c_int32),
+        ("B", c_int32), ("N", c_int64),
+        ("planes_out", c_void_p), ("H", c_int32), ("W", c_int32), ("planes_chunks", c_int32),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol include/segmif_hip.h declares
 SIGNATURES = {
     "segmif_abi_version": (c_int, []),
@@ -60,6 +70,11 @@ SIGNATURES = {
     "segmif_planes_weight_bytes": (c_int64, [c_int, c_int, c_int]),
     "segmif_planes_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "segmif_conv3x3_planes_bf16x6": (c_int, [POINTER(SegmifConvPlanes), c_void_p]),
+    "segmif_crosspath_gram_blocks": (c_int, [c_int64]),
+    "segmif_crosspath_gram_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "segmif_crosspath_fold_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_float, c_void_p]),
+    "segmif_crosspath_tail_f32": (c_int, [POINTER(SegmifCrossTail), c_void_p]),
     "segmif_upsum_act_nhwc_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                           c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "segmif_confusion_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

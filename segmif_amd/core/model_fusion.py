@@ -115,14 +115,15 @@ class DRDB(nn.Module):
 
     PLANES_CHUNKS = 12  # 64 input + 4 x 32 grown channels; the fifth conv's result never leaves the kernel
 
-    def forward_planes(self, x, planes, out=None):
+    def forward_planes(self, x, planes, out=None, preloaded=False):
         """Inference on pre-split activations (csrc/conv3x3_planes.hip): x (B,H,W,64) fp32 rows view, planes a
         12-chunk ops.Planes scratch buffer.  Dcov1-4 read / append chunk images, Dcov5 also carries the closing
         1x1 conv + ReLU + residual (ref :153-157), so the 224-channel concat is never materialised in fp32."""
         B, H, W, _ = x.shape
         if out is None:
             out = torch.empty((B, H, W, self.in_ch), device=x.device, dtype=torch.float32)
-        planes.load_f32(x, 0)
+        if not preloaded:  # (a producer may already have written x as chunks 0..3, e.g. the CrossPath tail)
+            planes.load_f32(x, 0)
         ch = self.in_ch
         for i in range(1, 6):
             conv = getattr(self, f"Dcov{i}")
@@ -248,6 +249,36 @@ class CrossPath(nn.Module):
                                    ln=(norm.weight, norm.bias, norm.eps), out=o))
         return outs[0], outs[1]
 
+    def forward_tokens_gram(self, x1, x2, seg, out1=None, out2=None, planes1=None, planes2=None, hw=None):
+        """forward_tokens without the 128-wide intermediates (csrc/crosspath.hip): K^T V = Wk (Y^T Y) Wv^T needs only the
+        Gram matrix of each projected half, and each consumer recomputes the 64-wide half of channel_proj it needs.
+        Three Gram passes + two fused tails instead of three GEMMs, three kv reductions and two two-source GEMMs.
+        planes_i: optional ops.Planes receiving out_i as chunks 0..3 (the next DRDB's input, already split)."""
+        C = self.dim
+        cp = [getattr(self, f"channel_proj{i}") for i in (1, 2, 3)]
+        halves = self._pk.get_multi("cp_halves", [m.weight for m in cp],
+                                    lambda: [(m.weight[:C].contiguous(), m.weight[C:].contiguous()) for m in cp])
+        bias = [(m.bias[:C], m.bias[C:]) if m.bias is not None else (None, None) for m in cp]
+        g1 = ops.crosspath_gram(x1, halves[0][0], bias[0][0])   # y1 -> ctx1 (cross_attn2.kv1)
+        g2 = ops.crosspath_gram(x2, halves[1][0], bias[1][0])   # y2 -> ctx2 (cross_attn2.kv2)
+        g3 = ops.crosspath_gram(seg, halves[2][1], bias[2][1])  # u3 -> ctx3 (cross_attn.kv3)
+        B = x1.shape[0]
+        outs = []
+        for i, (x, g, kv, o, pl) in enumerate(((x1, g1, self.cross_attn2.kv1, out1, planes1),
+                                               (x2, g2, self.cross_attn2.kv2, out2, planes2)), start=1):
+            end = getattr(self, f"end_proj{i}")
+            norm = getattr(self, f"norm{i}")
+            weff = torch.empty((B, C, 2 * C), device=x.device, dtype=torch.float32)
+            ops.crosspath_fold(g, kv.weight, end.weight, weff, wofs=0, kofs=0, scale=self.cross_attn2.scale)
+            ops.crosspath_fold(g3, self.cross_attn.kv3.weight, end.weight, weff, wofs=C, kofs=C, scale=self.cross_attn.scale)
+            outs.append(ops.crosspath_tail(seg, x, halves[2][0], bias[2][0], halves[i - 1][1], bias[i - 1][1], weff, end.bias,
+                                           (norm.weight, norm.bias, norm.eps), out=o, planes=pl, hw=hw))
+        return outs[0], outs[1]
+
+    def gram_ok(self):
+        return ops.crosspath_mode() == "gram" and self.cross_attn.kv3.bias is None and self.cross_attn2.kv1.bias is None \
+            and self.cross_attn2.kv2.bias is None
+
     def forward_tokens_train(self, x1, x2, seg):
         """autograd path: heavy contractions in HIP Functions, the 8x8 context softmax and the fold into
         end_proj (tensors of a few KB) in torch autograd."""
@@ -279,7 +310,8 @@ class CrossPath(nn.Module):
         require_device(x1, "CrossPath input")
         if wants_grad(self, x1, x2, segfeature):
             return self.forward_tokens_train(x1.contiguous(), x2.contiguous(), segfeature.contiguous())
-        return self.forward_tokens(x1.contiguous(), x2.contiguous(), segfeature.contiguous())
+        fn = self.forward_tokens_gram if self.gram_ok() else self.forward_tokens
+        return fn(x1.contiguous(), x2.contiguous(), segfeature.contiguous())
 
 
 class FeatureFusionModule(nn.Module):
@@ -288,15 +320,21 @@ class FeatureFusionModule(nn.Module):
         self.cross = CrossPath(dim=dim, reduction=reduction, num_heads=num_heads)
         init_reference_style(self)
 
-    def forward_nhwc(self, x1, x2, seg, out1=None, out2=None):
-        """NHWC in / out; out_i may be channel slices of wider buffers (e.g. a DRDB concat buffer)."""
+    def forward_nhwc(self, x1, x2, seg, out1=None, out2=None, planes1=None, planes2=None):
+        """NHWC in / out; out_i may be channel slices of wider buffers (e.g. a DRDB concat buffer); planes_i: optional
+        ops.Planes that also receive out_i pre-split (inference on the Gram path only)."""
         B, H, W, C = x1.shape
         if wants_grad(self, x1, x2, seg):
             r1, r2 = self.cross.forward_tokens_train(x1.reshape(B, H * W, C), x2.reshape(B, H * W, C),
                                                      seg.reshape(B, H * W, C))
             return r1.view(B, H, W, C), r2.view(B, H, W, C)
         tok = lambda t: None if t is None else t.view(B, H * W, t.shape[-1])
-        r1, r2 = self.cross.forward_tokens(tok(x1), tok(x2), tok(seg), tok(out1), tok(out2))
+        if self.cross.gram_ok():
+            r1, r2 = self.cross.forward_tokens_gram(tok(x1), tok(x2), tok(seg), tok(out1), tok(out2), planes1, planes2, (H, W))
+        else:
+            if planes1 is not None or planes2 is not None:
+                raise RuntimeError("planes outputs need the Gram CrossPath path")
+            r1, r2 = self.cross.forward_tokens(tok(x1), tok(x2), tok(seg), tok(out1), tok(out2))
         return r1.view(B, H, W, C), r2.view(B, H, W, C)
 
     def forward(self, x1, x2, segfeature):
@@ -435,9 +473,11 @@ class Fusion_Network3_ac(nn.Module):
         y1 = self.DRDB1.forward_planes(xs[0], pls[0])
         y2 = self.DRDB2.forward_planes(xs[1], pls[1])
         seg = seg1_fn()
-        x1, x2 = self.ffm.forward_nhwc(y1, y2, seg, out1=xs[0], out2=xs[1])
-        y1 = self.DRDB3.forward_planes(x1, pls[0], out=y1)
-        y2 = self.DRDB4.forward_planes(x2, pls[1], out=y2)
+        pre = self.ffm.cross.gram_ok()  # the CrossPath tail then writes the DRDB inputs pre-split as well
+        x1, x2 = self.ffm.forward_nhwc(y1, y2, seg, out1=xs[0], out2=xs[1], planes1=pls[0] if pre else None,
+                                       planes2=pls[1] if pre else None)
+        y1 = self.DRDB3.forward_planes(x1, pls[0], out=y1, preloaded=pre)
+        y2 = self.DRDB4.forward_planes(x2, pls[1], out=y2, preloaded=pre)
         del pls, xs, x1, x2
         seg = seg2_fn()
         cat = torch.empty((B, H, W, 128), device=dev, dtype=torch.float32)

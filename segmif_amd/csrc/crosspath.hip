@@ -1,0 +1,440 @@
+// CrossPath (core/model_fusion.py:329-361) in inference, restructured around what its linear attention needs.
+//
+// Reference data flow per modality i (tokens x_i, segmentation tokens x_3, all (B, N, 64), N = H*W):
+//     [y_i | u_i] = ReLU(channel_proj_i(x_i))                      three 64 -> 128 Linears          (:351-353)
+//     ctx_3 = softmax((K^T V) d^-1/2),  [K | V] = kv3(u_3)        cross_attn,  8 heads of 8        (:281-286)
+//     ctx_i = softmax((K^T V) d^-1/2),  [K | V] = kv_i(y_i)       cross_attn2                      (:316-326)
+//     out_i = LayerNorm(x_i + end_proj_i([y_3 @ ctx_i | u_i @ ctx_3]))                               (:357-360)
+// Round 1 ran this as 3 GEMMs (channel_proj, 128-wide outputs written to HBM), 3 fused kv-projection + K^T V
+// reductions and 2 two-source GEMMs with the contexts folded into a per-image end_proj weight: 5.1 KB of HBM
+// traffic per pixel per call, HBM-bound at 3-4 TB/s, 19.7 ms per call at 32 x 480 x 640.  Two observations remove
+// most of it:
+//   * K^T V = Wk (Y^T Y) Wv^T: the reduction over N only needs the 64 x 64 Gram matrix of the projected tokens
+//     (Y = y_i or u_3); the kv projection of 9.8 M tokens disappears into two 64 x 64 matrix products per image.
+//   * each consumer needs only ONE 64-wide half of a channel_proj output, so recomputing that half where it is
+//     consumed costs the same FLOPs as producing both halves once — and the 128-wide tensors never exist.
+// crosspath_gram_kernel:  G_b = sum_n relu(W x_n + c) relu(W x_n + c)^T     (reads x: 256 B per pixel)
+// crosspath_tail_kernel:  out = LN(x_i + Weff_b [relu(W3 x_3 + c3) | relu(Wi x_i + ci)] + e)
+//                                                                            (reads x_3, x_i, writes out: 768 B)
+// Both keep a wave's 32 pixels in registers from load to store: with D = A B on v_mfma_f32_32x32x2_f32 the
+// accumulator of one product is, register by register, the K-pair operand of the next (the K order inside a
+// contraction is free as long as both operands agree), so neither the 64-channel intermediate nor its transpose
+// ever goes through LDS.  Weights sit in LDS once per workgroup; there is no barrier in the pixel loop.
+// Accuracy: the Gram sums run in fp32 over 32-pixel runs and in fp64 across runs, like round 1's K^T V.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "segmif_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int WP = 68;    // LDS pitch of a 64-wide weight row (floats): conflict-free ds_read_b128 down the rows
+constexpr int WP2 = 132;  // pitch of a 128-wide row
+constexpr int CP_WAVES = 8;
+constexpr int GRAM_WGS = 8;   // workgroups per image (x 8 waves x 32-pixel tiles)
+constexpr int TAIL_WGS = 8;
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) z[v] = 0.f;
+  return z;
+}
+
+// rows [0, 64) of a row-major (64+, 64) fp32 matrix -> LDS [64][WP]
+__device__ __forceinline__ void stage_w64(const float* __restrict__ w, float* dst, int tid, int nthreads) {
+  for (int u = tid; u < 64 * 16; u += nthreads) {
+    const int row = u >> 4, q = (u & 15) * 4;
+    *reinterpret_cast<f32x4*>(dst + row * WP + q) = *reinterpret_cast<const f32x4*>(w + row * 64 + q);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, double* __restrict__ partial,
+                                                             long long N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                                            // [64][WP]
+  double* Red = reinterpret_cast<double*>(smem + 64 * WP);     // [3][16][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const float* __restrict__ xb = x + (long long)b * N * ldx;
+  stage_w64(w, Ws, tid, 512);
+  __syncthreads();
+  const float bias0 = bias ? bias[r] : 0.f, bias1 = bias ? bias[32 + r] : 0.f;
+
+  double g64[3][16];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) g64[a][v] = 0.0;
+
+  const long long ntiles = (N + 31) / 32;
+  for (long long t = (long long)blockIdx.x * CP_WAVES + wave; t < ntiles; t += (long long)gridDim.x * CP_WAVES) {
+    const long long px = t * 32 + r;
+    const bool ok = px < N;
+    int zo = 0;  // opaque zero in every LDS address below: the weight fragments are loop invariant, and hoisted out of
+    asm volatile("" : "+v"(zo));  // the tile loop they would occupy 64+ registers for the whole kernel
+    f32x4 xa[8];  // x[px][8q + 4h .. +3]
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      xa[q] = ok ? *reinterpret_cast<const f32x4*>(xb + px * ldx + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // stage 1: Y[px][n] = relu(sum_k x[px][k] W[n][k] + c[n]); lane = column n, register v = pixel (v&3)+8(v>>2)+4h
+    f32x16 y[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + zo + r * WP + 8 * q + 4 * h);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + zo + (32 + r) * WP + 8 * q + 4 * h);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        y[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[q][s], b0[s], y[0], 0, 0, 0);
+        y[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[q][s], b1[s], y[1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const bool pv = t * 32 + (v & 3) + 8 * (v >> 2) + 4 * h < N;  // pixels past the end contribute nothing
+      y[0][v] = pv ? fmaxf(y[0][v] + bias0, 0.f) : 0.f;
+      y[1][v] = pv ? fmaxf(y[1][v] + bias1, 0.f) : 0.f;
+    }
+    // stage 2: G[i][j] += sum_px Y[px][i] Y[px][j]: the accumulator registers of stage 1 are the K-pair operands
+    f32x16 g[3] = {zero16(), zero16(), zero16()};
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      g[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y[0][v], y[0][v], g[0], 0, 0, 0);
+      g[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y[0][v], y[1][v], g[1], 0, 0, 0);
+      g[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(y[1][v], y[1][v], g[2], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) g64[a][v] += (double)g[a][v];
+  }
+  // deterministic reduction over the 8 waves, then one partial per workgroup
+  for (int wv = 0; wv < CP_WAVES; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          double* p = Red + (a * 16 + v) * 64 + lane;
+          *p = wv == 0 ? g64[a][v] : *p + g64[a][v];
+        }
+    }
+    __syncthreads();
+  }
+  // canonical layout: tile a in {(0,0), (0,1), (1,1)}, element (i, j) at a*1024 + i*32 + j
+  double* dst = partial + ((long long)b * gridDim.x + blockIdx.x) * 3072;
+  for (int u = tid; u < 3072; u += 512) {
+    const int a = u >> 10, i = (u >> 5) & 31, j = u & 31;
+    const int hh = (i >> 2) & 1, v = (i & 3) + 4 * (i >> 3);
+    dst[u] = Red[(a * 16 + v) * 64 + hh * 32 + j];
+  }
+}
+
+// G = sum of the partial Gram matrices (fp64), ctx_h = softmax_{dim -2}((Wk_h G Wv_h^T) scale), folded into end_proj:
+//   Weff[b][n][kofs + h*8 + i] = sum_j ctx[b][h][i][j] * Wend[n][wofs + h*8 + j]      (as segmif_linattn_fold_f32)
+__global__ __launch_bounds__(1024) void crosspath_fold_kernel(const double* __restrict__ partial, int nblk,
+                                                              const float* __restrict__ wkv, const float* __restrict__ wend,
+                                                              float* __restrict__ weff, int Nout, int ldw, int wofs, int ldweff,
+                                                              int kofs, float scale) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double* G = dsm;            // [64][64]
+  double* T1 = dsm + 4096;    // [64][64]  Wk G
+  double* ctx = T1 + 4096;    // [8][8][8]
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const double* p = partial + (long long)b * nblk * 3072;
+  for (int u = tid; u < 4096; u += 1024) {
+    const int i = u >> 6, j = u & 63;
+    const int ti = i >> 5, tj = j >> 5;
+    const int a = ti == 0 ? tj : 2;                                            // tile (0,0), (0,1), (1,1); (1,0) mirrors (0,1)
+    const int idx = (ti == 1 && tj == 0) ? 1024 + (j & 31) * 32 + (i & 31) : a * 1024 + (i & 31) * 32 + (j & 31);
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += p[(long long)k * 3072 + idx];          // fixed order: deterministic
+    G[u] = s;
+  }
+  __syncthreads();
+  for (int u = tid; u < 4096; u += 1024) {  // T1[c][bq] = sum_a Wk[c][a] G[a][bq]
+    const int c = u >> 6, bq = u & 63;
+    double s = 0.0;
+    for (int a = 0; a < 64; ++a) s += (double)wkv[c * 64 + a] * G[a * 64 + bq];
+    T1[u] = s;
+  }
+  __syncthreads();
+  if (tid < 512) {  // (K^T V)[h][i][j] = sum_b T1[h*8+i][b] Wv[h*8+j][b]
+    const int hh = tid >> 6, i = (tid >> 3) & 7, j = tid & 7;
+    double s = 0.0;
+    for (int q = 0; q < 64; ++q) s += T1[(hh * 8 + i) * 64 + q] * (double)wkv[(64 + hh * 8 + j) * 64 + q];
+    ctx[tid] = s * (double)scale;
+  }
+  __syncthreads();
+  if (tid < 64) {  // one (h, j) column per thread: softmax over i (dim = -2)
+    const int hh = tid >> 3, j = tid & 7;
+    double mx = -1e300;
+    for (int i = 0; i < 8; ++i) mx = fmax(mx, ctx[hh * 64 + i * 8 + j]);
+    double ev[8], sum = 0.0;
+    for (int i = 0; i < 8; ++i) {
+      ev[i] = exp(ctx[hh * 64 + i * 8 + j] - mx);
+      sum += ev[i];
+    }
+    for (int i = 0; i < 8; ++i) ctx[hh * 64 + i * 8 + j] = ev[i] / sum;
+  }
+  __syncthreads();
+  for (int o = tid; o < Nout * 64; o += 1024) {
+    const int n = o >> 6, c = o & 63, hh = c >> 3, i = c & 7;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = fmaf((float)ctx[hh * 64 + i * 8 + j], wend[(long long)n * ldw + wofs + hh * 8 + j], acc);
+    weff[((long long)b * Nout + n) * ldweff + kofs + c] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+struct TailK {
+  const float* x3; const float* xi;
+  const float* w3; const float* b3;   // 64 x 64 rows of channel_proj3 (the y half), its bias
+  const float* wi; const float* bi;   // 64 x 64 rows of channel_proj_i (the u half), its bias
+  const float* weff;                  // [B][64][128] per-image end_proj with both contexts folded in
+  const float* bend; const float* gamma; const float* beta;
+  float* out;
+  unsigned char* planes;              // optional split-bf16 copy of out (conv3x3_planes.hip format) or null
+  long long N;
+  int ld3, ldi, ldo;
+  int W, Hp, Wp, chunks;              // planes geometry (image width, padded dims, chunk images per batch element)
+  float eps;
+};
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+  p1 = pk_bf16(r0, r1);
+  r0 -= __uint_as_float(p1 << 16);
+  r1 -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = pk_bf16(r0, r1);
+}
+
+__global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W3s = smem;                 // [64][WP]
+  float* Wis = W3s + 64 * WP;        // [64][WP]
+  float* Wes = Wis + 64 * WP;        // [64][WP2]
+  float* Cst = Wes + 64 * WP2;       // b3[64] bi[64] bend[64] gamma[64] beta[64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  stage_w64(p.w3, W3s, tid, 512);
+  stage_w64(p.wi, Wis, tid, 512);
+  {
+    const float* we = p.weff + (long long)b * 64 * 128;
+    for (int u = tid; u < 64 * 32; u += 512) {
+      const int row = u >> 5, q = (u & 31) * 4;
+      *reinterpret_cast<f32x4*>(Wes + row * WP2 + q) = *reinterpret_cast<const f32x4*>(we + row * 128 + q);
+    }
+    if (tid < 320) {
+      const int a = tid >> 6, c = tid & 63;
+      const float* src = a == 0 ? p.b3 : a == 1 ? p.bi : a == 2 ? p.bend : a == 3 ? p.gamma : p.beta;
+      Cst[tid] = src ? src[c] : (a == 3 ? 1.f : 0.f);
+    }
+  }
+  __syncthreads();
+  const float* __restrict__ x3b = p.x3 + (long long)b * p.N * p.ld3;
+  const float* __restrict__ xib = p.xi + (long long)b * p.N * p.ldi;
+  float* __restrict__ outb = p.out + (long long)b * p.N * p.ldo;
+
+  const long long ntiles = (p.N + 31) / 32;
+  for (long long t = (long long)blockIdx.x * CP_WAVES + wave; t < ntiles; t += (long long)gridDim.x * CP_WAVES) {
+    const long long px = t * 32 + r;
+    const bool ok = px < p.N;
+    int zo = 0;  // opaque zero in every LDS address below (see the Gram kernel): keeps ~200 registers of loop-invariant
+    asm volatile("" : "+v"(zo));  // weight fragments from being hoisted out of the tile loop
+    f32x4 x3[8], xi[8];  // this pixel's channels 8q + 4h .. +3
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      x3[q] = ok ? *reinterpret_cast<const f32x4*>(x3b + px * p.ld3 + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xi[q] = ok ? *reinterpret_cast<const f32x4*>(xib + px * p.ldi + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // stage 1 (transposed): T[c][px] = relu(sum_k W[c][k] x[px][k] + bias[c]); lane = pixel, register v = channel
+    // (v&3) + 8 (v>>2) + 4h of the 32-row tile.  ty = y_3 half (from x_3), tu = u_i half (from x_i).
+    f32x16 ty[2] = {zero16(), zero16()}, tu[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 a3 = *reinterpret_cast<const f32x4*>(W3s + zo + (nt * 32 + r) * WP + 8 * q + 4 * h);
+        const f32x4 ai = *reinterpret_cast<const f32x4*>(Wis + zo + (nt * 32 + r) * WP + 8 * q + 4 * h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          ty[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[s], x3[q][s], ty[nt], 0, 0, 0);
+          tu[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[s], xi[q][s], tu[nt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 c3 = *reinterpret_cast<const f32x4*>(Cst + zo + nt * 32 + 8 * g + 4 * h);
+        const f32x4 ci = *reinterpret_cast<const f32x4*>(Cst + zo + 64 + nt * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ty[nt][4 * g + e] = fmaxf(ty[nt][4 * g + e] + c3[e], 0.f);
+          tu[nt][4 * g + e] = fmaxf(tu[nt][4 * g + e] + ci[e], 0.f);
+        }
+      }
+    // stage 2: Z[m][px] = sum_c Weff[m][c] T[c][px], c = [y_3 (64) | u_i (64)]: register v of stage 1 IS the K-pair
+    // operand (channel 32nt + 8g + 4h + e for v = 4g + e), the matching Weff entries are one float4 per (nt, g)
+    f32x16 z[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = half * 64 + nt * 32 + 8 * g + 4 * h;
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(Wes + zo + r * WP2 + col);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(Wes + zo + (32 + r) * WP2 + col);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float tv = half == 0 ? ty[nt][4 * g + e] : tu[nt][4 * g + e];
+            z[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], tv, z[0], 0, 0, 0);
+            z[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], tv, z[1], 0, 0, 0);
+          }
+        }
+    // epilogue: + bias + residual x_i (already in registers, same channel layout), LayerNorm over the pixel's 64 channels
+    // (32 in this lane, 32 in lane ^ 32)
+    float o[32];
+    float s1 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 be = *reinterpret_cast<const f32x4*>(Cst + zo + 128 + mt * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = z[mt][4 * g + e] + be[e] + xi[4 * mt + g][e];
+          o[mt * 16 + 4 * g + e] = v;
+          s1 += v;
+        }
+      }
+    s1 += __shfl_xor(s1, 32);
+    const float mean = s1 * (1.0f / 64.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      o[k] -= mean;
+      s2 = fmaf(o[k], o[k], s2);
+    }
+    s2 += __shfl_xor(s2, 32);
+    const float rstd = 1.0f / sqrtf(s2 * (1.0f / 64.0f) + p.eps);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(Cst + zo + 192 + mt * 32 + 8 * g + 4 * h);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(Cst + zo + 256 + mt * 32 + 8 * g + 4 * h);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = o[mt * 16 + 4 * g + e] * rstd * ga[e] + bt[e];
+          o[mt * 16 + 4 * g + e] = v[e];
+        }
+        if (ok) *reinterpret_cast<f32x4*>(outb + px * p.ldo + mt * 32 + 8 * g + 4 * h) = v;
+      }
+    if (p.planes && ok) {  // positions 8h .. 8h+7 of chunk c = channels 16c + {4h..4h+3, 8+4h..8+4h+3}: this lane's o[8c .. 8c+7]
+      const int yy = (int)(px / p.W), xx = (int)(px - (long long)yy * p.W);
+      unsigned char* dst = p.planes + ((((long long)b * p.chunks) * p.Hp + yy + 2) * p.Wp + xx + 2) * 96 + h * 16;
+      const long long cstride = (long long)p.Hp * p.Wp * 96;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        u32x4 p0, p1, p2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t a, bb, cc;
+          split3(o[8 * c + 2 * e], o[8 * c + 2 * e + 1], a, bb, cc);
+          p0[e] = a; p1[e] = bb; p2[e] = cc;
+        }
+        *reinterpret_cast<u32x4*>(dst + c * cstride) = p0;
+        *reinterpret_cast<u32x4*>(dst + c * cstride + 32) = p1;
+        *reinterpret_cast<u32x4*>(dst + c * cstride + 64) = p2;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int segmif_crosspath_gram_blocks(int64_t N) {
+  const long long ntiles = (N + 31) / 32;
+  const long long want = (ntiles + CP_WAVES - 1) / CP_WAVES;
+  return (int)(want < GRAM_WGS ? (want < 1 ? 1 : want) : GRAM_WGS);
+}
+
+extern "C" int segmif_crosspath_gram_f32(const float* x, int ldx, const float* w, const float* bias, double* partial, int B,
+                                         int64_t N, void* stream) {
+  if (!x || !w || !partial || B <= 0 || N <= 0 || ldx < 64 || (ldx & 3)) return SEGMIF_EINVAL;
+  if ((((uintptr_t)x | (uintptr_t)w) & 15) || ((uintptr_t)partial & 7)) return SEGMIF_EINVAL;
+  const int nblk = segmif_crosspath_gram_blocks(N);
+  constexpr size_t smem = (size_t)64 * WP * sizeof(float) + 3 * 16 * 64 * sizeof(double);
+  hipLaunchKernelGGL(crosspath_gram_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(512), smem, (hipStream_t)stream, x, ldx, w,
+                     bias, partial, (long long)N);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_crosspath_fold_f32(const double* partial, int nblk, const float* wkv, const float* wend, float* weff, int B,
+                                         int Nout, int ldw, int wofs, int ldweff, int kofs, float scale, void* stream) {
+  if (!partial || !wkv || !wend || !weff || B <= 0 || nblk <= 0 || Nout <= 0) return SEGMIF_EINVAL;
+  constexpr size_t smem = (size_t)(2 * 4096 + 512) * sizeof(double);
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)crosspath_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(crosspath_fold_kernel, dim3((unsigned)B), dim3(1024), smem, (hipStream_t)stream, partial, nblk, wkv, wend,
+                     weff, Nout, ldw, wofs, ldweff, kofs, scale);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream) {
+  if (!d || !d->x3 || !d->xi || !d->w3 || !d->wi || !d->weff || !d->out || d->B <= 0 || d->N <= 0) return SEGMIF_EINVAL;
+  if (d->ld3 < 64 || d->ldi < 64 || d->ldo < 64 || ((d->ld3 | d->ldi | d->ldo) & 3)) return SEGMIF_EINVAL;
+  if (((uintptr_t)d->x3 | (uintptr_t)d->xi | (uintptr_t)d->w3 | (uintptr_t)d->wi | (uintptr_t)d->weff | (uintptr_t)d->out) & 15)
+    return SEGMIF_EINVAL;
+  TailK k;
+  k.x3 = d->x3; k.xi = d->xi; k.w3 = d->w3; k.b3 = d->b3; k.wi = d->wi; k.bi = d->bi; k.weff = d->weff;
+  k.bend = d->bend; k.gamma = d->ln_gamma; k.beta = d->ln_beta; k.out = d->out;
+  k.planes = (unsigned char*)d->planes_out;
+  k.N = d->N; k.ld3 = d->ld3; k.ldi = d->ldi; k.ldo = d->ldo;
+  k.W = 0; k.Hp = 0; k.Wp = 0; k.chunks = 0;
+  if (k.planes) {
+    if (d->H <= 0 || d->W <= 0 || (int64_t)d->H * d->W != d->N || d->planes_chunks < 4) return SEGMIF_EINVAL;
+    int hp, wp;
+    if (segmif_planes_dims(d->H, d->W, &hp, &wp) != 0) return SEGMIF_EINVAL;
+    k.W = d->W; k.Hp = hp; k.Wp = wp; k.chunks = d->planes_chunks;
+  }
+  k.eps = d->ln_eps;
+  const long long ntiles = (d->N + 31) / 32;
+  long long wgs = (ntiles + CP_WAVES - 1) / CP_WAVES;
+  if (wgs > TAIL_WGS) wgs = TAIL_WGS;
+  constexpr size_t smem = (size_t)(2 * 64 * WP + 64 * WP2 + 320) * sizeof(float);
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)crosspath_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(crosspath_tail_kernel, dim3((unsigned)wgs, (unsigned)d->B), dim3(512), smem, (hipStream_t)stream, k);
+  return (int)hipGetLastError();
+}

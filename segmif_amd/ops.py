@@ -76,6 +76,26 @@ if _conv3x3_mode not in _CONV3X3_MODES:
     raise RuntimeError(f"SEGMIF_CONV3X3 must be one of {_CONV3X3_MODES}, got {_conv3x3_mode!r}")
 
 
+_CROSSPATH_MODES = ("gram", "gemm")
+_crosspath_mode = os.environ.get("SEGMIF_CROSSPATH", "gram")
+if _crosspath_mode not in _CROSSPATH_MODES:
+    raise RuntimeError(f"SEGMIF_CROSSPATH must be one of {_CROSSPATH_MODES}, got {_crosspath_mode!r}")
+
+
+def crosspath_mode():
+    return _crosspath_mode
+
+
+def set_crosspath_mode(mode):
+    """'gram' (default): CrossPath in inference on the Gram-matrix kernels of csrc/crosspath.hip; 'gemm': round 1's
+    channel_proj GEMMs + fused kv reductions + two-source end_proj GEMM."""
+    global _crosspath_mode
+    if mode not in _CROSSPATH_MODES:
+        raise ValueError(f"mode must be one of {_CROSSPATH_MODES}")
+    prev, _crosspath_mode = _crosspath_mode, mode
+    return prev
+
+
 def conv3x3_mode():
     return _conv3x3_mode
 
@@ -496,6 +516,70 @@ def linattn_fold(part, wend, weff, wofs, kofs, scale, heads=8):
                                                    nblk, heads, d, Nout, wend.stride(0), wofs, weff.stride(1), kofs,
                                                    float(scale), _stream()), "segmif_linattn_fold_f32")
     return weff
+
+
+def crosspath_gram(x, w_half, b_half):
+    """Per-image Gram partials of relu(x @ w_half^T + b_half): x (B, N, 64) rows view, w_half a contiguous (64, 64) slice
+    of a channel_proj weight -> (B, nblk, 3072) fp64 (segmif_crosspath_gram_f32)."""
+    _req(x, "x"), _req(w_half, "w_half")
+    if x.dim() != 3 or x.shape[2] != 64 or x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
+        raise RuntimeError("crosspath_gram expects a (B, N, 64) rows view")
+    if tuple(w_half.shape) != (64, 64) or not w_half.is_contiguous():
+        raise RuntimeError("crosspath_gram expects a contiguous (64, 64) weight slice")
+    B, N, _ = x.shape
+    lib = _lib.load()
+    nblk = lib.segmif_crosspath_gram_blocks(N)
+    part = torch.empty((B, nblk, 3072), device=x.device, dtype=torch.float64)
+    _lib.check(lib.segmif_crosspath_gram_f32(x.data_ptr(), x.stride(1), w_half.data_ptr(),
+                                             _req(b_half, "bias").data_ptr() if b_half is not None else None,
+                                             part.data_ptr(), B, N, _stream()), "segmif_crosspath_gram_f32")
+    return part
+
+
+def crosspath_fold(part, wkv, wend, weff, wofs, kofs, scale):
+    """softmax((Wk G Wv^T) * scale) per head from Gram partials, folded into end_proj: writes weff[:, :, kofs:kofs+64]."""
+    B, nblk, _ = part.shape
+    if tuple(_req(wkv, "wkv").shape) != (128, 64) or not wkv.is_contiguous():
+        raise RuntimeError("crosspath_fold expects the raw contiguous (128, 64) kv weight")
+    Nout = wend.shape[0]
+    _lib.check(_lib.load().segmif_crosspath_fold_f32(part.data_ptr(), nblk, wkv.data_ptr(), _req(wend).data_ptr(),
+                                                     _req(weff).data_ptr(), B, Nout, wend.stride(0), wofs, weff.stride(1), kofs,
+                                                     float(scale), _stream()), "segmif_crosspath_fold_f32")
+    return weff
+
+
+def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None, hw=None):
+    """out = LN(x_i + weff_b @ [relu(w3 x_3 + b3) | relu(wi x_i + bi)] + bend): x3, xi (B, N, 64) rows views, w3 / wi
+    contiguous (64, 64) slices, weff (B, 64, 128), ln = (gamma, beta, eps).  planes: optional ops.Planes that receives
+    out as chunks 0..3 (hw = (H, W) with H * W == N)."""
+    for t, nm in ((x3, "x3"), (xi, "xi")):
+        _req(t, nm)
+        if t.dim() != 3 or t.shape[2] != 64 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise RuntimeError(f"crosspath_tail: {nm} must be a (B, N, 64) rows view")
+    B, N, _ = xi.shape
+    if out is None:
+        out = torch.empty((B, N, 64), device=xi.device, dtype=torch.float32)
+    if tuple(out.shape) != (B, N, 64) or out.stride(2) != 1 or out.stride(0) != N * out.stride(1):
+        raise RuntimeError("crosspath_tail: out must be a (B, N, 64) rows view")
+    for t in (w3, wi):
+        if tuple(_req(t, "w").shape) != (64, 64) or not t.is_contiguous():
+            raise RuntimeError("crosspath_tail expects contiguous (64, 64) weight slices")
+    if tuple(_req(weff, "weff").shape) != (B, 64, 128) or not weff.is_contiguous():
+        raise RuntimeError("crosspath_tail expects a contiguous (B, 64, 128) folded weight")
+    d = _lib.SegmifCrossTail()
+    d.x3, d.xi, d.ld3, d.ldi = x3.data_ptr(), xi.data_ptr(), x3.stride(1), xi.stride(1)
+    d.w3, d.wi, d.weff = w3.data_ptr(), wi.data_ptr(), weff.data_ptr()
+    d.b3 = _req(b3).data_ptr() if b3 is not None else None
+    d.bi = _req(bi).data_ptr() if bi is not None else None
+    d.bend = _req(bend).data_ptr() if bend is not None else None
+    d.ln_gamma, d.ln_beta, d.ln_eps = _req(ln[0]).data_ptr(), _req(ln[1]).data_ptr(), float(ln[2])
+    d.out, d.ldo, d.B, d.N = out.data_ptr(), out.stride(1), B, N
+    if planes is not None:
+        if hw is None or hw[0] * hw[1] != N or (planes.B, planes.H, planes.W) != (B, hw[0], hw[1]):
+            raise RuntimeError("crosspath_tail: planes geometry does not match the tokens")
+        d.planes_out, d.H, d.W, d.planes_chunks = planes.data.data_ptr(), hw[0], hw[1], planes.chunks
+    _lib.check(_lib.load().segmif_crosspath_tail_f32(ctypes.byref(d), _stream()), "segmif_crosspath_tail_f32")
+    return out
 
 
 def seg_normalize(x):

@@ -293,6 +293,74 @@ def test_conv3x3_planes_rejects_bad_arguments(ops):
         ops.pack_weight_planes(rnd(48, 64, 3, 3, seed=5).cuda())  # N % 32
 
 
+def _gram_from_partials(part):
+    p = part.double().cpu().sum(dim=1)  # (B, 3072)
+    B = p.shape[0]
+    G = torch.zeros(B, 64, 64, dtype=torch.float64)
+    G[:, :32, :32] = p[:, :1024].view(B, 32, 32)
+    G[:, :32, 32:] = p[:, 1024:2048].view(B, 32, 32)
+    G[:, 32:, :32] = p[:, 1024:2048].view(B, 32, 32).transpose(1, 2)
+    G[:, 32:, 32:] = p[:, 2048:].view(B, 32, 32)
+    return G
+
+
+@pytest.mark.parametrize("N", [1500, 70001])
+def test_crosspath_gram_and_fold(ops, N):
+    """csrc/crosspath.hip: G = sum relu(Wx+b) relu(Wx+b)^T against fp64 (N not a multiple of the 32-pixel tile), then
+    softmax((Wk G Wv^T) scale) folded into end_proj against the fp64 statement of core/model_fusion.py:281-286 and
+    against round 1's kv-projection kernels on the same data."""
+    B = 2
+    x = rnd(B, N, 224, seed=61).cuda()[..., 32:96]  # pitched rows view
+    w, b = rnd(64, 64, seed=62) * 0.3, rnd(64, seed=63) * 0.1
+    wkv, wend = rnd(128, 64, seed=64) * 0.05, rnd(64, 128, seed=65)
+    y = F.relu(x.cpu().double() @ w.double().t() + b.double())
+    part = ops.crosspath_gram(x, w.cuda(), b.cuda())
+    G = _gram_from_partials(part)
+    Gref = torch.einsum("bni,bnj->bij", y, y)
+    assert float((G - Gref).abs().max() / Gref.abs().max()) < 1e-6
+    scale = 8 ** -0.5
+    weff = torch.zeros(B, 64, 128, device="cuda")
+    ops.crosspath_fold(part, wkv.cuda(), wend.cuda(), weff, wofs=64, kofs=64, scale=scale)
+    kv = y @ wkv.double().t()
+    k, v = kv[..., :64].view(B, N, 8, 8), kv[..., 64:].view(B, N, 8, 8)
+    ctx = torch.softmax(torch.einsum("bnhi,bnhj->bhij", k, v) * scale, dim=-2)
+    ref = torch.einsum("bhij,nhj->bnhi", ctx, wend.double()[:, 64:].view(64, 8, 8)).reshape(B, 64, 64)
+    assert err(weff[..., 64:], ref) < TOL
+    assert float(weff[..., :64].abs().max()) == 0.0
+    # round 1's path on the same tokens: projection GEMM, fused kv reduction, fold
+    yf = ops.linear(x, ops.pack_weight(w.cuda()), 64, bias=b.cuda(), act=1)
+    weff1 = torch.zeros(B, 64, 128, device="cuda")
+    ops.linattn_fold(ops.linattn_kvpartial(yf, wkv.cuda()), wend.cuda(), weff1, wofs=64, kofs=64, scale=scale)
+    assert err(weff[..., 64:], weff1[..., 64:].cpu()) < TOL
+
+
+def test_crosspath_tail(ops):
+    """out = LN(x_i + Weff_b [relu(W3 x_3 + b3) | relu(Wi x_i + bi)] + e) against fp64, pitched views, a token count
+    that is not a multiple of 32, plus the planes copy of the result (next DRDB's input)."""
+    B, H, W = 2, 13, 37
+    N = H * W
+    x3 = rnd(B, N, 64, seed=71).cuda()
+    xi = rnd(B, N, 224, seed=72).cuda()[..., :64]
+    w3, b3, wi, bi = rnd(64, 64, seed=73) * 0.3, rnd(64, seed=74) * 0.1, rnd(64, 64, seed=75) * 0.3, rnd(64, seed=76) * 0.1
+    weff, bend = rnd(B, 64, 128, seed=77) * 0.2, rnd(64, seed=78) * 0.1
+    gm, bt = rnd(64, seed=79, lo=0.5, hi=1.5), rnd(64, seed=80)
+    t = torch.cat((F.relu(x3.cpu().double() @ w3.double().t() + b3.double()),
+                   F.relu(xi.cpu().double() @ wi.double().t() + bi.double())), dim=-1)
+    pre = xi.cpu().double() + torch.einsum("bnk,bok->bno", t, weff.double()) + bend.double()
+    ref = F.layer_norm(pre, (64,), gm.double(), bt.double(), 1e-5)
+    wide = torch.zeros(B, N, 128, device="cuda")
+    pl = ops.Planes(B, H, W, 6, "cuda")
+    out = ops.crosspath_tail(x3, xi, w3.cuda(), b3.cuda(), wi.cuda(), bi.cuda(), weff.cuda(), bend.cuda(),
+                             (gm.cuda(), bt.cuda(), 1e-5), out=wide[..., :64], planes=pl, hw=(H, W))
+    assert err(out, ref) < TOL
+    assert float(wide[..., 64:].abs().max()) == 0.0
+    got, raw = _planes_decode(pl, 0, 4)
+    assert float((got.view(B, N, 64) - out.double().cpu()).abs().max()) < 2.0 ** -22 * float(ref.abs().max())
+    mask = torch.ones_like(raw, dtype=torch.bool)
+    mask[:, :4, 2:2 + H, 2:2 + W] = False
+    assert float(raw[:, :4][mask[:, :4]].abs().max()) == 0.0  # border untouched (chunks 4, 5 are uninitialised scratch)
+
+
 def test_drdb_concat_in_place(ops):
     """A conv reading the first Cin channels of a 224-wide buffer and writing its 32 channels in place."""
     B, H, W = 2, 14, 18

@@ -106,6 +106,31 @@ def test_fusion_blocks_vs_reference(fus, golden_dir):
         assert rel(o1, g["ffm_o1"]) < TIGHT and rel(o2, g["ffm_o2"]) < TIGHT
 
 
+def test_crosspath_in_both_modes(net_b1, fus, golden_dir):
+    """FeatureFusionModule / the whole fusion net on the Gram-matrix CrossPath kernels (default) and on round 1's
+    GEMM + kv-reduction path: both against the reference fixtures, and against each other."""
+    from segmif_amd import ops
+    g = load(golden_dir, "fusion_blocks.npz")
+    gp = load(golden_dir, "pair_b1_64x96.npz")
+    ir, vis, mask = (torch.from_numpy(gp[k]).cuda() for k in ("ir", "vis", "mask"))
+    outs = {}
+    prev = ops.crosspath_mode()
+    try:
+        with torch.no_grad():
+            out0, out1 = net_b1.denoise_net.encoder.forward_fusion(mask)
+            for mode in ("gram", "gemm"):
+                ops.set_crosspath_mode(mode)
+                o1, o2 = fus.ffm(*(torch.from_numpy(g[k]).cuda() for k in ("ffm_x1", "ffm_x2", "ffm_seg")))
+                assert rel(o1, g["ffm_o1"]) < TIGHT and rel(o2, g["ffm_o2"]) < TIGHT, mode
+                yf = fus(ir, vis, out0, out1)
+                assert rel(yf, gp["y_fused"]) < 5 * TIGHT, mode
+                outs[mode] = (o1, yf)
+    finally:
+        ops.set_crosspath_mode(prev)
+    assert rel(outs["gram"][0], outs["gemm"][0].cpu()) < 5e-6
+    assert rel(outs["gram"][1], outs["gemm"][1].cpu()) < 5e-6
+
+
 def test_fusion_net_in_all_conv3x3_modes(net_b1, fus, golden_dir):
     """The 3x3 convs have three modes (planes, default: bf16x6 arithmetic with the DRDBs on pre-split
     activations and the fused 1x1 tail; bf16x6: split operands made on the fly; fp32: exact-fp32 MFMA): all
