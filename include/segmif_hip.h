@@ -121,6 +121,21 @@ int64_t segmif_conv3x3_split_weight_bytes(int N, int Cin);
 int segmif_conv3x3_split_pack(const float* packed, int N, int Cin, int ldw, void* out, void* stream);
 
 /*
+ * Dense GEMM with bf16x6 arithmetic (csrc/gemm_split.hip): out = res + act(A W^T + bias), A (M, K) fp32 rows (pitch lda,
+ * 16-byte aligned), K % 32 == 0, any M / N.  `w` is the segmif_gemm_split_pack image of the (N, K) weight (row pitch ldw
+ * floats), segmif_gemm_split_weight_bytes(N, K) bytes.  fp32-class accuracy (three bf16 terms per operand, six products)
+ * at 2.7x the fp32 MFMA rate: the MiT encoder's and SegFormer head's nn.Linear layers
+ * (core/mix_transformer.py:46-53, :94-115; core/segformer_head.py:23).
+ */
+typedef struct SegmifGemmSplit {
+  const float* a; const void* w; const float* bias; const float* res; const float* prelu; float* out;
+  int64_t M; int32_t N, K, lda, ldo, ldr, act;
+} SegmifGemmSplit;
+int64_t segmif_gemm_split_weight_bytes(int N, int K);
+int segmif_gemm_split_pack(const float* w, int N, int K, int ldw, void* out, void* stream);
+int segmif_gemm_split_f32(const SegmifGemmSplit* desc, void* stream);
+
+/*
  * "Planes" activations: the bf16x6 operand split done ONCE by the producer instead of in every
  * consumer (csrc/conv3x3_planes.hip).  A planes buffer holds `chunks` 16-channel chunk images per batch
  * element, [b][chunk][Hp][Wp][plane 0..2][16] bf16 (x = p0 + p1 + p2, 24 significand bits), with

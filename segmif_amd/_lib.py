@@ -42,6 +42,12 @@ class SegmifConvPlanes(ctypes.Structure):
     ]
 
 
+class SegmifGemmSplit(ctypes.Structure):
+    _fields_ = [("a", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("prelu", c_void_p), ("out", c_void_p),
+                ("M", c_int64), ("N", c_int32), ("K", c_int32), ("lda", c_int32), ("ldo", c_int32), ("ldr", c_int32),
+                ("act", c_int32)]
+
+
 class SegmifCrossTail(ctypes.Structure):
     _fields_ = [
         ("x3", c_void_p), ("xi", c_void_p), ("w3", c_void_p), ("b3", c_void_p), ("wi", c_void_p), ("bi", c_void_p),
@@ -63,6 +69,9 @@ SIGNATURES = {
     "segmif_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "segmif_conv3x3_split_weight_bytes": (c_int64, [c_int, c_int]),
     "segmif_conv3x3_split_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "segmif_gemm_split_weight_bytes": (c_int64, [c_int, c_int]),
+    "segmif_gemm_split_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "segmif_gemm_split_f32": (c_int, [POINTER(SegmifGemmSplit), c_void_p]),
     "segmif_planes_dims": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "segmif_planes_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "segmif_planes_zero_border": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -62,14 +62,15 @@ class Mlp(nn.Module):
             y = self.forward_train(x.contiguous(), H, W)
             return y if residual is None else residual + y
         pk = self._pk
-        h = ops.linear(x, pk.get("fc1", self.fc1.weight, ops.pack_weight), self.fc1.out_features,
-                       bias=self.fc1.bias)
+        lm = ops.linear_mode()
+        h = ops.linear_auto(x, pk.get("fc1:" + lm, self.fc1.weight, ops.pack_linear), self.fc1.out_features,
+                            bias=self.fc1.bias)
         h = ops.dwconv3x3_gelu(h, pk.get("dw", self.dwconv.dwconv.weight, ops.pack_dw_weight),
                                self.dwconv.dwconv.bias, H, W)
         if self.drop.p > 0 and self.training:
             h = self.drop(h)
-        y = ops.linear(h, pk.get("fc2", self.fc2.weight, ops.pack_weight), self.fc2.out_features,
-                       bias=self.fc2.bias, res=residual, out=residual)
+        y = ops.linear_auto(h, pk.get("fc2:" + lm, self.fc2.weight, ops.pack_linear), self.fc2.out_features,
+                            bias=self.fc2.bias, res=residual, out=residual)
         if self.drop.p > 0 and self.training:
             y = self.drop(y)
         return y
@@ -114,7 +115,8 @@ class Attention(nn.Module):
             return y if residual is None else residual + y
         B, N, C = x.shape
         pk = self._pk
-        q = ops.linear(x, pk.get("q", self.q.weight, ops.pack_weight), C, bias=self.q.bias)
+        lm = ops.linear_mode()
+        q = ops.linear_auto(x, pk.get("q:" + lm, self.q.weight, ops.pack_linear), C, bias=self.q.bias)
         if self.sr_ratio > 1:
             red = ops.conv2d(x.view(B, H, W, C), pk.get("sr", self.sr.weight, ops.pack_weight), C, self.sr_ratio,
                              stride=self.sr_ratio, bias=self.sr.bias)
@@ -122,10 +124,10 @@ class Attention(nn.Module):
             red = ops.layernorm(red, self.norm.weight, self.norm.bias, self.norm.eps, out=red)
         else:
             red = x
-        kv = ops.linear(red, pk.get("kv", self.kv.weight, ops.pack_weight), 2 * C, bias=self.kv.bias)
+        kv = ops.linear_auto(red, pk.get("kv:" + lm, self.kv.weight, ops.pack_linear), 2 * C, bias=self.kv.bias)
         a = ops.sr_attention(q, kv, self.num_heads, self.scale)
-        return ops.linear(a, pk.get("proj", self.proj.weight, ops.pack_weight), C, bias=self.proj.bias,
-                          res=residual, out=residual)
+        return ops.linear_auto(a, pk.get("proj:" + lm, self.proj.weight, ops.pack_linear), C, bias=self.proj.bias,
+                               res=residual, out=residual)
 
 
 class Block(nn.Module):

@@ -261,58 +261,84 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first (activation plane)
   constexpr int PW[6] = {0, 1, 2, 0, 1, 0};  // (weight plane)
 
+  // A chunk = 9 balanced steps of 12 MFMAs, three per column offset kx, in which the two accumulators alternate:
+  //   A: acc0 += W[1][kx] F1, acc1 += W[0][kx] F1      F_m = halo row R0 + m * DIL at column offset kx * DIL
+  //   B: acc0 += W[2][kx] F2, acc1 += W[1][kx] F2
+  //   C: acc0 += W[0][kx] F0, acc1 += W[2][kx] F3      (the two taps without a partner share a step)
+  // Two consecutive MFMAs never target the same accumulator, so the fragment reads issued between them cost ~6 cycles
+  // each instead of the ~43-cycle re-issue penalty of a dependent pair (the 12-step order had 36 such MFMAs per chunk).
+  // A step's operands are requested while the previous step multiplies.
   auto compute = [&](int slot) {
     const unsigned char* w_lane = Wsb + slot * W3_BYTES + r * PXB + wsw;
     const unsigned char* w1_lane = W1sb + slot * W1_BYTES + r * PXB + wsw;
-    bf16x8 F[3][3], Wr[3][3];  // fragments are requested two steps ahead: one wave per SIMD has no partner to cover LDS latency
-    auto load_f = [&](int st) {
-      const int kx = st >> 2, m = st & 3;
+    bf16x8 Fa[2][3], Fb[3], Fc[2][3], W0[2][3], W1[2][3], W2[3];  // [kx & 1] where a fragment outlives its column
+    auto ld_f = [&](bf16x8* dst, int kx, int m) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        F[st % 3][pl] = *reinterpret_cast<const bf16x8*>(a_lane[kx] + (m * DIL * HW) * PXB + pl * 32);
+      for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const bf16x8*>(a_lane[kx] + (m * DIL * HW) * PXB + pl * 32);
     };
-    auto load_w = [&](int st) {
-      const int kx = st >> 2, m = st & 3;
-      if (m < 3) {
+    auto ld_w = [&](bf16x8* dst, int kx, int ky) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          Wr[m][pl] = *reinterpret_cast<const bf16x8*>(w_lane + ((m * 3 + kx) * 32) * PXB + pl * 32);
-      }
+      for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const bf16x8*>(w_lane + ((ky * 3 + kx) * 32) * PXB + pl * 32);
     };
-    load_f(0);
-    load_w(0);
-    load_f(1);
-    load_w(1);
-#pragma unroll
-    for (int st = 0; st < 12; ++st) {
-      const int m = st & 3;
-      if (st + 2 < 12) {
-        load_f(st + 2);
-        load_w(st + 2);
-      }
+    auto mm = [&](const bf16x8* wa, const bf16x8* fa, const bf16x8* wb, const bf16x8* fb) {
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
-        if (m < 3) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[m][PW[t]], F[st % 3][PA[t]], acc[0], 0, 0, 0);
-        if (m > 0) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[m - 1][PW[t]], F[st % 3][PA[t]], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[PW[t]], fa[PA[t]], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[PW[t]], fb[PA[t]], acc[1], 0, 0, 0);
       }
-      if (FUSE && (st == 5 || st == 6)) {  // centre tap of sub-tile st - 5: the 1x1 conv's input at this pixel
+    };
+    auto fence = [&](int n) {  // one scheduling region per step: every MFMA is followed by one of the next step's reads
+#pragma unroll
+      for (int t = 0; t < n; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    ld_f(Fa[0], 0, 1);
+    ld_w(W1[0], 0, 1);
+    ld_w(W0[0], 0, 0);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int c = kx & 1, n = c ^ 1;
+      // step A (operands loaded during the previous step); request step B's
+      ld_f(Fb, kx, 2);
+      ld_w(W2, kx, 2);
+      mm(W1[c], Fa[c], W0[c], Fa[c]);
+      if (FUSE && kx == 1) {  // centre tap of sub-tile 0: the 1x1 conv's input at this pixel
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           bf16x8 W1f[3];
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) W1f[pl] = *reinterpret_cast<const bf16x8*>(w1_lane + (nt * 32) * PXB + pl * 32);
 #pragma unroll
-          for (int t = 0; t < 6; ++t)
-            acc1[st - 5][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1f[PW[t]], F[st % 3][PA[t]], acc1[st - 5][nt], 0, 0, 0);
+          for (int t = 0; t < 6; ++t) acc1[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1f[PW[t]], Fa[c][PA[t]], acc1[0][nt], 0, 0, 0);
         }
       }
-      // one scheduling region per step: every MFMA is followed by one of the next step's fragment reads
+      fence(FUSE && kx == 1 ? 24 : 12);
+      // step B; request step C's
+      ld_f(Fc[0], kx, 0);
+      ld_f(Fc[1], kx, 3);
+      mm(W2, Fb, W1[c], Fb);
+      if (FUSE && kx == 1) {  // centre tap of sub-tile 1
 #pragma unroll
-      for (int t = 0; t < (FUSE && (st == 5 || st == 6) ? 24 : 12); ++t) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        for (int nt = 0; nt < 2; ++nt) {
+          bf16x8 W1f[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) W1f[pl] = *reinterpret_cast<const bf16x8*>(w1_lane + (nt * 32) * PXB + pl * 32);
+#pragma unroll
+          for (int t = 0; t < 6; ++t) acc1[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1f[PW[t]], Fb[PA[t]], acc1[1][nt], 0, 0, 0);
+        }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      fence(FUSE && kx == 1 ? 24 : 12);
+      // step C; request the next column's step A
+      if (kx < 2) {
+        ld_f(Fa[n], kx + 1, 1);
+        ld_w(W1[n], kx + 1, 1);
+        ld_w(W0[n], kx + 1, 0);
+      }
+      mm(W0[c], Fc[0], W2, Fc[1]);
+      fence(12);
     }
   };
 

@@ -38,7 +38,7 @@ constexpr int WP = 68;    // LDS pitch of a 64-wide weight row (floats): conflic
 constexpr int WP2 = 132;  // pitch of a 128-wide row
 constexpr int CP_WAVES = 8;
 constexpr int GRAM_WGS = 8;   // workgroups per image (x 8 waves x 32-pixel tiles)
-constexpr int TAIL_WGS = 8;
+constexpr int TAIL_WGS = 16;  // 124 VGPRs, 70 KB of LDS: two workgroups per CU
 
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;

@@ -1,0 +1,252 @@
+// Dense GEMM on the bf16 matrix pipe with 3-way split operands ("bf16x6", numerics as in conv3x3_split.hip): the MiT
+// encoder's nn.Linear layers (core/mix_transformer.py:46-53 fc1 / fc2, :94-115 q / kv / proj) and the SegFormer head's,
+//     out = res + act(A W^T + bias),   A: (M, K) fp32 rows with pitch lda,  W: (N, K).
+// Round 1 ran these on the exact-fp32 matrix pipe at 60-85 % of its 157 TFLOP/s; six bf16 products per fp32-equivalent
+// MAC cost 6 x 32 cycles per 32x32x16 block against 8 x 64, i.e. the same fp32-class result at 2.7x the matrix rate.
+//
+// Tile 128 x 128 x 32, 4 waves of 64 x 64.  A stays fp32 in HBM: a thread loads 4 x 16 bytes of the next K step while
+// the current one multiplies, splits them in registers (x = x0 + x1 + x2, bf16 each, the two residual subtractions are
+// exact) and writes the three planes to LDS.  W is split once per parameter version (segmif_gemm_split_pack) into the
+// kernel's LDS image, one contiguous 26 KB block per (column tile, K step) that goes HBM/L2 -> LDS by LDS-DMA.
+// LDS rows are [K half][plane][16 bf16] = 192 bytes + 16 of padding: 13 sixteen-byte slots per row, so the 16 lanes of
+// a ds_read_b128 service group land on 16 distinct slots.  53 KB per workgroup: three workgroups share a CU and cover
+// each other's staging phases.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "igemm_common.h"
+#include "segmif_hip.h"
+
+namespace segmif {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int GBM = 128, GBN = 128, GBK = 32;
+constexpr int GPITCH = 208;                   // bytes per LDS row
+constexpr int GTILE = GBM * GPITCH;           // 26 624 bytes = 26 DMA instructions of 1 KB
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+  p1 = pk_bf16(r0, r1);
+  r0 -= __uint_as_float(p1 << 16);
+  r1 -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = pk_bf16(r0, r1);
+}
+
+struct GemmSplitK {
+  const float* a;
+  const unsigned char* w;  // packed [n-tile][k-step][128][208]
+  const float* bias;
+  const float* res;
+  const float* prelu;
+  float* out;
+  long long M;
+  int N, K, lda, ldo, ldr, act;
+  int ntm, ntn;
+};
+
+__global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+  unsigned char* As = smem_g;
+  unsigned char* Bs = smem_g + GTILE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int bid = blockIdx.x;
+  {  // XCD-aware remap: an XCD owns a contiguous run of tiles; column tiles of one row block are neighbours (A from L2)
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int mt = bid / p.ntn, nt = bid - mt * p.ntn;
+  const long long m0 = (long long)mt * GBM;
+  const int n0 = nt * GBN;
+  const int nks = p.K / GBK;
+
+  // A staging: unit u = tid + 256 j -> row u >> 3, K quarter kq = u & 7 (floats 4 kq .. 4 kq + 3 of the step)
+  const int kq = tid & 7;
+  const float* a_ptr[4];
+  bool a_ok[4];
+  int a_dst[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (tid >> 3) + 32 * j;
+    a_ok[j] = m0 + row < p.M;
+    a_ptr[j] = p.a + (a_ok[j] ? (m0 + row) : 0) * (long long)p.lda + kq * 4;
+    a_dst[j] = row * GPITCH + (kq >> 2) * 96 + (kq & 3) * 8;
+  }
+  f32x4 ra[4];
+  auto gload = [&](int ks) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(a_ptr[j] + ks * GBK);
+  };
+  auto a_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 x = a_ok[j] ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      uint32_t p0a, p1a, p2a, p0b, p1b, p2b;
+      split3(x[0], x[1], p0a, p1a, p2a);
+      split3(x[2], x[3], p0b, p1b, p2b);
+      *reinterpret_cast<u32x2*>(As + a_dst[j]) = u32x2{p0a, p0b};
+      *reinterpret_cast<u32x2*>(As + a_dst[j] + 32) = u32x2{p1a, p1b};
+      *reinterpret_cast<u32x2*>(As + a_dst[j] + 64) = u32x2{p2a, p2b};
+    }
+  };
+  const unsigned char* __restrict__ wt = p.w + (long long)nt * nks * GTILE + lane * 16;
+  auto b_dma = [&](int ks) {
+    const unsigned char* src = wt + (long long)ks * GTILE;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int i = j * 4 + wave;
+      if (i < GTILE / 1024)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(Bs + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  const unsigned char* a_lane = As + (wm * 64 + r) * GPITCH + h * 16;
+  const unsigned char* b_lane = Bs + (wn * 64 + r) * GPITCH + h * 16;
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first
+  constexpr int PW[6] = {0, 1, 2, 0, 1, 0};
+
+  // Single-buffered on purpose: three workgroups per CU cover each other's staging phases.  (An 8-wave, LDS
+  // double-buffered variant with one barrier per step at one workgroup per CU measured 10 % slower over the encoder's
+  // shapes: profiles/r02_gemm_split.txt.)
+  gload(0);
+  a_store();  // before the DMA: beside an LDS-DMA in flight hipcc waits vmcnt(0) at the first use of a plain load's result
+  b_dma(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int ks = 0; ks < nks; ++ks) {
+    const bool more = ks + 1 < nks;
+    if (more) gload(ks + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_lane + i * 32 * GPITCH + s * 96 + pl * 32);
+          fb[i][pl] = *reinterpret_cast<const bf16x8*>(b_lane + i * 32 * GPITCH + s * 96 + pl * 32);
+        }
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[t]], fb[j][PW[t]], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done reading this step's tiles
+    if (more) {
+      a_store();
+      b_dma(ks + 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation (+ residual), 128-byte row segments per half wave ----------------
+  const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + r;
+      if (n >= p.N) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const long long m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float y = acc[i][j][v] + bv;
+        if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
+        else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
+        else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
+        if (p.res) y += p.res[m * p.ldr + n];
+        p.out[m * p.ldo + n] = y;
+      }
+    }
+}
+
+// fp32 [N][ldw] -> [n-tile][k-step][128 rows][K half][plane][16] bf16 with 208-byte rows, zero filled past N / K
+__global__ void gemm_split_pack_kernel(const float* __restrict__ w, int N, int K, int ldw, int nks, long long total,
+                                       uint16_t* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int kk = (int)(idx & 31);
+  long long t = idx >> 5;
+  const int row = (int)(t & 127); t >>= 7;
+  const int ks = (int)(t % nks);
+  const int nt = (int)(t / nks);
+  const int n = nt * GBN + row, k = ks * GBK + kk;
+  const float x = (n < N && k < K) ? w[(long long)n * ldw + k] : 0.f;
+  uint32_t p0, p1, p2;
+  split3(x, 0.f, p0, p1, p2);
+  uint16_t* dst = out + (((long long)nt * nks + ks) * GBM + row) * (GPITCH / 2) + (kk >> 4) * 48 + (kk & 15);
+  dst[0] = (uint16_t)(p0 & 0xffffu);
+  dst[16] = (uint16_t)(p1 & 0xffffu);
+  dst[32] = (uint16_t)(p2 & 0xffffu);
+  if (kk < 8) out[(((long long)nt * nks + ks) * GBM + row) * (GPITCH / 2) + 96 + kk] = 0;  // the 16 padding bytes
+}
+
+}  // namespace
+}  // namespace segmif
+
+using namespace segmif;
+
+extern "C" int64_t segmif_gemm_split_weight_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % GBK) return 0;
+  return (int64_t)((N + GBN - 1) / GBN) * (K / GBK) * GTILE;
+}
+
+extern "C" int segmif_gemm_split_pack(const float* w, int N, int K, int ldw, void* out, void* stream) {
+  if (!w || !out || segmif_gemm_split_weight_bytes(N, K) == 0 || ldw < K) return SEGMIF_EINVAL;
+  const int nks = K / GBK;
+  const long long total = (long long)((N + GBN - 1) / GBN) * nks * GBM * GBK;
+  hipLaunchKernelGGL(gemm_split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, K,
+                     ldw, nks, total, (uint16_t*)out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_gemm_split_f32(const SegmifGemmSplit* d, void* stream) {
+  if (!d || !d->a || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % GBK) return SEGMIF_EINVAL;
+  if (d->lda < d->K || (d->lda & 3) || ((uintptr_t)d->a & 15) || ((uintptr_t)d->w & 15)) return SEGMIF_EINVAL;
+  if (d->act == SEGMIF_ACT_PRELU && !d->prelu) return SEGMIF_EINVAL;
+  if (d->res && d->ldr <= 0) return SEGMIF_EINVAL;
+  GemmSplitK k;
+  k.a = d->a; k.w = (const unsigned char*)d->w; k.bias = d->bias; k.res = d->res; k.prelu = d->prelu; k.out = d->out;
+  k.M = d->M; k.N = d->N; k.K = d->K; k.lda = d->lda; k.ldo = d->ldo; k.ldr = d->ldr; k.act = d->act;
+  k.ntm = (int)((d->M + GBM - 1) / GBM);
+  k.ntn = (d->N + GBN - 1) / GBN;
+  constexpr size_t smem = 2 * (size_t)GTILE;
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)((long long)k.ntm * k.ntn)), dim3(256), smem, (hipStream_t)stream, k);
+  return (int)hipGetLastError();
+}

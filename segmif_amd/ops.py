@@ -227,6 +227,74 @@ def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None,
         go()
 
 
+class GemmSplitWeight:
+    """segmif_gemm_split_pack image of an (N, K) Linear weight (bf16x6 dense GEMM, csrc/gemm_split.hip)."""
+    __slots__ = ("data", "N", "K")
+
+    def __init__(self, data, N, K):
+        self.data, self.N, self.K = data, N, K
+
+
+_LINEAR_MODES = ("bf16x6", "fp32")
+_linear_mode = os.environ.get("SEGMIF_LINEAR", "bf16x6")
+if _linear_mode not in _LINEAR_MODES:
+    raise RuntimeError(f"SEGMIF_LINEAR must be one of {_LINEAR_MODES}, got {_linear_mode!r}")
+GEMM_SPLIT_MIN_ROWS = 2048  # below this the 128-row tiles leave the chip idle; the fp32 tiles with split-K win
+
+
+def linear_mode():
+    return _linear_mode
+
+
+def set_linear_mode(mode):
+    """'bf16x6' (default): nn.Linear layers with K % 32 == 0 run on the bf16 matrix pipe with 3-way split operands
+    (fp32-class accuracy); 'fp32': exact-fp32 MFMA."""
+    global _linear_mode
+    if mode not in _LINEAR_MODES:
+        raise ValueError(f"mode must be one of {_LINEAR_MODES}")
+    prev, _linear_mode = _linear_mode, mode
+    return prev
+
+
+def pack_linear(w):
+    """(N, K) Linear weight -> (fp32 packing, GemmSplitWeight or None).  Cache entries must be keyed on linear_mode()."""
+    packed = pack_weight(w)
+    N, K = w.shape[0], w.shape[1]
+    if _linear_mode != "bf16x6" or w.dim() != 2 or K % 32 or N < 32:
+        return packed, None
+    lib = _lib.load()
+    out = torch.empty((lib.segmif_gemm_split_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.segmif_gemm_split_pack(w.detach().contiguous().data_ptr(), N, K, K, out.data_ptr(), _stream()),
+               "segmif_gemm_split_pack")
+    return packed, GemmSplitWeight(out, N, K)
+
+
+def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):
+    """out = res + act(x @ W^T + bias) with packs = pack_linear(W): the bf16x6 GEMM for tall problems, the fp32 tiles
+    (with split-K) for short ones."""
+    packed, split = packs
+    rows, K, lda = rows_view(x, "x")
+    # (N < 128 would leave half of the 128-column tile idle: measured slower than the fp32 64-column tiles)
+    if split is None or rows < GEMM_SPLIT_MIN_ROWS or N < 128 or lda % 4 or x.data_ptr() % 16:
+        return linear(x, packed, N, bias=bias, act=act, res=res, out=out)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+    orow, oc, ldo = rows_view(out, "out")
+    if orow != rows or oc != N or (split.N, split.K) != (N, K):
+        raise RuntimeError(f"linear_auto: shapes do not fit (rows {rows}/{orow}, N {N}/{oc}, weight {split.N}x{split.K})")
+    d = _lib.SegmifGemmSplit()
+    d.a, d.w, d.out = x.data_ptr(), split.data.data_ptr(), out.data_ptr()
+    d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
+    d.M, d.N, d.K, d.lda, d.ldo, d.act = rows, N, K, lda, ldo, act
+    if res is not None:
+        rrow, rc, ldr = rows_view(res, "res")
+        if rc != N or rrow != rows:
+            raise RuntimeError("residual shape mismatch")
+        d.res, d.ldr = res.data_ptr(), ldr
+    _lib.check(_lib.load().segmif_gemm_split_f32(ctypes.byref(d), _stream()), "segmif_gemm_split_f32")
+    return out
+
+
 class LaunchTimer:
     """Brackets tagged kernel launches with HIP events on the launch stream (torch's current
     stream) so bench.py can report the dominant kernel's average duration live."""

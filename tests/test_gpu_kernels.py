@@ -191,6 +191,37 @@ def test_conv3x3_split_rejects_bad_geometry(ops):
         ops.pack_weight_split(rnd(32, 24, 3, 3, seed=5).cuda())  # Cin % 16
 
 
+@pytest.mark.parametrize("M,N,K", [(4099, 320, 320), (2500, 1280, 320), (3000, 128, 256), (2048, 160, 64), (5000, 512, 2048)])
+def test_gemm_split_bf16x6(ops, M, N, K):
+    """csrc/gemm_split.hip: the encoder's Linear layers on the bf16 matrix pipe with 3-way split operands — same fp64
+    yardstick and tolerance as the exact-fp32 MFMA GEMM and an error within 3x of it (the dropped cross terms are
+    2^-23 of a product, one fp32 rounding; against heavy-tailed operands spanning 1e-4 .. 1e2 they show up at 2-2.5x the
+    fp32 chain's own rounding, i.e. 5e-7 of the output scale); bias, GELU / ReLU, residual, ragged M / N, pitched views."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.rand(M, K, generator=g) * 2 - 1) * 10.0 ** (torch.rand(M, K, generator=g) * 6 - 4)
+    w, b, r = rnd(N, K, seed=2) * 0.1, rnd(N, seed=3), rnd(M, N, seed=4)
+    ref_lin = x.double() @ w.double().t() + b.double()
+    packs = ops.pack_linear(w.cuda())
+    assert packs[1] is not None
+    wide = torch.zeros(M, K + 32, device="cuda")
+    wide[:, :K] = x.cuda()
+    xv = wide[:, :K]  # pitched rows view
+    for act, use_res in ((0, False), (3, True), (1, False)):
+        ref = act_ref(ref_lin, act)
+        if use_res:
+            ref = ref + r.double()
+        y = ops.linear_auto(xv, packs, N, bias=b.cuda(), act=act, res=r.cuda() if use_res else None)
+        y32 = ops.linear(xv, packs[0], N, bias=b.cuda(), act=act, res=r.cuda() if use_res else None)
+        e, e32 = err(y, ref), err(y32, ref)
+        assert e < TOL and e <= 3.0 * e32 + 1e-7, (act, e, e32)
+    # elementwise, relative to each output's conditioning
+    cond = x.double().abs() @ w.double().abs().t() + b.double().abs()
+    y = ops.linear_auto(xv, packs, N, bias=b.cuda())
+    assert float(((y.double().cpu() - ref_lin).abs() / cond).max()) < 1e-6
+    # short problems keep the fp32 tiles (split-K); unsupported K falls back at pack time
+    assert ops.pack_linear(rnd(64, 48, seed=9).cuda())[1] is None
+
+
 def _sigma16():
     return torch.tensor([(j & 3) + 4 * (j >> 3) + 8 * ((j >> 2) & 1) for j in range(16)])
 
