@@ -387,6 +387,28 @@ int segmif_bn_bwd_apply_f32(const float* x, const float* dz, const float* mu, co
  * taps11 is a HOST pointer to the 11 window weights. */
 int segmif_gauss_blur11_f32(const float* x, float* y, int planes, int H, int W, const float* taps11, void* stream);
 
+/* Fusion losses of train_fusion as fused kernels (csrc/losses.hip), single-channel images of n = planes*H*W pixels:
+ *  Fusionloss_grad3 (core/loss.py:506-517) = MSE + 1.1 (1 - SSIM), SSIM of pytorch_ssim/__init__.py:19-43:
+ *    segmif_ssim_prep_f32   stack5 = [gen, mask, gen^2, mask^2, gen*mask]  (then segmif_gauss_blur11_f32 over 5*planes)
+ *    segmif_ssim_map_f32    sums2 = {sum of the SSIM map, sum (mask - gen)^2} (partial: 2*segmif_loss_blocks(n) doubles)
+ *                           and, if der3 != NULL, the planes dS/dmu1, dS/dE[gen^2], dS/dE[gen*mask] for the backward
+ *    segmif_ssim_grad_f32   grad = upstream * (coef_ssim * (B0 + 2 gen B1 + mask B2) + coef_mse * (gen - mask)), B = the
+ *                           blurred der3 planes (the Gaussian window is symmetric: its adjoint is the same blur)
+ *  Fusionloss3 (core/loss.py:459-476, Sobelxy :634-650) = L1(mask, gen) + L1(Sobel(mask), Sobel(gen)):
+ *    segmif_sobel_l1_f32    sums2 = {sum |mask - gen|, sum |S(mask) - S(gen)|}; pxy2 (optional) = the backward's two planes
+ *    segmif_sobel_l1_bwd_f32  grad = upstream / n * (sign(gen - mask) + adjoint Sobel stencils of pxy2)
+ * `upstream` is a device scalar (d loss / d this term). */
+int segmif_loss_blocks(int64_t n);
+int segmif_ssim_prep_f32(const float* gen, const float* mask, float* stack5, int64_t n, void* stream);
+int segmif_ssim_map_f32(const float* blurred5, const float* gen, const float* mask, float* der3, double* partial, double* sums2,
+                        int64_t n, void* stream);
+int segmif_ssim_grad_f32(const float* blurred_der3, const float* gen, const float* mask, float* grad, int64_t n,
+                         const float* upstream, float coef_ssim, float coef_mse, void* stream);
+int segmif_sobel_l1_f32(const float* gen, const float* mask, float* pxy2, double* partial, double* sums2, int planes, int H, int W,
+                        void* stream);
+int segmif_sobel_l1_bwd_f32(const float* pxy2, const float* gen, const float* mask, float* grad, int planes, int H, int W,
+                            const float* upstream, void* stream);
+
 /* multi-tensor AdamW (utils/optimizer.py:6 -> torch.optim.AdamW arithmetic). table: device array of
  * {float* p; const float* g; float* m; float* v; int64 n; float lr; float wd;} entries
  * (segmif_adamw_entry_bytes() each); chunk_entry / chunk_off map each block to (entry, offset).

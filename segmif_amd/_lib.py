@@ -125,6 +125,12 @@ SIGNATURES = {
     "segmif_bn_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "segmif_bn_bwd_apply_f32": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_void_p]),
     "segmif_gauss_blur11_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p]),
+    "segmif_loss_blocks": (c_int, [c_int64]),
+    "segmif_ssim_prep_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "segmif_ssim_map_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "segmif_ssim_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p]),
+    "segmif_sobel_l1_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "segmif_sobel_l1_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "segmif_adamw_entry_bytes": (c_int, []),
     "segmif_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
                                c_void_p]),

@@ -631,6 +631,79 @@ class GaussBlurFn(torch.autograd.Function):
         return GaussBlurFn._run(g)
 
 
+def _blur_planes(x, planes, H, W):
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().segmif_gauss_blur11_f32(x.data_ptr(), y.data_ptr(), planes, H, W, GaussBlurFn.taps(), _stream()),
+               "segmif_gauss_blur11_f32")
+    return y
+
+
+class FusionLossGrad3Fn(torch.autograd.Function):
+    """MSE(mask, gen) + 1.1 (1 - SSIM(gen, mask)) on single-channel images (core/loss.py:506-517), csrc/losses.hip:
+    product planes -> separable Gaussian blur -> SSIM map + reductions (+ derivative planes); backward = blur of the
+    three derivative planes + one assembly kernel.  No gradient w.r.t. the mask (the reference's is a data tensor)."""
+
+    @staticmethod
+    def forward(ctx, gen, mask):
+        lib = _lib.load()
+        g, m = gen.contiguous(), mask.contiguous()
+        B, C, H, W = g.shape
+        n = g.numel()
+        stack = torch.empty((5, n), device=g.device, dtype=torch.float32)
+        _lib.check(lib.segmif_ssim_prep_f32(g.data_ptr(), m.data_ptr(), stack.data_ptr(), n, _stream()), "segmif_ssim_prep_f32")
+        bl = _blur_planes(stack, 5 * B * C, H, W)
+        need = ctx.needs_input_grad[0]
+        der = torch.empty((3, n), device=g.device, dtype=torch.float32) if need else None
+        part = torch.empty((2 * lib.segmif_loss_blocks(n),), device=g.device, dtype=torch.float64)
+        sums = torch.empty((2,), device=g.device, dtype=torch.float64)
+        _lib.check(lib.segmif_ssim_map_f32(bl.data_ptr(), g.data_ptr(), m.data_ptr(), der.data_ptr() if need else None,
+                                           part.data_ptr(), sums.data_ptr(), n, _stream()), "segmif_ssim_map_f32")
+        ctx.save_for_backward(g, m, der)
+        ctx.geom = (B * C, H, W, n)
+        return (sums[1] / n + 1.1 * (1.0 - sums[0] / n)).float()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        g, m, der = ctx.saved_tensors
+        planes, H, W, n = ctx.geom
+        bd = _blur_planes(der, 3 * planes, H, W)
+        grad = torch.empty_like(g)
+        up = dloss.reshape(1).float().contiguous()
+        _lib.check(_lib.load().segmif_ssim_grad_f32(bd.data_ptr(), g.data_ptr(), m.data_ptr(), grad.data_ptr(), n, up.data_ptr(),
+                                                    -1.1 / n, 2.0 / n, _stream()), "segmif_ssim_grad_f32")
+        return grad, None
+
+
+class FusionLoss3Fn(torch.autograd.Function):
+    """L1(mask, gen) + L1(Sobelxy(mask), Sobelxy(gen)) (core/loss.py:459-476, :634-650), csrc/losses.hip."""
+
+    @staticmethod
+    def forward(ctx, gen, mask):
+        lib = _lib.load()
+        g, m = gen.contiguous(), mask.contiguous()
+        B, C, H, W = g.shape
+        n = g.numel()
+        need = ctx.needs_input_grad[0]
+        pxy = torch.empty((2, n), device=g.device, dtype=torch.float32) if need else None
+        part = torch.empty((2 * lib.segmif_loss_blocks(n),), device=g.device, dtype=torch.float64)
+        sums = torch.empty((2,), device=g.device, dtype=torch.float64)
+        _lib.check(lib.segmif_sobel_l1_f32(g.data_ptr(), m.data_ptr(), pxy.data_ptr() if need else None, part.data_ptr(),
+                                           sums.data_ptr(), B * C, H, W, _stream()), "segmif_sobel_l1_f32")
+        ctx.save_for_backward(g, m, pxy)
+        ctx.geom = (B * C, H, W)
+        return ((sums[0] + sums[1]) / n).float()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        g, m, pxy = ctx.saved_tensors
+        planes, H, W = ctx.geom
+        grad = torch.empty_like(g)
+        up = dloss.reshape(1).float().contiguous()
+        _lib.check(_lib.load().segmif_sobel_l1_bwd_f32(pxy.data_ptr(), g.data_ptr(), m.data_ptr(), grad.data_ptr(), planes, H, W,
+                                                       up.data_ptr(), _stream()), "segmif_sobel_l1_bwd_f32")
+        return grad, None
+
+
 # functional front-ends ------------------------------------------------------------------------------
 def linear(x, w, b=None, act=ACT_NONE, slope=None):
     return LinearFn.apply(x, w, b, act, slope)

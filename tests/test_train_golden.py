@@ -125,6 +125,19 @@ def test_losses_on_the_hip_path_match_the_reference():
         assert float((gv.cpu() - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max())), name
     s = losses.ssim(gen, mask[:, :1])
     assert abs(float(s) - float(g["ssim"])) < 2e-6
+    # odd sizes (partial 32 x 32 blur tiles, Sobel at every border) against the reference-pinned torch formulation in fp64
+    gg = torch.Generator().manual_seed(3)
+    gen2 = (torch.rand(3, 1, 67, 45, generator=gg) * 1.2 - 0.1)
+    mask2 = torch.rand(3, 3, 67, 45, generator=gg)
+    up = 0.37
+    for fn in (losses.fusion_loss_grad3, losses.fusion_loss3):
+        a = gen2.double().requires_grad_(True)
+        (fn(a, mask2.double()) * up).backward()
+        b = gen2.cuda().requires_grad_(True)
+        v = fn(b, mask2.cuda())
+        (v * up).backward()
+        assert abs(float(v) - float(fn(gen2.double(), mask2.double()))) < 5e-6
+        assert float((b.grad.cpu().double() - a.grad).abs().max()) < 2e-6 * float(a.grad.abs().max()) + 1e-9, fn.__name__
 
 
 def _check_params(module, g, lr_scale):
