@@ -282,3 +282,66 @@ def test_grad_allreducer_over_the_hip_backward_on_rccl():
             net._loss(x, y, crit).backward()
     finally:
         tdist.destroy_process_group()
+
+
+@gpu
+def test_config2_full_size_train_steps_property_run():
+    """BASELINE config[2] at its real size (mit_b3, 480x640): one segmentation step at batch 8 and one fusion step at
+    batch 2 (the oracle's CPU fusion forward bounds the batch here) — the losses the steps report equal the losses of the
+    CPU oracle's forward on the same weights and inputs, every gradient is finite, parameters move."""
+    need_gpu()
+    import torch.nn.functional as F
+    import detweights as dw
+    import segmif_oracle as so
+    from segmif_amd import losses
+    from segmif_amd.core import Fusion_Network3_ac, Network3
+    from segmif_amd.train import FusionTrainer, seg_train_step
+    from segmif_amd.utils.optimizer import PolyWarmupAdamW, PolyWarmupAdamW_seg
+    H, W = 480, 640
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+    net = Network3("mit_b3", 9, pretrained=None)
+    sd_seg = dw.load_det_weights(net, seed=0)
+    net = net.cuda().eval()
+    # --- segmentation step, batch 8 ---
+    B = 8
+    x = dw.det_input("c2_x", (B, 3, H, W))
+    y = dw.det_labels("c2_y", (B, H, W), 9)
+    y[:, :7, :] = 255
+    with torch.no_grad():
+        ref = F.cross_entropy(F.interpolate(so.network3_forward(sd_seg, x, "mit_b3"), size=[H, W], mode="bilinear",
+                                            align_corners=False), y, ignore_index=255)
+    groups = net.denoise_net.get_param_groups()
+    opt = PolyWarmupAdamW_seg([{"params": groups[0], "lr": 8e-5, "weight_decay": 0.01},
+                               {"params": groups[1], "lr": 8e-5, "weight_decay": 0.0},
+                               {"params": groups[2], "lr": 8e-4, "weight_decay": 0.01}], iter_curr=10000, **SEG_KW)
+    before = net.denoise_net.decoder.linear_pred.weight.detach().clone()
+    loss = seg_train_step(net, opt, x.cuda(), y.cuda(), crit)
+    assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref)), (float(loss), float(ref))
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    assert float((net.denoise_net.decoder.linear_pred.weight - before).abs().max()) > 0
+    # --- fusion step, batch 2 (fresh segmentation weights: the step above moved them) ---
+    dw.load_det_weights(net, seed=0)
+    fus = Fusion_Network3_ac()
+    sd_fus = dw.load_det_weights(fus, seed=0)
+    fus = fus.cuda().eval()
+    B, iter_ = 2, 2
+    ir3 = dw.det_input("c2_ir", (B, 1, H, W)).repeat(1, 3, 1, 1)
+    vis3 = dw.det_input("c2_vis", (B, 3, H, W))
+    mask3 = dw.det_input("c2_mask", (B, 1, H, W)).repeat(1, 3, 1, 1)
+    labels = dw.det_labels("c2_lab", (B, H, W), 9)
+    with torch.no_grad():
+        vis = so.rgb2ycrcb(vis3)
+        o0, o1 = so.mit_forward_fusion(sd_seg, "denoise_net.encoder.", mask3, "mit_b3")
+        fusion = so.fusion_network3_ac(sd_fus, ir3[:, :1], vis, o0, o1)
+        l1 = losses.fusion_loss_grad3(fusion, mask3)
+        rgb = so.ycrcb2rgb(torch.cat((fusion, vis[:, 1:2], vis[:, 2:3]), dim=1))
+        l2 = F.cross_entropy(F.interpolate(so.network3_forward(sd_seg, rgb, "mit_b3"), size=[H, W], mode="bilinear",
+                                           align_corners=False), labels)
+        ref_total = (0.4 / iter_) * l1 + 0.8 * l2
+    opt2 = PolyWarmupAdamW([{"params": fus.parameters(), "lr": 8e-5 / iter_, "weight_decay": 0.01}], **fus_kw(iter_))
+    tr = FusionTrainer(net, fus, opt2, crit, iter_=iter_)
+    total = tr.step(ir3.cuda(), vis3.cuda(), mask3.cuda(), labels.cuda())
+    assert abs(tr.history[0][0] - float(l1)) < 2e-4 * abs(float(l1)), (tr.history[0][0], float(l1))
+    assert abs(tr.history[0][1] - float(l2)) < 2e-4 * abs(float(l2)), (tr.history[0][1], float(l2))
+    assert abs(float(total) - float(ref_total)) < 2e-4 * abs(float(ref_total))
+    assert all(torch.isfinite(p.grad).all() for p in fus.parameters() if p.grad is not None)
