@@ -330,6 +330,9 @@ int segmif_confusion_i32(const int32_t* pred, const int64_t* label, int64_t* con
  * uint8(255.0 * ((a - min) / (max - min))) in float64, written NHWC (the reference's transpose(0,2,3,1));
  * x is (B, C, HW) fp32 already clamped to [0, 1]; minmax: 2 int32 of scratch (returns {min, max}) */
 int segmif_quantize_u8(const float* x_nchw, uint8_t* out_nhwc, int32_t* minmax, int B, int C, int64_t HW, void* stream);
+/* the way back, as test_segmentation.py's loader reads those PNGs (TaskFusion_dataset2.py:84-88): NHWC uint8 ->
+ * NCHW fp32 = float(u) / 255 with an IEEE division (PairForward(uint8_roundtrip=True)) */
+int segmif_dequantize_u8(const uint8_t* in_nhwc, float* out_nchw, int B, int C, int64_t HW, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Training path (backward of the ops above; autograd in the reference: loss.backward() at

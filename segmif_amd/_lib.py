@@ -88,6 +88,7 @@ SIGNATURES = {
                                           c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "segmif_confusion_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "segmif_quantize_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "segmif_dequantize_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "segmif_wgrad_workspace_size": (c_int64, [c_int64, c_int, c_int]),
     "segmif_wgrad_f32": (c_int, [POINTER(SegmifIgemm), c_void_p, c_int, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                  c_void_p, c_int, c_void_p]),

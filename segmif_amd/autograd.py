@@ -252,6 +252,8 @@ class LayerNormFn(torch.autograd.Function):
         _lib.check(lib.segmif_layernorm_bwd_f32(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
                                                 partial.data_ptr(), rows, C, ldx, C, C, float(ctx.eps), _stream()),
                    "segmif_layernorm_bwd_f32")
+        if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            return dx, None, None, None
         gb = colsum(partial)
         return dx, gb[:C], gb[C:], None
 
@@ -280,9 +282,11 @@ class DwconvGeluFn(torch.autograd.Function):
         _lib.check(lib.segmif_dwconv3x3_gelu_bwd_f32(h.data_ptr(), w9.data_ptr(), b.data_ptr(), dy.data_ptr(),
                                                      dz.data_ptr(), partial.data_ptr(), B, H, W, C, _stream()),
                    "segmif_dwconv3x3_gelu_bwd_f32")
-        sums = colsum(partial).view(10, C)
-        dw = sums[:9].t().reshape(C, 1, 3, 3)
-        db = sums[9]
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            sums = colsum(partial).view(10, C)
+            dw = sums[:9].t().reshape(C, 1, 3, 3)
+            db = sums[9]
         dh = None
         if ctx.needs_input_grad[0]:
             dh = torch.empty_like(h)

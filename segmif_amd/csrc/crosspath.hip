@@ -12,15 +12,19 @@
 //   * K^T V = Wk (Y^T Y) Wv^T: the reduction over N only needs the 64 x 64 Gram matrix of the projected tokens
 //     (Y = y_i or u_3); the kv projection of 9.8 M tokens disappears into two 64 x 64 matrix products per image.
 //   * each consumer needs only ONE 64-wide half of a channel_proj output, so recomputing that half where it is
-//     consumed costs the same FLOPs as producing both halves once — and the 128-wide tensors never exist.
+//     consumed costs the same FLOPs as producing both halves once - and the 128-wide tensors never exist.
 // crosspath_gram_kernel:  G_b = sum_n relu(W x_n + c) relu(W x_n + c)^T     (reads x: 256 B per pixel)
 // crosspath_tail_kernel:  out = LN(x_i + Weff_b [relu(W3 x_3 + c3) | relu(Wi x_i + ci)] + e)
 //                                                                            (reads x_3, x_i, writes out: 768 B)
-// Both keep a wave's 32 pixels in registers from load to store: with D = A B on v_mfma_f32_32x32x2_f32 the
-// accumulator of one product is, register by register, the K-pair operand of the next (the K order inside a
-// contraction is free as long as both operands agree), so neither the 64-channel intermediate nor its transpose
-// ever goes through LDS.  Weights sit in LDS once per workgroup; there is no barrier in the pixel loop.
-// Accuracy: the Gram sums run in fp32 over 32-pixel runs and in fp64 across runs, like round 1's K^T V.
+// Both keep a wave's 32 pixels in registers from load to store.  Arithmetic: every fp32 operand is split in registers
+// into three bf16 planes (x = x0 + x1 + x2, round-to-nearest at each step) and every product runs as six
+// v_mfma_f32_32x32x16_bf16 (the same fp32-class scheme as csrc/conv3x3_planes.hip: 2.65x the fp32 matrix pipe's rate;
+// the first version of these kernels sat at 70 % of that pipe: profiles/r02_bench_kernel_stats_v3.txt).  The accumulator
+// of one product is, register by register, the K operand of the next: a lane holds 16 rows of a 32 x 32 result, rows
+// (v&3) + 8(v>>2) + 4h, and registers 8s .. 8s+7 are exactly the 8 K-slots a lane feeds to one MFMA - the K order inside
+// a contraction is free as long as both operands agree, so the weights are staged in LDS in that order and neither the
+// 64-channel intermediate nor its transpose ever goes through LDS.  There is no barrier in the pixel loop.
+// Accuracy: the Gram sums run in fp32 over 32-pixel runs (inside the MFMA accumulator) and in fp64 across runs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,15 +34,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int WP = 68;    // LDS pitch of a 64-wide weight row (floats): conflict-free ds_read_b128 down the rows
-constexpr int WP2 = 132;  // pitch of a 128-wide row
+// LDS image of a weight matrix with 64 (or 128) input columns: row n = [plane 0..2][position 0..63(127)] bf16 + 16 B.
+// Position 16 s + 8 h + j holds column 16 s + 4 h + (j & 3) + 8 (j >> 2): the 8 positions (s, h, .) are what lane-half h
+// feeds to the MFMA of K-step s, and the columns are the ones that lane-half holds - both for pixels loaded as
+// x[px][8q + 4h .. +3] (q = 2s, 2s+1) and for accumulator registers 8s' .. 8s'+7 of a 32-row tile (s = 2 tile + s').
+// Pitch = 16 B mod 128 B: ds_read_b128 down the rows is conflict free.
+constexpr int WPB = 3 * 128 + 16;    // bytes per row, 64 columns
+constexpr int WPB2 = 3 * 256 + 16;   // 128 columns
 constexpr int CP_WAVES = 8;
 constexpr int GRAM_WGS = 8;   // workgroups per image (x 8 waves x 32-pixel tiles)
-constexpr int TAIL_WGS = 16;  // 124 VGPRs, 70 KB of LDS: two workgroups per CU
+constexpr int PX6[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first: plane of the first operand ...
+constexpr int PY6[6] = {0, 1, 2, 0, 1, 0};  // ... and of the second
 
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
@@ -47,26 +58,85 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
-// rows [0, 64) of a row-major (64+, 64) fp32 matrix -> LDS [64][WP]
-__device__ __forceinline__ void stage_w64(const float* __restrict__ w, float* dst, int tid, int nthreads) {
-  for (int u = tid; u < 64 * 16; u += nthreads) {
-    const int row = u >> 4, q = (u & 15) * 4;
-    *reinterpret_cast<f32x4*>(dst + row * WP + q) = *reinterpret_cast<const f32x4*>(w + row * 64 + q);
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+  p1 = pk_bf16(r0, r1);
+  r0 -= __uint_as_float(p1 << 16);
+  r1 -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = pk_bf16(r0, r1);
+}
+
+// 8 consecutive K-slots of a lane -> one MFMA operand per plane
+struct Op3 {
+  u32x4 p[3];
+};
+__device__ __forceinline__ Op3 split8(const f32x4 lo, const f32x4 hi) {
+  Op3 o;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    uint32_t a, b, c;
+    split3(lo[2 * e], lo[2 * e + 1], a, b, c);
+    o.p[0][e] = a; o.p[1][e] = b; o.p[2][e] = c;
+    split3(hi[2 * e], hi[2 * e + 1], a, b, c);
+    o.p[0][2 + e] = a; o.p[1][2 + e] = b; o.p[2][2 + e] = c;
   }
+  return o;
+}
+__device__ __forceinline__ Op3 split8(const f32x16 t, int s) {  // accumulator registers 8s .. 8s+7
+  return split8(f32x4{t[8 * s], t[8 * s + 1], t[8 * s + 2], t[8 * s + 3]},
+                f32x4{t[8 * s + 4], t[8 * s + 5], t[8 * s + 6], t[8 * s + 7]});
+}
+__device__ __forceinline__ bf16x8 op(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// six-product fp32-class accumulate: acc += A B with A's planes `a` (first MFMA operand: rows) and B's planes `b`
+__device__ __forceinline__ f32x16 mma6(const u32x4* a, const u32x4* b, f32x16 acc) {
+#pragma unroll
+  for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a[PX6[t]]), op(b[PY6[t]]), acc, 0, 0, 0);
+  return acc;
+}
+
+// 64 rows x 64 columns [col0, col0 + 64) of a row-major fp32 matrix -> split LDS image at positions [pos0, pos0 + 64)
+__device__ __forceinline__ void stage_split64(const float* __restrict__ w, int ldw, int col0, unsigned char* dst, int pitch,
+                                              int pos0, int plane_bytes, int tid, int nthreads) {
+  for (int u = tid; u < 64 * 32; u += nthreads) {
+    const int row = u >> 5, pp = 2 * (u & 31);  // positions pp, pp + 1 = adjacent columns
+    const int s = pp >> 4, hh = (pp >> 3) & 1, j = pp & 7;
+    const int col = 16 * s + 4 * hh + (j & 3) + 8 * (j >> 2);
+    const f32x2 v = *reinterpret_cast<const f32x2*>(w + (long long)row * ldw + col0 + col);
+    uint32_t a, b, c;
+    split3(v[0], v[1], a, b, c);
+    unsigned char* d = dst + row * pitch + (pos0 + pp) * 2;
+    *reinterpret_cast<uint32_t*>(d) = a;
+    *reinterpret_cast<uint32_t*>(d + plane_bytes) = b;
+    *reinterpret_cast<uint32_t*>(d + 2 * plane_bytes) = c;
+  }
+}
+
+// the three planes of the 8 positions (ks, h, .) of weight row `row`
+__device__ __forceinline__ void wfrag(const unsigned char* base, int row, int pitch, int plane_bytes, int ks, int h, u32x4* out) {
+  const unsigned char* a = base + row * pitch + (ks * 16 + 8 * h) * 2;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) out[k] = *reinterpret_cast<const u32x4*>(a + k * plane_bytes);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                              const float* __restrict__ bias, double* __restrict__ partial,
                                                              long long N) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ws = smem;                                            // [64][WP]
-  double* Red = reinterpret_cast<double*>(smem + 64 * WP);     // [3][16][64]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* Ws = smem_raw;                                   // [64][WPB]
+  double* Red = reinterpret_cast<double*>(smem_raw + 64 * WPB);   // [3][16][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
   const float* __restrict__ xb = x + (long long)b * N * ldx;
-  stage_w64(w, Ws, tid, 512);
+  stage_split64(w, 64, 0, Ws, WPB, 0, 128, tid, 512);
   __syncthreads();
   const float bias0 = bias ? bias[r] : 0.f, bias1 = bias ? bias[32 + r] : 0.f;
 
@@ -77,45 +147,65 @@ __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __rest
     for (int v = 0; v < 16; ++v) g64[a][v] = 0.0;
 
   const long long ntiles = (N + 31) / 32;
-  for (long long t = (long long)blockIdx.x * CP_WAVES + wave; t < ntiles; t += (long long)gridDim.x * CP_WAVES) {
-    const long long px = t * 32 + r;
-    const bool ok = px < N;
-    int zo = 0;  // opaque zero in every LDS address below: the weight fragments are loop invariant, and hoisted out of
-    asm volatile("" : "+v"(zo));  // the tile loop they would occupy 64+ registers for the whole kernel
-    f32x4 xa[8];  // x[px][8q + 4h .. +3]
+  const long long stride = (long long)gridDim.x * CP_WAVES;
+  auto load = [&](long long tt, f32x4* dst) {  // x[px][8q + 4h .. +3]
+    const long long px = tt * 32 + r;
+    const bool ok = tt < ntiles && px < N;
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      xa[q] = ok ? *reinterpret_cast<const f32x4*>(xb + px * ldx + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+      dst[q] = ok ? *reinterpret_cast<const f32x4*>(xb + px * ldx + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // one 32-pixel tile: `cur` holds its rows, the next tile's rows are requested into `nxt` before the arithmetic starts
+  // (two register sets used alternately: no copies on the loop edge)
+  auto tile = [&](long long t, const f32x4* cur, f32x4* nxt) {
+    int zo = 0;  // opaque zero in every LDS address below: the weight fragments are loop invariant, and hoisted out of
+    asm volatile("" : "+v"(zo));  // the tile loop they would occupy 100+ registers for the whole kernel
+    load(t + stride, nxt);
     // stage 1: Y[px][n] = relu(sum_k x[px][k] W[n][k] + c[n]); lane = column n, register v = pixel (v&3)+8(v>>2)+4h
     f32x16 y[2] = {zero16(), zero16()};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + zo + r * WP + 8 * q + 4 * h);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + zo + (32 + r) * WP + 8 * q + 4 * h);
+    for (int s = 0; s < 4; ++s) {
+      const Op3 xs = split8(cur[2 * s], cur[2 * s + 1]);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        y[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[q][s], b0[s], y[0], 0, 0, 0);
-        y[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[q][s], b1[s], y[1], 0, 0, 0);
+      for (int nt = 0; nt < 2; ++nt) {
+        u32x4 wf[3];
+        wfrag(Ws + zo, nt * 32 + r, WPB, 128, s, h, wf);
+        y[nt] = mma6(xs.p, wf, y[nt]);
       }
     }
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-      const bool pv = t * 32 + (v & 3) + 8 * (v >> 2) + 4 * h < N;  // pixels past the end contribute nothing
-      y[0][v] = pv ? fmaxf(y[0][v] + bias0, 0.f) : 0.f;
-      y[1][v] = pv ? fmaxf(y[1][v] + bias1, 0.f) : 0.f;
+      y[0][v] = fmaxf(y[0][v] + bias0, 0.f);
+      y[1][v] = fmaxf(y[1][v] + bias1, 0.f);
     }
-    // stage 2: G[i][j] += sum_px Y[px][i] Y[px][j]: the accumulator registers of stage 1 are the K-pair operands
+    if (t * 32 + 32 > N) {  // the image's last, partial tile: pixels past the end contribute nothing
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const bool pv = t * 32 + (v & 3) + 8 * (v >> 2) + 4 * h < N;
+        y[0][v] = pv ? y[0][v] : 0.f;
+        y[1][v] = pv ? y[1][v] : 0.f;
+      }
+    }
+    // stage 2: G[i][j] += sum_px Y[px][i] Y[px][j]: registers 8s .. 8s+7 of stage 1 are the 8 K-slots (pixels) of step s
     f32x16 g[3] = {zero16(), zero16(), zero16()};
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      g[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y[0][v], y[0][v], g[0], 0, 0, 0);
-      g[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y[0][v], y[1][v], g[1], 0, 0, 0);
-      g[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(y[1][v], y[1][v], g[2], 0, 0, 0);
+    for (int s = 0; s < 2; ++s) {
+      const Op3 y0 = split8(y[0], s), y1 = split8(y[1], s);
+      g[0] = mma6(y0.p, y0.p, g[0]);
+      g[1] = mma6(y0.p, y1.p, g[1]);
+      g[2] = mma6(y1.p, y1.p, g[2]);
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int v = 0; v < 16; ++v) g64[a][v] += (double)g[a][v];
+  };
+  f32x4 xa[8], xb2[8];
+  long long t = (long long)blockIdx.x * CP_WAVES + wave;
+  load(t, xa);
+  for (; t < ntiles; t += 2 * stride) {
+    tile(t, xa, xb2);
+    if (t + stride < ntiles) tile(t + stride, xb2, xa);
   }
   // deterministic reduction over the 8 waves, then one partial per workgroup
   for (int wv = 0; wv < CP_WAVES; ++wv) {
@@ -211,37 +301,21 @@ struct TailK {
   float eps;
 };
 
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-
-__device__ __forceinline__ void split3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-  p0 = pk_bf16(x0, x1);
-  float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
-  p1 = pk_bf16(r0, r1);
-  r0 -= __uint_as_float(p1 << 16);
-  r1 -= __uint_as_float(p1 & 0xffff0000u);
-  p2 = pk_bf16(r0, r1);
-}
-
 __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W3s = smem;                 // [64][WP]
-  float* Wis = W3s + 64 * WP;        // [64][WP]
-  float* Wes = Wis + 64 * WP;        // [64][WP2]
-  float* Cst = Wes + 64 * WP2;       // b3[64] bi[64] bend[64] gamma[64] beta[64]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* W3s = smem_raw;             // [64][WPB]
+  unsigned char* Wis = W3s + 64 * WPB;       // [64][WPB]
+  unsigned char* Wes = Wis + 64 * WPB;       // [64][WPB2]
+  float* Cst = reinterpret_cast<float*>(Wes + 64 * WPB2);  // b3[64] bi[64] bend[64] gamma[64] beta[64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
-  stage_w64(p.w3, W3s, tid, 512);
-  stage_w64(p.wi, Wis, tid, 512);
+  stage_split64(p.w3, 64, 0, W3s, WPB, 0, 128, tid, 512);
+  stage_split64(p.wi, 64, 0, Wis, WPB, 0, 128, tid, 512);
   {
     const float* we = p.weff + (long long)b * 64 * 128;
-    for (int u = tid; u < 64 * 32; u += 512) {
-      const int row = u >> 5, q = (u & 31) * 4;
-      *reinterpret_cast<f32x4*>(Wes + row * WP2 + q) = *reinterpret_cast<const f32x4*>(we + row * 128 + q);
-    }
+    stage_split64(we, 128, 0, Wes, WPB2, 0, 256, tid, 512);
+    stage_split64(we, 128, 64, Wes, WPB2, 64, 256, tid, 512);
     if (tid < 320) {
       const int a = tid >> 6, c = tid & 63;
       const float* src = a == 0 ? p.b3 : a == 1 ? p.bi : a == 2 ? p.bend : a == 3 ? p.gamma : p.beta;
@@ -254,80 +328,86 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
   float* __restrict__ outb = p.out + (long long)b * p.N * p.ldo;
 
   const long long ntiles = (p.N + 31) / 32;
-  for (long long t = (long long)blockIdx.x * CP_WAVES + wave; t < ntiles; t += (long long)gridDim.x * CP_WAVES) {
+  const long long stride = (long long)gridDim.x * CP_WAVES;
+  auto load = [&](long long tt, const float* __restrict__ base, int ld, f32x4* dst) {  // a pixel's channels 8q + 4h .. +3
+    const long long px = tt * 32 + r;
+    const bool ok = tt < ntiles && px < p.N;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      dst[q] = ok ? *reinterpret_cast<const f32x4*>(base + px * ld + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // accumulator tile initialised with a per-row constant: register v = row (v&3) + 8(v>>2) + 4h of the 32-row tile
+  auto rows16 = [&](const float* c) {
+    f32x16 a;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 cb = *reinterpret_cast<const f32x4*>(c + 8 * g + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[4 * g + e] = cb[e];
+    }
+    return a;
+  };
+  // one 32-pixel tile; c3 / ci hold its rows of x_3 / x_i, the next tile's are requested into n3 / ni while it is
+  // computed (two register sets used alternately: no copies on the loop edge)
+  auto tile = [&](long long t, const f32x4* c3, const f32x4* ci, f32x4* n3, f32x4* ni) {
     const long long px = t * 32 + r;
     const bool ok = px < p.N;
     int zo = 0;  // opaque zero in every LDS address below (see the Gram kernel): keeps ~200 registers of loop-invariant
     asm volatile("" : "+v"(zo));  // weight fragments from being hoisted out of the tile loop
-    f32x4 x3[8], xi[8];  // this pixel's channels 8q + 4h .. +3
+    f32x16 z[2] = {rows16(Cst + zo + 128), rows16(Cst + zo + 160)};  // end_proj bias
+    // two passes: source 0 = x_3 -> y_3 half (W3, columns 0..63 of Weff), source 1 = x_i -> u_i half (Wi, columns 64..127)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      x3[q] = ok ? *reinterpret_cast<const f32x4*>(x3b + px * p.ld3 + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-      xi[q] = ok ? *reinterpret_cast<const f32x4*>(xib + px * p.ldi + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // stage 1 (transposed): T[c][px] = relu(sum_k W[c][k] x[px][k] + bias[c]); lane = pixel, register v = channel
-    // (v&3) + 8 (v>>2) + 4h of the 32-row tile.  ty = y_3 half (from x_3), tu = u_i half (from x_i).
-    f32x16 ty[2] = {zero16(), zero16()}, tu[2] = {zero16(), zero16()};
+    for (int src = 0; src < 2; ++src) {
+      if (src == 0) load(t + stride, x3b, p.ld3, n3);
+      else load(t + stride, xib, p.ldi, ni);
+      const f32x4* xc = src == 0 ? c3 : ci;
+      // stage 1 (transposed): T[c][px] = relu(sum_k W[c][k] x[px][k] + bias[c]); lane = pixel, register v = channel
+      // (v&3) + 8 (v>>2) + 4h of the 32-row tile
+      const unsigned char* Wsrc = (src == 0 ? W3s : Wis) + zo;
+      f32x16 tt[2] = {rows16(Cst + zo + src * 64), rows16(Cst + zo + src * 64 + 32)};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+      for (int s = 0; s < 4; ++s) {
+        const Op3 xs = split8(xc[2 * s], xc[2 * s + 1]);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const f32x4 a3 = *reinterpret_cast<const f32x4*>(W3s + zo + (nt * 32 + r) * WP + 8 * q + 4 * h);
-        const f32x4 ai = *reinterpret_cast<const f32x4*>(Wis + zo + (nt * 32 + r) * WP + 8 * q + 4 * h);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          ty[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[s], x3[q][s], ty[nt], 0, 0, 0);
-          tu[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[s], xi[q][s], tu[nt], 0, 0, 0);
+        for (int nt = 0; nt < 2; ++nt) {
+          u32x4 wf[3];
+          wfrag(Wsrc, nt * 32 + r, WPB, 128, s, h, wf);
+          tt[nt] = mma6(wf, xs.p, tt[nt]);
         }
       }
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 c3 = *reinterpret_cast<const f32x4*>(Cst + zo + nt * 32 + 8 * g + 4 * h);
-        const f32x4 ci = *reinterpret_cast<const f32x4*>(Cst + zo + 64 + nt * 32 + 8 * g + 4 * h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ty[nt][4 * g + e] = fmaxf(ty[nt][4 * g + e] + c3[e], 0.f);
-          tu[nt][4 * g + e] = fmaxf(tu[nt][4 * g + e] + ci[e], 0.f);
-        }
-      }
-    // stage 2: Z[m][px] = sum_c Weff[m][c] T[c][px], c = [y_3 (64) | u_i (64)]: register v of stage 1 IS the K-pair
-    // operand (channel 32nt + 8g + 4h + e for v = 4g + e), the matching Weff entries are one float4 per (nt, g)
-    f32x16 z[2] = {zero16(), zero16()};
-#pragma unroll
-    for (int half = 0; half < 2; ++half)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = half * 64 + nt * 32 + 8 * g + 4 * h;
-          const f32x4 a0 = *reinterpret_cast<const f32x4*>(Wes + zo + r * WP2 + col);
-          const f32x4 a1 = *reinterpret_cast<const f32x4*>(Wes + zo + (32 + r) * WP2 + col);
+        for (int v = 0; v < 16; ++v) tt[nt][v] = fmaxf(tt[nt][v], 0.f);
+      // stage 2: Z[m][px] += sum_c Weff[m][c] T[c][px]: registers 8s' .. 8s'+7 of tile nt are the K-slots of step 2nt + s'
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float tv = half == 0 ? ty[nt][4 * g + e] : tu[nt][4 * g + e];
-            z[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], tv, z[0], 0, 0, 0);
-            z[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], tv, z[1], 0, 0, 0);
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          const Op3 tk = split8(tt[nt], sp);
+          const int ks = src * 4 + nt * 2 + sp;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            u32x4 wf[3];
+            wfrag(Wes + zo, mt * 32 + r, WPB2, 256, ks, h, wf);
+            z[mt] = mma6(wf, tk.p, z[mt]);
           }
         }
-    // epilogue: + bias + residual x_i (already in registers, same channel layout), LayerNorm over the pixel's 64 channels
-    // (32 in this lane, 32 in lane ^ 32)
+    }
+    // epilogue: + residual x_i (same channel layout: channel 32 mt + 8 g + 4 h + e = ci[4 mt + g][e]), LayerNorm over the
+    // pixel's 64 channels (32 in this lane, 32 in lane ^ 32)
     float o[32];
     float s1 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 be = *reinterpret_cast<const f32x4*>(Cst + zo + 128 + mt * 32 + 8 * g + 4 * h);
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = z[mt][4 * g + e] + be[e] + xi[4 * mt + g][e];
+          const float v = z[mt][4 * g + e] + ci[4 * mt + g][e];
           o[mt * 16 + 4 * g + e] = v;
           s1 += v;
         }
-      }
     s1 += __shfl_xor(s1, 32);
     const float mean = s1 * (1.0f / 64.0f);
     float s2 = 0.f;
@@ -358,18 +438,21 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
       const long long cstride = (long long)p.Hp * p.Wp * 96;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        u32x4 p0, p1, p2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          uint32_t a, bb, cc;
-          split3(o[8 * c + 2 * e], o[8 * c + 2 * e + 1], a, bb, cc);
-          p0[e] = a; p1[e] = bb; p2[e] = cc;
-        }
-        *reinterpret_cast<u32x4*>(dst + c * cstride) = p0;
-        *reinterpret_cast<u32x4*>(dst + c * cstride + 32) = p1;
-        *reinterpret_cast<u32x4*>(dst + c * cstride + 64) = p2;
+        const Op3 pl = split8(f32x4{o[8 * c], o[8 * c + 1], o[8 * c + 2], o[8 * c + 3]},
+                              f32x4{o[8 * c + 4], o[8 * c + 5], o[8 * c + 6], o[8 * c + 7]});
+        *reinterpret_cast<u32x4*>(dst + c * cstride) = pl.p[0];
+        *reinterpret_cast<u32x4*>(dst + c * cstride + 32) = pl.p[1];
+        *reinterpret_cast<u32x4*>(dst + c * cstride + 64) = pl.p[2];
       }
     }
+  };
+  f32x4 a3[8], ai[8], b3[8], bi[8];
+  long long t = (long long)blockIdx.x * CP_WAVES + wave;
+  load(t, x3b, p.ld3, a3);
+  load(t, xib, p.ldi, ai);
+  for (; t < ntiles; t += 2 * stride) {
+    tile(t, a3, ai, b3, bi);
+    if (t + stride < ntiles) tile(t + stride, b3, bi, a3, ai);
   }
 }
 
@@ -386,7 +469,7 @@ extern "C" int segmif_crosspath_gram_f32(const float* x, int ldx, const float* w
   if (!x || !w || !partial || B <= 0 || N <= 0 || ldx < 64 || (ldx & 3)) return SEGMIF_EINVAL;
   if ((((uintptr_t)x | (uintptr_t)w) & 15) || ((uintptr_t)partial & 7)) return SEGMIF_EINVAL;
   const int nblk = segmif_crosspath_gram_blocks(N);
-  constexpr size_t smem = (size_t)64 * WP * sizeof(float) + 3 * 16 * 64 * sizeof(double);
+  constexpr size_t smem = (size_t)64 * WPB + 3 * 16 * 64 * sizeof(double);
   hipLaunchKernelGGL(crosspath_gram_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(512), smem, (hipStream_t)stream, x, ldx, w,
                      bias, partial, (long long)N);
   return (int)hipGetLastError();
@@ -427,8 +510,9 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
   k.eps = d->ln_eps;
   const long long ntiles = (d->N + 31) / 32;
   long long wgs = (ntiles + CP_WAVES - 1) / CP_WAVES;
-  if (wgs > TAIL_WGS) wgs = TAIL_WGS;
-  constexpr size_t smem = (size_t)(2 * 64 * WP + 64 * WP2 + 320) * sizeof(float);
+  const long long per_image = (2 * 256 + d->B - 1) / d->B;  // 100 KB of LDS: one workgroup per CU, two rounds of them
+  if (wgs > per_image) wgs = per_image;
+  constexpr size_t smem = (size_t)2 * 64 * WPB + 64 * WPB2 + 320 * sizeof(float);
   static bool raised = false;
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)crosspath_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -69,7 +69,26 @@ __global__ __launch_bounds__(256) void u8_quantize_kernel(const float* __restric
   out[i] = q;
 }
 
+// NHWC uint8 -> NCHW fp32 / 255 (IEEE division, as numpy's float32 array / 255.0)
+__global__ __launch_bounds__(256) void u8_dequantize_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int C,
+                                                            long long HW, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // output index (b, c, pix)
+  if (i >= total) return;
+  const long long pix = i % HW;
+  const int c = (int)((i / HW) % C);
+  const long long b = i / ((long long)C * HW);
+  out[i] = __fdiv_rn((float)in[(b * HW + pix) * C + c], 255.0f);
+}
+
 }  // namespace
+
+extern "C" int segmif_dequantize_u8(const uint8_t* in_nhwc, float* out_nchw, int B, int C, int64_t HW, void* stream) {
+  if (!in_nhwc || !out_nchw || B <= 0 || C <= 0 || HW <= 0) return SEGMIF_EINVAL;
+  const long long total = (long long)B * C * HW;
+  hipLaunchKernelGGL(u8_dequantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in_nhwc,
+                     out_nchw, C, (long long)HW, total);
+  return (int)hipGetLastError();
+}
 
 extern "C" int segmif_confusion_i32(const int32_t* pred, const int64_t* label, int64_t* conf, int64_t n, int K,
                                     void* stream) {

@@ -6,12 +6,19 @@ import torch
 
 from . import ops
 from .core.model_fusion import fuse_to_rgb
+from .utils.metrics import dequantize_fused, quantize_fused
 
 
 class PairForward:
-    def __init__(self, seg_net, fusion_net, commute_resize=True):
+    def __init__(self, seg_net, fusion_net, commute_resize=True, uint8_roundtrip=False):
+        """uint8_roundtrip: the reference's scripted flow hands the fused image from test_fusion.py to
+        test_segmentation.py through uint8 PNG files (uint8(255 x), global min-max rescale over the batch, uint8 -
+        test_fusion.py:112-120; read back as float32 / 255 - TaskFusion_dataset2.py:84-88).  True reproduces that
+        quantisation in memory: the segmentation net then sees exactly the pixels the script's PNGs hold
+        and the returned `fused` is that de-quantised image.  False (default) keeps the fp32 image."""
         self.seg, self.fus = seg_net, fusion_net
         self.commute_resize = commute_resize
+        self.uint8_roundtrip = uint8_roundtrip
         self._graph = None
         self._static = None
 
@@ -24,6 +31,8 @@ class PairForward:
             out0, out1 = enc.forward_fusion(mask3)
             y_f = self.fus(ir, vis, out0, out1)
         fused = fuse_to_rgb(vis, y_f)
+        if self.uint8_roundtrip:
+            fused = dequantize_fused(quantize_fused(fused))
         return fused, self.seg.predict_labels(fused, vis.shape[2:])
 
     def capture(self, ir, vis, mask3, warmup=2):

@@ -68,3 +68,15 @@ def quantize_fused(fused):
     _lib.check(_lib.load().segmif_quantize_u8(fused.data_ptr(), out.data_ptr(), mm.data_ptr(), B, C, H * W, _stream()),
                "segmif_quantize_u8")
     return out
+
+
+def dequantize_fused(q):
+    """(B, H, W, C) uint8 (quantize_fused output = the PNG pixels) -> (B, C, H, W) fp32 = u / 255, the image
+    test_segmentation.py's loader hands to the network (TaskFusion_dataset2.py:84-88)."""
+    q = _dev(q, "q", torch.uint8)
+    if q.dim() != 4 or not q.is_contiguous():
+        raise RuntimeError("dequantize_fused expects a contiguous (B, H, W, C) uint8 tensor")
+    B, H, W, C = q.shape
+    out = torch.empty((B, C, H, W), device=q.device, dtype=torch.float32)
+    _lib.check(_lib.load().segmif_dequantize_u8(q.data_ptr(), out.data_ptr(), B, C, H * W, _stream()), "segmif_dequantize_u8")
+    return out

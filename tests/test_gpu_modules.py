@@ -182,6 +182,26 @@ def test_conv3_conv4_commute_with_the_resize(net_b1, fus, golden_dir):
         fus.forward_from_features(ir, vis, torch.zeros(1, 16, 24, 32).cuda(), torch.zeros(1, 8, 12, 64).cuda())
 
 
+def test_pair_forward_uint8_roundtrip_flag(net_b1, fus, golden_dir):
+    """with uint8_roundtrip the segmentation net is fed what test_segmentation.py reads back from the PNGs
+    test_fusion.py:112-120 wrote (uint8(255 x) -> batch-global min-max -> uint8, then float32 / 255 as
+    TaskFusion_dataset2.py:84-88 loads it); emulated here in numpy from the fp32 fused image, bit for bit."""
+    from segmif_amd.pipeline import PairForward
+    gp = load(golden_dir, "pair_b1_64x96.npz")
+    ir, vis, mask = (torch.from_numpy(gp[k]).cuda() for k in ("ir", "vis", "mask"))
+    fused32, labels32 = PairForward(net_b1, fus)(ir, vis, mask)
+    fused_q, labels_q = PairForward(net_b1, fus, uint8_roundtrip=True)(ir, vis, mask)
+    u = np.uint8(255.0 * fused32.cpu().numpy()).transpose((0, 2, 3, 1))
+    u = (u - np.min(u)) / (np.max(u) - np.min(u))
+    u = np.uint8(255.0 * u)
+    back = np.asarray(u, dtype=np.float32).transpose((0, 3, 1, 2)) / 255.0
+    assert np.array_equal(fused_q.cpu().numpy(), back)
+    with torch.no_grad():
+        direct = net_b1.predict_labels(torch.from_numpy(back).cuda(), vis.shape[2:])
+    assert torch.equal(labels_q, direct)
+    assert labels_q.shape == labels32.shape and float((labels_q == labels32).float().mean()) > 0.9
+
+
 def test_head_fuse_commutes_with_the_resize(net_b1, golden_dir):
     """SURVEY §8(f) N4, second half: SegFormerHead in eval mode applies linear_fuse per scale before the
     bilinear resize (composed with the scale's Linear, BatchNorm folded); same function as the textbook

@@ -203,7 +203,8 @@ def test_seg_train_step_three_iterations_vs_reference():
 
 
 @gpu
-def test_fusion_train_step_three_iterations_vs_reference():
+@pytest.mark.parametrize("seg_weight_grads", [False, True])
+def test_fusion_train_step_three_iterations_vs_reference(seg_weight_grads):
     """train.py:351-385 (iter_ = 2) assembled: FusionTrainer.step — no-grad forward_fusion, fusion net, Fusionloss_grad3,
     CE through the segmentation net, fixed weights 0.4 / iter_ and 0.8 while n_iter <= 10, PolyWarmupAdamW on the
     fusion net — three iterations against the reference's losses and updated parameters (ffm2.* gradient-less)."""
@@ -220,7 +221,8 @@ def test_fusion_train_step_three_iterations_vs_reference():
     dw.load_det_weights(fus, seed=0)
     net, fus = net.cuda().eval(), fus.cuda().eval()
     opt = PolyWarmupAdamW([{"params": fus.parameters(), "lr": 8e-5 / iter_, "weight_decay": 0.01}], **fus_kw(iter_))
-    tr = FusionTrainer(net, fus, opt, torch.nn.CrossEntropyLoss(ignore_index=255), iter_=iter_)
+    tr = FusionTrainer(net, fus, opt, torch.nn.CrossEntropyLoss(ignore_index=255), iter_=iter_,
+                       seg_weight_grads=seg_weight_grads)
     B, H, W = 2, 32, 48
     for st in range(3):
         ir3 = dw.det_input(f"trf_ir{st}", (B, 1, H, W)).repeat(1, 3, 1, 1).cuda()
@@ -233,6 +235,10 @@ def test_fusion_train_step_three_iterations_vs_reference():
         assert abs(tr.history[st][1] - float(g["loss2"][st])) < 5e-5 * abs(float(g["loss2"][st]))
     assert sorted(n for n, p in fus.named_parameters() if p.grad is None) == sorted(g["no_grad_params"].tolist())
     _check_params(fus, g, 4e-5)
+    # the segmentation net's own weight gradients: the reference's unread side effect, formed only on request
+    with_grad = [n for n, p in net.named_parameters() if p.grad is not None]
+    assert all(p.requires_grad for p in net.parameters())
+    assert (len(with_grad) > 100) if seg_weight_grads else (with_grad == [])
 
 
 @gpu
