@@ -253,6 +253,14 @@ int segmif_upsum_act_nhwc_f32(const float* base, int ldb, const float* x0, int i
 int segmif_sr_attention_f32(const float* q, const float* k, const float* v, float* out,
                             int B, int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo,
                             float scale, void* stream);
+/* The same function on the bf16 matrix pipe (csrc/attention_split.hip): operands split three ways into bf16, six MFMA
+ * products per fp32 product (fp32-class, like segmif_conv3x3_planes_bf16x6).  hd == 64 only.  K and V are split once per
+ * call into `workspace` (segmif_sr_attention_split_workspace(B, heads, Nk) bytes, 16-byte aligned, device memory),
+ * which the attention workgroups then read by LDS-DMA. */
+int64_t segmif_sr_attention_split_workspace(int B, int heads, int Nk);
+int segmif_sr_attention_split_f32(const float* q, const float* k, const float* v, float* out, void* workspace,
+                                  int B, int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo,
+                                  float scale, void* stream);
 
 /*
  * Linear ("efficient") cross attention context, step 1: per (batch, head) partial sums of

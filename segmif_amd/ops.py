@@ -531,6 +531,25 @@ def upsum_act(base, srcs, OH, OW, bias=None, act=ACT_NONE, out=None):
     return out
 
 
+_ATTENTION_MODES = ("bf16x6", "fp32")
+_attention_mode = os.environ.get("SEGMIF_ATTENTION", "bf16x6")
+if _attention_mode not in _ATTENTION_MODES:
+    raise RuntimeError(f"SEGMIF_ATTENTION must be one of {_ATTENTION_MODES}, got {_attention_mode!r}")
+
+
+def attention_mode():
+    return _attention_mode
+
+
+def set_attention_mode(mode):
+    """'bf16x6': csrc/attention_split.hip (head_dim 64; bf16 MFMA, six split products, fp32-class); 'fp32':
+    csrc/attention.hip (fp32 MFMA) everywhere.  head_dim 32 always runs the fp32 kernel."""
+    global _attention_mode
+    if mode not in _ATTENTION_MODES:
+        raise ValueError(f"mode must be one of {_ATTENTION_MODES}")
+    _attention_mode = mode
+
+
 def sr_attention(q, kv, heads, scale):
     """q: (B, N, C) contiguous; kv: (B, Nk, 2C) contiguous (k | v) -> (B, N, C)."""
     _req(q, "q"), _req(kv, "kv")
@@ -541,8 +560,15 @@ def sr_attention(q, kv, heads, scale):
         raise RuntimeError("sr_attention expects contiguous q (B,N,C) and kv (B,Nk,2C)")
     out = torch.empty_like(q)
     kptr = kv.data_ptr()
-    _lib.check(_lib.load().segmif_sr_attention_f32(q.data_ptr(), kptr, kptr + 4 * C, out.data_ptr(), B, heads, N, Nk,
-                                                   hd, C, 2 * C, C, float(scale), _stream()),
+    lib = _lib.load()
+    if hd == 64 and _attention_mode == "bf16x6" and N >= 1024:  # below that the K/V pack launch outweighs the matrix-pipe gain
+        ws = torch.empty((lib.segmif_sr_attention_split_workspace(B, heads, Nk),), device=q.device, dtype=torch.uint8)
+        _lib.check(lib.segmif_sr_attention_split_f32(q.data_ptr(), kptr, kptr + 4 * C, out.data_ptr(), ws.data_ptr(), B, heads, N,
+                                                     Nk, hd, C, 2 * C, C, float(scale), _stream()),
+                   "segmif_sr_attention_split_f32")
+        return out
+    _lib.check(lib.segmif_sr_attention_f32(q.data_ptr(), kptr, kptr + 4 * C, out.data_ptr(), B, heads, N, Nk,
+                                           hd, C, 2 * C, C, float(scale), _stream()),
                "segmif_sr_attention_f32")
     return out
 

@@ -443,7 +443,10 @@ def test_bilinear(ops, B, IH, IW, OH, OW, C):
 @pytest.mark.parametrize("B,heads,N,Nk,hd", [(2, 2, 96, 6, 64), (1, 1, 19200, 300, 64), (2, 5, 1200, 300, 64),
                                              (1, 8, 300, 300, 64), (1, 2, 1024, 64, 32), (1, 1, 130, 1, 64),
                                              (1, 1, 4096, 1024, 64), (1, 5, 35, 35, 32)])
-def test_sr_attention(ops, B, heads, N, Nk, hd):
+@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
+def test_sr_attention(ops, B, heads, N, Nk, hd, mode):
+    """csrc/attention_split.hip (head_dim 64, bf16 MFMA x 6 split products) and csrc/attention.hip (fp32 MFMA) against
+    fp64 softmax attention; head_dim 32 runs the fp32 kernel in either mode."""
     C = heads * hd
     q, kv = rnd(B, N, C, seed=26, lo=-2, hi=2), rnd(B, Nk, 2 * C, seed=27, lo=-2, hi=2)
     scale = hd ** -0.5
@@ -451,17 +454,29 @@ def test_sr_attention(ops, B, heads, N, Nk, hd):
     kvh = kv.double().reshape(B, Nk, 2, heads, hd)
     k, v = kvh[:, :, 0].permute(0, 2, 1, 3), kvh[:, :, 1].permute(0, 2, 1, 3)
     ref = (torch.softmax(qh @ k.transpose(-2, -1) * scale, -1) @ v).transpose(1, 2).reshape(B, N, C)
-    y = ops.sr_attention(q.cuda(), kv.cuda(), heads, scale)
+    prev = ops.attention_mode()
+    ops.set_attention_mode(mode)
+    try:
+        y = ops.sr_attention(q.cuda(), kv.cuda(), heads, scale)
+    finally:
+        ops.set_attention_mode(prev)
     assert err(y, ref) < TOL
 
 
-def test_sr_attention_large_logits(ops):
+@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
+def test_sr_attention_large_logits(ops, mode):
     """Online-softmax rescale path: one key dominates late in the sequence."""
     B, heads, N, Nk, hd = 1, 1, 64, 100, 64
     q, kv = rnd(B, N, hd, seed=28), rnd(B, Nk, 2 * hd, seed=29)
     kv[:, 77, :hd] = 40.0 * q[0, 5]  # spike: row 5's max jumps at tile 2
     ref = torch.softmax(q.double() @ kv[..., :hd].double().transpose(-2, -1) * 0.125, -1) @ kv[..., hd:].double()
-    assert err(ops.sr_attention(q.cuda(), kv.cuda(), heads, 0.125), ref) < TOL
+    prev = ops.attention_mode()
+    ops.set_attention_mode(mode)
+    try:
+        y = ops.sr_attention(q.cuda(), kv.cuda(), heads, 0.125)
+    finally:
+        ops.set_attention_mode(prev)
+    assert err(y, ref) < TOL
 
 
 @pytest.mark.parametrize("B,N", [(2, 3000), (1, 1024), (3, 37), (1, 70000)])
