@@ -183,13 +183,16 @@ def main():
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / elapsed
+        all_fp32 = (ops.conv3x3_mode(), ops.linear_mode(), ops.crosspath_mode(), ops.attention_mode()) == ("fp32", "fp32", "gemm", "fp32")
         out = {
             "metric": "IR+visible image-pairs/sec fwd", "value": value, "unit": "img-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if ops.conv3x3_mode() == "fp32" else "f32 (3x3 convs: fp32-equivalent 3-way bf16 split, 6 MFMA products)",
+            "dtype": "f32" if all_fp32 else "f32 (large contractions: fp32-equivalent 3-way bf16 split, 6 MFMA products; see arithmetic_modes)",
             "conv3x3_mode": ops.conv3x3_mode(),
+            "arithmetic_modes": {"conv3x3": ops.conv3x3_mode(), "linear": ops.linear_mode(), "crosspath": ops.crosspath_mode(),
+                                 "attention": ops.attention_mode()},
             "data": "synthetic",
             "config": {"workload": f"{args.backbone} pair forward (forward_fusion + Fusion_Network3_ac + Network3 "
                                    f"+ x4 bilinear + argmax), {H}x{W}, {B} pairs per GPU per step, eval mode, "
