@@ -25,6 +25,19 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef GEMM_DBG
+#define GEMM_DBG 0  // tuning aid: 1 = s_memtime timeline probe (tools/gemm_timeline.py)
+#endif
+#if GEMM_DBG
+__device__ unsigned long long gemm_timeline[1024][16][8];
+#define GEMM_TL(step, slot)                                                                        \
+  do {                                                                                            \
+    if (tid == 0 && blockIdx.x < 1024 && (step) < 16) gemm_timeline[blockIdx.x][step][slot] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define GEMM_TL(step, slot)
+#endif
+
 constexpr int GBM = 128, GBN = 128, GBK = 32;
 constexpr int GPITCH = 208;                   // bytes per LDS row
 constexpr int GTILE = GBM * GPITCH;           // 26 624 bytes = 26 DMA instructions of 1 KB
@@ -139,6 +152,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
   __syncthreads();
   for (int ks = 0; ks < nks; ++ks) {
     const bool more = ks + 1 < nks;
+    GEMM_TL(ks, 0);
     if (more) gload(ks + 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -156,38 +170,52 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[t]], fb[j][PW[t]], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][PW[t]], fa[i][PA[t]], acc[i][j], 0, 0, 0);
     }
+    GEMM_TL(ks, 1);
     __syncthreads();  // every wave is done reading this step's tiles
+    GEMM_TL(ks, 2);
     if (more) {
       a_store();
+      GEMM_TL(ks, 3);
       b_dma(ks + 1);
+      GEMM_TL(ks, 4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    GEMM_TL(ks, 5);
     __syncthreads();
+    GEMM_TL(ks, 6);
   }
+  GEMM_TL(15, 7);
 
-  // ---- epilogue: bias + activation (+ residual), 128-byte row segments per half wave ----------------
+  // ---- epilogue: bias + activation (+ residual).  The products run transposed (weights as the MFMA's row operand), so a
+  // lane owns one output row and its registers 4g .. 4g+3 are four consecutive columns: 16-byte stores, a quarter of the
+  // vector-memory instructions of a row-per-register layout.  (tools/gemm_timeline.py: the epilogue is 20 000+ cycles of a
+  // K = 320 tile's 95 000 - every workgroup of a round stores at the same time and the burst drains at HBM write rate.)
   const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    const long long m = m0 + wm * 64 + i * 32 + r;
+    if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + r;
-      if (n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const long long m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float y = acc[i][j][v] + bv;
-        if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
-        else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
-        else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
-        if (p.res) y += p.res[m * p.ldr + n];
-        p.out[m * p.ldo + n] = y;
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
+        if (n >= p.N) continue;  // N % 4 == 0: a group of four is inside or outside as a whole
+        f32x4 y = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (p.bias) y += *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (p.act == SEGMIF_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+          else if (p.act == SEGMIF_ACT_PRELU) y[e] = y[e] >= 0.f ? y[e] : slope * y[e];
+          else if (p.act == SEGMIF_ACT_GELU) y[e] = gelu_exact(y[e]);
+        }
+        if (p.res) y += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n);
+        *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = y;
       }
-    }
+  }
+  GEMM_TL(14, 7);
 }
 
 // fp32 [N][ldw] -> [n-tile][k-step][128 rows][K half][plane][16] bf16 with 208-byte rows, zero filled past N / K
@@ -216,6 +244,12 @@ __global__ void gemm_split_pack_kernel(const float* __restrict__ w, int N, int K
 
 using namespace segmif;
 
+#if GEMM_DBG
+extern "C" int segmif_debug_gemm_timeline(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gemm_timeline), bytes < sizeof(gemm_timeline) ? bytes : sizeof(gemm_timeline));
+}
+#endif
+
 extern "C" int64_t segmif_gemm_split_weight_bytes(int N, int K) {
   if (N <= 0 || K <= 0 || K % GBK) return 0;
   return (int64_t)((N + GBN - 1) / GBN) * (K / GBK) * GTILE;
@@ -234,7 +268,8 @@ extern "C" int segmif_gemm_split_f32(const SegmifGemmSplit* d, void* stream) {
   if (!d || !d->a || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % GBK) return SEGMIF_EINVAL;
   if (d->lda < d->K || (d->lda & 3) || ((uintptr_t)d->a & 15) || ((uintptr_t)d->w & 15)) return SEGMIF_EINVAL;
   if (d->act == SEGMIF_ACT_PRELU && !d->prelu) return SEGMIF_EINVAL;
-  if (d->res && d->ldr <= 0) return SEGMIF_EINVAL;
+  if (d->res && (d->ldr <= 0 || (d->ldr & 3) || ((uintptr_t)d->res & 15))) return SEGMIF_EINVAL;
+  if ((d->N & 3) || (d->ldo & 3) || ((uintptr_t)d->out & 15) || ((uintptr_t)d->bias & 15)) return SEGMIF_EINVAL;  // float4 epilogue
   GemmSplitK k;
   k.a = d->a; k.w = (const unsigned char*)d->w; k.bias = d->bias; k.res = d->res; k.prelu = d->prelu; k.out = d->out;
   k.M = d->M; k.N = d->N; k.K = d->K; k.lda = d->lda; k.ldo = d->ldo; k.ldr = d->ldr; k.act = d->act;

@@ -275,7 +275,13 @@ def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):
     packed, split = packs
     rows, K, lda = rows_view(x, "x")
     # (N < 128 would leave half of the 128-column tile idle: measured slower than the fp32 64-column tiles)
-    if split is None or rows < GEMM_SPLIT_MIN_ROWS or N < 128 or lda % 4 or x.data_ptr() % 16:
+    if split is None or rows < GEMM_SPLIT_MIN_ROWS or N < 128 or N % 4 or lda % 4 or x.data_ptr() % 16:
+        return linear(x, packed, N, bias=bias, act=act, res=res, out=out)
+
+    def _vec4(t):  # the kernel's 16-byte epilogue accesses
+        return t is None or (t.data_ptr() % 16 == 0 and (t.dim() < 2 or t.stride(-2) % 4 == 0))
+
+    if not (_vec4(out) and _vec4(res) and _vec4(bias)):
         return linear(x, packed, N, bias=bias, act=act, res=res, out=out)
     if out is None:
         out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
