@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][s], a[i][s], acc[i][j], 0, 0, 0);  // D[n][m]: a lane owns output row m
     }
   };
 
@@ -255,78 +255,170 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
     }
   }
 
+  // ---- epilogues.  The products run transposed (weights as the MFMA's row operand; same products, same summation order,
+  // so the values are bit-identical to the row-per-register form): lane (r, h) owns output row 32 i + r of the wave tile
+  // and its registers 4g .. 4g+3 of sub-tile j are columns 32 j + 8 g + 4 h .. + 3.  16-byte accesses when the operands
+  // allow (p.vec4), all loads ahead of the first store: on gfx9 vmcnt counts stores as well, so a load issued after a
+  // store waits out the store's full round trip.
+  const int er = lane & 31, eh = lane >> 5;
+  auto col_of = [&](int j, int g) { return n0 + wn * WN + j * 32 + 8 * g + 4 * eh; };
+  auto row_of = [&](int i) { return m0 + wm * WM + i * 32 + er; };
   if (p.splitk > 1) {  // raw partial sums; bias / activation / residual are applied by splitk_reduce_kernel
     float* __restrict__ wsp = p.ws + (long long)zsplit * p.M * p.N;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      const long long m = row_of(i);
+      if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + (lane & 31);
-        if (n >= p.N) continue;
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const long long m = m0 + wm * WM + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-          if (m < p.M) wsp[m * p.N + n] = acc[i][j][v];
+        for (int g = 0; g < 4; ++g) {
+          const int n = col_of(j, g);
+          if (p.vec4) {
+            if (n < p.N)
+              *reinterpret_cast<f32x4*>(wsp + m * p.N + n) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.N) wsp[m * p.N + n + e] = acc[i][j][4 * g + e];
+          }
         }
-      }
+    }
     return;
   }
-  // ---- epilogue: bias + activation (+ residual), 128-byte row segments per half wave ----------
   float* __restrict__ out = p.out + zb * p.out_zs + z2 * p.out_zs2;
   const float* __restrict__ res = p.res ? p.res + zb * p.res_zs + z2 * p.res_zs2 : nullptr;
+  // per-column constants of this block's BN columns -> LDS (the K loop's tiles are dead): bias, and for the fused
+  // LayerNorm gamma and beta; read back as float4 (lgkmcnt, not in the way of the vector-memory queue)
+  float* Cs = As;  // [3][BN]
+  __syncthreads();
+  for (int u = tid; u < BN; u += 256) {
+    const int n = n0 + u;
+    Cs[u] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    if (p.ln_gamma) {
+      Cs[BN + u] = n < p.N ? p.ln_gamma[n] : 0.f;
+      Cs[2 * BN + u] = n < p.N ? p.ln_beta[n] : 0.f;
+    }
+  }
+  __syncthreads();
+  const float* cl = Cs + wn * WN + 4 * eh;  // + 32 j + 8 g
   if constexpr (WN == 64 && BN == 64) {
-    if (p.ln_gamma) {  // out = LayerNorm_64(res + acc + bias): a row lives in the 32 lanes of a half wave x 2 sub-tiles
-      const int nl = lane & 31;
-      const float b0 = p.bias ? p.bias[nl] : 0.f, b1 = p.bias ? p.bias[32 + nl] : 0.f;
-      const float g0 = p.ln_gamma[nl], g1 = p.ln_gamma[32 + nl], t0 = p.ln_beta[nl], t1 = p.ln_beta[32 + nl];
+    if (p.ln_gamma) {  // out = LayerNorm_64(res + acc + bias) (vec4 guaranteed by the host): a row = 32 values here + 32 in lane ^ 32
+      f32x4 rr[TM][2][4];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
+        const long long m = row_of(i);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const long long m = m0 + wm * WM + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-          const bool ok = m < p.M;
-          float y0 = acc[i][0][v] + b0, y1 = acc[i][1][v] + b1;
-          if (res && ok) {
-            y0 += res[m * p.ldr + nl];
-            y1 += res[m * p.ldr + 32 + nl];
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            rr[i][j][g] = (res && m < p.M) ? *reinterpret_cast<const f32x4*>(res + m * p.ldr + col_of(j, g)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const long long m = row_of(i);
+        float y[2][16];
+        float s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(cl + 32 * j + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              y[j][4 * g + e] = acc[i][j][4 * g + e] + bb[e] + rr[i][j][g][e];
+              s1 += y[j][4 * g + e];
+            }
           }
-          float s1 = y0 + y1;
+        s1 += __shfl_xor(s1, 32);
+        const float mean = s1 * (1.0f / 64.0f);
+        float s2 = 0.f;
 #pragma unroll
-          for (int off = 16; off > 0; off >>= 1) s1 += __shfl_xor(s1, off);
-          const float mean = s1 * (1.0f / 64.0f);
-          const float d0 = y0 - mean, d1 = y1 - mean;
-          float s2 = d0 * d0 + d1 * d1;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int off = 16; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
-          const float rstd = 1.0f / sqrtf(s2 * (1.0f / 64.0f) + p.ln_eps);
-          if (ok) {
-            out[m * p.ldo + nl] = d0 * rstd * g0 + t0;
-            out[m * p.ldo + 32 + nl] = d1 * rstd * g1 + t1;
+          for (int v = 0; v < 16; ++v) {
+            y[j][v] -= mean;
+            s2 = fmaf(y[j][v], y[j][v], s2);
           }
+        s2 += __shfl_xor(s2, 32);
+        const float rstd = 1.0f / sqrtf(s2 * (1.0f / 64.0f) + p.ln_eps);
+        if (m < p.M) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 ga = *reinterpret_cast<const f32x4*>(cl + BN + 32 * j + 8 * g);
+              const f32x4 be = *reinterpret_cast<const f32x4*>(cl + 2 * BN + 32 * j + 8 * g);
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = y[j][4 * g + e] * rstd * ga[e] + be[e];
+              *reinterpret_cast<f32x4*>(out + m * p.ldo + col_of(j, g)) = o;
+            }
         }
       }
       return;
     }
   }
   const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
+  auto activate = [&](float y) {
+    if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
+    else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
+    else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
+    return y;
+  };
+  if (p.vec4) {
+    f32x4 rr[TM][TN][4];
+    if (res) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
+        const long long m = row_of(i);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * WN + j * 32 + (lane & 31);
-      if (n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const long long m = m0 + wm * WM + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-        if (m >= p.M) continue;
-        float y = acc[i][j][v] + bv;
-        if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
-        else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
-        else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
-        if (res) y += res[m * p.ldr + n];
-        out[m * p.ldo + n] = y;
+          for (int g = 0; g < 4; ++g) {
+            const int n = col_of(j, g);
+            rr[i][j][g] = (m < p.M && n < p.N) ? *reinterpret_cast<const f32x4*>(res + m * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
       }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long long m = row_of(i);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = col_of(j, g);
+          if (n >= p.N) continue;  // N % 4 == 0: a group of four is inside or outside as a whole
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(cl + 32 * j + 8 * g);
+          f32x4 y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            y[e] = activate(acc[i][j][4 * g + e] + bb[e]);
+            if (res) y[e] += rr[i][j][g][e];
+          }
+          *reinterpret_cast<f32x4*>(out + m * p.ldo + n) = y;
+        }
+    }
+  } else {  // ragged N or unaligned views: element by element
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long long m = row_of(i);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = col_of(j, g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e >= p.N) continue;
+            float y = activate(acc[i][j][4 * g + e] + cl[32 * j + 8 * g + e]);
+            if (res) y += res[m * p.ldr + n + e];
+            out[m * p.ldo + n + e] = y;
+          }
+        }
     }
   }
 }
@@ -482,6 +574,7 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
   if (k.splitk > 1) {
     if (!d->workspace || d->workspace_floats < (int64_t)k.splitk * k.M * k.N) k.splitk = 1;  // no room: plain launch
     else k.ws = d->workspace;
+    if ((uintptr_t)k.ws & 15) k.vec4 = 0;
   }
   int r;
   const int gz = k.splitk > 1 ? k.splitk : nz;
@@ -516,6 +609,9 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   const int nz = (d->nz > 0 ? d->nz : 1) * k.nz2;
   if (d->act == SEGMIF_ACT_PRELU && !d->prelu) return SEGMIF_EINVAL;
   if (d->res && d->ldr <= 0) return SEGMIF_EINVAL;
+  k.vec4 = !(d->N & 3) && !(d->ldo & 3) && !((uintptr_t)d->out & 15) && !(k.out_zs & 3) && !(k.out_zs2 & 3) &&
+           (!d->res || (!(d->ldr & 3) && !((uintptr_t)d->res & 15) && !(k.res_zs & 3) && !(k.res_zs2 & 3)));
+  if (k.ln_gamma && !k.vec4) return SEGMIF_EINVAL;  // the fused LayerNorm epilogue only exists in its 16-byte form
 
   const bool is_conv = !(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0);
   int mode;

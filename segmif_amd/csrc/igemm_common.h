@@ -33,6 +33,7 @@ struct IgemmK {
   const float* ln_beta;
   float ln_eps;
   int ntm, ntn;
+  int vec4;  // epilogue may use 16-byte accesses: N, ldo, ldr, z strides multiples of 4 and out / res / bias / ws 16-byte aligned
 };
 
 __device__ __forceinline__ float gelu_exact(float x) {
