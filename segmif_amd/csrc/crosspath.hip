@@ -47,7 +47,7 @@ namespace {
 constexpr int WPB = 3 * 128 + 16;    // bytes per row, 64 columns
 constexpr int WPB2 = 3 * 256 + 16;   // 128 columns
 constexpr int CP_WAVES = 8;
-constexpr int GRAM_WGS = 8;   // workgroups per image (x 8 waves x 32-pixel tiles)
+constexpr int GRAM_WGS = 64;  // workgroups per image (x 8 waves x 32-pixel tiles): independent of the batch, so results do not depend on it; 8 left a single image on 8 CUs
 constexpr int PX6[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first: plane of the first operand ...
 constexpr int PY6[6] = {0, 1, 2, 0, 1, 0};  // ... and of the second
 
