@@ -91,6 +91,12 @@ typedef struct SegmifIgemm {
   const float* ln_gamma;
   const float* ln_beta;
   float ln_eps;
+  /* optional second copy of the output as "planes" chunks (see segmif_planes_* below): conv output (B, OH, OW, N) with
+   * N % 16 == 0 written as chunks [planes_chunk0, planes_chunk0 + N/16) of a planes buffer of planes_chunks chunk
+   * images per batch element, geometry of segmif_planes_dims(OH, OW).  Needs the 16-byte epilogue (N, ldo multiples of 4,
+   * aligned out) and nz <= 1; conv1 of Fusion_Network3_ac hands its result to the first DRDB this way. */
+  void* planes_out;
+  int32_t planes_chunks, planes_chunk0;
 } SegmifIgemm;
 
 int segmif_igemm_f32(const SegmifIgemm* desc, void* stream);

@@ -28,6 +28,7 @@ class SegmifIgemm(ctypes.Structure):
         ("in_zstride2", c_int64), ("wt_zstride2", c_int64), ("out_zstride2", c_int64), ("res_zstride2", c_int64),
         ("workspace", c_void_p), ("workspace_floats", c_int64),
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
+        ("planes_out", c_void_p), ("planes_chunks", c_int32), ("planes_chunk0", c_int32),
     ]
 
 

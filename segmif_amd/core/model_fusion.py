@@ -467,11 +467,12 @@ class Fusion_Network3_ac(nn.Module):
         PRELU = ops.ACT_PRELU
         xs, pls = [], []
         for x, conv, name in ((ir, self.conv1_ir, "conv1_ir"), (vis, self.conv1_vis, "conv1_vis")):
-            xs.append(ops.conv2d(self._first_channel_nhwc(x), self._w(name), 64, 3, pad=1, bias=conv.bias, act=PRELU,
-                                 prelu=slope))
             pls.append(ops.Planes(B, H, W, DRDB.PLANES_CHUNKS, dev))
-        y1 = self.DRDB1.forward_planes(xs[0], pls[0])
-        y2 = self.DRDB2.forward_planes(xs[1], pls[1])
+            # conv1 writes its 64 channels as fp32 (the DRDB's residual input) and, split, as the DRDB's first four chunks
+            xs.append(ops.conv2d(self._first_channel_nhwc(x), self._w(name), 64, 3, pad=1, bias=conv.bias, act=PRELU,
+                                 prelu=slope, planes=pls[-1]))
+        y1 = self.DRDB1.forward_planes(xs[0], pls[0], preloaded=True)
+        y2 = self.DRDB2.forward_planes(xs[1], pls[1], preloaded=True)
         seg = seg1_fn()
         pre = self.ffm.cross.gram_ok()  # the CrossPath tail then writes the DRDB inputs pre-split as well
         x1, x2 = self.ffm.forward_nhwc(y1, y2, seg, out1=xs[0], out2=xs[1], planes1=pls[0] if pre else None,

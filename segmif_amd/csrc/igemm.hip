@@ -31,6 +31,24 @@ using namespace segmif;
 
 namespace {
 
+typedef __bf16 ig_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ig_f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t ig_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t ig_pk_bf16(float a, float b) {
+  ig_f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ig_bf16x2));
+}
+// x = p0 + p1 + p2, three bf16 each (round to nearest, exact residuals): the planes format's split (conv3x3_planes.hip)
+__device__ __forceinline__ void ig_split3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = ig_pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+  p1 = ig_pk_bf16(r0, r1);
+  r0 -= __uint_as_float(p1 << 16);
+  r1 -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = ig_pk_bf16(r0, r1);
+}
+
 enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_GENERIC = 2, MODE_DENSE2 = 3 };
 
 template <int BM, int BN, int WM, int WN, int BK, int MODE, int PF = 1>
@@ -385,20 +403,49 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
     for (int i = 0; i < TM; ++i) {
       const long long m = row_of(i);
       if (m >= p.M) continue;
+      unsigned char* pl_px = nullptr;
+      if (p.planes) {  // output pixel m = (b, oy, ox) -> its 96-byte slot in chunk image 0 of batch element b
+        const long long ohw = (long long)p.OH * p.OW;
+        const long long b = m / ohw;
+        const int rem = (int)(m - b * ohw);
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        pl_px = p.planes + ((((long long)b * p.pl_chunks + p.pl_chunk0) * p.pl_Hp + oy + 2) * p.pl_Wp + ox + 2) * 96 + eh * 16;
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = col_of(j, g);
-          if (n >= p.N) continue;  // N % 4 == 0: a group of four is inside or outside as a whole
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(cl + 32 * j + 8 * g);
-          f32x4 y;
+        for (int q = 0; q < 2; ++q) {  // columns 32 j + 16 q .. + 15 = planes chunk (n0 + wn WN + 32 j) / 16 + q
+          float yy[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            y[e] = activate(acc[i][j][4 * g + e] + bb[e]);
-            if (res) y[e] += rr[i][j][g][e];
+          for (int gg = 0; gg < 2; ++gg) {
+            const int g = 2 * q + gg;
+            const int n = col_of(j, g);
+            if (n >= p.N) continue;  // N % 4 == 0: a group of four is inside or outside as a whole
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(cl + 32 * j + 8 * g);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              y[e] = activate(acc[i][j][4 * g + e] + bb[e]);
+              if (res) y[e] += rr[i][j][g][e];
+              yy[4 * gg + e] = y[e];
+            }
+            *reinterpret_cast<f32x4*>(out + m * p.ldo + n) = y;
           }
-          *reinterpret_cast<f32x4*>(out + m * p.ldo + n) = y;
+          if (p.planes && col_of(j, 2 * q) < p.N) {
+            // this lane's 8 of the chunk's 16 channels are positions 8 h .. 8 h + 7 of the chunk (sigma order): one
+            // 16-byte store per plane
+            ig_u32x4 pp[3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              uint32_t a, b, c;
+              ig_split3(yy[2 * e], yy[2 * e + 1], a, b, c);
+              pp[0][e] = a; pp[1][e] = b; pp[2][e] = c;
+            }
+            const int chunk = (n0 + wn * WN + 32 * j) / 16 + q;
+            unsigned char* dst = pl_px + (long long)chunk * p.pl_Hp * p.pl_Wp * 96;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<ig_u32x4*>(dst + k * 32) = pp[k];
+          }
         }
     }
   } else {  // ragged N or unaligned views: element by element
@@ -612,6 +659,15 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   k.vec4 = !(d->N & 3) && !(d->ldo & 3) && !((uintptr_t)d->out & 15) && !(k.out_zs & 3) && !(k.out_zs2 & 3) &&
            (!d->res || (!(d->ldr & 3) && !((uintptr_t)d->res & 15) && !(k.res_zs & 3) && !(k.res_zs2 & 3)));
   if (k.ln_gamma && !k.vec4) return SEGMIF_EINVAL;  // the fused LayerNorm epilogue only exists in its 16-byte form
+  k.planes = (unsigned char*)d->planes_out;
+  k.pl_Hp = k.pl_Wp = k.pl_chunks = k.pl_chunk0 = 0;
+  if (k.planes) {
+    int hp, wp;
+    if (!k.vec4 || (d->N & 15) || nz > 1 || k.ln_gamma || d->planes_chunk0 < 0 || d->planes_chunk0 + d->N / 16 > d->planes_chunks ||
+        d->M % ((long long)d->OH * d->OW) || segmif_planes_dims(d->OH, d->OW, &hp, &wp) != 0 || ((uintptr_t)k.planes & 15))
+      return SEGMIF_EINVAL;
+    k.pl_Hp = hp; k.pl_Wp = wp; k.pl_chunks = d->planes_chunks; k.pl_chunk0 = d->planes_chunk0;
+  }
 
   const bool is_conv = !(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0);
   int mode;
@@ -630,7 +686,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   const bool bk32_ok = (k.Kp % 32 == 0) && (mode != MODE_CONV || d->Cin % 32 == 0) &&
                        (mode != MODE_DENSE2 || (d->K1 % 32 == 0));
   int tile = d->tile;
-  const bool halo_ok = mode == MODE_CONV && nz == 1 && k.ldw == k.Kp && !k.ln_gamma && conv3x3_halo_eligible(k);
+  const bool halo_ok = mode == MODE_CONV && nz == 1 && k.ldw == k.Kp && !k.ln_gamma && !k.planes && conv3x3_halo_eligible(k);
   if (k.ln_gamma) {
     if (mode == MODE_GENERIC || (tile >= 0 && tile != 7 && tile != 8)) return SEGMIF_EINVAL;
     if (tile < 0) tile = 7;  // the fused LayerNorm needs a wave tile spanning all 64 columns
@@ -654,7 +710,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   if (auto_tile && tile == 6 && d->K >= 128 && mode != MODE_GENERIC) tile = 12;  // prefetch distance 2: +3..9 % (profiles/r01_enc_gemm_tiles.txt)
   k.ntm = (int)((d->M + kTiles[tile].BM - 1) / kTiles[tile].BM);
   k.ntn = (d->N + kTiles[tile].BN - 1) / kTiles[tile].BN;
-  if (auto_tile && nz == 1 && (mode == MODE_DENSE || mode == MODE_CONV) && k.ldw == k.Kp && !k.ln_gamma) {
+  if (auto_tile && nz == 1 && (mode == MODE_DENSE || mode == MODE_CONV) && k.ldw == k.Kp && !k.ln_gamma && !k.planes) {
     k.splitk = plan_splitk(d->M, d->N, k.Kp, tile);
     if (k.splitk > 1) {
       const int nk = k.Kp / kTiles[tile].BK;

@@ -33,6 +33,8 @@ struct IgemmK {
   const float* ln_beta;
   float ln_eps;
   int ntm, ntn;
+  unsigned char* planes;  // optional planes copy of the output (conv3x3_planes.hip format): chunks [pl_chunk0, pl_chunk0 + N/16)
+  int pl_Hp, pl_Wp, pl_chunks, pl_chunk0;
   int vec4;  // epilogue may use 16-byte accesses: N, ldo, ldr, z strides multiples of 4 and out / res / bias / ws 16-byte aligned
 };
 

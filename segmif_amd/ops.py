@@ -414,9 +414,11 @@ def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
 
 
 def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
-           tile=-1, tag=None):
+           tile=-1, tag=None, planes=None, planes_chunk0=0):
     """NHWC convolution.  x: (B, H, W, Cin) rows view (may be a channel slice of a wider buffer);
-    wt packed (N, Kp); out: (B, OH, OW, N) rows view (may be a channel slice) or None."""
+    wt packed (N, Kp); out: (B, OH, OW, N) rows view (may be a channel slice) or None.
+    planes: optional ops.Planes of the output geometry that also receives the result, split, as chunks
+    [planes_chunk0, planes_chunk0 + N / 16) (fp32-packed weights only)."""
     if x.dim() != 4:
         raise RuntimeError("conv2d expects (B, H, W, C)")
     _, cin, lda = rows_view(x, "x")
@@ -454,6 +456,10 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
     d.H, d.W, d.Cin, d.KH, d.KW = H, W, cin, k, k
     d.stride, d.pad, d.dil, d.OH, d.OW = stride, pad, dil, OH, OW
     d.act, d.nz, d.tile = act, 1, tile
+    if planes is not None:
+        if isinstance(wt, SplitWeight) or (planes.B, planes.H, planes.W) != (B, OH, OW):
+            raise RuntimeError("conv2d: planes output needs fp32-packed weights and a planes buffer of the output geometry")
+        d.planes_out, d.planes_chunks, d.planes_chunk0 = planes.data.data_ptr(), planes.chunks, planes_chunk0
     _igemm(d, tag, dev=x.device)
     return out
 

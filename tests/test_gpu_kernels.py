@@ -222,6 +222,30 @@ def test_gemm_split_bf16x6(ops, M, N, K):
     assert ops.pack_linear(rnd(64, 48, seed=9).cuda())[1] is None
 
 
+@pytest.mark.parametrize("cin,H,W", [(1, 37, 50), (16, 24, 40)])
+def test_conv2d_planes_copy_of_the_output(ops, cin, H, W):
+    """ops.conv2d(planes=...): the implicit-GEMM epilogue also writes its (activated) result as planes chunks - byte for byte
+    what segmif_planes_from_f32 makes of the fp32 output (conv1 of Fusion_Network3_ac feeds the first DRDB this way);
+    ragged sizes, scalar-gather (Cin = 1) and vector modes, chunk offset."""
+    B, N = 2, 64
+    x = rnd(B, H, W, cin, seed=70).cuda()
+    w = (rnd(N, cin, 3, 3, seed=71) * 0.3).cuda()
+    b, slope = rnd(N, seed=72).cuda(), torch.tensor([0.2], device="cuda")
+    pw = ops.pack_weight(w)
+    for chunk0, chunks in ((0, 4), (2, 7)):
+        pl = ops.Planes(B, H, W, chunks, "cuda")
+        pl.data.zero_()
+        y = ops.conv2d(x, pw, N, 3, pad=1, bias=b, act=ops.ACT_PRELU, prelu=slope, planes=pl, planes_chunk0=chunk0)
+        y_plain = ops.conv2d(x, pw, N, 3, pad=1, bias=b, act=ops.ACT_PRELU, prelu=slope)
+        assert err(y, y_plain.cpu()) < TOL  # (the plain call may take the halo-tiled kernel: another summation order)
+        ref = ops.Planes(B, H, W, chunks, "cuda")
+        ref.data.zero_()
+        ref.load_f32(y, chunk0=chunk0)
+        assert torch.equal(pl.data, ref.data)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x, pw, N, 3, pad=1, planes=ops.Planes(B, H, W, 3, "cuda"))  # 64 channels need four chunks
+
+
 def _sigma16():
     return torch.tensor([(j & 3) + 4 * (j >> 3) + 8 * ((j >> 2) & 1) for j in range(16)])
 
