@@ -118,6 +118,8 @@ class Attention(nn.Module):
         lm = ops.linear_mode()
         q = ops.linear_auto(x, pk.get("q:" + lm, self.q.weight, ops.pack_linear), C, bias=self.q.bias)
         if self.sr_ratio > 1:
+            # (the LayerNorm stays a kernel of its own here: the reduced map has few rows and a long K, which the conv
+            # covers with split-K - and split-K partials cannot carry a fused row normalisation)
             red = ops.conv2d(x.view(B, H, W, C), pk.get("sr", self.sr.weight, ops.pack_weight), C, self.sr_ratio,
                              stride=self.sr_ratio, bias=self.sr.bias)
             red = red.view(B, -1, C)
@@ -206,11 +208,14 @@ class OverlapPatchEmbed(nn.Module):
             B, H, W, C = y.shape
             return ag.layernorm(y.view(B, H * W, C), self.norm.weight, self.norm.bias, self.norm.eps), H, W
         xh = ops.to_nhwc(x)
-        y = ops.conv2d(xh, self._pk.get("proj", self.proj.weight, ops.pack_weight), self.proj.out_channels, k,
-                       stride=self.stride, pad=k // 2, bias=self.proj.bias)
+        C = self.proj.out_channels
+        fuse = ops.conv_ln_fusable(C)  # K1: bias + LayerNorm in the conv's epilogue where a row fits a wave tile (C = 64)
+        y = ops.conv2d(xh, self._pk.get("proj", self.proj.weight, ops.pack_weight), C, k, stride=self.stride, pad=k // 2,
+                       bias=self.proj.bias, ln=(self.norm.weight, self.norm.bias, self.norm.eps) if fuse else None)
         B, H, W, C = y.shape
         t = y.view(B, H * W, C)
-        ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps, out=t)
+        if not fuse:
+            ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps, out=t)
         return t, H, W
 
 

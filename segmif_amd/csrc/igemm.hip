@@ -527,6 +527,7 @@ int dispatch_generic(int tile, const IgemmK& k, int nz, hipStream_t s) {
     case 0: return launch<256, 32, 64, 32, 16, MODE_GENERIC>(k, nz, s);
     case 2: return launch<128, 64, 64, 32, 16, MODE_GENERIC>(k, nz, s);
     case 6: return launch<64, 64, 32, 32, 16, MODE_GENERIC>(k, nz, s);
+    case 7: return launch<256, 64, 64, 64, 16, MODE_GENERIC>(k, nz, s);  // the fused-LayerNorm tile (stage-1 patch embed, Cin = 3)
   }
   return SEGMIF_EINVAL;
 }
@@ -688,7 +689,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   int tile = d->tile;
   const bool halo_ok = mode == MODE_CONV && nz == 1 && k.ldw == k.Kp && !k.ln_gamma && !k.planes && conv3x3_halo_eligible(k);
   if (k.ln_gamma) {
-    if (mode == MODE_GENERIC || (tile >= 0 && tile != 7 && tile != 8)) return SEGMIF_EINVAL;
+    if (tile >= 0 && tile != 7 && (tile != 8 || mode == MODE_GENERIC)) return SEGMIF_EINVAL;
     if (tile < 0) tile = 7;  // the fused LayerNorm needs a wave tile spanning all 64 columns
   }
   if (tile < 0 && halo_ok) tile = kHaloTile0 + 1;  // 8-channel chunks: best on every shape (profiles/r01_kernel_bench_halo.txt)

@@ -414,11 +414,12 @@ def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
 
 
 def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
-           tile=-1, tag=None, planes=None, planes_chunk0=0):
+           tile=-1, tag=None, planes=None, planes_chunk0=0, ln=None):
     """NHWC convolution.  x: (B, H, W, Cin) rows view (may be a channel slice of a wider buffer);
     wt packed (N, Kp); out: (B, OH, OW, N) rows view (may be a channel slice) or None.
     planes: optional ops.Planes of the output geometry that also receives the result, split, as chunks
-    [planes_chunk0, planes_chunk0 + N / 16) (fp32-packed weights only)."""
+    [planes_chunk0, planes_chunk0 + N / 16) (fp32-packed weights only).
+    ln = (gamma, beta, eps): LayerNorm over the N = 64 output channels in the conv's epilogue (conv_ln_fusable)."""
     if x.dim() != 4:
         raise RuntimeError("conv2d expects (B, H, W, C)")
     _, cin, lda = rows_view(x, "x")
@@ -456,12 +457,24 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
     d.H, d.W, d.Cin, d.KH, d.KW = H, W, cin, k, k
     d.stride, d.pad, d.dil, d.OH, d.OW = stride, pad, dil, OH, OW
     d.act, d.nz, d.tile = act, 1, tile
+    if ln is not None:
+        if isinstance(wt, SplitWeight) or N != 64 or act != ACT_NONE:
+            raise RuntimeError("conv2d: the fused LayerNorm epilogue needs fp32-packed weights, N = 64 and no activation")
+        d.ln_gamma, d.ln_beta, d.ln_eps = _req(ln[0]).data_ptr(), _req(ln[1]).data_ptr(), float(ln[2])
     if planes is not None:
         if isinstance(wt, SplitWeight) or (planes.B, planes.H, planes.W) != (B, OH, OW):
             raise RuntimeError("conv2d: planes output needs fp32-packed weights and a planes buffer of the output geometry")
         d.planes_out, d.planes_chunks, d.planes_chunk0 = planes.data.data_ptr(), planes.chunks, planes_chunk0
     _igemm(d, tag, dev=x.device)
     return out
+
+
+def conv_ln_fusable(N):
+    """True when a conv's LayerNorm can ride in its epilogue: the row (all N channels) must sit in one wave tile - N = 64,
+    i.e. the stage-1 patch embed of mit_b1 .. b5 (614 400 rows at 32 images of 480x640: the only patch-embed LayerNorm over
+    a large tensor); wider stages (128 .. 512 channels) would need a 32-row x full-N workgroup tile that re-reads the whole
+    weight matrix per 32 rows, and the spatial-reduction convs run split-K."""
+    return N == 64
 
 
 def layernorm(x, gamma, beta, eps, out=None):

@@ -246,6 +246,24 @@ def test_conv2d_planes_copy_of_the_output(ops, cin, H, W):
         ops.conv2d(x, pw, N, 3, pad=1, planes=ops.Planes(B, H, W, 3, "cuda"))  # 64 channels need four chunks
 
 
+def test_conv2d_fused_layernorm_epilogue(ops):
+    """OverlapPatchEmbed's conv (7x7, stride 4, Cin = 3 -> 64: mix_transformer.py:193-196) with bias + LayerNorm in
+    the implicit GEMM's epilogue (scalar-gather mode, the 256 x 64 tile whose wave spans the row) against conv + LayerNorm in
+    fp64; ragged output size; and a dense-mode case (Cin = 16)."""
+    for cin, k, stride, H, W in ((3, 7, 4, 61, 83), (16, 3, 2, 40, 56)):
+        B, N = 2, 64
+        x = rnd(B, H, W, cin, seed=80).cuda()
+        w = rnd(N, cin, k, k, seed=81) * 0.2
+        b, g, t = rnd(N, seed=82), rnd(N, seed=83, lo=0.5, hi=1.5), rnd(N, seed=84)
+        y = ops.conv2d(x, ops.pack_weight(w.cuda()), N, k, stride=stride, pad=k // 2, bias=b.cuda(), ln=(g.cuda(), t.cuda(), 1e-5))
+        ref = torch.nn.functional.conv2d(x.cpu().double().permute(0, 3, 1, 2), w.double(), b.double(), stride=stride, padding=k // 2)
+        ref = torch.nn.functional.layer_norm(ref.permute(0, 2, 3, 1), (N,), g.double(), t.double(), 1e-5)
+        assert tuple(y.shape) == tuple(ref.shape)
+        assert err(y, ref) < TOL, (cin, err(y, ref))
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x, ops.pack_weight(rnd(128, 16, 3, 3, seed=85).cuda()), 128, 3, pad=1, ln=(g.cuda(), t.cuda(), 1e-5))
+
+
 def _sigma16():
     return torch.tensor([(j & 3) + 4 * (j >> 3) + 8 * ((j >> 2) & 1) for j in range(16)])
 
