@@ -105,8 +105,9 @@ extern "C" int segmif_quantize_u8(const float* x_nchw, uint8_t* out_nhwc, int32_
                                   void* stream) {
   if (!x_nchw || !out_nhwc || !minmax || B <= 0 || C <= 0 || HW <= 0) return SEGMIF_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const int init[2] = {255, 0};
-  hipError_t e = hipMemcpyAsync(minmax, init, sizeof(init), hipMemcpyHostToDevice, s);
+  // {min, max} start at {255, 0}: two device-side fills (stream ordered, graph capturable; no host buffer involved)
+  hipError_t e = hipMemsetD32Async((hipDeviceptr_t)minmax, 255, 1, s);
+  if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(minmax + 1), 0, 1, s);
   if (e != hipSuccess) return (int)e;
   const long long n = (long long)B * C * HW;
   long long blocks = (n + 255) / 256;
