@@ -111,6 +111,22 @@ def main():
         fus0_mean=np.float64(o0.double().mean()), fus1_mean=np.float64(o1.double().mean()),
         seg=npy(seg))
 
+    # ---- 2b. mit_b2 / mit_b4 (depths 3-4-6-3 / 3-8-27-3), ragged 72x104: the two constructors no other record exercises --
+    for bb in ("mit_b2", "mit_b4"):
+        netx = quiet(mf.Network3, bb, NUM_CLASSES, pretrained=None).eval()
+        dw.load_det_weights(netx, seed=0)
+        xx = dw.det_input(bb + "_72x104", (1, 3, 72, 104))
+        fx = netx.denoise_net.encoder(xx)
+        q0, q1 = netx.denoise_net.encoder.forward_fusion(xx)
+        _, _, segx = netx.forward(xx.clone())
+        np.savez_compressed(
+            os.path.join(OUT, bb + "_72x104.npz"),
+            f1=npy(fx[0]), f2=npy(fx[1]), f3=npy(fx[2]), f4=npy(fx[3]),
+            fus0_sample=npy(q0[:, :, 1::5, 2::7]), fus1_sample=npy(q1[:, :, 1::5, 2::7]),
+            fus0_mean=np.float64(q0.double().mean()), fus1_mean=np.float64(q1.double().mean()),
+            seg=npy(segx))
+        del netx
+
     # F2: the fusion net cannot consume mit_b0 features (64/128 channels hard-coded)
     fus = quiet(mf.Fusion_Network3_ac).eval()
     dw.load_det_weights(fus, seed=0)
@@ -291,7 +307,11 @@ def main():
         meta["full5_label_hist"] = rec["label_hist"].tolist()
         meta["full5_margin_min"] = mmin
 
-    with open(os.path.join(OUT, "meta.json"), "w") as f:
+    meta_path = os.path.join(OUT, "meta.json")
+    if os.path.exists(meta_path):  # a run without --full / --full5 keeps the entries those legs recorded earlier
+        with open(meta_path) as f:
+            meta = {**json.load(f), **meta}
+    with open(meta_path, "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote fixtures to", OUT)
     for fn in sorted(os.listdir(OUT)):

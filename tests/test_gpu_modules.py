@@ -81,6 +81,25 @@ def test_mit_b0_ragged_vs_reference(core, golden_dir):
     assert tuple(seg.shape) == (1, 9, 18, 26) and rel(seg, g["seg"]) < TIGHT
 
 
+@pytest.mark.parametrize("bb", ["mit_b2", "mit_b4"])
+def test_mit_b2_b4_ragged_vs_reference(core, golden_dir, bb):
+    """The two constructors no other record exercises (core/mix_transformer.py:399-423), ragged 72x104: HIP encoder features,
+    forward_fusion and logits vs the reference's."""
+    g = load(golden_dir, bb + "_72x104.npz")
+    net = build(core, core.Network3, bb, 9, pretrained=None)
+    x = dw.det_input(bb + "_72x104", (1, 3, 72, 104)).cuda()
+    with torch.no_grad():
+        feats = net.denoise_net.encoder(x)
+        o0, o1 = net.denoise_net.encoder.forward_fusion(x)
+        _, _, seg = net(x)
+    assert [tuple(f.shape) for f in feats] == [(1, 64, 18, 26), (1, 128, 9, 13), (1, 320, 5, 7), (1, 512, 3, 4)]
+    for i, f in enumerate(feats):
+        assert rel(f, g[f"f{i + 1}"]) < TIGHT, i
+    assert rel(o0[:, :, 1::5, 2::7], g["fus0_sample"]) < TIGHT
+    assert rel(o1[:, :, 1::5, 2::7], g["fus1_sample"]) < TIGHT
+    assert tuple(seg.shape) == (1, 9, 18, 26) and rel(seg, g["seg"]) < TIGHT
+
+
 def test_mit_blocks_vs_reference(net_b1, golden_dir):
     g = load(golden_dir, "mit_blocks.npz")
     enc = net_b1.denoise_net.encoder

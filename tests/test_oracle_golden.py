@@ -53,6 +53,26 @@ def test_mit_b0_ragged(golden_dir):
     assert rel_err(so.network3_forward(sd, x, "mit_b0"), g["seg"]) < TOL
 
 
+@pytest.mark.parametrize("bb,shapes", [
+    ("mit_b2", [(1, 64, 18, 26), (1, 128, 9, 13), (1, 320, 5, 7), (1, 512, 3, 4)]),
+    ("mit_b4", [(1, 64, 18, 26), (1, 128, 9, 13), (1, 320, 5, 7), (1, 512, 3, 4)])])
+def test_mit_b2_b4_ragged(golden_dir, bb, shapes):
+    """mit_b2 (depths 3-4-6-3) and mit_b4 (3-8-27-3), core/mix_transformer.py:399-423: encoder features, forward_fusion and
+    the segmentation logits against records taken from the imported reference (oracle/make_golden.py section 2b)."""
+    g = load(golden_dir, bb + "_72x104.npz")
+    sd = dw.det_state_dict(so.network3_shapes(bb, 9), seed=0)
+    x = dw.det_input(bb + "_72x104", (1, 3, 72, 104))
+    feats = so.mit_forward_features(sd, "denoise_net.encoder.", x, bb)
+    assert [tuple(f.shape) for f in feats] == shapes
+    for i, f in enumerate(feats):
+        assert rel_err(f, g[f"f{i + 1}"]) < TOL
+    o0, o1 = so.mit_forward_fusion(sd, "denoise_net.encoder.", x, bb)
+    assert rel_err(o0[:, :, 1::5, 2::7], g["fus0_sample"]) < TOL
+    assert rel_err(o1[:, :, 1::5, 2::7], g["fus1_sample"]) < TOL
+    assert abs(float(o0.double().mean()) - float(g["fus0_mean"])) < 1e-6
+    assert rel_err(so.network3_forward(sd, x, bb), g["seg"]) < TOL
+
+
 def test_f2_mit_b0_features_do_not_fit_fusion_net(golden_dir, sd_fus):
     meta = json.load(open(os.path.join(golden_dir, "meta.json")))
     assert meta["F2_mit_b0_fusion_raises"] is True
