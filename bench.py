@@ -18,7 +18,6 @@ One process per GPU; the path shards over independent pairs, so there is no data
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -65,6 +64,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the step into a hipGraph and replay it")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (BASELINE configs [2] / [3])")
+    ap.add_argument("--train-batch", type=int, default=8, help="samples per GPU per training step (config[2]: 8)")
+    ap.add_argument("--train-steps", type=int, default=0, help="timed steps per training variant (0: min(--steps, 8))")
     return ap.parse_args()
 
 
@@ -109,16 +111,105 @@ def cpu_baseline(backbone, H, W):
                       f"pair, best of {len(times)} timed pairs ({', '.join(f'{t:.2f}' for t in times)} s)"}
 
 
+# algorithmic work of the two training steps, GFLOP per sample at 480x640
+GFLOP_TRAIN = {("mit_b3", "seg"): 300.0, ("mit_b3", "fusion"): 2304.0}
+
+
+def train_leg(args, rank, world, seg, fus):
+    """BASELINE configs [2] (one GPU) and [3] (data parallel): the two steps of the reference's train.py on synthetic data,
+    B = --train-batch per GPU, AFTER the forward metric's timed region (never part of `value`):
+      seg     train.py:217-227  forward, x4 bilinear + CE(ignore 255), backward, PolyWarmupAdamW_seg
+      fusion  train.py:351-385  no-grad forward_fusion, fusion net, MSE + 1.1 (1 - SSIM) (+ LapLoss2 evaluated as a
+                                reported extra term), CE through the segmentation net, backward, PolyWarmupAdamW
+    each in TRAIN mode (DropPath, Dropout2d(0.1), BatchNorm batch statistics: the mode BASELINE.md section 3 states) and,
+    as a second figure, in the eval-mode regime the reference's train_seg drifts into.  With WORLD_SIZE > 1
+    gradients go through segmif_amd.parallel.GradAllReducer (bucketed RCCL all-reduce launched from autograd hooks) and the
+    non-overlapped part of the exchange is reported.  Same fencing as the forward leg: barrier + device sync on both sides,
+    max over ranks."""
+    import detweights as dw
+    from segmif_amd import dist
+    from segmif_amd.parallel import GradAllReducer
+    from segmif_amd.train import FusionTrainer, seg_train_step
+    from segmif_amd.utils.optimizer import PolyWarmupAdamW, PolyWarmupAdamW_seg
+
+    B, H, W = args.train_batch, args.height, args.width
+    steps = args.train_steps or max(1, min(args.steps, 8))
+    warm = 2
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+    labels = dw.det_labels(f"trb_y{rank}", (B, H, W), 9).cuda()
+    x = dw.det_input(f"trb_x{rank}", (B, 3, H, W)).cuda()
+    ir3 = dw.det_input(f"trb_ir{rank}", (B, 1, H, W)).repeat(1, 3, 1, 1).cuda()
+    vis3 = dw.det_input(f"trb_vis{rank}", (B, 3, H, W)).cuda()
+    mask3 = dw.det_input(f"trb_m{rank}", (B, 1, H, W)).repeat(1, 3, 1, 1).cuda()
+    g = seg.denoise_net.get_param_groups()
+    # constructor arguments of train.py:171-199 / :316-331 (configs/voc.yaml; iter_ = 2)
+    opt_seg = PolyWarmupAdamW_seg([{"params": g[0], "lr": 8e-5, "weight_decay": 0.01}, {"params": g[1], "lr": 8e-5, "weight_decay": 0.0},
+                                   {"params": g[2], "lr": 8e-4, "weight_decay": 0.01}], lr=8e-5, weight_decay=0.01,
+                                  betas=(0.9, 0.999), iter_curr=0, warmup_iter=3000, max_iter=160000, warmup_ratio=1e-6, power=1.0)
+    opt_fus = PolyWarmupAdamW([{"params": fus.parameters(), "lr": 8e-5 / 2, "weight_decay": 0.01}], lr=3e-4 / 2, weight_decay=0.01,
+                              betas=(0.9, 0.999), warmup_iter=3e-5 / 2, max_iter=160000, warmup_ratio=1e-6, power=1.0)
+    red_seg = GradAllReducer([p for grp in g for p in grp]) if world > 1 else None
+    red_fus = GradAllReducer(list(fus.parameters())) if world > 1 else None
+    trainer = FusionTrainer(seg, fus, opt_fus, crit, iter_=2, reducer=red_fus, report_lap=True)
+
+    def timed(step, reducer):
+        for _ in range(warm):
+            loss = step()
+        if reducer is not None:
+            reducer.time_exposed_wait = True
+        exposed = []
+        dist.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+            if reducer is not None:
+                exposed.append(reducer.exposed_wait_s)
+        dist.fence()
+        dt = dist.max_over_ranks((time.perf_counter() - t0) / steps)
+        if reducer is not None:
+            reducer.time_exposed_wait = False
+        return dt, float(loss), (1e3 * sum(exposed) / len(exposed) if exposed else None)
+
+    out = {"batch_per_gpu": B, "global_batch": B * world, "steps": steps, "warmup": warm, "world_size": world,
+           "backbone": args.backbone, "height": H, "width": W}
+    for mode in ("train", "eval_regime"):
+        seg.train(mode == "train")
+        fus.train(mode == "train")
+        for name, step, red in (("seg", lambda: seg_train_step(seg, opt_seg, x, labels, crit, red_seg), red_seg),
+                                ("fusion", lambda: trainer.step(ir3, vis3, mask3, labels), red_fus)):
+            dt, loss, exposed_ms = timed(step, red)
+            gf = GFLOP_TRAIN.get((args.backbone, name))
+            rec = {"ms_per_step": 1e3 * dt, "samples_per_s": world * B / dt, "loss": loss,
+                   "tflops_per_gpu": (gf * B / dt / 1e3) if gf and (H, W) == (480, 640) else None,
+                   "gflop_per_sample": gf, "allreduce_exposed_ms": exposed_ms,
+                   "grad_bytes": red.gradient_bytes() if red is not None else
+                   4 * sum(p.numel() for p in (fus.parameters() if name == "fusion" else [q for grp in g for q in grp])
+                           if p.grad is not None)}
+            if name == "fusion" and trainer.last_lap is not None:
+                rec["lap_loss2_reported"] = float(trainer.last_lap)
+            out[f"{name}_{mode}"] = rec
+    seg.eval()
+    fus.eval()
+    out["modes"] = {"train": "DropPath, Dropout2d(0.1), BatchNorm batch statistics active (BASELINE.md section 3)",
+                    "eval_regime": "module.eval() with gradients: the regime train_seg drifts into after its first validation (SURVEY F11)"}
+    out["fusion_step_seg_weight_grads"] = False
+    out["peak_bf16x6_tflops"] = PEAK_BF16X6_TFLOPS
+    if world > 1:
+        out["collective"] = {"backend": torch.distributed.get_backend(), "rccl_version": ".".join(map(str, torch.cuda.nccl.version())),
+                             "world_size": torch.distributed.get_world_size(), "bucket_mb": 25.0,
+                             "overlap": "buckets launched from post-accumulate-grad hooks during backward"}
+    out["peak_mem_GB"] = torch.cuda.max_memory_allocated() / 2 ** 30
+    return out
+
+
 def self_launch(args, script=None, argv=None):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU
     (script / argv: what to run, for the CPU test of this entry; default: this file with the same arguments)."""
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)]
+    # --standalone: the launcher binds its own free rendezvous port (no bind-then-close race with other jobs on the host)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", script or os.path.abspath(__file__)]
     cmd += sys.argv[1:] if argv is None else list(argv)
     raise SystemExit(subprocess.call(cmd, env=env))
 
@@ -180,6 +271,12 @@ def main():
 
     elapsed = dist.max_over_ranks(elapsed)
 
+    train = None
+    if not args.no_train and not args.graph:
+        del pipe, labels
+        torch.cuda.empty_cache()
+        train = train_leg(args, rank, world, seg, fus)  # every rank: the data-parallel steps hold collectives
+
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / elapsed
@@ -236,6 +333,8 @@ def main():
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                 "launches_timed": n, "avg_launch_ms": ms, "avg_launch_gflop": flops / 1e9,
             }
+        if train is not None:
+            out["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.backbone, H, W)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

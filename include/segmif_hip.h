@@ -231,6 +231,9 @@ int segmif_layernorm_f32(const float* x, const float* gamma, const float* beta, 
  */
 int segmif_dwconv3x3_gelu_f32(const float* x, const float* w9, const float* bias, float* y,
                               int B, int H, int W, int C, void* stream);
+/* DWConv.forward called on its own (core/mix_transformer.py:381-387): depthwise 3x3 + bias, no activation. */
+int segmif_dwconv3x3_bias_f32(const float* x, const float* w9, const float* bias, float* y,
+                              int B, int H, int W, int C, void* stream);
 
 /*
  * Bilinear resize, align_corners=False, NHWC: (B, IH, IW, C) -> (B, OH, OW, C) written with
@@ -368,6 +371,10 @@ int64_t segmif_dwconv_bwd_partial_rows(int B, int H, int W);
 int segmif_dwconv3x3_gelu_bwd_f32(const float* h, const float* w9, const float* bias, const float* dy, float* dz,
                                   float* partial, int B, int H, int W, int C, void* stream);
 int segmif_dwconv3x3_plain_f32(const float* x, const float* w9, float* y, int B, int H, int W, int C, void* stream);
+/* parameter-gradient partials of the bare depthwise conv (segmif_dwconv3x3_bias_f32): same [9 taps | bias][C] rows as above
+ * with dz = dy; the input gradient is segmif_dwconv3x3_plain_f32(dy, taps flipped). */
+int segmif_dwconv3x3_bias_bwd_f32(const float* h, const float* w9, const float* dy, float* partial, int B, int H, int W,
+                                  int C, void* stream);
 
 /* adjoint of segmif_bilinear_nhwc_f32 (gather form): dy (B,OH,OW,C) -> dx (B,IH,IW,C) */
 int segmif_bilinear_nhwc_bwd_f32(const float* dy, float* dx, int B, int IH, int IW, int OH, int OW, int C,
@@ -425,6 +432,25 @@ int segmif_sobel_l1_f32(const float* gen, const float* mask, float* pxy2, double
                         void* stream);
 int segmif_sobel_l1_bwd_f32(const float* pxy2, const float* gen, const float* mask, float* grad, int planes, int H, int W,
                             const float* upstream, void* stream);
+
+/* LapLoss2 (lap_loss.py:100-118, built by Fusionloss_grad3 at core/loss.py:509): d_k(img) = img - G_k * img for the three
+ * zero-padded Gaussians G_3, G_5, G_7 (sigma 2, lap_loss.py:39-80), loss = 10 (L1_3 + L1_5) + L1_7,
+ * L1_k = mean | d_k(gen) - max(d_k(ir), d_k(vis)) | over n = planes*H*W pixels.
+ *   segmif_laploss2_f32      sums2[0] = sum of 10 |a_3| + 10 |a_5| + |a_7| (divide by n); sign3 (optional, [3][n]) = sign(a_k)
+ *   segmif_laploss2_bwd_f32  grad = upstream / n * sum_k c_k (s_k - G_k * s_k)   (gradient w.r.t. gen only)
+ * partial: 2*segmif_loss_blocks(n) doubles. */
+int segmif_laploss2_f32(const float* gen, const float* ir, const float* vis, float* sign3, double* partial, double* sums2,
+                        int planes, int H, int W, void* stream);
+int segmif_laploss2_bwd_f32(const float* sign3, float* grad, int planes, int H, int W, const float* upstream, void* stream);
+
+/* The fusion net's shared scalar PReLU (core/model_fusion.py:1038) on the training path, kept apart from the conv so
+ * that the backward reads the branch off the pre-activation z (any slope, also <= 0): y = z > 0 ? z : a z;
+ * dz = dy (z > 0 ? 1 : a), dslope[0] = sum over z <= 0 of dy z (fp64 two-pass).  16-byte path when n % 4 == 0 and the
+ * pointers are aligned, scalar otherwise.  partial: 2 * (segmif_prelu_bwd_blocks(n) + 1) doubles. */
+int segmif_prelu_f32(const float* z, const float* slope, float* y, int64_t n, void* stream);
+int segmif_prelu_bwd_blocks(int64_t n);
+int segmif_prelu_bwd_f32(const float* dy, const float* z, const float* slope, float* dz, double* partial, float* dslope,
+                         int64_t n, void* stream);
 
 /* multi-tensor AdamW (utils/optimizer.py:6 -> torch.optim.AdamW arithmetic). table: device array of
  * {float* p; const float* g; float* m; float* v; int64 n; float lr; float wd;} entries

@@ -212,6 +212,52 @@ def cross_path(sd, pfx, x1, x2, seg, heads=8):
     return o1, o2
 
 
+def cross_attention(sd, pfx, x1, x2, seg, heads=8):
+    """CrossAttention.forward on its own (core/model_fusion.py:263-288): one context from the segmentation feature (kv3,
+    no bias), applied to the two modality features used as queries."""
+    ctx3 = _linear_attention_context(_lin(seg, sd, pfx + "kv3"), heads)
+    return _apply_context(x1, ctx3, heads), _apply_context(x2, ctx3, heads)
+
+
+def cross_attention2(sd, pfx, x1, x2, seg, heads=8):
+    """CrossAttention2.forward on its own (core/model_fusion.py:303-328): one context per modality (kv1 / kv2, no bias),
+    each applied to the segmentation feature used as the query."""
+    ctx1 = _linear_attention_context(_lin(x1, sd, pfx + "kv1"), heads)
+    ctx2 = _linear_attention_context(_lin(x2, sd, pfx + "kv2"), heads)
+    return _apply_context(seg, ctx1, heads), _apply_context(seg, ctx2, heads)
+
+
+def dwconv_tokens(sd, pfx, x, H, W):
+    """DWConv.forward (core/mix_transformer.py:381-387): tokens -> image, depthwise 3x3 (pad 1) + bias, back to tokens."""
+    B, N, C = x.shape
+    img = x.transpose(1, 2).reshape(B, C, H, W)
+    img = F.conv2d(img, sd[pfx + "dwconv.weight"], sd[pfx + "dwconv.bias"], padding=1, groups=C)
+    return img.flatten(2).transpose(1, 2)
+
+
+def _lap_window(size, sigma=2.0):
+    """lap_loss.py:39-80 `smoothing`: exp(-((x - m)^2 + (y - m)^2) / (2 sigma^2)) / (2 pi sigma^2), m = (size - 1) / 2,
+    normalised to sum 1, fp32."""
+    c = torch.arange(size, dtype=torch.float32)
+    xg = c.repeat(size).view(size, size)
+    d2 = (xg - (size - 1) / 2.0) ** 2 + (xg.t() - (size - 1) / 2.0) ** 2
+    g = (1.0 / (2.0 * math.pi * sigma ** 2)) * torch.exp(-d2 / (2 * sigma ** 2))
+    return (g / g.sum()).view(1, 1, size, size)
+
+
+def lap_loss2(gen, ir, vis):
+    """lap_loss.LapLoss2.forward (lap_loss.py:100-118, laplacian_pyramid :71-79): "levels" img - G_k * img for the 3 / 5 / 7
+    windows (zero padding k // 2), 10 * (L1 of levels 0 and 1) + L1 of level 2 against max(level(ir), level(vis))."""
+    C = gen.shape[1]
+    levels = []
+    for size in (3, 5, 7):
+        w = _lap_window(size).repeat(C, 1, 1, 1)
+        levels.append([t - F.conv2d(t, w, padding=size // 2, groups=C) for t in (gen, ir, vis)])
+    loss = 10.0 * sum(F.l1_loss(a, torch.maximum(b, c)) for a, b, c in levels[:-1])
+    a, b, c = levels[-1]
+    return loss + F.l1_loss(a, torch.maximum(b, c))
+
+
 def feature_fusion_module(sd, pfx, x1, x2, seg):
     """core/model_fusion.py:453-463: NCHW -> tokens -> CrossPath -> NCHW."""
     B, C, H, W = x1.shape

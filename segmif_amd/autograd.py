@@ -91,26 +91,11 @@ def conv_wgrad(x, dy, w_shape, k, stride, pad, dil, want_bias=False):
     return (dw, db) if want_bias else dw
 
 
-_slope_checked = {}
-
-
-def _require_positive_slope(slope):
-    """The PReLU backward reads the negative branch off the sign of the activation OUTPUT and divides by the slope
-    (act_bwd kernel, _slope_grad): both need slope > 0.  The reference initialises it to 0.25 and AdamW keeps it
-    there in practice, but nothing forces that; check once per parameter version (one host sync per optimizer step)."""
-    key = (slope.data_ptr(), slope._version)
-    if _slope_checked.get("key") != key:
-        v = float(slope.detach().reshape(-1)[0])
-        if not v > 0.0:
-            raise RuntimeError(f"segmif_amd: the shared PReLU slope is {v}; the HIP backward needs slope > 0")
-        _slope_checked["key"] = key
-
-
-def _slope_grad(dy, y, slope):
-    """d(loss)/d(slope) of the shared scalar PReLU: sum over y < 0 of dy * pre, pre = y / slope."""
-    # TODO(next): fold into act_bwd's kernel; parameter-scalar reduction, negligible next to the convs
-    neg = y < 0
-    return (dy * torch.where(neg, y, torch.zeros_like(y))).sum().reshape(1) / slope
+def _no_prelu(act):
+    if act == ACT_PRELU:
+        raise RuntimeError("segmif_amd.autograd: the shared PReLU is its own node on the training path (ag.conv2d / ag.linear "
+                           "compose it after an un-activated conv): its backward needs the pre-activation, which a fused "
+                           "epilogue does not keep")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -119,32 +104,25 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, act, slope):
+        _no_prelu(act)
         N = w.shape[0]
         w2 = w.reshape(N, -1)
         K = w2.shape[1]
         wt = w2.contiguous() if K % 16 == 0 else ops.pack_weight(w2)
         y = ops.linear(x, wt, N, bias=b, act=act, prelu=slope)
         ctx.act = act
-        ctx.save_for_backward(x, w, y if act in (ACT_RELU, ACT_PRELU) else None, slope)
+        ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.has_bias = b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y, slope = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         N = w.shape[0]
         w2 = w.reshape(N, -1)
         K = w2.shape[1]
         dy = dy.contiguous()
-        dslope = None
-        if ctx.act in (ACT_RELU, ACT_PRELU):
-            if ctx.act == ACT_PRELU:
-                _require_positive_slope(slope)
-            if ctx.act == ACT_PRELU and ctx.needs_input_grad[4]:
-                dslope = _slope_grad(dy, y, slope)
-            dz = act_bwd(dy, y, ctx.act, slope)
-        else:
-            dz = dy
+        dz = act_bwd(dy, y, ACT_RELU) if ctx.act == ACT_RELU else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wtT = w2.t().contiguous()  # (K, N): "weights" of the input-gradient GEMM
@@ -157,7 +135,7 @@ class LinearFn(torch.autograd.Function):
             dw = dw.reshape(w.shape)
         elif want_b:
             db = colsum(dz)
-        return dx, dw, db, None, dslope
+        return dx, dw, db, None, None
 
 
 def _pack_conv(w, k, stride, pad, dil):
@@ -173,29 +151,22 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, k, stride, pad, dil, act, slope):
+        _no_prelu(act)
         N = w.shape[0]
         y = ops.conv2d(x, _pack_conv(w, k, stride, pad, dil), N, k, stride=stride, pad=pad, dil=dil, bias=b, act=act,
                        prelu=slope)
         ctx.geom = (k, stride, pad, dil, act)
         ctx.has_bias = b is not None
-        ctx.save_for_backward(x, w, y if act in (ACT_RELU, ACT_PRELU) else None, slope)
+        ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y, slope = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         k, stride, pad, dil, act = ctx.geom
         N, cin = w.shape[0], w.shape[1]
         dy = dy.contiguous()
-        dslope = None
-        if act in (ACT_RELU, ACT_PRELU):
-            if act == ACT_PRELU:
-                _require_positive_slope(slope)
-            if act == ACT_PRELU and ctx.needs_input_grad[8]:
-                dslope = _slope_grad(dy, y, slope)
-            dz = act_bwd(dy, y, act, slope)
-        else:
-            dz = dy
+        dz = act_bwd(dy, y, ACT_RELU) if act == ACT_RELU else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             B, H, W, _ = x.shape
@@ -229,7 +200,35 @@ class ConvFn(torch.autograd.Function):
             dw, db = (r if want_b else (r, None))
         elif want_b:
             db = colsum(dz)
-        return dx, dw, db, None, None, None, None, None, dslope
+        return dx, dw, db, None, None, None, None, None, None
+
+
+class PReluFn(torch.autograd.Function):
+    """y = z > 0 ? z : a z with the fusion net's shared scalar slope `a` (core/model_fusion.py:1038).  A node of its own on
+    the training path: the backward branches on the saved PRE-activation, so it is exact for any slope (nn.PReLU trains
+    through a <= 0; AdamW's weight decay can take it there), and d loss / d a comes out of the same kernel."""
+
+    @staticmethod
+    def forward(ctx, z, slope):
+        z = z.contiguous()
+        y = torch.empty_like(z)
+        _lib.check(_lib.load().segmif_prelu_f32(z.data_ptr(), _req(slope, "slope").data_ptr(), y.data_ptr(), z.numel(), _stream()),
+                   "segmif_prelu_f32")
+        ctx.save_for_backward(z, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, slope = ctx.saved_tensors
+        dy = dy.contiguous()
+        lib = _lib.load()
+        n = z.numel()
+        dz = torch.empty_like(z)
+        part = torch.empty((2 * (lib.segmif_prelu_bwd_blocks(n) + 1),), device=z.device, dtype=torch.float64)
+        dslope = torch.empty((1,), device=z.device, dtype=torch.float32)
+        _lib.check(lib.segmif_prelu_bwd_f32(dy.data_ptr(), z.data_ptr(), slope.data_ptr(), dz.data_ptr(), part.data_ptr(),
+                                            dslope.data_ptr(), n, _stream()), "segmif_prelu_bwd_f32")
+        return dz, (dslope.reshape(slope.shape) if ctx.needs_input_grad[1] else None)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -293,6 +292,38 @@ class DwconvGeluFn(torch.autograd.Function):
             w9f = w9.flip(0).contiguous()
             _lib.check(lib.segmif_dwconv3x3_plain_f32(dz.data_ptr(), w9f.data_ptr(), dh.data_ptr(), B, H, W, C,
                                                       _stream()), "segmif_dwconv3x3_plain_f32")
+        return dh, dw, db, None, None
+
+
+class DwconvFn(torch.autograd.Function):
+    """DWConv.forward on its own: tokens (B, H*W, C) -> dwconv3x3(tokens as image) + b (core/mix_transformer.py:381-387)."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, H, W):
+        ctx.hw = (H, W)
+        ctx.save_for_backward(h, w)
+        return ops.dwconv3x3_bias(h, ops.pack_dw_weight(w), b, H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w = ctx.saved_tensors
+        H, W = ctx.hw
+        B, _, C = h.shape
+        dy = dy.contiguous()
+        lib = _lib.load()
+        w9 = ops.pack_dw_weight(w)
+        dw = db = dh = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            partial = torch.empty((lib.segmif_dwconv_bwd_partial_rows(B, H, W), 10 * C), device=h.device, dtype=torch.float32)
+            _lib.check(lib.segmif_dwconv3x3_bias_bwd_f32(h.data_ptr(), w9.data_ptr(), dy.data_ptr(), partial.data_ptr(), B, H, W,
+                                                         C, _stream()), "segmif_dwconv3x3_bias_bwd_f32")
+            sums = colsum(partial).view(10, C)
+            dw = sums[:9].t().reshape(C, 1, 3, 3)
+            db = sums[9]
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty_like(h)
+            _lib.check(lib.segmif_dwconv3x3_plain_f32(dy.data_ptr(), w9.flip(0).contiguous().data_ptr(), dh.data_ptr(), B, H, W,
+                                                      C, _stream()), "segmif_dwconv3x3_plain_f32")
         return dh, dw, db, None, None
 
 
@@ -708,17 +739,60 @@ class FusionLoss3Fn(torch.autograd.Function):
         return grad, None
 
 
+class LapLoss2Fn(torch.autograd.Function):
+    """LapLoss2(gen, ir, vis) (lap_loss.py:100-118) on single-channel images, csrc/losses.hip: one pass over the 7 x 7
+    neighbourhood for the three Gaussian levels of the three images, sign planes kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, gen, ir, vis):
+        lib = _lib.load()
+        g, a, b = gen.contiguous(), ir.contiguous(), vis.contiguous()
+        B, C, H, W = g.shape
+        n = g.numel()
+        need = ctx.needs_input_grad[0]
+        sign3 = torch.empty((3, n), device=g.device, dtype=torch.float32) if need else None
+        part = torch.empty((2 * lib.segmif_loss_blocks(n),), device=g.device, dtype=torch.float64)
+        sums = torch.empty((2,), device=g.device, dtype=torch.float64)
+        _lib.check(lib.segmif_laploss2_f32(g.data_ptr(), a.data_ptr(), b.data_ptr(), sign3.data_ptr() if need else None,
+                                           part.data_ptr(), sums.data_ptr(), B * C, H, W, _stream()), "segmif_laploss2_f32")
+        ctx.save_for_backward(sign3)
+        ctx.geom = (B * C, H, W, g.shape)
+        return (sums[0] / n).float()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (sign3,) = ctx.saved_tensors
+        planes, H, W, shape = ctx.geom
+        grad = torch.empty(shape, device=sign3.device, dtype=torch.float32)
+        up = dloss.reshape(1).float().contiguous()
+        _lib.check(_lib.load().segmif_laploss2_bwd_f32(sign3.data_ptr(), grad.data_ptr(), planes, H, W, up.data_ptr(), _stream()),
+                   "segmif_laploss2_bwd_f32")
+        return grad, None, None
+
+
 # functional front-ends ------------------------------------------------------------------------------
 def linear(x, w, b=None, act=ACT_NONE, slope=None):
+    if act == ACT_PRELU:  # the shared PReLU is a node of its own: its backward reads the pre-activation (PReluFn)
+        return PReluFn.apply(LinearFn.apply(x, w, b, ACT_NONE, None), slope)
     return LinearFn.apply(x, w, b, act, slope)
 
 
 def conv2d(x, w, b=None, k=3, stride=1, pad=0, dil=1, act=ACT_NONE, slope=None):
+    if act == ACT_PRELU:
+        return PReluFn.apply(ConvFn.apply(x, w, b, k, stride, pad, dil, ACT_NONE, None), slope)
     return ConvFn.apply(x, w, b, k, stride, pad, dil, act, slope)
+
+
+def prelu(z, slope):
+    return PReluFn.apply(z, slope)
 
 
 def layernorm(x, gamma, beta, eps):
     return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+def dwconv(h, w, b, H, W):
+    return DwconvFn.apply(h, w, b, H, W)
 
 
 def dwconv_gelu(h, w, b, H, W):

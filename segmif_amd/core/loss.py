@@ -10,7 +10,7 @@ import torch.nn as nn
 from .. import losses
 from .model_fusion import RGB2YCrCb  # noqa: F401
 
-__all__ = ["Sobelxy", "Fusionloss3", "Fusionloss_grad3", "RGB2YCrCb", "Total_fusion_loss", "Total_fusion_loss2",
+__all__ = ["Sobelxy", "Fusionloss3", "Fusionloss_grad3", "LapLoss2", "RGB2YCrCb", "Total_fusion_loss", "Total_fusion_loss2",
            "Fusionloss", "Fusionloss_add", "Fusionloss2", "Fusionloss4"]
 
 
@@ -31,9 +31,28 @@ class Fusionloss3(nn.Module):
         return losses.fusion_loss3(generate_img, mask)
 
 
+class LapLoss2(nn.Module):
+    """lap_loss.py:100-118: three Gaussian-difference levels (3 / 5 / 7 taps, sigma 2) of the fused image against the
+    pixel-wise maximum of the same levels of the two sources; the `device` argument is accepted for signature
+    compatibility (the windows are constants of the HIP kernel)."""
+
+    def __init__(self, max_levels=3, channels=1, device=None):
+        super().__init__()
+        if max_levels != 3 or channels != 1:
+            raise NotImplementedError("LapLoss2 is built for the reference's only use: 3 levels, single-channel images")
+        self.max_levels = max_levels
+
+    def forward(self, input, ir, vis):
+        return losses.lap_loss2(input, ir, vis)
+
+
 class Fusionloss_grad3(nn.Module):
-    """MSE(mask_0, fused) + 1.1 * (1 - SSIM(fused, mask_0)).  (The reference also constructs a LapLoss2 it
-    never evaluates, core/loss.py:509.)"""
+    """MSE(mask_0, fused) + 1.1 * (1 - SSIM(fused, mask_0)).  Like the reference (core/loss.py:509) it owns a LapLoss2
+    that its forward never evaluates; segmif_amd.train.FusionTrainer(report_lap=True) reports that term beside the loss."""
+
+    def __init__(self):
+        super().__init__()
+        self.lap = LapLoss2()
 
     def forward(self, image_ir, image_vis, generate_img, mask):
         return losses.fusion_loss_grad3(generate_img, mask)

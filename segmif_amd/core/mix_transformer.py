@@ -22,18 +22,30 @@ import torch.nn as nn
 
 from .. import autograd as ag
 from .. import ops
-from ._util import PackedCache, drop_path_scale, init_reference_style, wants_grad
+from ._util import PackedCache, drop_path_scale, init_reference_style, require_device, wants_grad
 
 __all__ = ["Mlp", "Attention", "Block", "OverlapPatchEmbed", "MixVisionTransformer", "DWConv",
            "mit_b0", "mit_b1", "mit_b2", "mit_b3", "mit_b4", "mit_b5"]
 
 
 class DWConv(nn.Module):
-    """Parameter holder for the 3x3 depthwise conv (key: dwconv.weight / dwconv.bias)."""
+    """3x3 depthwise conv on tokens (ref :376-387; keys dwconv.weight / dwconv.bias).  Inside Mlp it runs fused with the
+    GELU that follows it (dwconv3x3_gelu); called on its own it is the bare depthwise conv + bias."""
 
     def __init__(self, dim=768):
         super().__init__()
         self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
+        self._pk = PackedCache()
+
+    def forward(self, x, H, W):
+        """x: (B, H*W, C) tokens -> (B, H*W, C)."""
+        require_device(x, "DWConv input")
+        if x.dim() != 3 or x.shape[1] != H * W or x.shape[2] != self.dwconv.weight.shape[0]:
+            raise RuntimeError(f"DWConv expects (B, {H * W}, {self.dwconv.weight.shape[0]}) tokens, got {tuple(x.shape)}")
+        if wants_grad(self, x):
+            return ag.dwconv(x.contiguous(), self.dwconv.weight, self.dwconv.bias, H, W)
+        return ops.dwconv3x3_bias(x.contiguous(), self._pk.get("dw", self.dwconv.weight, ops.pack_dw_weight),
+                                  self.dwconv.bias, H, W)
 
 
 class Mlp(nn.Module):

@@ -139,7 +139,10 @@ class DRDB(nn.Module):
         return out
 
     def planes_ok(self):
-        return ops.conv3x3_mode() == "planes" and self.in_ch == 64 and self.growth == 32
+        """The planes kernels take 16-byte bias loads: parameters living at odd offsets of a flattened buffer fall back to
+        the fp32-buffer DRDB (forward_buffer) instead of failing."""
+        return ops.conv3x3_mode() == "planes" and self.in_ch == 64 and self.growth == 32 \
+            and ops.aligned16(self.conv.bias, *(getattr(self, f"Dcov{i}").bias for i in range(1, 6)))
 
     def _params(self):
         ps = []
@@ -163,7 +166,58 @@ class DRDB(nn.Module):
         return ops.as_nchw(self.forward_buffer(buf))
 
 
-class CrossAttention(nn.Module):
+class _LinearCrossAttention(nn.Module):
+    """Shared machinery of CrossAttention / CrossAttention2 (ref :250-328): softmax_{dim=-2}((K^T V) * scale) per head is an
+    8 x 8 "context" ctx[b][h][i][j]; applying it to a query, out[b, n, 8 h + j] = sum_i x[b, n, 8 h + i] ctx[b, h, i, j]
+    with the heads re-interleaved (ref :285-286, :325-326), is one GEMM per image against the block-diagonal 64 x 64
+    matrix of that image's eight contexts.  The kernels (csrc/linattn.hip) are built for the one configuration SegMiF
+    instantiates: dim 64, 8 heads of 8."""
+
+    def _check(self):
+        if self.dim != 64 or self.num_heads != 8:
+            raise NotImplementedError("the linear-attention kernels are built for dim 64, 8 heads of 8 (the only "
+                                      "configuration SegMiF instantiates)")
+
+    def _partial(self, lin, name, x):
+        if lin.bias is None:  # the configuration SegMiF uses: fused projection + reduction
+            return ops.linattn_kvpartial(x, lin.weight, self.num_heads)
+        kv = ops.linear(x, self._pk.get(name, lin.weight, ops.pack_weight), 2 * self.dim, bias=lin.bias)
+        return ops.linattn_partial(kv, self.num_heads)
+
+    def _context_weight(self, lin, name, x):
+        """Inference: (B, 64, 64) block-diagonal W with q @ ctx == q @ W^T, straight from the fp64 K^T V partial sums
+        (segmif_linattn_fold_f32 against an identity end_proj)."""
+        part = self._partial(lin, name, x)
+        eye = self._pk.get_multi("eye", (), lambda: torch.eye(self.dim, device=x.device, dtype=torch.float32))
+        w = torch.empty((x.shape[0], self.dim, self.dim), device=x.device, dtype=torch.float32)
+        return ops.linattn_fold(part, eye, w, wofs=0, kofs=0, scale=self.scale, heads=self.num_heads)
+
+    def _context_weight_train(self, lin, x):
+        if lin.bias is not None:
+            raise NotImplementedError("training through a linear cross attention with qkv_bias=True is not implemented "
+                                      "(SegMiF builds these modules without bias)")
+        ctx = torch.softmax(ag.kv_context(x, lin.weight) * self.scale, dim=-2)  # (B, 8, 8, 8) fp64, [h][i][j]
+        return _block_diag_batched(ctx).float()
+
+    @staticmethod
+    def _tokens(*ts):
+        for t in ts:
+            require_device(t, "CrossAttention input")
+            if t.dim() != 3 or t.shape[-1] != 64:
+                raise RuntimeError(f"CrossAttention expects (B, N, 64) tokens, got {tuple(t.shape)}")
+        return [t.contiguous() for t in ts]
+
+
+def _block_diag_batched(ctx):
+    """(B, h, d, d) contexts [i][j] -> (B, h d, h d) with W[b][h d + j][h d + i] = ctx[b][h][i][j] (q @ ctx == q @ W^T)."""
+    B, h, d, _ = ctx.shape
+    w = ctx.new_zeros((B, h * d, h * d))
+    for k in range(h):
+        w[:, k * d:(k + 1) * d, k * d:(k + 1) * d] = ctx[:, k].transpose(1, 2)
+    return w
+
+
+class CrossAttention(_LinearCrossAttention):
     """Context from the segmentation feature, queries = the two modality features (ref :250-288)."""
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None):
@@ -175,13 +229,20 @@ class CrossAttention(nn.Module):
         self._pk = PackedCache()
 
     def context_partial(self, seg):
-        if self.kv3.bias is None:  # the configuration SegMiF uses: fused projection + reduction
-            return ops.linattn_kvpartial(seg, self.kv3.weight, self.num_heads)
-        kv = ops.linear(seg, self._pk.get("kv3", self.kv3.weight, ops.pack_weight), 2 * self.dim, bias=self.kv3.bias)
-        return ops.linattn_partial(kv, self.num_heads)
+        return self._partial(self.kv3, "kv3", seg)
+
+    def forward(self, x1, x2, segfeature):
+        """(B, N, C) x 3 -> (q1 @ ctx3, q2 @ ctx3), ctx3 = softmax_{dim=-2}(K3^T V3 * scale) per head (ref :263-288)."""
+        self._check()
+        x1, x2, seg = self._tokens(x1, x2, segfeature)
+        if wants_grad(self, x1, x2, seg):
+            w = self._context_weight_train(self.kv3, seg)
+            return ag.batched_linear(x1, w), ag.batched_linear(x2, w)
+        w = self._context_weight(self.kv3, "kv3", seg)
+        return ops.linear(x1, w, self.dim, batched_weight=True), ops.linear(x2, w, self.dim, batched_weight=True)
 
 
-class CrossAttention2(nn.Module):
+class CrossAttention2(_LinearCrossAttention):
     """Contexts from each modality, query = the segmentation feature (ref :290-328)."""
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None):
@@ -194,11 +255,18 @@ class CrossAttention2(nn.Module):
         self._pk = PackedCache()
 
     def context_partial(self, which, x):
-        lin = self.kv1 if which == 1 else self.kv2
-        if lin.bias is None:
-            return ops.linattn_kvpartial(x, lin.weight, self.num_heads)
-        kv = ops.linear(x, self._pk.get(f"kv{which}", lin.weight, ops.pack_weight), 2 * self.dim, bias=lin.bias)
-        return ops.linattn_partial(kv, self.num_heads)
+        return self._partial(self.kv1 if which == 1 else self.kv2, f"kv{which}", x)
+
+    def forward(self, x1, x2, segfeature):
+        """(B, N, C) x 3 -> (q3 @ ctx1, q3 @ ctx2), ctx_i = softmax_{dim=-2}(K_i^T V_i * scale) per head (ref :303-328)."""
+        self._check()
+        x1, x2, seg = self._tokens(x1, x2, segfeature)
+        if wants_grad(self, x1, x2, seg):
+            return (ag.batched_linear(seg, self._context_weight_train(self.kv1, x1)),
+                    ag.batched_linear(seg, self._context_weight_train(self.kv2, x2)))
+        w1 = self._context_weight(self.kv1, "kv1", x1)
+        w2 = self._context_weight(self.kv2, "kv2", x2)
+        return ops.linear(seg, w1, self.dim, batched_weight=True), ops.linear(seg, w2, self.dim, batched_weight=True)
 
 
 class CrossPath(nn.Module):
@@ -277,7 +345,8 @@ class CrossPath(nn.Module):
 
     def gram_ok(self):
         return ops.crosspath_mode() == "gram" and self.cross_attn.kv3.bias is None and self.cross_attn2.kv1.bias is None \
-            and self.cross_attn2.kv2.bias is None
+            and self.cross_attn2.kv2.bias is None \
+            and ops.aligned16(*(p for p in self.parameters() if p.dim() == 1))  # 16-byte bias / LayerNorm loads in the tail
 
     def forward_tokens_train(self, x1, x2, seg):
         """autograd path: heavy contractions in HIP Functions, the 8x8 context softmax and the fold into
@@ -379,13 +448,15 @@ class Fusion_Network3_ac(nn.Module):
         forward and backward are HIP kernels."""
         B, _, H, W = ir.shape
         slope = self.relu.weight
-        PRELU = ops.ACT_PRELU
 
         def nhwc1(x):  # x[:, 0:1] as NHWC, autograd-aware
             return x[:, 0:1].permute(0, 2, 3, 1).contiguous()
 
-        x1 = ag.conv2d(nhwc1(ir), self.conv1_ir.weight, self.conv1_ir.bias, k=3, pad=1, act=PRELU, slope=slope)
-        x2 = ag.conv2d(nhwc1(vis), self.conv1_vis.weight, self.conv1_vis.bias, k=3, pad=1, act=PRELU, slope=slope)
+        def conv_prelu(x, conv):  # (ag.conv2d keeps the shared PReLU a node of its own: exact backward for any slope)
+            return ag.conv2d(x, conv.weight, conv.bias, k=3, pad=1, act=ops.ACT_PRELU, slope=slope)
+
+        x1 = conv_prelu(nhwc1(ir), self.conv1_ir)
+        x2 = conv_prelu(nhwc1(vis), self.conv1_vis)
         x1 = self.DRDB1.forward_train_nhwc(x1)
         x2 = self.DRDB2.forward_train_nhwc(x2)
         seg = ag.linear(out1.permute(0, 2, 3, 1).contiguous(), self.conv3.weight, self.conv3.bias)
@@ -394,9 +465,9 @@ class Fusion_Network3_ac(nn.Module):
         x2 = self.DRDB4.forward_train_nhwc(x2)
         seg = ag.linear(out2.permute(0, 2, 3, 1).contiguous(), self.conv4.weight, self.conv4.bias)
         x1, x2 = self.ffm.forward_nhwc(x1, x2, seg)
-        f = ag.conv2d(torch.cat((x1, x2), dim=-1), self.conv2.weight, self.conv2.bias, k=3, pad=1, act=PRELU, slope=slope)
-        f = ag.conv2d(f, self.conv21.weight, self.conv21.bias, k=3, pad=1, act=PRELU, slope=slope)
-        f = ag.conv2d(f, self.conv22.weight, self.conv22.bias, k=3, pad=1, act=PRELU, slope=slope)
+        f = conv_prelu(torch.cat((x1, x2), dim=-1), self.conv2)
+        f = conv_prelu(f, self.conv21)
+        f = conv_prelu(f, self.conv22)
         return f.permute(0, 3, 1, 2)
 
     def forward(self, ir, vis, out1, out2):

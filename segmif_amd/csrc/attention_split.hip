@@ -19,6 +19,7 @@
 // 16 s + 4 h + (j & 3) + 8 (j >> 2) again - so P feeds the second product without leaving its registers and the V
 // image is stored transposed in that key order.
 #include <hip/hip_runtime.h>
+#include "device_once.h"
 #include <stdint.h>
 
 #include "segmif_hip.h"
@@ -258,7 +259,8 @@ extern "C" int segmif_sr_attention_split_f32(const float* q, const float* k, con
   if (((uintptr_t)k | (uintptr_t)v) & 7) return SEGMIF_EINVAL;
   const int ntiles = (Nk + KT - 1) / KT;
   hipStream_t s = (hipStream_t)stream;
-  static bool raised = false;
+  static segmif::PerDeviceFlag raised_flag;
+  bool& raised = raised_flag.here();
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)sr_attention_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
     if (e != hipSuccess) return (int)e;

@@ -138,6 +138,7 @@ int launch_ln_bwd(const float* x, const float* dy, const float* g, float* dx, fl
 // ---------------------------------------------------------------------------------------------------
 constexpr int DWB_TY = 8;
 
+template <bool GELU>
 __global__ __launch_bounds__(256) void dwconv_gelu_bwd_kernel(const float* __restrict__ hin, const float* __restrict__ w9,
                                                               const float* __restrict__ bias, const float* __restrict__ dy,
                                                               float* __restrict__ dz, float* __restrict__ partial, int H,
@@ -184,15 +185,17 @@ __global__ __launch_bounds__(256) void dwconv_gelu_bwd_kernel(const float* __res
         for (int kx = 0; kx < 3; ++kx) z += win[ky][kx] * wv[ky * 3 + kx];
       const long long o = (img + (long long)yo * W + xo) * C + c;
       const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
-      f32x4 d;
+      f32x4 d = g;
+      if (GELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = z[e];
-        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-        const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
-        d[e] = g[e] * (cdf + v * pdf);
+        for (int e = 0; e < 4; ++e) {
+          const float v = z[e];
+          const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+          const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+          d[e] = g[e] * (cdf + v * pdf);
+        }
+        *reinterpret_cast<f32x4*>(dz + o) = d;
       }
-      *reinterpret_cast<f32x4*>(dz + o) = d;
       acc[9] += d;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
@@ -643,8 +646,20 @@ extern "C" int segmif_dwconv3x3_gelu_bwd_f32(const float* h, const float* w9, co
   if (!h || !w9 || !bias || !dy || !dz || !partial || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 128)) return SEGMIF_EINVAL;
   const int xtiles = (W + 7) / 8;
   dim3 grid((unsigned)((C / 128) * xtiles), (unsigned)((H + DWB_TY - 1) / DWB_TY), (unsigned)B);
-  hipLaunchKernelGGL(dwconv_gelu_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, h, w9, bias, dy, dz, partial, H, W,
+  hipLaunchKernelGGL(dwconv_gelu_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, h, w9, bias, dy, dz, partial, H, W,
                      C, xtiles);
+  return (int)hipGetLastError();
+}
+
+// parameter-gradient partials of a bare depthwise 3x3 + bias (DWConv.forward without the GELU): same partial layout,
+// dz == dy so nothing else is written
+extern "C" int segmif_dwconv3x3_bias_bwd_f32(const float* h, const float* w9, const float* dy, float* partial, int B, int H,
+                                             int W, int C, void* stream) {
+  if (!h || !w9 || !dy || !partial || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 128)) return SEGMIF_EINVAL;
+  const int xtiles = (W + 7) / 8;
+  dim3 grid((unsigned)((C / 128) * xtiles), (unsigned)((H + DWB_TY - 1) / DWB_TY), (unsigned)B);
+  hipLaunchKernelGGL(dwconv_gelu_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, h, w9, w9 /* bias unused */, dy,
+                     (float*)nullptr, partial, H, W, C, xtiles);
   return (int)hipGetLastError();
 }
 

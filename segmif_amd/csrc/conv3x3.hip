@@ -14,6 +14,7 @@
 // pixels (row pitch CK+4 dwords -> conflict-free ds_read_b128).  One LDS buffer, register
 // prefetch: chunk c+1 streams into registers under chunk c's 9 * CK/2 MFMAs per sub-tile.
 #include <hip/hip_runtime.h>
+#include "device_once.h"
 #include <stdint.h>
 
 #include "igemm_common.h"
@@ -183,7 +184,8 @@ int launch(const IgemmK& k, hipStream_t stream) {
   constexpr size_t smem = (size_t)(HP + 9 * NOUT) * (CK + 4) * sizeof(float);
   auto fn = conv3x3_halo_kernel<NOUT, CK, DIL>;
   if (smem > 64 * 1024) {
-    static bool raised = false;
+    static segmif::PerDeviceFlag raised_flag;
+  bool& raised = raised_flag.here();
     if (!raised) {
       hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;

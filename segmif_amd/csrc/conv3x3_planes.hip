@@ -30,6 +30,7 @@
 // LDS) plus the 32 channels the conv itself produces (in the accumulators), so 12 + 24 extra MFMAs per
 // sub-tile replace a separate HBM-bound pass over the 224-channel buffer.
 #include <hip/hip_runtime.h>
+#include "device_once.h"
 #include <stdint.h>
 
 #include "igemm_common.h"
@@ -482,13 +483,15 @@ int launch(const PlanesConvK& k, hipStream_t stream) {
   constexpr int A_UNITS = (TH + 2 * DIL) * (TW + 2 * DIL) * 6;
   constexpr size_t smem = 2 * ((size_t)((A_UNITS + 63) / 64) * 1024 + W3_BYTES + (FUSE ? W1_BYTES : 0)) + 512;
   auto fn = conv3x3_planes_kernel<DIL, FUSE>;
-  static bool raised = false;  // idempotent attribute; benign race
+  static segmif::PerDeviceFlag raised_flag;  // idempotent attribute; benign race
+  bool& raised = raised_flag.here();
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
-  static int ncu = 0;
+  static segmif::PerDeviceValue<int> ncu_dev;
+  int& ncu = ncu_dev.here();
   if (ncu == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -630,7 +633,8 @@ extern "C" int segmif_conv3x3_planes_bf16x6(const SegmifConvPlanes* d, void* str
   k.pin = (const unsigned char*)d->planes_in;
   k.pout = (unsigned char*)d->planes_out;
   k.wt = (const unsigned char*)d->wt;
-  static const float* zero_bias = nullptr;  // benign race: every thread resolves the same symbol
+  static segmif::PerDeviceValue<const float*> zero_bias_dev;  // a __device__ symbol has one address per device
+  const float*& zero_bias = zero_bias_dev.here();
   if (!zero_bias && hipGetSymbolAddress((void**)&zero_bias, HIP_SYMBOL(planes_zero_bias)) != hipSuccess) return SEGMIF_EINVAL;
   k.bias = d->bias ? d->bias : zero_bias;
   k.prelu = d->prelu;

@@ -39,6 +39,7 @@
 // by a barrier per phase), static wave priority by LDS slot, four accumulation chains, contiguous
 // instead of 64-byte halo reads.  Next (round 2): a persistent, LDS-double-buffered schedule.
 #include <hip/hip_runtime.h>
+#include "device_once.h"
 #include <stdint.h>
 
 #include "igemm_common.h"
@@ -326,7 +327,8 @@ int launch(const IgemmK& k, hipStream_t stream) {
   constexpr int HP = (STH + 2 * DIL) * (STW + 2 * DIL);
   constexpr size_t smem = (size_t)(HP + 9 * NOUT) * ROWB + ((SPLIT_DBG & 64) && STH == 8 ? 40960 : 0);  // 64: one workgroup per CU
   auto fn = conv3x3_split_kernel<NOUT, DIL, STH>;
-  static bool raised = false;  // idempotent attribute; benign race
+  static segmif::PerDeviceFlag raised_flag;  // idempotent attribute; benign race
+  bool& raised = raised_flag.here();
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;

@@ -26,6 +26,7 @@
 // 64-channel intermediate nor its transpose ever goes through LDS.  There is no barrier in the pixel loop.
 // Accuracy: the Gram sums run in fp32 over 32-pixel runs (inside the MFMA accumulator) and in fp64 across runs.
 #include <hip/hip_runtime.h>
+#include "device_once.h"
 #include <stdint.h>
 
 #include "segmif_hip.h"
@@ -479,7 +480,8 @@ extern "C" int segmif_crosspath_fold_f32(const double* partial, int nblk, const 
                                          int Nout, int ldw, int wofs, int ldweff, int kofs, float scale, void* stream) {
   if (!partial || !wkv || !wend || !weff || B <= 0 || nblk <= 0 || Nout <= 0) return SEGMIF_EINVAL;
   constexpr size_t smem = (size_t)(2 * 4096 + 512) * sizeof(double);
-  static bool raised = false;
+  static segmif::PerDeviceFlag raised_flag;
+  bool& raised = raised_flag.here();
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)crosspath_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
@@ -513,7 +515,8 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
   const long long per_image = (2 * 256 + d->B - 1) / d->B;  // 100 KB of LDS: one workgroup per CU, two rounds of them
   if (wgs > per_image) wgs = per_image;
   constexpr size_t smem = (size_t)2 * 64 * WPB + 64 * WPB2 + 320 * sizeof(float);
-  static bool raised = false;
+  static segmif::PerDeviceFlag raised_flag;
+  bool& raised = raised_flag.here();
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)crosspath_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;

@@ -12,6 +12,7 @@
 // a ds_read_b128 service group land on 16 distinct slots.  53 KB per workgroup: three workgroups share a CU and cover
 // each other's staging phases.
 #include <hip/hip_runtime.h>
+#include "device_once.h"
 #include <stdint.h>
 
 #include "igemm_common.h"
@@ -276,7 +277,8 @@ extern "C" int segmif_gemm_split_f32(const SegmifGemmSplit* d, void* stream) {
   k.ntm = (int)((d->M + GBM - 1) / GBM);
   k.ntn = (d->N + GBN - 1) / GBN;
   constexpr size_t smem = 2 * (size_t)GTILE;
-  static bool raised = false;
+  static segmif::PerDeviceFlag raised_flag;
+  bool& raised = raised_flag.here();
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;

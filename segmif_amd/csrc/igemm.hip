@@ -21,6 +21,7 @@
 //   Block ids are remapped so that each XCD (private L2) owns a contiguous range of M tiles:
 //   neighbouring tiles share their 3x3 halo rows.
 #include <hip/hip_runtime.h>
+#include "device_once.h"
 #include <stdint.h>
 
 #include "segmif_hip.h"
@@ -490,7 +491,8 @@ int launch(const IgemmK& k, int nz, hipStream_t stream) {
   constexpr size_t smem = 2ull * (BM + BN) * (BK + 4) * sizeof(float);
   auto fn = igemm_kernel<BM, BN, WM, WN, BK, MODE, PF>;
   if (smem > 64 * 1024) {
-    static bool raised = false;  // idempotent attribute; benign race
+    static segmif::PerDeviceFlag raised_flag;  // idempotent attribute; benign race
+  bool& raised = raised_flag.here();
     if (!raised) {
       hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;

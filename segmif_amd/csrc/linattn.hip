@@ -16,6 +16,7 @@
 //      per-image 64x128 weight (segmif_igemm_f32, two-source mode) — z/v (2 x 157 MB per image)
 //      are never written.
 #include <hip/hip_runtime.h>
+#include "device_once.h"
 #include <stdint.h>
 
 #include "segmif_hip.h"
@@ -236,7 +237,8 @@ extern "C" int segmif_linattn_kvpartial_f32(const float* y, const float* wkv, do
   if ((((uintptr_t)y | (uintptr_t)wkv) & 15) || ((uintptr_t)partial & 7)) return SEGMIF_EINVAL;
   const int nblk = segmif_linattn_num_blocks(N);
   constexpr size_t smem = (size_t)(2 * 128 * KVP + 128 * KVT) * sizeof(float);
-  static bool raised = false;
+  static segmif::PerDeviceFlag raised_flag;
+  bool& raised = raised_flag.here();
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)linattn_kvpartial_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -7,6 +7,7 @@
 // derivative planes, the gradient assembly, the Sobel stencils and their adjoint — is here.  Reductions are two-pass and
 // deterministic: per-block partial sums in double, then one fixed-order sum.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "segmif_hip.h"
@@ -142,6 +143,139 @@ __global__ __launch_bounds__(256) void sobel_l1_bwd_kernel(const float* __restri
   grad[i] = upstream[0] * c * (sgn(g[i] - m[i]) + acc);
 }
 
+// ---- LapLoss2 (lap_loss.py:100-118; constructed at core/loss.py:509) ---------------------------------------------------
+// Three "Laplacian" levels d_k(img) = img - G_k * img with G_k the k x k (k = 3, 5, 7), sigma = 2 Gaussian of
+// lap_loss.py:39-80 (zero padding k // 2, normalised to sum 1; exp(-(x^2 + y^2) / 2 sigma^2) factorises, so the 2-D window
+// is the outer product of the normalised 1-D windows); loss = 10 (L1_3 + L1_5) + L1_7 with
+// L1_k = mean | d_k(gen) - max(d_k(ir), d_k(vis)) |.  One pass over the 7 x 7 neighbourhood serves all three windows.
+struct LapTaps {
+  float g3[3], g5[5], g7[7];
+};
+
+__device__ __forceinline__ void lap_levels(const float* p, int H, int W, int y, int x, const LapTaps& t, float& d3, float& d5, float& d7) {
+  float b3 = 0.f, b5 = 0.f, b7 = 0.f;
+#pragma unroll
+  for (int dy = -3; dy <= 3; ++dy) {
+    float r3 = 0.f, r5 = 0.f, r7 = 0.f;
+#pragma unroll
+    for (int dx = -3; dx <= 3; ++dx) {
+      const float v = at(p, H, W, y + dy, x + dx);
+      r7 += t.g7[dx + 3] * v;
+      if (dx >= -2 && dx <= 2) r5 += t.g5[dx + 2] * v;
+      if (dx >= -1 && dx <= 1) r3 += t.g3[dx + 1] * v;
+    }
+    b7 += t.g7[dy + 3] * r7;
+    if (dy >= -2 && dy <= 2) b5 += t.g5[dy + 2] * r5;
+    if (dy >= -1 && dy <= 1) b3 += t.g3[dy + 1] * r3;
+  }
+  const float c = p[(long long)y * W + x];
+  d3 = c - b3;
+  d5 = c - b5;
+  d7 = c - b7;
+}
+
+// partial[blk] = {sum 10 |a3| + 10 |a5| + |a7|, 0}; sign3 [3][n] (optional): sign(a_k), a_k = d_k(gen) - max(d_k(ir), d_k(vis))
+__global__ __launch_bounds__(256) void laploss2_kernel(const float* __restrict__ g, const float* __restrict__ ir,
+                                                       const float* __restrict__ vis, float* __restrict__ sign3,
+                                                       double* __restrict__ partial, int H, int W, long long n, LapTaps t) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  double s = 0.0;
+  if (i < n) {
+    const long long img = i / ((long long)H * W);
+    const int rem = (int)(i - img * H * W), y = rem / W, x = rem - y * W;
+    float a[3], b[3], c[3];
+    lap_levels(g + img * H * W, H, W, y, x, t, a[0], a[1], a[2]);
+    lap_levels(ir + img * H * W, H, W, y, x, t, b[0], b[1], b[2]);
+    lap_levels(vis + img * H * W, H, W, y, x, t, c[0], c[1], c[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float e = a[k] - fmaxf(b[k], c[k]);
+      s += (double)((k < 2 ? 10.f : 1.f) * fabsf(e));
+      if (sign3) sign3[k * n + i] = sgn(e);
+    }
+  }
+  block_sum2(s, 0.0, partial + 2 * (long long)blockIdx.x);
+}
+
+// grad = u / n * sum_k c_k (s_k - G_k * s_k)   (the windows are symmetric: the adjoint of a zero-padded blur is that blur)
+__global__ __launch_bounds__(256) void laploss2_bwd_kernel(const float* __restrict__ sign3, float* __restrict__ grad, int H, int W,
+                                                           long long n, const float* __restrict__ upstream, float inv_n, LapTaps t) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long img = i / ((long long)H * W);
+  const int rem = (int)(i - img * H * W), y = rem / W, x = rem - y * W;
+  float d3, d5, d7, q;
+  lap_levels(sign3 + img * H * W, H, W, y, x, t, d3, q, q);
+  lap_levels(sign3 + n + img * H * W, H, W, y, x, t, q, d5, q);
+  lap_levels(sign3 + 2 * n + img * H * W, H, W, y, x, t, q, q, d7);
+  grad[i] = upstream[0] * inv_n * (10.f * d3 + 10.f * d5 + d7);
+}
+
+LapTaps lap_taps() {
+  LapTaps t;
+  float* dst[3] = {t.g3, t.g5, t.g7};
+  for (int k = 0; k < 3; ++k) {
+    const int size = 3 + 2 * k;
+    double w[7], sum = 0.0;
+    for (int j = 0; j < size; ++j) {
+      const double d = j - (size - 1) / 2.0;
+      w[j] = exp(-d * d / (2.0 * 2.0 * 2.0));
+      sum += w[j];
+    }
+    for (int j = 0; j < size; ++j) dst[k][j] = (float)(w[j] / sum);
+  }
+  return t;
+}
+
+// ---- the shared scalar PReLU of the fusion net (core/model_fusion.py:1038) on the training path: y = z > 0 ? z : a z kept
+// apart from the conv so that the backward reads the branch off the PRE-activation (any slope, also <= 0) ----------------------
+template <int V>
+__global__ __launch_bounds__(256) void prelu_kernel(const float* __restrict__ z, const float* __restrict__ slope, float* __restrict__ y,
+                                                    long long nv) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nv) return;
+  const float a = slope[0];
+  float v[V], o[V];
+  if (V == 4) *reinterpret_cast<float4*>(v) = reinterpret_cast<const float4*>(z)[i];
+  else v[0] = z[i];
+#pragma unroll
+  for (int e = 0; e < V; ++e) o[e] = v[e] > 0.f ? v[e] : a * v[e];
+  if (V == 4) reinterpret_cast<float4*>(y)[i] = *reinterpret_cast<float4*>(o);
+  else y[i] = o[0];
+}
+
+// dz = dy (z > 0 ? 1 : a); partial[blk] = {sum over z <= 0 of dy z, 0}   (torch's PReLU backward, incl. its z == 0 branch)
+template <int V>
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                        const float* __restrict__ slope, float* __restrict__ dz,
+                                                        double* __restrict__ partial, long long nv) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  double s = 0.0;
+  if (i < nv) {
+    const float a = slope[0];
+    float g[V], v[V], o[V];
+    if (V == 4) {
+      *reinterpret_cast<float4*>(g) = reinterpret_cast<const float4*>(dy)[i];
+      *reinterpret_cast<float4*>(v) = reinterpret_cast<const float4*>(z)[i];
+    } else {
+      g[0] = dy[i];
+      v[0] = z[i];
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      o[e] = v[e] > 0.f ? g[e] : a * g[e];
+      t += v[e] > 0.f ? 0.f : g[e] * v[e];
+    }
+    if (V == 4) reinterpret_cast<float4*>(dz)[i] = *reinterpret_cast<float4*>(o);
+    else dz[i] = o[0];
+    s = (double)t;
+  }
+  block_sum2(s, 0.0, partial + 2 * (long long)blockIdx.x);
+}
+
+__global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out) { out[0] = (float)in[0]; }
+
 // out[0..1] = fixed-order sums of the two columns of partial (nblk x 2)
 __global__ __launch_bounds__(256) void reduce2_kernel(const double* __restrict__ partial, int nblk, double* __restrict__ out) {
   double a = 0.0, b = 0.0;
@@ -197,5 +331,61 @@ extern "C" int segmif_sobel_l1_bwd_f32(const float* pxy2, const float* gen, cons
   const long long n = (long long)planes * H * W;
   hipLaunchKernelGGL(sobel_l1_bwd_kernel, dim3((unsigned)segmif_loss_blocks(n)), dim3(256), 0, (hipStream_t)stream, pxy2, gen,
                      mask, grad, H, W, n, upstream, 1.0f / (float)n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_laploss2_f32(const float* gen, const float* ir, const float* vis, float* sign3, double* partial,
+                                   double* sums2, int planes, int H, int W, void* stream) {
+  if (!gen || !ir || !vis || !partial || !sums2 || planes <= 0 || H <= 0 || W <= 0) return SEGMIF_EINVAL;
+  const long long n = (long long)planes * H * W;
+  const int nblk = segmif_loss_blocks(n);
+  hipLaunchKernelGGL(laploss2_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, gen, ir, vis, sign3, partial, H, W, n,
+                     lap_taps());
+  hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk, sums2);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_laploss2_bwd_f32(const float* sign3, float* grad, int planes, int H, int W, const float* upstream,
+                                       void* stream) {
+  if (!sign3 || !grad || !upstream || planes <= 0 || H <= 0 || W <= 0) return SEGMIF_EINVAL;
+  const long long n = (long long)planes * H * W;
+  hipLaunchKernelGGL(laploss2_bwd_kernel, dim3((unsigned)segmif_loss_blocks(n)), dim3(256), 0, (hipStream_t)stream, sign3, grad, H,
+                     W, n, upstream, 1.0f / (float)n, lap_taps());
+  return (int)hipGetLastError();
+}
+
+static bool prelu_vec(const void* p0, const void* p1, const void* p2, int64_t n) {
+  return !(n & 3) && !(((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15);
+}
+
+extern "C" int segmif_prelu_f32(const float* z, const float* slope, float* y, int64_t n, void* stream) {
+  if (!z || !slope || !y || n <= 0) return SEGMIF_EINVAL;
+  if (prelu_vec(z, y, y, n))
+    hipLaunchKernelGGL(prelu_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, slope, y,
+                       (long long)(n / 4));
+  else
+    hipLaunchKernelGGL(prelu_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, slope, y,
+                       (long long)n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_prelu_bwd_blocks(int64_t n) { return (int)((n + 255) / 256); }  // upper bound for both paths
+
+extern "C" int segmif_prelu_bwd_f32(const float* dy, const float* z, const float* slope, float* dz, double* partial,
+                                    float* dslope, int64_t n, void* stream) {
+  if (!dy || !z || !slope || !dz || !partial || !dslope || n <= 0) return SEGMIF_EINVAL;
+  int nblk;
+  if (prelu_vec(dy, z, dz, n)) {
+    nblk = (int)((n / 4 + 255) / 256);
+    hipLaunchKernelGGL(prelu_bwd_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, z, slope, dz, partial,
+                       (long long)(n / 4));
+  } else {
+    nblk = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(prelu_bwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, z, slope, dz, partial,
+                       (long long)n);
+  }
+  // partial holds 2 * (segmif_prelu_bwd_blocks(n) + 1) doubles: the pair after the last block's receives the fixed-order sum
+  hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk, partial + 2 * (long long)nblk);
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, partial + 2 * (long long)nblk, dslope);
   return (int)hipGetLastError();
 }

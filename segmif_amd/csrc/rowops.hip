@@ -86,6 +86,7 @@ __device__ __forceinline__ float gelu_exact(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+template <bool GELU>
 __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __restrict__ x, const float* __restrict__ w9,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              int H, int W, int C) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __rest
       for (int kx = 0; kx < 3; ++kx) acc += win[ky][kx] * wv[ky * 3 + kx];
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = gelu_exact(acc[e]);
+    for (int e = 0; e < 4; ++e) o[e] = GELU ? gelu_exact(acc[e]) : acc[e];
     *reinterpret_cast<f32x4*>(y + (img + (long long)yo * W + xo) * C + c) = o;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
@@ -384,7 +385,18 @@ extern "C" int segmif_dwconv3x3_gelu_f32(const float* x, const float* w9, const 
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w9 | (uintptr_t)bias) & 15) return SEGMIF_EINVAL;
   const long long per_row = (long long)W * (C >> 2);
   dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)((H + DW_TY - 1) / DW_TY), (unsigned)B);
-  hipLaunchKernelGGL(dwconv3x3_gelu_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w9, bias, y, H, W, C);
+  hipLaunchKernelGGL(dwconv3x3_gelu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, w9, bias, y, H, W, C);
+  return (int)hipGetLastError();
+}
+
+// DWConv.forward on its own (core/mix_transformer.py:381-387): depthwise 3x3 + bias, no activation
+extern "C" int segmif_dwconv3x3_bias_f32(const float* x, const float* w9, const float* bias, float* y, int B, int H,
+                                         int W, int C, void* stream) {
+  if (!x || !w9 || !bias || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return SEGMIF_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w9 | (uintptr_t)bias) & 15) return SEGMIF_EINVAL;
+  const long long per_row = (long long)W * (C >> 2);
+  dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)((H + DW_TY - 1) / DW_TY), (unsigned)B);
+  hipLaunchKernelGGL(dwconv3x3_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, w9, bias, y, H, W, C);
   return (int)hipGetLastError();
 }
 

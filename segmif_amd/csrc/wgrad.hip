@@ -14,6 +14,7 @@
 // per-chunk partials are summed by a second, deterministic pass (fp64 accumulation) straight into
 // the parameter's OIHW / (N, K) gradient layout — no atomics, bitwise reproducible.
 #include <hip/hip_runtime.h>
+#include "device_once.h"
 #include <stdint.h>
 
 #include "igemm_common.h"
@@ -524,7 +525,8 @@ extern "C" int segmif_wgrad_f32(const SegmifIgemm* d, const float* dy, int ldy, 
       dim3 grid((unsigned)(strips * w.nchunks), (unsigned)ntiles_n);
       const int HPd = (8 + 2 * d->dil) * (32 + 2 * d->dil);
       const size_t smem = (size_t)(256 * 32 + HPd * 32) * sizeof(float);
-      static bool raised1 = false, raised2 = false;
+      static segmif::PerDeviceFlag raised_flag1, raised_flag2;
+      bool &raised1 = raised_flag1.here(), &raised2 = raised_flag2.here();
       if (d->dil == 1) {
         if (!raised1) { hipFuncSetAttribute((const void*)wgrad3x3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); raised1 = true; }
         hipLaunchKernelGGL(wgrad3x3_halo_kernel<1>, grid, dim3(256), smem, s, w);

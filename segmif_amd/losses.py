@@ -1,5 +1,5 @@
 """Fusion losses used by the reference's train_fusion (core/loss.py:459-476 Fusionloss3, :506-517
-Fusionloss_grad3, :634-650 Sobelxy; pytorch_ssim/__init__.py:8-43).
+Fusionloss_grad3, :634-650 Sobelxy; pytorch_ssim/__init__.py:8-43) and LapLoss2 (lap_loss.py:100-118).
 
 On the GPU both objectives are fused HIP kernels, forward and backward (csrc/losses.hip + the separable blur of
 csrc/rowops.hip; autograd.FusionLossGrad3Fn / FusionLoss3Fn): SURVEY §8(f) N1.  The torch formulations below are what
@@ -67,3 +67,27 @@ def fusion_loss3(generate_img, mask):
         from . import autograd as ag
         return ag.FusionLoss3Fn.apply(generate_img, m.detach())
     return F.l1_loss(m, generate_img) + F.l1_loss(sobel_xy(m), sobel_xy(generate_img))
+
+
+def _lap_window(size, sigma=2.0, device=None, dtype=torch.float32):
+    """lap_loss.py:39-80 `smoothing`: the normalised size x size Gaussian (zero padding size // 2 at the call site)."""
+    x = torch.arange(size, dtype=torch.float64) - (size - 1) / 2.0
+    g = torch.exp(-(x[:, None] ** 2 + x[None, :] ** 2) / (2.0 * sigma ** 2))
+    return (g / g.sum()).to(dtype).to(device)[None, None]
+
+
+def lap_loss2(generate_img, ir, vis):
+    """LapLoss2.forward (lap_loss.py:100-118): d_k(img) = img - G_k * img for the 3 / 5 / 7-tap sigma-2 Gaussians;
+    10 (L1_3 + L1_5) + L1_7 with L1_k = mean |d_k(gen) - max(d_k(ir), d_k(vis))|.  Fusionloss_grad3 builds one and never
+    evaluates it (core/loss.py:509); FusionTrainer(report_lap=True) reports it beside the loss (BASELINE config[2])."""
+    if generate_img.is_cuda and generate_img.dtype == torch.float32 and generate_img.shape[1] == 1 \
+            and ir.shape == generate_img.shape and vis.shape == generate_img.shape:
+        from . import autograd as ag
+        return ag.LapLoss2Fn.apply(generate_img, ir.detach().float(), vis.detach().float())
+    C = generate_img.shape[1]
+    total = 0.0
+    for size, coef in ((3, 10.0), (5, 10.0), (7, 1.0)):
+        w = _lap_window(size, 2.0, generate_img.device, generate_img.dtype).expand(C, 1, size, size).contiguous()
+        d = [t - F.conv2d(t, w, padding=size // 2, groups=C) for t in (generate_img, ir, vis)]
+        total = total + coef * F.l1_loss(d[0], torch.maximum(d[1], d[2]))
+    return total

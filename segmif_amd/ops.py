@@ -46,6 +46,18 @@ def rows_view(t, name="tensor"):
     return rows, t.shape[-1], ld
 
 
+def aligned16(*tensors):
+    """True when every given tensor (None is skipped) can take the kernels' 16-byte vector accesses: base pointer on a
+    16-byte boundary and, for rows views, a pitch that is a multiple of four floats.  Parameters normally are (torch
+    allocations are 512-byte aligned); views into a flattened parameter buffer or odd channel-slice offsets may not be."""
+    for t in tensors:
+        if t is None:
+            continue
+        if t.data_ptr() % 16 or (t.dim() >= 2 and t.stride(-2) % 4):
+            return False
+    return True
+
+
 def pack_weight(w):
     """OIHW conv weight or (N, K) linear weight -> packed [N, Kp] (tap-major, channel-minor)."""
     _req(w, "weight")
@@ -358,6 +370,10 @@ def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
     """out = res + act(x @ wt^T + bias).  x: rows view (..., K); wt: packed (N, Kp).
     x2: optional second source (..., K2): A = [x | x2] along K (no concat materialised).
     batched_weight: wt is (B, N, Kp) with one weight per leading batch index of x (x.dim() == 3)."""
+    if ln is not None and not aligned16(out, res, bias, ln[0], ln[1]):
+        # the fused LayerNorm epilogue only exists in its 16-byte form: run the GEMM and the normalisation apart
+        y = linear(x, wt, N, bias=bias, act=act, prelu=prelu, res=res, out=out, x2=x2, tile=tile, batched_weight=batched_weight)
+        return layernorm(y, ln[0], ln[1], ln[2], out=y)
     rows, K1, lda = rows_view(x, "x")
     K = K1
     d = _lib.SegmifIgemm()
@@ -422,6 +438,10 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
     ln = (gamma, beta, eps): LayerNorm over the N = 64 output channels in the conv's epilogue (conv_ln_fusable)."""
     if x.dim() != 4:
         raise RuntimeError("conv2d expects (B, H, W, C)")
+    if ln is not None and not aligned16(out, res, bias, ln[0], ln[1]):
+        y = conv2d(x, wt, N, k, stride=stride, pad=pad, dil=dil, bias=bias, act=act, prelu=prelu, res=res, out=out, tile=tile,
+                   tag=tag, planes=planes, planes_chunk0=planes_chunk0)
+        return layernorm(y, ln[0], ln[1], ln[2], out=y)
     _, cin, lda = rows_view(x, "x")
     B, H, W = x.shape[0], x.shape[1], x.shape[2]
     OH = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
@@ -484,6 +504,8 @@ def layernorm(x, gamma, beta, eps, out=None):
     orow, oc, ldy = rows_view(out, "out")
     if (orow, oc) != (rows, C):
         raise RuntimeError("layernorm out shape mismatch")
+    if not aligned16(gamma, beta):  # parameters at an odd offset of a flattened buffer: the kernel loads them 16 bytes at a time
+        gamma, beta = gamma.detach().clone(), beta.detach().clone()
     _lib.check(_lib.load().segmif_layernorm_f32(x.data_ptr(), _req(gamma).data_ptr(), _req(beta).data_ptr(),
                                                 out.data_ptr(), rows, C, ldx, ldy, float(eps), _stream()),
                "segmif_layernorm_f32")
@@ -505,6 +527,19 @@ def dwconv3x3_gelu(x, w9, bias, H, W):
     _lib.check(_lib.load().segmif_dwconv3x3_gelu_f32(x.data_ptr(), _req(w9).data_ptr(), _req(bias).data_ptr(),
                                                      out.data_ptr(), B, H, W, C, _stream()),
                "segmif_dwconv3x3_gelu_f32")
+    return out
+
+
+def dwconv3x3_bias(x, w9, bias, H, W):
+    """DWConv.forward (core/mix_transformer.py:381-387): depthwise 3x3 + bias on contiguous tokens (B, H*W, C)."""
+    _req(x, "x")
+    if not x.is_contiguous() or x.dim() != 3 or x.shape[1] != H * W:
+        raise RuntimeError("dwconv3x3_bias expects contiguous (B, H*W, C)")
+    B, _, C = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().segmif_dwconv3x3_bias_f32(x.data_ptr(), _req(w9).data_ptr(), _req(bias).data_ptr(),
+                                                     out.data_ptr(), B, H, W, C, _stream()),
+               "segmif_dwconv3x3_bias_f32")
     return out
 
 
@@ -572,7 +607,8 @@ def set_attention_mode(mode):
     global _attention_mode
     if mode not in _ATTENTION_MODES:
         raise ValueError(f"mode must be one of {_ATTENTION_MODES}")
-    _attention_mode = mode
+    prev, _attention_mode = _attention_mode, mode
+    return prev
 
 
 def sr_attention(q, kv, heads, scale):

@@ -10,6 +10,8 @@ gradients are averaged over ranks, parameters whose grad is None are skipped on 
 xGMI note: a ring all-reduce is bound by one ~153 GB/s link; the seg step's 178 MB of gradients in
 ~25 MB buckets take a few ms in total and hide under a >100 ms backward.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -26,6 +28,8 @@ class GradAllReducer:
         self._handles = []
         self._hooks = []
         self._stream = None
+        self.time_exposed_wait = False  # measure the non-overlapped part of the all-reduce in finish() (adds device syncs)
+        self.exposed_wait_s = 0.0
 
     # ---- bucket layout ------------------------------------------------------------------------
     def _build(self, active):
@@ -64,7 +68,12 @@ class GradAllReducer:
             # bucket whose all-reduce is already in flight: not supported, say so instead of corrupting gradients
             raise RuntimeError("GradAllReducer: a parameter received a second gradient before finish(); call "
                                "finish() after every backward (gradient accumulation is not supported)")
-        self._flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
+        dst = self._flat[bi][off:off + p.numel()]
+        if p.grad.data_ptr() != dst.data_ptr():
+            # (after finish() p.grad IS this slice; with optimizer.zero_grad(set_to_none=False) autograd then accumulates
+            # straight into the bucket and there is nothing to copy.  set_to_none=True - what segmif_amd.train uses - gives
+            # a fresh gradient tensor every step, copied here.)
+            dst.copy_(p.grad.reshape(-1))
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
@@ -76,7 +85,9 @@ class GradAllReducer:
 
     # ---- call after loss.backward() ---------------------------------------------------------------
     def finish(self):
-        """Wait for the exchange and leave the rank-averaged gradients in p.grad."""
+        """Wait for the exchange and leave the rank-averaged gradients in p.grad (each p.grad becomes a view of its flat
+        bucket: correct under both zero_grad(set_to_none=True) and in-place zeroing, see _on_grad)."""
+        self.exposed_wait_s = 0.0
         if self._buckets is None:
             # first step: discover which parameters actually receive gradients, exchange without overlap
             active = [p for p in self.params if p.grad is not None]
@@ -91,8 +102,19 @@ class GradAllReducer:
             if missing:
                 raise RuntimeError(f"gradient buckets {missing} were not completed by backward: the set of "
                                    "parameters receiving gradients changed; rebuild the GradAllReducer")
-        for h in self._handles:
-            h.wait()
+        if self._handles and self.time_exposed_wait:
+            # how long the host-visible stream still has to wait for the collectives once backward has been issued: the
+            # part of the exchange that did NOT hide under backward (two device syncs; bench.py's train leg only)
+            cur = torch.cuda.current_stream()
+            cur.synchronize()  # backward's kernels only: RCCL runs on its own stream and keeps going
+            t0 = time.perf_counter()
+            for h in self._handles:
+                h.wait()  # the compute stream now depends on the collectives
+            cur.synchronize()
+            self.exposed_wait_s = time.perf_counter() - t0
+        else:
+            for h in self._handles:
+                h.wait()
         inv = 1.0 / self.world
         for b, flat in zip(self._buckets, self._flat):
             if self.world > 1:

@@ -50,11 +50,14 @@ class FusionTrainer:
     THROUGH the segmentation net without forming its weight gradients - same fusion-net update, ~1/5 less device
     work per step; True reproduces the reference's side effect."""
 
-    def __init__(self, seg_net, fusion_net, optimizer, criterion, iter_=2, reducer=None, seg_weight_grads=False):
+    def __init__(self, seg_net, fusion_net, optimizer, criterion, iter_=2, reducer=None, seg_weight_grads=False,
+                 report_lap=False):
         self.seg, self.fus, self.opt, self.crit = seg_net, fusion_net, optimizer, criterion
         self.iter_ = iter_
         self.reducer = reducer
         self.seg_weight_grads = seg_weight_grads
+        self.report_lap = report_lap  # evaluate LapLoss2(fused, ir, vis_Y) as a reported extra term (never part of the loss:
+        self.last_lap = None          # core/loss.py:509 builds it, :512-517 does not call it); device scalar, no host sync
         self.history = []  # (loss1, loss2) per step, rank-averaged
 
     def step(self, ir3, vis3, mask3, labels, sync_loss_history=True):
@@ -64,6 +67,9 @@ class FusionTrainer:
             out0, out1 = self.seg.denoise_net.encoder.forward_fusion(mask3)
         fusion = self.fus(ir, vis, out0, out1)
         self.opt.zero_grad(set_to_none=True)
+        if self.report_lap:
+            with torch.no_grad():
+                self.last_lap = losses.lap_loss2(fusion.detach(), ir, vis[:, 0:1])
         if self.iter_ > 1:
             loss1 = losses.fusion_loss_grad3(fusion, mask3)
             fused_rgb = YCrCb2RGB(torch.cat((fusion, vis[:, 1:2], vis[:, 2:3]), dim=1))

@@ -280,3 +280,53 @@ def test_quantize_restatement_properties():
     expect = np.floor(255.0 * (a - a.min()) / (a.max() - a.min()))
     assert np.array_equal(q.astype(np.float64), expect)
     assert not so.quantize_fused_u8(np.full((1, 3, 4, 4), 0.5, np.float32)).any()
+
+
+def test_cross_attention_modules_and_dwconv_in_isolation(golden_dir):
+    """CrossAttention / CrossAttention2 / DWConv called on their own (every a-row module in isolation):
+    outputs and the reference autograd's gradients, through the oracle's restatement and torch autograd."""
+    g = load(golden_dir, "cross_modules.npz")
+    B, N, C = 2, 48 * 64, 64
+    xs = [dw.det_input("ca_" + n, (B, N, C), lo=-1.0, hi=1.0).requires_grad_(True) for n in ("x1", "x2", "seg")]
+    cot = [dw.det_input("ca_cot_" + n, (B, N, C), lo=-1.0, hi=1.0) for n in ("o1", "o2")]
+    for tag, fn, keys in (("ca", so.cross_attention, ("kv3.weight",)), ("ca2", so.cross_attention2, ("kv1.weight", "kv2.weight"))):
+        sd = {k: v.requires_grad_(True) for k, v in dw.det_state_dict({k: (128, 64) for k in keys}, seed=0).items()}
+        o1, o2 = fn(sd, "", *xs)
+        assert rel_err(o1[:, ::8].detach(), g[tag + "_o1"]) < TOL and rel_err(o2[:, ::8].detach(), g[tag + "_o2"]) < TOL
+        grads = torch.autograd.grad((o1 * cot[0]).sum() + (o2 * cot[1]).sum(), xs + [sd[k] for k in keys], allow_unused=True)
+        for n, gr in zip(("x1", "x2", "seg"), grads[:3]):
+            ref = g[f"{tag}_d{n}"]
+            assert rel_err(gr[:, ::8], ref) < 1e-4, (tag, n)
+        for k, gr in zip(keys, grads[3:]):
+            # (the contexts are saturated softmaxes over sums of 3072 products: their gradients are ill-conditioned)
+            assert rel_err(gr, g[f"{tag}_d{k}"]) < 2e-3, (tag, k)
+    sd = dw.det_state_dict({"dwconv.weight": (256, 1, 3, 3), "dwconv.bias": (256,)}, seed=0)
+    x = dw.det_input("dwconv_x", (2, 9 * 13, 256), lo=-1.0, hi=1.0)
+    assert rel_err(so.dwconv_tokens(sd, "", x, 9, 13), g["dw_y"]) < TOL
+
+
+def test_laploss2_restatement_and_product_host_formula(golden_dir):
+    """LapLoss2 (lap_loss.py:100-118): the oracle's restatement and segmif_amd.losses.lap_loss2's torch formulation (the
+    CPU side of the product's loss module) against the value and gradient the reference produced."""
+    from segmif_amd import losses
+    g = load(golden_dir, "laploss.npz")
+    ir, vis = torch.from_numpy(g["ir"]), torch.from_numpy(g["vis"])
+    for fn in (so.lap_loss2, losses.lap_loss2):
+        gen = torch.from_numpy(g["gen"]).requires_grad_(True)
+        v = fn(gen, ir, vis)
+        (gr,) = torch.autograd.grad(v, gen)
+        assert abs(float(v) - float(g["lap"])) < 1e-5 * abs(float(g["lap"])), fn
+        assert rel_err(gr, g["lap_grad"]) < 1e-4, fn
+
+
+def test_config1_geometry_mit_b1_480x640_checksum(golden_dir, sd_fus):
+    """BASELINE config[1]'s backbone and resolution (mit_b1, 480x640): oracle vs the reference's record."""
+    g = load(golden_dir, "pair_b1_480x640_checksum.npz")
+    sd = dw.det_state_dict(so.network3_shapes("mit_b1", 9), seed=0)
+    H, W = 480, 640
+    ir = dw.det_input("b1f_ir", (1, 1, H, W))
+    vis = dw.det_input("b1f_vis", (1, 3, H, W))
+    mask = dw.det_input("b1f_mask", (1, 1, H, W)).repeat(1, 3, 1, 1)
+    with torch.no_grad():
+        r = so.pair_forward(sd, sd_fus, ir, vis, mask, "mit_b1", return_all=True)
+    _check_samples(r, g, ("out0", "out1", "y_fused", "fused", "seg", "logits"))
