@@ -360,18 +360,26 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
 }
 
 // column sums of a rows x N matrix (bias gradients, LN / dwconv / BN parameter partials):
-// stage 1: a block owns CS_ROWS rows.  Vector path (N % 4 == 0, 16-byte aligned rows): QPR lanes cover the
+// stage 1: a block owns cs_rows(rows) rows.  Vector path (N % 4 == 0, 16-byte aligned rows): QPR lanes cover the
 // column quads of a row (QPR = 8..64), 256/QPR row slots per block, four rows in flight per thread; scalar
 // path otherwise.  Slots are combined in LDS and written as one fp64 partial row; stage 2 sums the partial rows.
-constexpr int CS_ROWS = 1024;
+// rows per block: a fixed function of the row count (results stay deterministic) that keeps a few hundred blocks in
+// flight - with a constant 1024 the parameter-gradient partials of a LayerNorm / dwconv backward (<= 1024 rows of
+// 2C / 10C floats) were summed by ONE workgroup (90 us per call, 13 % of the round-2 segmentation step)
+__host__ __device__ inline int cs_rows(long long rows) {
+  long long r = (rows + 511) / 512;
+  r = (r + 15) / 16 * 16;
+  return (int)(r < 16 ? 16 : (r > 1024 ? 1024 : r));
+}
 template <int QPR>
 __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* __restrict__ x, double* __restrict__ partial,
                                                                  long long rows, int N, int ldx) {
   constexpr int SLOTS = 256 / QPR;
   __shared__ f32x4 red[256];
   const int q = threadIdx.x % QPR, slot = threadIdx.x / QPR;
-  const long long r0 = (long long)blockIdx.x * CS_ROWS;
-  const long long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+  const int rpb = cs_rows(rows);
+  const long long r0 = (long long)blockIdx.x * rpb;
+  const long long r1 = r0 + rpb < rows ? r0 + rpb : rows;
   const int nq = N >> 2;
   for (int q0 = 0; q0 < nq; q0 += QPR) {
     const int qq = q0 + q;
@@ -407,8 +415,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                                                              long long rows, int N, int ldx) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, slot = threadIdx.x >> 6;
-  const long long r0 = (long long)blockIdx.x * CS_ROWS;
-  const long long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+  const int rpb = cs_rows(rows);
+  const long long r0 = (long long)blockIdx.x * rpb;
+  const long long r1 = r0 + rpb < rows ? r0 + rpb : rows;
   for (int n0 = 0; n0 < N; n0 += 64) {
     const int n = n0 + c;
     float s = 0.f;
@@ -571,7 +580,7 @@ extern "C" int segmif_wgrad_f32(const SegmifIgemm* d, const float* dy, int ldy, 
   return (int)hipGetLastError();
 }
 
-extern "C" int segmif_colsum_blocks(int64_t rows) { return (int)((rows + CS_ROWS - 1) / CS_ROWS); }
+extern "C" int segmif_colsum_blocks(int64_t rows) { return (int)((rows + cs_rows(rows) - 1) / cs_rows(rows)); }
 
 extern "C" int segmif_colsum_f32(const float* x, float* out, double* workspace, int64_t rows, int N, int ldx,
                                  int accumulate, void* stream) {
