@@ -91,6 +91,16 @@ def conv_wgrad(x, dy, w_shape, k, stride, pad, dil, want_bias=False):
     return (dw, db) if want_bias else dw
 
 
+def _gemm(x, w_nk, N, bias=None, act=ACT_NONE):
+    """x @ w_nk^T (+ bias, act) for a plain (N, K) weight matrix: the bf16x6 GEMM for tall problems (same size rule as
+    inference, ops.linear_auto), the fp32 tiles otherwise.  Training re-packs per call: the weights change every step."""
+    rows, K, _ = rows_view(x, "x")
+    if ops.linear_wants_split(rows, N, K):
+        return ops.linear_auto(x, ops.pack_linear(w_nk), N, bias=bias, act=act)
+    wt = w_nk if (K % 16 == 0 and w_nk.is_contiguous()) else ops.pack_weight(w_nk)
+    return ops.linear(x, wt, N, bias=bias, act=act)
+
+
 def _no_prelu(act):
     if act == ACT_PRELU:
         raise RuntimeError("segmif_amd.autograd: the shared PReLU is its own node on the training path (ag.conv2d / ag.linear "
@@ -107,9 +117,7 @@ class LinearFn(torch.autograd.Function):
         _no_prelu(act)
         N = w.shape[0]
         w2 = w.reshape(N, -1)
-        K = w2.shape[1]
-        wt = w2.contiguous() if K % 16 == 0 else ops.pack_weight(w2)
-        y = ops.linear(x, wt, N, bias=b, act=act, prelu=slope)
+        y = _gemm(x, w2.detach().contiguous(), N, bias=b, act=act)
         ctx.act = act
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.has_bias = b is not None
@@ -125,9 +133,7 @@ class LinearFn(torch.autograd.Function):
         dz = act_bwd(dy, y, ACT_RELU) if ctx.act == ACT_RELU else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wtT = w2.t().contiguous()  # (K, N): "weights" of the input-gradient GEMM
-            wtT = wtT if N % 16 == 0 else ops.pack_weight(wtT)
-            dx = ops.linear(dz, wtT, K)
+            dx = _gemm(dz, w2.detach().t().contiguous(), K)  # (K, N): "weights" of the input-gradient GEMM
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             r = linear_wgrad(x, dz, N, want_bias=want_b)

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include "device_once.h"
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "igemm_common.h"
 #include "segmif_hip.h"
@@ -41,7 +43,11 @@ struct WgradK {
   float* bias_partial;  // optional [batch][chunk][N]: column sums of dY (bias gradient), k-tile 0 blocks only
 };
 
-template <int NT, int KT>
+// FAST: dense problem (nn.Linear / 1x1 conv), 16-byte loadable dY rows, N % BN == 0 and K % BK == 0 - every prefetch load
+// is unconditional (rows past the chunk's end are clamped to its last row and zeroed when the tile goes to LDS).  Loads
+// under divergent branches made the compiler wait for ALL outstanding loads at each join, i.e. before the MFMA loop the
+// prefetch is meant to hide under.
+template <int NT, int KT, bool FAST>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   constexpr int BN = 32 * NT, BK = 32 * KT;
   constexpr int YU = MR * BN / 4 / 256 > 0 ? MR * BN / 4 / 256 : 1;  // float4 units per thread (dY tile)
@@ -66,7 +72,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   f32x4 ry[YU], rx[XU];
   f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};  // this thread's column quad of sum_m dY (every tile is loaded once)
   const bool want_bias = p.bias_partial != nullptr && kt == 0;
+  unsigned okbits = 0;  // FAST: bit j = ry[j]'s row exists, bit 16 + j = rx[j]'s row exists
   auto gload = [&](long long m0) {
+    if (FAST) {
+      okbits = 0;
+#pragma unroll
+      for (int j = 0; j < YU; ++j) {
+        const int u = min(tid + 256 * j, MR * YUPR - 1);
+        const int row = u / YUPR, q = (u % YUPR) * 4;
+        const long long m = m0 + row;
+        ry[j] = *reinterpret_cast<const f32x4*>(dyp + (m < m_end ? m : m_end - 1) * p.ldy + n0 + q);
+        okbits |= (unsigned)(m < m_end) << j;
+      }
+#pragma unroll
+      for (int j = 0; j < XU; ++j) {
+        const int u = tid + 256 * j;
+        const int row = u / XUPR, q = (u % XUPR) * 4;
+        const long long m = m0 + row;
+        rx[j] = *reinterpret_cast<const f32x4*>(inp + (m < m_end ? m : m_end - 1) * p.lda + k0 + q);
+        okbits |= (unsigned)(m < m_end) << (16 + j);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < YU; ++j) {
       const int u = tid + 256 * j;
@@ -82,7 +109,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
             if (n0 + q + e < p.N) ry[j][e] = src[e];
         }
       }
-      if (want_bias) bsum += ry[j];
     }
 #pragma unroll
     for (int j = 0; j < XU; ++j) {
@@ -123,13 +149,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     }
   };
   auto sstore = [&](int buf) {
+    const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < YU; ++j) {
       const int u = tid + 256 * j;
-      if (u < MR * YUPR) *reinterpret_cast<f32x4*>(&Ys[buf][u * 4]) = ry[j];
+      const f32x4 v = (!FAST || ((okbits >> j) & 1)) ? ry[j] : zero4;
+      if (u < MR * YUPR) {
+        *reinterpret_cast<f32x4*>(&Ys[buf][u * 4]) = v;
+        // (the bias sum is taken HERE, where the tile is consumed anyway: summing in gload made every prefetch wait for
+        // its own data before the MFMA loop it was meant to hide under)
+        if (want_bias) bsum += v;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < XU; ++j) *reinterpret_cast<f32x4*>(&Xs[buf][(tid + 256 * j) * 4]) = rx[j];
+    for (int j = 0; j < XU; ++j)
+      *reinterpret_cast<f32x4*>(&Xs[buf][(tid + 256 * j) * 4]) = (!FAST || ((okbits >> (16 + j)) & 1)) ? rx[j] : zero4;
   };
 
   f32x16 acc;
@@ -147,9 +181,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     if (t + 1 < ntiles) gload(m_begin + (t + 1) * MR);
     const float* ya = &Ys[cur][h * BN + wn * 32 + r];
     const float* xa = &Xs[cur][h * BK + wk * 32 + r];
+    float fa[MR / 2], fb[MR / 2];  // the tile's fragments first, then the MFMAs: one LDS round trip per tile, not one per pair
 #pragma unroll
-    for (int j = 0; j < MR / 2; ++j)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[2 * j * BN], xa[2 * j * BK], acc, 0, 0, 0);
+    for (int j = 0; j < MR / 2; ++j) {
+      fa[j] = ya[2 * j * BN];
+      fb[j] = xa[2 * j * BK];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < MR / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[j], acc, 0, 0, 0);
     if (t + 1 < ntiles) sstore(cur ^ 1);
     __syncthreads();
   }
@@ -195,9 +235,10 @@ struct Wg3K {
   float* bias_partial;  // [strips][N] or null (only channel-chunk 0 blocks write it)
   int B, H, W, Cin, N, Kp, ldy, lda;
   int tiles_x, tiles_y, tiles_total, tiles_per_strip, nchunks, yvec;
+  int dbg;  // diagnosis only (SEGMIF_WG3_DBG): 1 skip the MFMA loop, 2 skip the split + LDS stores, 4 skip the global loads
 };
 
-template <int DIL>
+template <int DIL, bool VEC>  // VEC: dY rows are 16-byte loadable and the block's 32 output channels all exist
 __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3K p) {
   constexpr int TH = 8, TW = 32, HH = TH + 2 * DIL, HWD = TW + 2 * DIL, HP = HH * HWD;
   constexpr int YJ = 8;  // dY float4 units per thread: 256 px * 8 / 256
@@ -222,12 +263,37 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3K p) {
   const bool want_bias = p.bias_partial != nullptr && chunk == 0;
 
   f32x4 ry[YJ], rx[XJ];
+  unsigned okbits = 0;  // VEC: bit j = ry[j] inside the image, bit 8 + j = rx[j] inside the image
   auto gload = [&](int tile) {
     const int tx = tile % p.tiles_x;
     const int ty = (tile / p.tiles_x) % p.tiles_y;
     const int b = tile / (p.tiles_x * p.tiles_y);
     const int x0 = tx * TW, y0 = ty * TH;
     const long long img = (long long)b * p.H * p.W;
+    if (VEC) {
+      // unconditional loads from clamped addresses, zeroed at the LDS store: a load under a divergent branch makes the
+      // compiler wait for every outstanding load at the join, i.e. BEFORE the MFMA loop this prefetch should hide under
+      okbits = 0;
+#pragma unroll
+      for (int j = 0; j < YJ; ++j) {
+        const int u = tid + 256 * j;
+        const int px = u >> 3, q = (u & 7) * 4;
+        const int gy = y0 + (px >> 5), gx = x0 + (px & 31);
+        ry[j] = *reinterpret_cast<const f32x4*>(p.dy + (img + (long long)min(gy, p.H - 1) * p.W + min(gx, p.W - 1)) * p.ldy + n0 + q);
+        okbits |= (unsigned)(gy < p.H && gx < p.W) << j;
+      }
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) {
+        const int u = min(tid + 256 * j, HP * 8 - 1);
+        const int pp = u >> 3, q = (u & 7) * 4;
+        const int hy = pp / HWD, hx = pp - hy * HWD;
+        const int gy = y0 - DIL + hy, gx = x0 - DIL + hx;
+        rx[j] = *reinterpret_cast<const f32x4*>(p.in + (img + (long long)min(max(gy, 0), p.H - 1) * p.W + min(max(gx, 0), p.W - 1)) * p.lda +
+                                                c0 + q);
+        okbits |= (unsigned)((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) << (8 + j);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < YJ; ++j) {
       const int u = tid + 256 * j;
@@ -243,7 +309,6 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3K p) {
             if (n0 + q + e < p.N) ry[j][e] = src[e];
         }
       }
-      if (want_bias) bsum += ry[j];
     }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
@@ -259,12 +324,17 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3K p) {
     }
   };
   auto sstore = [&]() {
+    const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < YJ; ++j) *reinterpret_cast<f32x4*>(Ys + (tid + 256 * j) * 4) = ry[j];
+    for (int j = 0; j < YJ; ++j) {
+      const f32x4 v = (!VEC || ((okbits >> j) & 1)) ? ry[j] : zero4;
+      *reinterpret_cast<f32x4*>(Ys + (tid + 256 * j) * 4) = v;
+      if (want_bias) bsum += v;
+    }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
       const int u = tid + 256 * j;
-      if (u < HP * 8) *reinterpret_cast<f32x4*>(Xs + u * 4) = rx[j];
+      if (u < HP * 8) *reinterpret_cast<f32x4*>(Xs + u * 4) = (!VEC || ((okbits >> (8 + j)) & 1)) ? rx[j] : zero4;
     }
   };
 
@@ -325,20 +395,257 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3K p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same weight gradient on the bf16 matrix pipe with 3-way split operands ("bf16x6", fp32-class: see
+// conv3x3_planes.hip), for the dilation-2 convs of the DRDBs - 15 % of the round-2 fusion training step sat in the
+// fp32 kernel above at 57 % of the fp32 pipe.  The contraction index is the PIXEL, and v_mfma_f32_32x32x16_bf16
+// wants 8 consecutive contraction slots per lane, while both operands arrive pixel-major / channel-minor: the
+// staging pass therefore stores PIXEL PAIRS - one dword = (px 2i, px 2i+1) of one channel, bf16 x 3 planes - as
+// [plane][pair][32 channels].  A lane (channel r, half h) then reads its 8 slots as 4 dwords 128 B apart
+// (conflict free: the 32 lanes of a half read 32 consecutive dwords), and with dilation 2 the three horizontal taps
+// of a halo row are the dword windows [0..3], [1..4], [2..5] of ONE 6-dword read (a shift of two pixels is one
+// dword).  Staging: a thread loads two adjacent pixels x 4 channels (16-byte loads, 8 lanes cover a pixel's 128
+// bytes), splits them, and writes one 16-byte unit per plane.  Same tiling, strip partials, bias sums and wave
+// combine as the fp32 kernel; the partial slabs go through the same deterministic reduce.
+// ---------------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t wg_pk_bf16(float a, float b) {
+  f32x2v v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
+}
+
+// (x0, x1) -> three dwords, each (bf16 of x0 in the low half, of x1 in the high half); x = p0 + p1 + p2 to 24 bits
+__device__ __forceinline__ void wg_split3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = wg_pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+  p1 = wg_pk_bf16(r0, r1);
+  r0 -= __uint_as_float(p1 << 16);
+  r1 -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = wg_pk_bf16(r0, r1);
+}
+
+__global__ __launch_bounds__(256) void wgrad3x3_split_kernel(const Wg3K p) {
+  constexpr int DIL = 2, TH = 8, TW = 32, HH = TH + 2 * DIL, HWD = TW + 2 * DIL;
+  constexpr int YPAIRS = TH * TW / 2;    // 128
+  constexpr int XROWP = HWD / 2;         // 18 pairs per halo row
+  constexpr int XPAIRS = HH * XROWP;     // 216
+  constexpr int YJ = YPAIRS * 8 / 256;   // 4 units (pair x channel quad) per thread
+  constexpr int XJ = (XPAIRS * 8 + 255) / 256;  // 7
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first: plane of dY ...
+  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};  // ... and of the input
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint32_t* Ys = reinterpret_cast<uint32_t*>(smem);  // [3][YPAIRS][32]
+  uint32_t* Xs = Ys + 3 * YPAIRS * 32;               // [3][XPAIRS][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int chunk = blockIdx.x % p.nchunks, strip = blockIdx.x / p.nchunks;
+  const int ntile = blockIdx.y;
+  const int c0 = chunk * 32, n0 = ntile * 32;
+  const int t_begin = strip * p.tiles_per_strip;
+  const int t_end = min(t_begin + p.tiles_per_strip, p.tiles_total);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+  f32x4 bsum{0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = p.bias_partial != nullptr && chunk == 0;
+  const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
+
+  // Prefetch registers + one validity bit per loaded pixel.  Every load is UNCONDITIONAL from a clamped (in-image) address and
+  // out-of-image pixels are zeroed when the tile is stored to LDS: a load under a divergent branch made the compiler wait
+  // for all outstanding loads at the join (s_waitcnt vmcnt(0) before the MFMA loop the prefetch is meant to hide under -
+  // measured: loads 1.12 ms + MFMA 0.85 ms = 2.03 ms per call, no overlap at all).
+  f32x4 ry[2 * YJ], rx[2 * XJ];
+  unsigned okbits = 0;  // bit 2j+e: ry[2j+e] valid; bit 16 + 2j+e: rx[2j+e] valid
+  auto gload = [&](int tile) {
+    const int tx = tile % p.tiles_x;
+    const int ty = (tile / p.tiles_x) % p.tiles_y;
+    const int b = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = tx * TW, y0 = ty * TH;
+    const long long img = (long long)b * p.H * p.W;
+    okbits = 0;
+    // (launched only for 16-byte loadable dY rows and N % 32 == 0: no element-wise path here)
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) {
+      const int u = tid + 256 * j;
+      const int pair = u >> 3, q = (u & 7) * 4;
+      const int gy = y0 + (pair >> 4), gx = x0 + 2 * (pair & 15);
+      const int cy = min(gy, p.H - 1);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int cx = min(gx + e, p.W - 1);
+        ry[2 * j + e] = *reinterpret_cast<const f32x4*>(p.dy + (img + (long long)cy * p.W + cx) * p.ldy + n0 + q);
+        okbits |= (unsigned)(gy < p.H && gx + e < p.W) << (2 * j + e);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int u = min(tid + 256 * j, XPAIRS * 8 - 1);  // (the last round's surplus threads re-load the last unit and drop it)
+      const int pair = u >> 3, q = (u & 7) * 4;
+      const int hy = pair / XROWP, hx = 2 * (pair - hy * XROWP);
+      const int gy = y0 - DIL + hy, gx = x0 - DIL + hx;
+      const int cy = min(max(gy, 0), p.H - 1);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int cx = min(max(gx + e, 0), p.W - 1);
+        rx[2 * j + e] = *reinterpret_cast<const f32x4*>(p.in + (img + (long long)cy * p.W + cx) * p.lda + c0 + q);
+        okbits |= (unsigned)((unsigned)gy < (unsigned)p.H && (unsigned)(gx + e) < (unsigned)p.W) << (16 + 2 * j + e);
+      }
+    }
+  };
+  auto put = [&](uint32_t* base, int npairs, int unit, const f32x4 v0, const f32x4 v1) {
+    u32x4 w0, w1, w2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint32_t a, b, d;
+      wg_split3(v0[c], v1[c], a, b, d);
+      w0[c] = a; w1[c] = b; w2[c] = d;
+    }
+    uint32_t* dst = base + unit * 4;  // (pair, quad) -> dword pair * 32 + quad * 4
+    *reinterpret_cast<u32x4*>(dst) = w0;
+    *reinterpret_cast<u32x4*>(dst + npairs * 32) = w1;
+    *reinterpret_cast<u32x4*>(dst + 2 * npairs * 32) = w2;
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) {
+      const f32x4 v0 = (okbits >> (2 * j)) & 1 ? ry[2 * j] : zero4, v1 = (okbits >> (2 * j + 1)) & 1 ? ry[2 * j + 1] : zero4;
+      put(Ys, YPAIRS, tid + 256 * j, v0, v1);
+      if (want_bias) bsum += v0 + v1;
+    }
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int u = tid + 256 * j;
+      const f32x4 v0 = (okbits >> (16 + 2 * j)) & 1 ? rx[2 * j] : zero4, v1 = (okbits >> (17 + 2 * j)) & 1 ? rx[2 * j + 1] : zero4;
+      if (u < XPAIRS * 8) put(Xs, XPAIRS, u, v0, v1);
+    }
+  };
+
+  if (t_begin < t_end) gload(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    if (!(p.dbg & 2)) sstore();
+    __syncthreads();
+    if (tile + 1 < t_end && !(p.dbg & 4)) gload(tile + 1);
+    if (p.dbg & 1) { __syncthreads(); continue; }
+    // 12 steps per tile: (row of the wave's two, 16-pixel k-step, vertical tap); a step = 18 MFMAs on one 6-dword halo
+    // window per plane (+ the dY fragment, re-read when the pixel run changes).  The LDS reads of step i + 1 are issued
+    // BEFORE the MFMAs of step i (one wave per SIMD: nothing else hides their latency).
+    auto read_a = [&](int it, u32x4* a) {
+      const int row = it / 6, ks = (it / 3) & 1;
+      // dY: pixels (ry_, 16 ks + 8 h + 0..7) of channel n = r  ->  pairs ry_*16 + 8 ks + 4 h + 0..3
+      const uint32_t* ya = Ys + ((2 * wave + row) * 16 + 8 * ks + 4 * h) * 32 + r;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[pl][i] = ya[(pl * YPAIRS + i) * 32];
+    };
+    auto read_b = [&](int it, uint32_t (*b6)[6]) {
+      const int row = it / 6, ks = (it / 3) & 1, ky = it % 3;
+      // halo row ry_ + ky*DIL, halo pixels 16 ks + 8 h + kx*DIL + 0..7  ->  pairs 8 ks + 4 h + kx + 0..3
+      const uint32_t* xa = Xs + ((2 * wave + row + ky * DIL) * XROWP + 8 * ks + 4 * h) * 32 + r;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) b6[pl][i] = xa[(pl * XPAIRS + i) * 32];
+    };
+    u32x4 a[2][3];
+    uint32_t b6[2][3][6];
+    read_a(0, a[0]);
+    read_b(0, b6[0]);
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      const int cb = it & 1, ca = (it / 3) & 1, ky = it % 3;
+      if (it + 1 < 12) {
+        if ((it + 1) % 3 == 0) read_a(it + 1, a[((it + 1) / 3) & 1]);
+        read_b(it + 1, b6[cb ^ 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // product-major, tap-minor: consecutive MFMAs go to three different accumulators (no back-to-back dependent issue)
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int pl = PB[t];
+          const u32x4 bw = u32x4{b6[cb][pl][kx], b6[cb][pl][kx + 1], b6[cb][pl][kx + 2], b6[cb][pl][kx + 3]};
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ca][PA[t]]),
+                                                                     __builtin_bit_cast(bf16x8, bw), acc[ky * 3 + kx], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  // combine the four waves (each holds 9 x [32 n][32 c]) tap by tap through LDS, write the partial slab
+  float* red = smem;  // [4][32][33]
+  float* out = p.partial + (long long)strip * p.N * p.Kp;
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int n = (v & 3) + 8 * (v >> 2) + 4 * h;
+      red[(wave * 32 + n) * 33 + r] = acc[t][v];
+    }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+      const int n = i >> 5, c = i & 31;
+      const float s4 = (red[(0 * 32 + n) * 33 + c] + red[(1 * 32 + n) * 33 + c]) +
+                       (red[(2 * 32 + n) * 33 + c] + red[(3 * 32 + n) * 33 + c]);
+      if (n0 + n < p.N) out[(long long)(n0 + n) * p.Kp + t * p.Cin + c0 + c] = s4;
+    }
+  }
+  if (want_bias) {
+    __syncthreads();
+    f32x4* rb = reinterpret_cast<f32x4*>(smem);
+    rb[tid] = bsum;
+    __syncthreads();
+    if (tid < 8) {
+      f32x4 sacc = rb[tid];
+      for (int i = 1; i < 32; ++i) sacc += rb[tid + 8 * i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n0 + tid * 4 + e < p.N) p.bias_partial[(long long)strip * p.N + n0 + tid * 4 + e] = sacc[e];
+    }
+  }
+}
+
 // sum over chunks (fp64) and scatter from the packed [N][Kp] (tap-major, channel-minor) order into the
 // parameter's own layout: OIHW for convs; element (n, k) -> dw[n*sn + k*sk] for dense problems.
 // accumulate != 0: grad += value.
+// A block covers T = 256 / S consecutive outputs; S slices of the chunk range are summed side by side (fp64) and combined
+// in LDS in slice order (fixed: deterministic).  S = 1 when there are enough outputs to fill the chip on their own; small
+// outputs with many chunks (conv1: 576 weights x 2048 chunks; a bias: 32 values x 1000 strips) take S = 16 - one thread
+// walking every chunk took 0.6 - 0.9 ms per call in round 2.
+template <int S>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            int chunks, int N, int K, int Kp, int Cin, int KH, int KW,
                                                            int dense, long long sn, long long sk, long long dw_zs,
                                                            int accumulate) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)N * K) return;
+  constexpr int T = 256 / S;
+  __shared__ double red[S > 1 ? 256 : 1];
+  const int t = threadIdx.x % T, sl = threadIdx.x / T;
+  const long long i = (long long)blockIdx.x * T + t;
+  const bool live = i < (long long)N * K;
   const int zb = blockIdx.y;
-  const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+  const int n = live ? (int)(i / K) : 0, k = live ? (int)(i - (long long)n * K) : 0;
   const float* p = partial + (long long)zb * chunks * N * Kp;
   double s = 0.0;
-  for (int c = 0; c < chunks; ++c) s += (double)p[((long long)c * N + n) * Kp + k];
+  if (live)
+    for (int c = sl; c < chunks; c += S) s += (double)p[((long long)c * N + n) * Kp + k];
+  if (S > 1) {
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl != 0) return;
+    s = red[t];
+#pragma unroll
+    for (int q = 1; q < S; ++q) s += red[q * T + t];
+  }
+  if (!live) return;
   long long dst;
   if (dense) dst = n * sn + k * sk;
   else {
@@ -350,12 +657,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   dw[dst] = accumulate ? dw[dst] + (float)s : (float)s;
 }
 
+void launch_wgrad_reduce(hipStream_t s, const float* partial, float* dw, int chunks, int N, int K, int Kp, int Cin, int KH, int KW,
+                         int dense, long long sn, long long sk, long long dw_zs, int accumulate, int nz) {
+  const long long total = (long long)N * K;
+  if (total >= 64 * 256 || chunks < 16)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((total + 255) / 256), (unsigned)nz), dim3(256), 0, s, partial, dw,
+                       chunks, N, K, Kp, Cin, KH, KW, dense, sn, sk, dw_zs, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16), (unsigned)nz), dim3(256), 0, s, partial, dw,
+                       chunks, N, K, Kp, Cin, KH, KW, dense, sn, sk, dw_zs, accumulate);
+}
+
+// db[n] = sum over (batch slice, chunk) of the per-block column sums: 16 columns x 16 slices per block, slices combined in order
 __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ db,
                                                                 int chunks, int nz, int N, int accumulate) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  __shared__ double red[256];
+  const int t = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + t;
   double s = 0.0;
-  for (int c = 0; c < chunks * nz; ++c) s += (double)partial[(long long)c * N + n];
+  if (n < N)
+    for (int c = sl; c < chunks * nz; c += 16) s += (double)partial[(long long)c * N + n];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sl != 0 || n >= N) return;
+  s = red[t];
+#pragma unroll
+  for (int q = 1; q < 16; ++q) s += red[q * 16 + t];
   db[n] = accumulate ? db[n] + (float)s : (float)s;
 }
 
@@ -534,23 +861,35 @@ extern "C" int segmif_wgrad_f32(const SegmifIgemm* d, const float* dy, int ldy, 
       dim3 grid((unsigned)(strips * w.nchunks), (unsigned)ntiles_n);
       const int HPd = (8 + 2 * d->dil) * (32 + 2 * d->dil);
       const size_t smem = (size_t)(256 * 32 + HPd * 32) * sizeof(float);
-      static segmif::PerDeviceFlag raised_flag1, raised_flag2;
-      bool &raised1 = raised_flag1.here(), &raised2 = raised_flag2.here();
-      if (d->dil == 1) {
-        if (!raised1) { hipFuncSetAttribute((const void*)wgrad3x3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); raised1 = true; }
-        hipLaunchKernelGGL(wgrad3x3_halo_kernel<1>, grid, dim3(256), smem, s, w);
+      const char* mode_env = getenv("SEGMIF_WGRAD3X3");  // "fp32": the exact-fp32 kernel for dilation 2 as well
+      const bool fp32_only = mode_env && !strcmp(mode_env, "fp32");
+      const char* dbg_env = getenv("SEGMIF_WG3_DBG");
+      w.dbg = dbg_env ? atoi(dbg_env) : 0;
+      if (d->dil == 2 && !fp32_only && k.yvec && d->N % 32 == 0) {
+        constexpr size_t smem_split = (size_t)(3 * 128 * 32 + 3 * 216 * 32) * sizeof(uint32_t);
+        static segmif::PerDeviceFlag raised_flag3;
+        bool& raised3 = raised_flag3.here();
+        if (!raised3) { hipFuncSetAttribute((const void*)wgrad3x3_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_split); raised3 = true; }
+        hipLaunchKernelGGL(wgrad3x3_split_kernel, grid, dim3(256), smem_split, s, w);
       } else {
-        if (!raised2) { hipFuncSetAttribute((const void*)wgrad3x3_halo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); raised2 = true; }
-        hipLaunchKernelGGL(wgrad3x3_halo_kernel<2>, grid, dim3(256), smem, s, w);
+        const bool vec = k.yvec && d->N % 32 == 0;
+        auto fn = d->dil == 1 ? (vec ? wgrad3x3_halo_kernel<1, true> : wgrad3x3_halo_kernel<1, false>)
+                              : (vec ? wgrad3x3_halo_kernel<2, true> : wgrad3x3_halo_kernel<2, false>);
+        static segmif::PerDeviceFlag raised_halo[4];
+        bool& raised = raised_halo[(d->dil == 2) * 2 + vec].here();
+        if (!raised) {
+          hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+          if (e != hipSuccess) return (int)e;
+          raised = true;
+        }
+        hipLaunchKernelGGL(fn, grid, dim3(256), smem, s, w);
       }
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return (int)e;
-      const long long total = (long long)d->N * d->K;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1u), dim3(256), 0, s, workspace, dw,
-                         (int)strips, d->N, d->K, k.Kp, k.Cin, k.KH, k.KW, 0, (long long)dw_sn, (long long)dw_sk, 0LL,
-                         accumulate);
+      launch_wgrad_reduce(s, workspace, dw, (int)strips, d->N, d->K, k.Kp, k.Cin, k.KH, k.KW, 0, (long long)dw_sn, (long long)dw_sk,
+                          0LL, accumulate, 1);
       if (dbias)
-        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->N + 255) / 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->N + 15) / 16)), dim3(256), 0, s,
                            w.bias_partial, dbias, (int)strips, 1, d->N, accumulate);
       return (int)hipGetLastError();
     }
@@ -566,16 +905,21 @@ extern "C" int segmif_wgrad_f32(const SegmifIgemm* d, const float* dy, int ldy, 
   k.nkt = (k.Kp + BK - 1) / BK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(k.nnt * k.nkt), 1, (unsigned)(chunks * nz));
-  if (narrow) hipLaunchKernelGGL((wgrad_kernel<1, 4>), grid, dim3(256), 0, s, k);
-  else hipLaunchKernelGGL((wgrad_kernel<2, 2>), grid, dim3(256), 0, s, k);
+  const int BNl = narrow ? 32 : 64, BKl = narrow ? 128 : 64;
+  const bool fast = k.conv == 0 && k.yvec && d->N % BNl == 0 && d->K % BKl == 0;
+  if (narrow) {
+    if (fast) hipLaunchKernelGGL((wgrad_kernel<1, 4, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((wgrad_kernel<1, 4, false>), grid, dim3(256), 0, s, k);
+  } else {
+    if (fast) hipLaunchKernelGGL((wgrad_kernel<2, 2, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((wgrad_kernel<2, 2, false>), grid, dim3(256), 0, s, k);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  const long long total = (long long)d->N * d->K;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)nz), dim3(256), 0, s,
-                     workspace, dw, (int)chunks, d->N, d->K, k.Kp, k.Cin, k.KH, k.KW, is_conv ? 0 : 1,
-                     (long long)dw_sn, (long long)dw_sk, (long long)d->out_zstride, accumulate);
+  launch_wgrad_reduce(s, workspace, dw, (int)chunks, d->N, d->K, k.Kp, k.Cin, k.KH, k.KW, is_conv ? 0 : 1, (long long)dw_sn,
+                      (long long)dw_sk, (long long)d->out_zstride, accumulate, nz);
   if (dbias)  // bias gradient: sum over every chunk of every batch slice
-    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->N + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->N + 15) / 16)), dim3(256), 0, s,
                        k.bias_partial, dbias, (int)chunks, nz, d->N, accumulate);
   return (int)hipGetLastError();
 }
@@ -599,11 +943,45 @@ extern "C" int segmif_colsum_f32(const float* x, float* out, double* workspace, 
   return (int)hipGetLastError();
 }
 
+// 16-byte form of act_bwd_kernel: a block owns `rb` rows and walks their (row, channel quad) units, 32-bit index math only
+__global__ __launch_bounds__(256) void act_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ ref,
+                                                          float* __restrict__ dx, long long rows, int c4n, int rb, int ldy, int ldr,
+                                                          int ldx, int act, const float* __restrict__ slope_p) {
+  const long long row0 = (long long)blockIdx.x * rb;
+  const int nrows = (int)(rows - row0 < rb ? rows - row0 : rb);
+  const float a = act == SEGMIF_ACT_PRELU ? *slope_p : 0.f;
+  for (int u = threadIdx.x; u < nrows * c4n; u += 256) {
+    const int r = u / c4n, cq = u - r * c4n;
+    const long long row = row0 + r;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + row * ldy + 4 * cq);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ref + row * ldr + 4 * cq);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (act == SEGMIF_ACT_RELU) o[e] = v[e] > 0.f ? g[e] : 0.f;
+      else if (act == SEGMIF_ACT_PRELU) o[e] = v[e] >= 0.f ? g[e] : g[e] * a;
+      else if (act == SEGMIF_ACT_GELU) {
+        const float cdf = 0.5f * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        const float pdf = 0.3989422804014327f * expf(-0.5f * v[e] * v[e]);
+        o[e] = g[e] * (cdf + v[e] * pdf);
+      } else o[e] = g[e];
+    }
+    *reinterpret_cast<f32x4*>(dx + row * ldx + 4 * cq) = o;
+  }
+}
+
 extern "C" int segmif_act_bwd_f32(const float* dy, const float* ref, float* dx, int64_t rows, int C, int ldy, int ldr,
                                   int ldx, int act, const float* slope, void* stream) {
   if (!dy || !ref || !dx || rows <= 0 || C <= 0) return SEGMIF_EINVAL;
   if (act == SEGMIF_ACT_PRELU && !slope) return SEGMIF_EINVAL;
   const long long total = (long long)rows * C;
+  if (!((C | ldy | ldr | ldx) & 3) && !(((uintptr_t)dy | (uintptr_t)ref | (uintptr_t)dx) & 15) && rows < (1ll << 33)) {
+    const int c4n = C >> 2;
+    const int rb = c4n >= 1024 ? 1 : 1024 / c4n;  // ~four 16-byte units per thread
+    hipLaunchKernelGGL(act_bwd_vec_kernel, dim3((unsigned)((rows + rb - 1) / rb)), dim3(256), 0, (hipStream_t)stream, dy, ref, dx,
+                       (long long)rows, c4n, rb, ldy, ldr, ldx, act, slope);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, ref,
                      dx, (long long)rows, C, ldy, ldr, ldx, act, slope);
   return (int)hipGetLastError();

@@ -258,16 +258,6 @@ def linear_mode():
     return _linear_mode
 
 
-def set_linear_mode(mode):
-    """'bf16x6' (default): nn.Linear layers with K % 32 == 0 run on the bf16 matrix pipe with 3-way split operands
-    (fp32-class accuracy); 'fp32': exact-fp32 MFMA."""
-    global _linear_mode
-    if mode not in _LINEAR_MODES:
-        raise ValueError(f"mode must be one of {_LINEAR_MODES}")
-    prev, _linear_mode = _linear_mode, mode
-    return prev
-
-
 def pack_linear(w):
     """(N, K) Linear weight -> (fp32 packing, GemmSplitWeight or None).  Cache entries must be keyed on linear_mode()."""
     packed = pack_weight(w)
@@ -279,6 +269,11 @@ def pack_linear(w):
     _lib.check(lib.segmif_gemm_split_pack(w.detach().contiguous().data_ptr(), N, K, K, out.data_ptr(), _stream()),
                "segmif_gemm_split_pack")
     return packed, GemmSplitWeight(out, N, K)
+
+
+def linear_wants_split(rows, N, K):
+    """The size rule of linear_auto, for callers that would rather not build a split weight image they will not use."""
+    return _linear_mode == "bf16x6" and rows >= GEMM_SPLIT_MIN_ROWS and N >= 128 and N % 4 == 0 and K % 32 == 0
 
 
 def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):

@@ -125,6 +125,44 @@ class GradAllReducer:
                 off += p.numel()
         self._reset()
 
+    def close(self):
+        """Detach from the parameters (removes the autograd hooks); the object must not be used afterwards."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def allreduce_static(self):
+        """Exchange for a backward that autograd did not run this step (a replayed hipGraph: no hooks fire, and the
+        gradients are the graph's static tensors, so p.grad must keep pointing at them): pack, all-reduce every bucket,
+        average, copy back in place.  Not overlapped with backward."""
+        if self._buckets is None:
+            active = [p for p in self.params if p.grad is not None]
+            buckets, cur, size = [], [], 0
+            for p in reversed(active):
+                nbytes = p.numel() * p.element_size()
+                if cur and size + nbytes > self.bucket_bytes:
+                    buckets.append(cur)
+                    cur, size = [], 0
+                cur.append(p)
+                size += nbytes
+            if cur:
+                buckets.append(cur)
+            self._buckets = buckets
+            self._flat = [torch.empty(sum(p.numel() for p in b), device=b[0].device, dtype=b[0].dtype) for b in buckets]
+            self._pending = [0] * len(buckets)
+        handles = []
+        for b, flat in zip(self._buckets, self._flat):
+            torch._foreach_copy_(list(flat.split([p.numel() for p in b])), [p.grad.reshape(-1) for p in b])
+            if dist.is_initialized():
+                handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for h in handles:
+            h.wait()
+        inv = 1.0 / self.world
+        for b, flat in zip(self._buckets, self._flat):
+            if self.world > 1:
+                flat.mul_(inv)
+            torch._foreach_copy_([p.grad.reshape(-1) for p in b], list(flat.split([p.numel() for p in b])))
+
     def gradient_bytes(self):
         return sum(f.numel() * f.element_size() for f in (self._flat or []))
 

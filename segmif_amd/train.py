@@ -25,6 +25,46 @@ def seg_train_step(seg_net, optimizer, images, labels, criterion, reducer=None):
     return loss.detach()
 
 
+class GraphedSegTrainStep:
+    """seg_train_step with forward + loss + backward captured ONCE into a hipGraph and replayed.
+
+    At 8 images per GPU the segmentation step is ~3 000 kernel launches of ~15 us each: the host (Python + ctypes) takes
+    longer to issue them than the GPU takes to run them (round 3: 40 ms of kernels in a 63 ms step).  A replayed graph
+    removes the host from the loop.  What stays outside the graph is everything whose arguments change on the host every
+    step: the PolyWarmupAdamW_seg update (learning rate, bias corrections) - one multi-tensor launch - and, in data
+    parallel runs, the gradient all-reduce (after the replay, not overlapped: use the eager step where that matters).
+    Inputs live in static buffers (copied in per step); gradients are the graph's own static tensors, rewritten by every
+    replay (so there is no zero_grad between steps).  Stochastic depth / Dropout2d draw from torch's graph-safe Philox
+    state: every replay sees fresh masks.  Shapes are fixed at capture."""
+
+    def __init__(self, seg_net, optimizer, criterion, images, labels, reducer=None, warmup=2):
+        self.seg, self.opt, self.crit, self.reducer = seg_net, optimizer, criterion, reducer
+        self.images, self.labels = images.clone(), labels.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):  # one-time work (LDS limits, allocator warm-up) must not land inside the capture
+                optimizer.zero_grad(set_to_none=True)
+                seg_net._loss(self.images, self.labels, criterion).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = seg_net._loss(self.images, self.labels, criterion)
+            self.loss.backward()
+
+    def __call__(self, images=None, labels=None):
+        if images is not None and images.data_ptr() != self.images.data_ptr():
+            self.images.copy_(images)
+        if labels is not None and labels.data_ptr() != self.labels.data_ptr():
+            self.labels.copy_(labels)
+        self.graph.replay()
+        if self.reducer is not None:
+            self.reducer.allreduce_static()
+        self.opt.step()
+        return self.loss.detach()
+
+
 class _WeightsFrozen:
     """requires_grad off on a module's parameters for the span of a `with` block (restored after)."""
 

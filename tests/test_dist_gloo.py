@@ -84,7 +84,19 @@ def _dp_worker(rank, world, port, q):
         red.finish()
         out.append([p.grad.tolist() if p.grad is not None else None for p in params])  # plain lists: no shared-memory handles
     mean_loss = allreduce_scalar_mean(float(loss.detach()))
-    q.put((rank, out, mean_loss, len(red._buckets)))
+    # the exchange used after a replayed hipGraph (no autograd hooks, p.grad must stay the same tensor): same averages
+    red.close()
+    red2 = GradAllReducer(params, bucket_mb=0.0002)
+    static_ok = True
+    for step in range(2):
+        for p in params:
+            p.grad = None
+        ((net(full_x[mine]) - full_y[mine]) ** 2).mean().backward()
+        ptrs = [p.grad.data_ptr() if p.grad is not None else 0 for p in params]
+        red2.allreduce_static()
+        static_ok &= ptrs == [p.grad.data_ptr() if p.grad is not None else 0 for p in params]
+        static_ok &= all(torch.allclose(p.grad, torch.tensor(g), atol=1e-7) for p, g in zip(params[:4], out[-1][:4]))
+    q.put((rank, out, mean_loss, len(red._buckets), static_ok))
     sdist.shutdown()
 
 
@@ -114,6 +126,7 @@ def test_data_parallel_gradient_allreduce_matches_full_batch():
                 assert torch.allclose(torch.tensor(g), r, atol=1e-6), (rank, step)
             assert grads[4] is None and grads[5] is None  # unused parameters stay grad-less
     assert abs(res[0][2] - res[1][2]) < 1e-12
+    assert res[0][4] and res[1][4]  # GradAllReducer.allreduce_static: same averages, gradients updated in place
 
 
 def test_bench_self_launch_entry_spawns_one_rank_per_gpu(tmp_path):

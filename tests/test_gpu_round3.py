@@ -297,3 +297,34 @@ def test_fusion_net_trains_through_a_nonpositive_slope(core):
     out.sum().backward()
     assert fus.relu.weight.grad is not None and torch.isfinite(fus.relu.weight.grad).all()
     assert all(torch.isfinite(p.grad).all() for p in fus.parameters() if p.grad is not None)
+
+
+def test_graphed_seg_train_step_equals_eager(core):
+    """GraphedSegTrainStep (forward + loss + backward replayed from a hipGraph, AdamW outside) takes the same steps as the
+    eager seg_train_step: every reduction on the path is fixed-order, so the parameters agree bitwise after three steps on
+    three different batches (eval-mode regime: no stochastic depth, so the two runs see the same function)."""
+    from segmif_amd.train import GraphedSegTrainStep, seg_train_step
+    from segmif_amd.utils.optimizer import PolyWarmupAdamW_seg
+
+    def make():
+        net = core.Network3("mit_b1", 9, pretrained=None)
+        dw.load_det_weights(net, seed=0)
+        net = net.cuda().eval()
+        g = net.denoise_net.get_param_groups()
+        opt = PolyWarmupAdamW_seg([{"params": g[0], "lr": 8e-5, "weight_decay": 0.01}, {"params": g[1], "lr": 8e-5, "weight_decay": 0.0},
+                                   {"params": g[2], "lr": 8e-4, "weight_decay": 0.01}], lr=8e-5, weight_decay=0.01, betas=(0.9, 0.999),
+                                  iter_curr=10000, warmup_iter=3000, max_iter=160000, warmup_ratio=1e-6, power=1.0)
+        return net, opt
+
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+    B, H, W = 2, 64, 96
+    xs = [dw.det_input(f"gs_x{i}", (B, 3, H, W)).cuda() for i in range(3)]
+    ys = [dw.det_labels(f"gs_y{i}", (B, H, W), 9).cuda() for i in range(3)]
+    net_e, opt_e = make()
+    losses_e = [float(seg_train_step(net_e, opt_e, x, y, crit)) for x, y in zip(xs, ys)]
+    net_g, opt_g = make()
+    step = GraphedSegTrainStep(net_g, opt_g, crit, xs[0], ys[0], warmup=1)
+    losses_g = [float(step(x, y)) for x, y in zip(xs, ys)]
+    assert losses_g == losses_e, (losses_g, losses_e)
+    for (n, a), (_, b) in zip(net_e.named_parameters(), net_g.named_parameters()):
+        assert torch.equal(a, b), n

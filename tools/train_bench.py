@@ -12,7 +12,7 @@ import detweights as dw
 from segmif_amd import dist
 from segmif_amd.core import Fusion_Network3_ac, Network3
 from segmif_amd.parallel import GradAllReducer
-from segmif_amd.train import FusionTrainer, seg_train_step
+from segmif_amd.train import FusionTrainer, GraphedSegTrainStep, seg_train_step
 from segmif_amd.utils.optimizer import PolyWarmupAdamW, PolyWarmupAdamW_seg
 
 ap = argparse.ArgumentParser()
@@ -20,6 +20,8 @@ ap.add_argument("--step", default="seg", choices=["seg", "fusion"])
 ap.add_argument("--backbone", default="mit_b3"); ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--height", type=int, default=480); ap.add_argument("--width", type=int, default=640)
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--graph", action="store_true", help="seg step: forward + backward replayed from a hipGraph")
+ap.add_argument("--train-mode", action="store_true", help="module.train(): DropPath, Dropout2d, BatchNorm batch statistics")
 a = ap.parse_args()
 rank, local_rank, world = dist.env_world()
 torch.cuda.set_device(local_rank)
@@ -35,7 +37,13 @@ if a.step == "seg":
                               iter_curr=0, warmup_iter=3000, max_iter=80000, warmup_ratio=1e-6, power=1.0)
     red = GradAllReducer([p for grp in g for p in grp]) if world > 1 else None
     x = dw.det_input(f"trb_x{rank}", (B, 3, H, W)).cuda()
-    step = lambda: seg_train_step(seg, opt, x, labels, crit, red)
+    if a.train_mode:
+        seg.train()
+    if a.graph:
+        gstep = GraphedSegTrainStep(seg, opt, crit, x, labels, reducer=red)
+        step = lambda: gstep()
+    else:
+        step = lambda: seg_train_step(seg, opt, x, labels, crit, red)
     gflop = {"mit_b3": 300.4, "mit_b1": 110.0}.get(a.backbone, 0)
 else:
     fus = Fusion_Network3_ac(); dw.load_det_weights(fus, seed=0); fus = fus.cuda()
@@ -52,7 +60,7 @@ dist.fence(); t0 = time.perf_counter()
 for _ in range(a.steps): l = step()
 dist.fence(); dt = dist.max_over_ranks((time.perf_counter() - t0) / a.steps)
 if rank == 0:
-    print(json.dumps({"what": f"{a.step}-train step (fwd+loss+bwd+AdamW), seg net in eval-mode regime", "backbone": a.backbone,
+    print(json.dumps({"what": f"{a.step}-train step (fwd+loss+bwd+AdamW), " + ("train mode" if a.train_mode else "seg net in eval-mode regime") + (", hipGraph replay" if a.graph else ""), "backbone": a.backbone,
                       "n_gpus": world, "batch_per_gpu": B, "ms_per_step": 1e3 * dt, "samples_per_s": world * B / dt,
                       "approx_tflops_per_gpu": gflop * B / dt / 1e3, "loss": float(l),
                       "grad_bytes_exchanged": red.gradient_bytes() if red else 0,
