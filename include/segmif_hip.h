@@ -206,6 +206,12 @@ int64_t segmif_wgrad_workspace_size(int64_t M, int N, int K);
 int segmif_wgrad_f32(const SegmifIgemm* desc, const float* dy, int ldy, int64_t dy_zstride, float* dw,
                      int64_t dw_sn, int64_t dw_sk, float* dbias /* optional [N]: sum_m dY, fused */,
                      float* workspace, int accumulate, void* stream);
+/* The same for a dense problem batched over TWO levels (batch z = z1 * desc->nz2 + z2; e.g. image x attention head):
+ * input / dY / dW offsets z1 * {in_zstride, dy_zstride, out_zstride} + z2 * {in_zstride2, dy_zstride2, out_zstride2}.
+ * One launch forms dK^T (or dV^T) of every head of every image in the spatial-reduction attention's backward
+ * (core/mix_transformer.py:107-111 under autograd).  workspace: segmif_wgrad_workspace_size(M, N, K) * nz * nz2 floats. */
+int segmif_wgrad_batched2_f32(const SegmifIgemm* desc, const float* dy, int ldy, int64_t dy_zstride, int64_t dy_zstride2,
+                              float* dw, int64_t dw_sn, int64_t dw_sk, float* workspace, int accumulate, void* stream);
 /* column sums of a rows x N matrix (bias gradients), two-pass, fp64 accumulation.
  * workspace: segmif_colsum_blocks(rows) * N doubles. */
 int segmif_colsum_blocks(int64_t rows);
@@ -394,6 +400,13 @@ int segmif_softmax_ce_f32(const float* logits, const int64_t* labels, float* dlo
 /* input gradient of a strided convolution (overlap patch embed, sr conv); wd = weight as [tap][n][c] */
 int segmif_conv_dgrad_strided_f32(const float* dy, const float* wd, float* dx, int B, int H, int W, int Cin, int N,
                                   int KH, int KW, int stride, int pad, int OH, int OW, int lddy, int lddx, void* stream);
+
+/* second half of the same gradient computed as GEMM + gather: cols (B, OH, OW, k*k*C) = dY . W^T with columns ordered
+ * (ky, kx, c) -> dx (B, H, W, C), dx[y][x] = sum of the taps ky = (y + pad) mod stride (+ stride ..), likewise kx, read from
+ * output pixel ((y + pad - ky) / stride, (x + pad - kx) / stride).  Replaces the scalar kernel above wherever the GEMM's
+ * scratch (rows x k*k*C floats) is affordable (every strided conv of the path: overlap patch embeds). */
+int segmif_col2im_f32(const float* cols, float* dx, int B, int H, int W, int C, int k, int stride, int pad, int OH, int OW,
+                      void* stream);
 
 /* Train-mode BatchNorm2d on NHWC rows (segformer_head.py:50-55: linear_fuse.bn with batch statistics).
  * segmif_bn_colstats_f32: mode 0 -> out[C] = sum_rows (x - mu)^2 ; mode 1 -> out[2C] = [sum dz | sum dz*xhat]

@@ -93,6 +93,8 @@ SIGNATURES = {
     "segmif_wgrad_workspace_size": (c_int64, [c_int64, c_int, c_int]),
     "segmif_wgrad_f32": (c_int, [POINTER(SegmifIgemm), c_void_p, c_int, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                  c_void_p, c_int, c_void_p]),
+    "segmif_wgrad_batched2_f32": (c_int, [POINTER(SegmifIgemm), c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                          c_void_p, c_int, c_void_p]),
     "segmif_colsum_blocks": (c_int, [c_int64]),
     "segmif_colsum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "segmif_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
@@ -132,6 +134,7 @@ SIGNATURES = {
     "segmif_softmax_ce_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                       c_void_p]),
     "segmif_conv_dgrad_strided_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
+    "segmif_col2im_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "segmif_bn_colstats_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                        c_void_p]),
     "segmif_bn_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

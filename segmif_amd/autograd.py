@@ -91,11 +91,16 @@ def conv_wgrad(x, dy, w_shape, k, stride, pad, dil, want_bias=False):
     return (dw, db) if want_bias else dw
 
 
+TRAIN_SPLIT_MIN_ROWS = 500000
+
+
 def _gemm(x, w_nk, N, bias=None, act=ACT_NONE):
     """x @ w_nk^T (+ bias, act) for a plain (N, K) weight matrix: the bf16x6 GEMM for tall problems (same size rule as
     inference, ops.linear_auto), the fp32 tiles otherwise.  Training re-packs per call: the weights change every step."""
     rows, K, _ = rows_view(x, "x")
-    if ops.linear_wants_split(rows, N, K):
+    # (measured at 8 images per step: with the per-call weight packing the bf16x6 GEMM only pays for the full-resolution
+    # problems of the fusion net; the encoder's Linears - at most 153 600 rows - are 2.5 ms per step faster on the fp32 tiles)
+    if rows >= TRAIN_SPLIT_MIN_ROWS and ops.linear_wants_split(rows, N, K):
         return ops.linear_auto(x, ops.pack_linear(w_nk), N, bias=bias, act=act)
     wt = w_nk if (K % 16 == 0 and w_nk.is_contiguous()) else ops.pack_weight(w_nk)
     return ops.linear(x, wt, N, bias=bias, act=act)
@@ -194,6 +199,14 @@ class ConvFn(torch.autograd.Function):
                 else:  # rows / columns the forward conv dropped receive no gradient
                     dx = torch.zeros((B, H, W, cin), device=x.device, dtype=torch.float32)
                     dx[:, :OH * k, :OW * k] = cols
+            elif dil == 1:
+                # overlapping strided conv (patch embeds): cols = dY W^T on the matrix pipe, then a gather (col2im)
+                OH, OW = dz.shape[1], dz.shape[2]
+                wt = w.detach().permute(2, 3, 1, 0).reshape(k * k * cin, N).contiguous()  # [(ky, kx, c)][n]
+                cols = _gemm(dz.view(B, OH * OW, N), wt, k * k * cin)
+                dx = torch.empty((B, H, W, cin), device=x.device, dtype=torch.float32)
+                _lib.check(_lib.load().segmif_col2im_f32(cols.data_ptr(), dx.data_ptr(), B, H, W, cin, k, stride, pad, OH, OW,
+                                                         _stream()), "segmif_col2im_f32")
             else:
                 wd = w.permute(2, 3, 0, 1).contiguous()  # [ky][kx][n][c]
                 dx = torch.empty((B, H, W, cin), device=x.device, dtype=torch.float32)
@@ -410,22 +423,21 @@ class SrAttentionFn(torch.autograd.Function):
         # dk^T[d][key] = sum_n q[n][d] dS[n][key] ; dv^T[d][key] = sum_n do[n][d] P[n][key]  (wgrad form).
         # Written with key stride 2C into a (B, Lp, 2C) buffer: rows >= Nk are padding and are sliced away.
         dkv = torch.empty((B, Lp, 2 * C), device=dev, dtype=torch.float32)
-        ws = torch.empty((lib.segmif_wgrad_workspace_size(N, hd, Lp) * B,), device=dev, dtype=torch.float32)
+        ws = torch.empty((lib.segmif_wgrad_workspace_size(N, hd, Lp) * B * heads,), device=dev, dtype=torch.float32)
         for src, probs, col0 in ((q, dS, 0), (do, P, C)):
-            for hh in range(heads):
-                d = _lib.SegmifIgemm()
-                d.in_ = probs.data_ptr() + 4 * hh * N * Lp
-                d.M, d.N, d.K, d.lda = N, hd, Lp, Lp
-                d.H = d.W = d.OH = d.OW = 1
-                d.Cin = Lp
-                d.KH = d.KW = d.stride = d.dil = 1
-                d.nz = B
-                d.in_zstride = heads * N * Lp
-                d.out_zstride = Lp * 2 * C
-                out = dkv.data_ptr() + 4 * (col0 + hh * hd)
-                # element (n = d, k = key) -> dkv[b][key][col0 + hh*hd + d]
-                _lib.check(lib.segmif_wgrad_f32(ctypes.byref(d), src.data_ptr() + 4 * hh * hd, C, N * C, out, 1,
-                                                2 * C, None, ws.data_ptr(), 0, _stream()), "segmif_wgrad_f32")
+            # every (image, head) in one launch: batch z = b * heads + h
+            d = _lib.SegmifIgemm()
+            d.in_ = probs.data_ptr()
+            d.M, d.N, d.K, d.lda = N, hd, Lp, Lp
+            d.H = d.W = d.OH = d.OW = 1
+            d.Cin = Lp
+            d.KH = d.KW = d.stride = d.dil = 1
+            d.nz, d.nz2 = B, heads
+            d.in_zstride, d.in_zstride2 = heads * N * Lp, N * Lp
+            d.out_zstride, d.out_zstride2 = Lp * 2 * C, hd
+            # element (n = d, k = key) of (b, h) -> dkv[b][key][col0 + h*hd + d]
+            _lib.check(lib.segmif_wgrad_batched2_f32(ctypes.byref(d), src.data_ptr(), C, N * C, hd, dkv.data_ptr() + 4 * col0, 1,
+                                                     2 * C, ws.data_ptr(), 0, _stream()), "segmif_wgrad_batched2_f32")
         return dq, dkv[:, :Nk], None, None
 
 

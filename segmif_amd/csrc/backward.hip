@@ -600,7 +600,63 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamEntry* __restrict_
   }
 }
 
+// Input gradient of a strided convolution, second half.  First half: cols = dY (rows = output pixels) x W^T as ONE dense GEMM
+// on the matrix pipe, cols[b][oy][ox][(ky, kx, c)]; this kernel gathers them back: input pixel (y, x) receives the taps
+// with ky = (y + pad) mod s (+ s, + 2 s ..) from output pixel ((y + pad - ky) / s, ..).  The scalar gather kernel it replaces
+// (conv_dgrad_strided_kernel) did the contraction itself on the vector ALU: 7 TFLOP/s on the stage-2 patch embed.
+template <int V>
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ cols, float* __restrict__ dx, int H, int W, int C,
+                                                     int k, int s, int pad, int OH, int OW, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = C / V;
+  const int c = (int)(idx % cv) * V;
+  const long long px = idx / cv;
+  const int x = (int)(px % W), y = (int)((px / W) % H);
+  const long long b = px / ((long long)W * H);
+  const long long K9 = (long long)k * k * C;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = 0.f;
+  for (int ky = (y + pad) % s; ky < k; ky += s) {
+    const int ty = y + pad - ky;
+    if (ty < 0) break;
+    const int oy = ty / s;
+    if (oy >= OH) continue;
+    for (int kx = (x + pad) % s; kx < k; kx += s) {
+      const int tx = x + pad - kx;
+      if (tx < 0) break;
+      const int ox = tx / s;
+      if (ox >= OW) continue;
+      const float* src = cols + ((b * OH + oy) * OW + ox) * K9 + (long long)(ky * k + kx) * C + c;
+      if (V == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+      } else acc[0] += src[0];
+    }
+  }
+  float* dst = dx + px * C + c;
+  if (V == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+  else dst[0] = acc[0];
+}
+
 }  // namespace
+
+extern "C" int segmif_col2im_f32(const float* cols, float* dx, int B, int H, int W, int C, int k, int stride, int pad, int OH,
+                                 int OW, void* stream) {
+  if (!cols || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0 || OH <= 0 || OW <= 0)
+    return SEGMIF_EINVAL;
+  const bool vec = !(C & 3) && !(((uintptr_t)cols | (uintptr_t)dx) & 15);
+  const long long total = (long long)B * H * W * (vec ? C / 4 : C);
+  if (vec)
+    hipLaunchKernelGGL(col2im_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cols, dx, H, W, C,
+                       k, stride, pad, OH, OW, total);
+  else
+    hipLaunchKernelGGL(col2im_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cols, dx, H, W, C,
+                       k, stride, pad, OH, OW, total);
+  return (int)hipGetLastError();
+}
 
 extern "C" int segmif_layernorm_bwd_blocks(int64_t rows, int C) {
   const int nvec = C >> 2;

@@ -40,6 +40,8 @@ struct WgradK {
   long long rows_per_chunk;
   int nkt, nnt, chunks;
   long long in_zs, dy_zs;  // batch strides (gridDim.z = batches * chunks)
+  int nz2;                 // second batch level (attention heads): batch z = z1 * nz2 + z2, offsets z1 * zs + z2 * zs2
+  long long in_zs2, dy_zs2;
   float* bias_partial;  // optional [batch][chunk][N]: column sums of dY (bias gradient), k-tile 0 blocks only
 };
 
@@ -62,8 +64,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   const int nt = blockIdx.x % p.nnt, kt = blockIdx.x / p.nnt;
   const int n0 = nt * BN, k0 = kt * BK;
   const int zb = blockIdx.z / p.chunks, chunk = blockIdx.z - zb * p.chunks;
-  const float* __restrict__ dyp = p.dy + (long long)zb * p.dy_zs;
-  const float* __restrict__ inp = p.in + (long long)zb * p.in_zs;
+  const int zb1 = zb / p.nz2, zb2 = zb - zb1 * p.nz2;
+  const float* __restrict__ dyp = p.dy + (long long)zb1 * p.dy_zs + (long long)zb2 * p.dy_zs2;
+  const float* __restrict__ inp = p.in + (long long)zb1 * p.in_zs + (long long)zb2 * p.in_zs2;
   const long long m_begin = (long long)chunk * p.rows_per_chunk;
   const long long m_end = (m_begin + p.rows_per_chunk < p.M) ? m_begin + p.rows_per_chunk : p.M;
 
@@ -625,7 +628,7 @@ template <int S>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            int chunks, int N, int K, int Kp, int Cin, int KH, int KW,
                                                            int dense, long long sn, long long sk, long long dw_zs,
-                                                           int accumulate) {
+                                                           int nz2, long long dw_zs2, int accumulate) {
   constexpr int T = 256 / S;
   __shared__ double red[S > 1 ? 256 : 1];
   const int t = threadIdx.x % T, sl = threadIdx.x / T;
@@ -653,19 +656,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int ky = tap / KW, kx = tap - ky * KW;
     dst = (((long long)n * Cin + ch) * KH + ky) * KW + kx;
   }
-  dst += zb * dw_zs;
+  dst += (zb / nz2) * dw_zs + (zb % nz2) * dw_zs2;
   dw[dst] = accumulate ? dw[dst] + (float)s : (float)s;
 }
 
 void launch_wgrad_reduce(hipStream_t s, const float* partial, float* dw, int chunks, int N, int K, int Kp, int Cin, int KH, int KW,
-                         int dense, long long sn, long long sk, long long dw_zs, int accumulate, int nz) {
+                         int dense, long long sn, long long sk, long long dw_zs, int accumulate, int nz, int nz2 = 1,
+                         long long dw_zs2 = 0) {
   const long long total = (long long)N * K;
   if (total >= 64 * 256 || chunks < 16)
     hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((total + 255) / 256), (unsigned)nz), dim3(256), 0, s, partial, dw,
-                       chunks, N, K, Kp, Cin, KH, KW, dense, sn, sk, dw_zs, accumulate);
+                       chunks, N, K, Kp, Cin, KH, KW, dense, sn, sk, dw_zs, nz2, dw_zs2, accumulate);
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16), (unsigned)nz), dim3(256), 0, s, partial, dw,
-                       chunks, N, K, Kp, Cin, KH, KW, dense, sn, sk, dw_zs, accumulate);
+                       chunks, N, K, Kp, Cin, KH, KW, dense, sn, sk, dw_zs, nz2, dw_zs2, accumulate);
 }
 
 // db[n] = sum over (batch slice, chunk) of the per-block column sums: 16 columns x 16 slices per block, slices combined in order
@@ -816,26 +820,44 @@ extern "C" int64_t segmif_wgrad_workspace_size(int64_t M, int N, int K) {
   return pick_chunks(M, N, K) * ((int64_t)N * Kp + N);  // weight partials + bias partials
 }
 
+static int wgrad_impl(const SegmifIgemm* d, const float* dy, int ldy, int64_t dy_zstride, int64_t dy_zstride2, float* dw,
+                      int64_t dw_sn, int64_t dw_sk, float* dbias, float* workspace, int accumulate, void* stream);
+
 extern "C" int segmif_wgrad_f32(const SegmifIgemm* d, const float* dy, int ldy, int64_t dy_zstride, float* dw,
                                 int64_t dw_sn, int64_t dw_sk, float* dbias, float* workspace, int accumulate,
                                 void* stream) {
+  if (d && d->nz2 > 1) return SEGMIF_EINVAL;  // two batch levels: segmif_wgrad_batched2_f32
+  return wgrad_impl(d, dy, ldy, dy_zstride, 0, dw, dw_sn, dw_sk, dbias, workspace, accumulate, stream);
+}
+
+extern "C" int segmif_wgrad_batched2_f32(const SegmifIgemm* d, const float* dy, int ldy, int64_t dy_zstride, int64_t dy_zstride2,
+                                         float* dw, int64_t dw_sn, int64_t dw_sk, float* workspace, int accumulate,
+                                         void* stream) {
+  if (!d || d->nz < 1 || d->nz2 < 1 || !(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0)) return SEGMIF_EINVAL;
+  return wgrad_impl(d, dy, ldy, dy_zstride, dy_zstride2, dw, dw_sn, dw_sk, nullptr, workspace, accumulate, stream);
+}
+
+static int wgrad_impl(const SegmifIgemm* d, const float* dy, int ldy, int64_t dy_zstride, int64_t dy_zstride2, float* dw,
+                      int64_t dw_sn, int64_t dw_sk, float* dbias, float* workspace, int accumulate, void* stream) {
   if (!d || !d->in || !dy || !dw || !workspace || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->in2) return SEGMIF_EINVAL;
   WgradK k;
   k.dy = dy; k.in = d->in; k.partial = workspace; k.M = d->M; k.N = d->N; k.K = d->K; k.Kp = (d->K + 15) / 16 * 16;
   k.ldy = ldy; k.lda = d->lda;
   k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad;
   k.dil = d->dil; k.OH = d->OH; k.OW = d->OW;
-  const int nz = d->nz > 0 ? d->nz : 1;
+  const int nz2 = d->nz2 > 1 ? d->nz2 : 1;
+  const int nz = (d->nz > 0 ? d->nz : 1) * nz2;  // total batch slices; z = z1 * nz2 + z2
   k.in_zs = d->in_zstride; k.dy_zs = dy_zstride;
+  k.nz2 = nz2; k.in_zs2 = nz2 > 1 ? d->in_zstride2 : 0; k.dy_zs2 = nz2 > 1 ? dy_zstride2 : 0;
   const bool is_conv = !(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0);
   if (!is_conv) {
-    if ((d->K % 4) || (d->lda % 4) || ((uintptr_t)d->in & 15) || (d->in_zstride % 4)) return SEGMIF_EINVAL;
+    if ((d->K % 4) || (d->lda % 4) || ((uintptr_t)d->in & 15) || (d->in_zstride % 4) || (k.in_zs2 % 4)) return SEGMIF_EINVAL;
     k.conv = 0;
     k.Cin = d->K; k.KH = k.KW = 1;
   } else {
     k.conv = (d->Cin % 4 == 0 && d->lda % 4 == 0 && !((uintptr_t)d->in & 15) && d->in_zstride % 4 == 0) ? 1 : 2;
   }
-  k.yvec = (ldy % 4 == 0) && !((uintptr_t)dy & 15) && (dy_zstride % 4 == 0);
+  k.yvec = (ldy % 4 == 0) && !((uintptr_t)dy & 15) && (dy_zstride % 4 == 0) && (k.dy_zs2 % 4 == 0);
   {  // halo-tiled path for 3x3 stride-1 convs (DRDB and friends)
     const bool halo = is_conv && d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) &&
                       d->pad == d->dil && d->OH == d->H && d->OW == d->W && d->Cin % 32 == 0 && d->lda % 4 == 0 &&
@@ -911,13 +933,16 @@ extern "C" int segmif_wgrad_f32(const SegmifIgemm* d, const float* dy, int ldy, 
     if (fast) hipLaunchKernelGGL((wgrad_kernel<1, 4, true>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((wgrad_kernel<1, 4, false>), grid, dim3(256), 0, s, k);
   } else {
+    // (a bf16x6 version of this kernel - row pairs packed like wgrad3x3_split_kernel - measured 2 ms per step SLOWER than
+    // the FAST fp32 path on both training steps: these problems are bound by their loads and partial slabs, not by the
+    // fp32 matrix pipe; profiles/r03_wgrad_dense_bf16x6_ab.txt)
     if (fast) hipLaunchKernelGGL((wgrad_kernel<2, 2, true>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((wgrad_kernel<2, 2, false>), grid, dim3(256), 0, s, k);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   launch_wgrad_reduce(s, workspace, dw, (int)chunks, d->N, d->K, k.Kp, k.Cin, k.KH, k.KW, is_conv ? 0 : 1, (long long)dw_sn,
-                      (long long)dw_sk, (long long)d->out_zstride, accumulate, nz);
+                      (long long)dw_sk, (long long)d->out_zstride, accumulate, nz, nz2, nz2 > 1 ? (long long)d->out_zstride2 : 0LL);
   if (dbias)  // bias gradient: sum over every chunk of every batch slice
     hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((d->N + 15) / 16)), dim3(256), 0, s,
                        k.bias_partial, dbias, (int)chunks, nz, d->N, accumulate);
