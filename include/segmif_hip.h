@@ -242,6 +242,15 @@ int segmif_dwconv3x3_bias_f32(const float* x, const float* w9, const float* bias
                               int B, int H, int W, int C, void* stream);
 
 /*
+ * 3x3 stride-1 "same" convolution from 32 channels to ONE + bias + act (NONE | RELU | PRELU): conv22 of Fusion_Network3_ac
+ * (core/model_fusion.py:1042, :1065), a bandwidth-bound stencil on the vector ALU (the matrix-pipe kernels pad the single
+ * output channel to a 32-wide tile).  x: (B, H, W, >= 32) rows with pixel pitch ldx (16-byte aligned, ldx % 4 == 0);
+ * wt: [9][32] tap-major = the segmif_pack_conv_weight image of the (1, 32, 3, 3) weight; y: (B, H, W) dense.
+ */
+int segmif_conv3x3_c32to1_f32(const float* x, int ldx, const float* wt, const float* bias, const float* prelu, int act, float* y,
+                              int B, int H, int W, void* stream);
+
+/*
  * Bilinear resize, align_corners=False, NHWC: (B, IH, IW, C) -> (B, OH, OW, C) written with
  * pixel pitch ldo at channel offset 0 of `y` (lets the SegFormer head write straight into its
  * concat buffer).  16-byte vector path when C, ldx, ldo are multiples of 4; scalar otherwise (9-class logits).

@@ -108,6 +108,7 @@ SIGNATURES = {
     "segmif_prelu_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "segmif_prelu_bwd_blocks": (c_int, [c_int64]),
     "segmif_prelu_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "segmif_conv3x3_c32to1_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "segmif_bilinear_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "segmif_sr_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_int, c_float, c_void_p]),

@@ -437,6 +437,12 @@ class Fusion_Network3_ac(nn.Module):
     def _w3(self, name):  # stride-1 "same" 3x3 convs: split-bf16 image when ops.conv3x3_mode() allows
         return self._pk.get(f"{name}:{ops.conv3x3_mode()}", getattr(self, name).weight, ops.pack_conv3x3)
 
+    def _conv22(self, f, slope):
+        """conv22 (32 -> 1 channel) + the shared PReLU: a bandwidth-bound stencil kernel instead of a 32-wide matrix tile."""
+        if ops.aligned16(f) and f.shape[-1] == 32:
+            return ops.conv3x3_c32to1(f, self._w("conv22"), bias=self.conv22.bias, act=ops.ACT_PRELU, prelu=slope)
+        return ops.conv2d(f, self._w("conv22"), 1, 3, pad=1, bias=self.conv22.bias, act=ops.ACT_PRELU, prelu=slope)
+
     @staticmethod
     def _first_channel_nhwc(x):
         """x[:, 0:1] of an NCHW image as an NHWC (B,H,W,1) tensor (identical memory for C == 1)."""
@@ -526,7 +532,7 @@ class Fusion_Network3_ac(nn.Module):
         self.ffm.forward_nhwc(x1, x2, seg, out1=cat[..., :64], out2=cat[..., 64:])
         f = ops.conv2d(cat, self._w3("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)
         f = ops.conv2d(f, self._w3("conv21"), 32, 3, pad=1, bias=self.conv21.bias, act=PRELU, prelu=slope)
-        f = ops.conv2d(f, self._w("conv22"), 1, 3, pad=1, bias=self.conv22.bias, act=PRELU, prelu=slope)
+        f = self._conv22(f, slope)
         return f.view(B, 1, H, W)
 
 
@@ -556,7 +562,7 @@ class Fusion_Network3_ac(nn.Module):
         self.ffm.forward_nhwc(y1, y2, seg, out1=cat[..., :64], out2=cat[..., 64:])
         f = ops.conv2d(cat, self._w3("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)
         f = ops.conv2d(f, self._w3("conv21"), 32, 3, pad=1, bias=self.conv21.bias, act=PRELU, prelu=slope)
-        f = ops.conv2d(f, self._w("conv22"), 1, 3, pad=1, bias=self.conv22.bias, act=PRELU, prelu=slope)
+        f = self._conv22(f, slope)
         return f.view(B, 1, H, W)
 
 

@@ -310,37 +310,50 @@ def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):
 
 class LaunchTimer:
     """Brackets tagged kernel launches with HIP events on the launch stream (torch's current
-    stream) so bench.py can report the dominant kernel's average duration live."""
+    stream) so bench.py can report a kernel's average duration live.  `work` is whatever the caller wants averaged
+    beside the time: flops for the matrix-pipe kernels, algorithmic bytes for the bandwidth-bound ones."""
 
     def __init__(self, tag):
         self.tag = tag
-        self.events = []  # (start, end, flops)
+        self.events = []  # (start, end, work)
 
-    def bracket(self, fn, flops):
+    def bracket(self, fn, work):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        self.events.append((s, e, flops))
+        self.events.append((s, e, work))
 
     def summary(self):
-        """-> (launches, mean ms per launch, mean flops per launch); call after a device sync."""
+        """-> (launches, mean ms per launch, mean work per launch); call after a device sync."""
         if not self.events:
             return 0, 0.0, 0.0
         ms = [s.elapsed_time(e) for s, e, _ in self.events]
         return len(ms), sum(ms) / len(ms), sum(f for _, _, f in self.events) / len(ms)
 
 
-_timer = None
+_timer = None      # the dominant kernel's timer (bench.py's `roofline` object)
+_side_timers = {}  # tag -> LaunchTimer for the bandwidth-bound kernels bench.py also reports
 
 
-def set_launch_timer(timer):
-    global _timer
+def set_launch_timer(timer, side=None):
+    """timer: LaunchTimer for the tagged matrix-pipe launches (or None); side: optional {tag: LaunchTimer} for the
+    bandwidth-bound kernels ('dwconv', 'cp_gram', 'cp_tail', 'bilinear')."""
+    global _timer, _side_timers
     _timer = timer
+    _side_timers = dict(side or {})
 
 
 def launch_timer_active():
-    return _timer is not None
+    return _timer is not None or bool(_side_timers)
+
+
+def _side(tag, fn, nbytes):
+    t = _side_timers.get(tag)
+    if t is None:
+        fn()
+    else:
+        t.bracket(fn, float(nbytes))
 
 
 def _igemm(desc, tag=None, dev="cuda"):
@@ -484,6 +497,21 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
     return out
 
 
+def conv3x3_c32to1(x, wt, *, bias=None, act=ACT_NONE, prelu=None):
+    """3x3 'same' conv from 32 channels to one (+ bias + act) as a vector-ALU stencil: x (B, H, W, 32) rows view, wt the
+    fp32 packing (1, 288) of the (1, 32, 3, 3) weight -> (B, H, W, 1)."""
+    _, cin, ldx = rows_view(x, "x")
+    if x.dim() != 4 or cin != 32 or tuple(_req(wt, "wt").shape) != (1, 288) or not wt.is_contiguous():
+        raise RuntimeError("conv3x3_c32to1 expects (B, H, W, 32) input and the packed (1, 288) weight")
+    B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    out = torch.empty((B, H, W, 1), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().segmif_conv3x3_c32to1_f32(x.data_ptr(), ldx, wt.data_ptr(),
+                                                     _req(bias, "bias").data_ptr() if bias is not None else None,
+                                                     _req(prelu, "prelu").data_ptr() if prelu is not None else None, act,
+                                                     out.data_ptr(), B, H, W, _stream()), "segmif_conv3x3_c32to1_f32")
+    return out
+
+
 def conv_ln_fusable(N):
     """True when a conv's LayerNorm can ride in its epilogue: the row (all N channels) must sit in one wave tile - N = 64,
     i.e. the stage-1 patch embed of mit_b1 .. b5 (614 400 rows at 32 images of 480x640: the only patch-embed LayerNorm over
@@ -519,9 +547,9 @@ def dwconv3x3_gelu(x, w9, bias, H, W):
         raise RuntimeError("dwconv3x3_gelu expects contiguous (B, H*W, C)")
     B, _, C = x.shape
     out = torch.empty_like(x)
-    _lib.check(_lib.load().segmif_dwconv3x3_gelu_f32(x.data_ptr(), _req(w9).data_ptr(), _req(bias).data_ptr(),
-                                                     out.data_ptr(), B, H, W, C, _stream()),
-               "segmif_dwconv3x3_gelu_f32")
+    _side("dwconv", lambda: _lib.check(_lib.load().segmif_dwconv3x3_gelu_f32(
+        x.data_ptr(), _req(w9).data_ptr(), _req(bias).data_ptr(), out.data_ptr(), B, H, W, C, _stream()),
+        "segmif_dwconv3x3_gelu_f32"), 8.0 * x.numel())
     return out
 
 
@@ -549,8 +577,9 @@ def bilinear(x, OH, OW, out=None):
     _, oc, ldo = rows_view(out, "out")
     if tuple(out.shape) != (B, OH, OW, C):
         raise RuntimeError("bilinear out shape mismatch")
-    _lib.check(_lib.load().segmif_bilinear_nhwc_f32(x.data_ptr(), out.data_ptr(), B, IH, IW, OH, OW, C, ldx, ldo,
-                                                    _stream()), "segmif_bilinear_nhwc_f32")
+    _side("bilinear", lambda: _lib.check(_lib.load().segmif_bilinear_nhwc_f32(
+        x.data_ptr(), out.data_ptr(), B, IH, IW, OH, OW, C, ldx, ldo, _stream()), "segmif_bilinear_nhwc_f32"),
+        4.0 * C * B * (IH * IW + OH * OW))
     return out
 
 
@@ -680,9 +709,9 @@ def crosspath_gram(x, w_half, b_half):
     lib = _lib.load()
     nblk = lib.segmif_crosspath_gram_blocks(N)
     part = torch.empty((B, nblk, 3072), device=x.device, dtype=torch.float64)
-    _lib.check(lib.segmif_crosspath_gram_f32(x.data_ptr(), x.stride(1), w_half.data_ptr(),
-                                             _req(b_half, "bias").data_ptr() if b_half is not None else None,
-                                             part.data_ptr(), B, N, _stream()), "segmif_crosspath_gram_f32")
+    _side("cp_gram", lambda: _lib.check(lib.segmif_crosspath_gram_f32(
+        x.data_ptr(), x.stride(1), w_half.data_ptr(), _req(b_half, "bias").data_ptr() if b_half is not None else None,
+        part.data_ptr(), B, N, _stream()), "segmif_crosspath_gram_f32"), 256.0 * B * N)
     return part
 
 
@@ -728,7 +757,8 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
         if hw is None or hw[0] * hw[1] != N or (planes.B, planes.H, planes.W) != (B, hw[0], hw[1]):
             raise RuntimeError("crosspath_tail: planes geometry does not match the tokens")
         d.planes_out, d.H, d.W, d.planes_chunks = planes.data.data_ptr(), hw[0], hw[1], planes.chunks
-    _lib.check(_lib.load().segmif_crosspath_tail_f32(ctypes.byref(d), _stream()), "segmif_crosspath_tail_f32")
+    _side("cp_tail", lambda: _lib.check(_lib.load().segmif_crosspath_tail_f32(ctypes.byref(d), _stream()),
+                                        "segmif_crosspath_tail_f32"), (768.0 + (384.0 if planes is not None else 0.0)) * B * N)
     return out
 
 

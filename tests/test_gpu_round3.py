@@ -328,3 +328,22 @@ def test_graphed_seg_train_step_equals_eager(core):
     assert losses_g == losses_e, (losses_g, losses_e)
     for (n, a), (_, b) in zip(net_e.named_parameters(), net_g.named_parameters()):
         assert torch.equal(a, b), n
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 21, 45), (1, 8, 32), (3, 40, 70)])
+def test_conv3x3_c32to1_stencil_vs_fp64(B, H, W):
+    """conv22's stencil kernel (32 channels -> 1, bias, PReLU / ReLU / none) against an fp64 convolution; ragged sizes, and
+    an input that is a channel slice of a wider buffer (pixel pitch 48)."""
+    from segmif_amd import ops
+    x = dw.det_input("c1_x", (B, 32, H, W), lo=-1.0, hi=1.0)
+    w = dw.det_input("c1_w", (1, 32, 3, 3), lo=-0.3, hi=0.3)
+    b = torch.tensor([0.07])
+    slope = torch.tensor([0.2])
+    ref0 = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    wide = torch.zeros((B, H, W, 48)).cuda()
+    wide[..., :32] = x.permute(0, 2, 3, 1).cuda()
+    for act, ref in ((ops.ACT_PRELU, torch.where(ref0 >= 0, ref0, 0.2 * ref0)), (ops.ACT_RELU, ref0.clamp(min=0)), (ops.ACT_NONE, ref0)):
+        for xin in (x.permute(0, 2, 3, 1).contiguous().cuda(), wide[..., :32]):
+            got = ops.conv3x3_c32to1(xin, ops.pack_weight(w.cuda()), bias=b.cuda(), act=act, prelu=slope.cuda())
+            assert tuple(got.shape) == (B, H, W, 1)
+            assert rel(got.view(B, 1, H, W), ref) < 2e-6
