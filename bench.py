@@ -272,6 +272,22 @@ def main():
 
     elapsed = dist.max_over_ranks(elapsed)
 
+    # beside the headline, never in it: the same step with the two encoder stages whose outputs forward_fusion() discards
+    # (the reference computes and drops them, core/mix_transformer.py:358-375) not computed - identical results
+    enc = seg.denoise_net.encoder
+    elapsed_dse = None
+    if not args.graph:
+        enc.skip_unused_fusion_stages = True
+        with torch.no_grad():
+            step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            elapsed_dse = dist.max_over_ranks(time.perf_counter() - t0)
+        enc.skip_unused_fusion_stages = False
+
     train = None
     if not args.no_train and not args.graph:
         del pipe, labels
@@ -340,6 +356,12 @@ def main():
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                 "launches_timed": n, "avg_launch_ms": ms, "avg_launch_gflop": flops / 1e9,
             }
+        if elapsed_dse is not None:
+            out["without_discarded_encoder_stages"] = {
+                "value": pairs / elapsed_dse, "ms_per_step": 1000.0 * elapsed_dse / args.steps,
+                "note": "NOT the headline: same pair forward, same outputs bit for bit, with stages 3-4 of the FIRST encoder pass "
+                        "(forward_fusion on the mask; the reference computes and discards them, mix_transformer.py:358-375) not "
+                        "computed (encoder.skip_unused_fusion_stages = True); 67.7 GFLOP per pair fewer executed"}
         if side:
             # bandwidth-bound kernels: algorithmic HBM bytes per launch / HIP-event time around the launch (peak 8 TB/s,
             # ~6.3 achievable: MI355X_MICROARCH.md)

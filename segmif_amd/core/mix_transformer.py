@@ -272,11 +272,17 @@ class MixVisionTransformer(nn.Module):
     def no_weight_decay(self):
         return {'pos_embed1', 'pos_embed2', 'pos_embed3', 'pos_embed4', 'cls_token'}
 
-    def forward_features_nhwc(self, x):
-        """-> 4 NHWC feature maps [(B, H/4, W/4, C1), ...]."""
+    # forward_fusion() returns the stage-1 / stage-2 features only, yet the reference runs all four stages first and drops
+    # the last two (ref :358-375): 76 % of an encoder pass whose results nothing reads.  False (default) does the same
+    # work as the reference; True stops after stage 2 - the same outputs, bit for bit (tests/test_gpu_round3.py).  bench.py
+    # reports the second figure beside the headline, never in it.
+    skip_unused_fusion_stages = False
+
+    def forward_features_nhwc(self, x, stages=4):
+        """-> `stages` NHWC feature maps [(B, H/4, W/4, C1), ...]."""
         feats = []
         train = wants_grad(self, x)
-        for s in range(4):
+        for s in range(stages):
             t, H, W = getattr(self, f"patch_embed{s + 1}")(x)
             for blk in getattr(self, f"block{s + 1}"):
                 t = blk.forward_train(t, H, W) if train else blk.forward_(t, H, W)
@@ -300,13 +306,13 @@ class MixVisionTransformer(nn.Module):
         """The two feature maps forward_fusion() up-samples, still at their own resolution and NHWC:
         (B, H/4, W/4, C1), (B, H/8, W/8, C2).  For consumers that apply a 1x1 conv next and can do it
         BEFORE the bilinear resize (Fusion_Network3_ac.forward_from_features)."""
-        feats = self.forward_features_nhwc(x)
+        feats = self.forward_features_nhwc(x, 2 if self.skip_unused_fusion_stages else 4)
         return feats[0], feats[1]
 
     def forward_fusion(self, x):
         """Stage-1 / stage-2 features bilinearly resized to the input resolution (ref :358-375)."""
         H, W = x.shape[2], x.shape[3]
-        feats = self.forward_features_nhwc(x)
+        feats = self.forward_features_nhwc(x, 2 if self.skip_unused_fusion_stages else 4)
         return ops.as_nchw(ops.bilinear(feats[0], H, W)), ops.as_nchw(ops.bilinear(feats[1], H, W))
 
 

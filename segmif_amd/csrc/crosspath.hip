@@ -48,7 +48,8 @@ namespace {
 constexpr int WPB = 3 * 128 + 16;    // bytes per row, 64 columns
 constexpr int WPB2 = 3 * 256 + 16;   // 128 columns
 constexpr int CP_WAVES = 8;
-constexpr int GRAM_WGS = 64;  // workgroups per image (x 8 waves x 32-pixel tiles): independent of the batch, so results do not depend on it; 8 left a single image on 8 CUs
+constexpr int GRAM_WGS = 64;  // workgroups per image at least (x 8 waves x 32-pixel tiles): independent of the batch, so results do not depend on it; 8 left a single image on 8 CUs
+constexpr int GRAM_RUN_TILES = 32;  // a wave accumulates at most this many tiles (1024 pixels) in fp32 before the fp64 combine
 constexpr int PX6[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first: plane of the first operand ...
 constexpr int PY6[6] = {0, 1, 2, 0, 1, 0};  // ... and of the second
 
@@ -141,27 +142,27 @@ __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __rest
   __syncthreads();
   const float bias0 = bias ? bias[r] : 0.f, bias1 = bias ? bias[32 + r] : 0.f;
 
-  double g64[3][16];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) g64[a][v] = 0.0;
+  // The wave's Gram sums stay in the MFMA accumulators (fp32) over its whole run of tiles - at most GRAM_RUN_TILES of them
+  // (segmif_crosspath_gram_blocks sizes the grid for that): every term y_i y_j is non-negative (y = ReLU(.)), so a run's
+  // sum has no cancellation and carries ~sqrt(pixels) x 2^-24 of relative error; the runs are then combined in fp64
+  // (below, and across workgroups in the fold kernel).  Round 2 converted to fp64 after every 32-pixel tile: 96 of a
+  // lane's 256 registers and ~700 vector-ALU cycles per tile, which left no room for a second tile of loads in flight.
+  f32x16 g[3] = {zero16(), zero16(), zero16()};
 
   const long long ntiles = (N + 31) / 32;
   const long long stride = (long long)gridDim.x * CP_WAVES;
-  auto load = [&](long long tt, f32x4* dst) {  // x[px][8q + 4h .. +3]
-    const long long px = tt * 32 + r;
-    const bool ok = tt < ntiles && px < N;
+  auto load = [&](long long tt, f32x4* dst) {  // x[px][8q + 4h .. +3]; unconditional (clamped row): rows past N are masked below
+    long long px = tt * 32 + r;
+    px = px < N ? px : N - 1;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      dst[q] = ok ? *reinterpret_cast<const f32x4*>(xb + px * ldx + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 8; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xb + px * ldx + 8 * q + 4 * h);
   };
-  // one 32-pixel tile: `cur` holds its rows, the next tile's rows are requested into `nxt` before the arithmetic starts
-  // (two register sets used alternately: no copies on the loop edge)
-  auto tile = [&](long long t, const f32x4* cur, f32x4* nxt) {
+  // one 32-pixel tile: `cur` holds its rows; the tile TWO steps ahead is requested into `pre` before the arithmetic starts
+  // (three register sets in rotation: two tiles of loads in flight per wave)
+  auto tile = [&](long long t, const f32x4* cur, f32x4* pre, long long tpre) {
     int zo = 0;  // opaque zero in every LDS address below: the weight fragments are loop invariant, and hoisted out of
     asm volatile("" : "+v"(zo));  // the tile loop they would occupy 100+ registers for the whole kernel
-    load(t + stride, nxt);
+    if (tpre < ntiles) load(tpre, pre);
     // stage 1: Y[px][n] = relu(sum_k x[px][k] W[n][k] + c[n]); lane = column n, register v = pixel (v&3)+8(v>>2)+4h
     f32x16 y[2] = {zero16(), zero16()};
 #pragma unroll
@@ -188,7 +189,6 @@ __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __rest
       }
     }
     // stage 2: G[i][j] += sum_px Y[px][i] Y[px][j]: registers 8s .. 8s+7 of stage 1 are the 8 K-slots (pixels) of step s
-    f32x16 g[3] = {zero16(), zero16(), zero16()};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const Op3 y0 = split8(y[0], s), y1 = split8(y[1], s);
@@ -196,17 +196,15 @@ __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __rest
       g[1] = mma6(y0.p, y1.p, g[1]);
       g[2] = mma6(y1.p, y1.p, g[2]);
     }
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) g64[a][v] += (double)g[a][v];
   };
-  f32x4 xa[8], xb2[8];
+  f32x4 xa[8], xb2[8], xc[8];
   long long t = (long long)blockIdx.x * CP_WAVES + wave;
-  load(t, xa);
-  for (; t < ntiles; t += 2 * stride) {
-    tile(t, xa, xb2);
-    if (t + stride < ntiles) tile(t + stride, xb2, xa);
+  if (t < ntiles) load(t, xa);
+  if (t + stride < ntiles) load(t + stride, xb2);
+  for (; t < ntiles; t += 3 * stride) {
+    tile(t, xa, xc, t + 2 * stride);
+    if (t + stride < ntiles) tile(t + stride, xb2, xa, t + 3 * stride);
+    if (t + 2 * stride < ntiles) tile(t + 2 * stride, xc, xb2, t + 4 * stride);
   }
   // deterministic reduction over the 8 waves, then one partial per workgroup
   for (int wv = 0; wv < CP_WAVES; ++wv) {
@@ -216,7 +214,7 @@ __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __rest
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           double* p = Red + (a * 16 + v) * 64 + lane;
-          *p = wv == 0 ? g64[a][v] : *p + g64[a][v];
+          *p = wv == 0 ? (double)g[a][v] : *p + (double)g[a][v];
         }
     }
     __syncthreads();
@@ -462,7 +460,9 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
 extern "C" int segmif_crosspath_gram_blocks(int64_t N) {
   const long long ntiles = (N + 31) / 32;
   const long long want = (ntiles + CP_WAVES - 1) / CP_WAVES;
-  return (int)(want < GRAM_WGS ? (want < 1 ? 1 : want) : GRAM_WGS);
+  if (want < GRAM_WGS) return (int)(want < 1 ? 1 : want);
+  const long long bounded = (ntiles + (long long)CP_WAVES * GRAM_RUN_TILES - 1) / ((long long)CP_WAVES * GRAM_RUN_TILES);
+  return (int)(bounded > GRAM_WGS ? bounded : GRAM_WGS);
 }
 
 extern "C" int segmif_crosspath_gram_f32(const float* x, int ldx, const float* w, const float* bias, double* partial, int B,

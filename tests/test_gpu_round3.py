@@ -347,3 +347,22 @@ def test_conv3x3_c32to1_stencil_vs_fp64(B, H, W):
             got = ops.conv3x3_c32to1(xin, ops.pack_weight(w.cuda()), bias=b.cuda(), act=act, prelu=slope.cuda())
             assert tuple(got.shape) == (B, H, W, 1)
             assert rel(got.view(B, 1, H, W), ref) < 2e-6
+
+
+def test_forward_fusion_without_its_discarded_stages_is_bitwise_the_same(core):
+    """forward_fusion() hands out the stage-1 / stage-2 features; stages 3-4 are computed by the reference and dropped
+    (core/mix_transformer.py:358-375).  encoder.skip_unused_fusion_stages = True does not compute them: same outputs."""
+    net = build(core.Network3, "mit_b1", 9, pretrained=None)
+    enc = net.denoise_net.encoder
+    x = dw.det_input("dse_x", (2, 3, 72, 104)).cuda()
+    with torch.no_grad():
+        a0, a1 = enc.forward_fusion(x)
+        f0, f1 = enc.forward_fusion_features(x)
+        enc.skip_unused_fusion_stages = True
+        try:
+            b0, b1 = enc.forward_fusion(x)
+            g0, g1 = enc.forward_fusion_features(x)
+        finally:
+            enc.skip_unused_fusion_stages = False
+        assert len(enc(x)) == 4  # the public forward() is untouched
+    assert torch.equal(a0, b0) and torch.equal(a1, b1) and torch.equal(f0, g0) and torch.equal(f1, g1)
