@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the step into a hipGraph and replay it")
+    ap.add_argument("--no-extras", action="store_true", help="skip the second timed region (forward_fusion without its discarded stages)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (BASELINE configs [2] / [3])")
     ap.add_argument("--train-batch", type=int, default=8, help="samples per GPU per training step (config[2]: 8)")
     ap.add_argument("--train-steps", type=int, default=0, help="timed steps per training variant (0: min(--steps, 8))")
@@ -276,7 +277,7 @@ def main():
     # (the reference computes and drops them, core/mix_transformer.py:358-375) not computed - identical results
     enc = seg.denoise_net.encoder
     elapsed_dse = None
-    if not args.graph:
+    if not args.graph and not args.no_extras:
         enc.skip_unused_fusion_stages = True
         with torch.no_grad():
             step()
