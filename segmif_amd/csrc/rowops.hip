@@ -4,6 +4,7 @@
 // every kernel here is HBM (~6.3 TB/s achievable), so the rule is: one read, one write, float4.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "segmif_hip.h"
 
@@ -379,6 +380,86 @@ extern "C" int segmif_layernorm_f32(const float* x, const float* gamma, const fl
   return launch_ln<64, 4>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s);
 }
 
+// XT output columns per thread (x0 = XT xp ..) and a 3 x (XT + 2) register window: XT + 2 16-byte loads per row serve XT
+// outputs (the one-column kernel above spends three per output: every element came out of L2 3.75 times), strips of 16
+// rows (halo rows 1.125x instead of 1.25x).  Loads are unconditional from clamped addresses; out-of-image taps are zeroed
+// by select.  Round 3: 3.67 -> 4.4 TB/s of algorithmic traffic at XT = 2 over the encoder's shapes.
+constexpr int DW2_TY = 16;
+template <bool GELU, int XT>
+__global__ __launch_bounds__(256) void dwconv3x3_xt_kernel(const float* __restrict__ x, const float* __restrict__ w9,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int H, int W, int C) {
+  const int c4n = C >> 2;
+  const int wp = (W + XT - 1) / XT;
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (unsigned)(wp * c4n)) return;
+  const int xp = (int)(idx / (unsigned)c4n), c = (int)(idx - (unsigned)xp * c4n) * 4;
+  const int x0 = XT * xp;
+  const int y0 = blockIdx.y * DW2_TY;
+  const long long img = (long long)blockIdx.z * H * W;
+  f32x4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w9 + t * C + c);
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+  const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+  auto load_row = [&](int yy, f32x4* v) {  // columns x0 - 1 .. x0 + XT
+    const bool in = (unsigned)yy < (unsigned)H;
+    const float* row = x + (img + (long long)(in ? yy : 0) * W) * C + c;
+#pragma unroll
+    for (int k = 0; k < XT + 2; ++k) {
+      const int xx = x0 - 1 + k;
+      const bool ok = in && (unsigned)xx < (unsigned)W;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(row + (long long)min(max(xx, 0), W - 1) * C);
+      v[k] = ok ? t : zero;
+    }
+  };
+  f32x4 win[3][XT + 2];
+  load_row(y0 - 1, win[0]);
+  load_row(y0, win[1]);
+#pragma unroll 2
+  for (int dy = 0; dy < DW2_TY; ++dy) {
+    const int yo = y0 + dy;
+    if (yo >= H) break;
+    load_row(yo + 1, win[2]);
+    float* dst = y + (img + (long long)yo * W + x0) * C + c;
+#pragma unroll
+    for (int j = 0; j < XT; ++j) {
+      f32x4 a = bv;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) a += win[ky][kx + j] * wv[ky * 3 + kx];
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = GELU ? gelu_exact(a[e]) : a[e];
+      if (x0 + j < W) *reinterpret_cast<f32x4*>(dst + (long long)j * C) = o;
+    }
+#pragma unroll
+    for (int k = 0; k < XT + 2; ++k) {
+      win[0][k] = win[1][k];
+      win[1][k] = win[2][k];
+    }
+  }
+}
+
+template <bool GELU>
+static int launch_dwconv(const float* x, const float* w9, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
+  const char* e = getenv("SEGMIF_DWCONV_XT");  // diagnosis: 1 = the one-column kernel, 2 / 4 = columns per thread
+  const int xt = e ? atoi(e) : (W >= 16 ? 2 : 1);
+  if (xt >= 2) {
+    const int XT = xt >= 4 ? 4 : 2;
+    const long long per_row = (long long)((W + XT - 1) / XT) * (C >> 2);
+    dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)((H + DW2_TY - 1) / DW2_TY), (unsigned)B);
+    if (XT == 4) hipLaunchKernelGGL((dwconv3x3_xt_kernel<GELU, 4>), grid, dim3(256), 0, s, x, w9, bias, y, H, W, C);
+    else hipLaunchKernelGGL((dwconv3x3_xt_kernel<GELU, 2>), grid, dim3(256), 0, s, x, w9, bias, y, H, W, C);
+  } else {
+    const long long per_row = (long long)W * (C >> 2);
+    dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)((H + DW_TY - 1) / DW_TY), (unsigned)B);
+    hipLaunchKernelGGL(dwconv3x3_gelu_kernel<GELU>, grid, dim3(256), 0, s, x, w9, bias, y, H, W, C);
+  }
+  return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3x3 "same" convolution from 32 channels to ONE (conv22 of Fusion_Network3_ac, core/model_fusion.py:1065) + bias + act.
 // On the matrix pipe this layer pads its single output channel to a 32-wide tile (3.5 ms per 64-image step for 11 GFLOP);
@@ -458,10 +539,7 @@ extern "C" int segmif_dwconv3x3_gelu_f32(const float* x, const float* w9, const 
                                          int W, int C, void* stream) {
   if (!x || !w9 || !bias || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return SEGMIF_EINVAL;
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w9 | (uintptr_t)bias) & 15) return SEGMIF_EINVAL;
-  const long long per_row = (long long)W * (C >> 2);
-  dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)((H + DW_TY - 1) / DW_TY), (unsigned)B);
-  hipLaunchKernelGGL(dwconv3x3_gelu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, w9, bias, y, H, W, C);
-  return (int)hipGetLastError();
+  return launch_dwconv<true>(x, w9, bias, y, B, H, W, C, (hipStream_t)stream);
 }
 
 // DWConv.forward on its own (core/mix_transformer.py:381-387): depthwise 3x3 + bias, no activation
@@ -469,10 +547,7 @@ extern "C" int segmif_dwconv3x3_bias_f32(const float* x, const float* w9, const 
                                          int W, int C, void* stream) {
   if (!x || !w9 || !bias || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return SEGMIF_EINVAL;
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w9 | (uintptr_t)bias) & 15) return SEGMIF_EINVAL;
-  const long long per_row = (long long)W * (C >> 2);
-  dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)((H + DW_TY - 1) / DW_TY), (unsigned)B);
-  hipLaunchKernelGGL(dwconv3x3_gelu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, w9, bias, y, H, W, C);
-  return (int)hipGetLastError();
+  return launch_dwconv<false>(x, w9, bias, y, B, H, W, C, (hipStream_t)stream);
 }
 
 extern "C" int segmif_bilinear_nhwc_f32(const float* x, float* y, int B, int IH, int IW, int OH, int OW, int C,

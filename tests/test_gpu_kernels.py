@@ -460,7 +460,8 @@ def test_layernorm(ops, C):
     assert err(wide[:, :C], F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-5)) < TOL
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 9, 13, 128), (1, 30, 40, 1280), (1, 1, 1, 32), (2, 8, 12, 512), (1, 17, 5, 64)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 13, 128), (1, 30, 40, 1280), (1, 1, 1, 32), (2, 8, 12, 512), (1, 17, 5, 64),
+                                     (2, 35, 17, 64), (1, 19, 16, 256), (1, 40, 21, 32)])  # W >= 16: the two-column kernel, odd widths
 def test_dwconv_gelu(ops, B, H, W, C):
     x, w, b = rnd(B, H * W, C, seed=22, lo=-2, hi=2), rnd(C, 1, 3, 3, seed=23), rnd(C, seed=24)
     img = x.double().transpose(1, 2).reshape(B, C, H, W)
