@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include "device_once.h"
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "igemm_common.h"
 #include "segmif_hip.h"
@@ -67,6 +69,7 @@ struct GemmSplitK {
   long long M;
   int N, K, lda, ldo, ldr, act;
   int ntm, ntn;
+  int epi;  // 1: the output leaves through LDS (rows written 256 contiguous bytes at a time), 0: straight from the accumulators
 };
 
 __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
@@ -194,6 +197,45 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
   // vector-memory instructions of a row-per-register layout.  (tools/gemm_timeline.py: the epilogue is 20 000+ cycles of a
   // K = 320 tile's 95 000 - every workgroup of a round stores at the same time and the burst drains at HBM write rate.)
   const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
+  if (p.epi) {
+    // Through LDS: a lane owns an output ROW of the accumulators, so a direct store instruction touches 32 rows x 32 bytes;
+    // staged in a wave-private [32][68] tile (the K loop's buffers are free after its last barrier) the same data leaves as
+    // 4 rows x 256 contiguous bytes per instruction, and the residual is read the same way.
+    float* T = reinterpret_cast<float*>(smem_g) + wave * (32 * 68);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cl = j * 32 + 8 * g + 4 * h;
+          const int n = n0 + wn * 64 + cl;
+          f32x4 y = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if (p.bias && n < p.N) y += *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (p.act == SEGMIF_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+            else if (p.act == SEGMIF_ACT_PRELU) y[e] = y[e] >= 0.f ? y[e] : slope * y[e];
+            else if (p.act == SEGMIF_ACT_GELU) y[e] = gelu_exact(y[e]);
+          }
+          *reinterpret_cast<f32x4*>(T + r * 68 + cl) = y;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: the wave's own LDS writes have landed
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int row = t * 4 + (lane >> 4), cl = (lane & 15) * 4;
+        const long long m = m0 + wm * 64 + i * 32 + row;
+        const int n = n0 + wn * 64 + cl;
+        f32x4 y = *reinterpret_cast<const f32x4*>(T + row * 68 + cl);
+        if (m < p.M && n < p.N) {
+          if (p.res) y += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n);
+          *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = y;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites the tile
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const long long m = m0 + wm * 64 + i * 32 + r;
@@ -274,6 +316,10 @@ extern "C" int segmif_gemm_split_f32(const SegmifGemmSplit* d, void* stream) {
   GemmSplitK k;
   k.a = d->a; k.w = (const unsigned char*)d->w; k.bias = d->bias; k.res = d->res; k.prelu = d->prelu; k.out = d->out;
   k.M = d->M; k.N = d->N; k.K = d->K; k.lda = d->lda; k.ldo = d->ldo; k.ldr = d->ldr; k.act = d->act;
+  {
+    const char* e = getenv("SEGMIF_GEMM_EPI");  // "direct": stores straight from the accumulators (round 2)
+    k.epi = (e && !strcmp(e, "direct")) ? 0 : 1;
+  }
   k.ntm = (int)((d->M + GBM - 1) / GBM);
   k.ntn = (d->N + GBN - 1) / GBN;
   constexpr size_t smem = 2 * (size_t)GTILE;
