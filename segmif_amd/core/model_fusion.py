@@ -188,7 +188,7 @@ class _LinearCrossAttention(nn.Module):
         """Inference: (B, 64, 64) block-diagonal W with q @ ctx == q @ W^T, straight from the fp64 K^T V partial sums
         (segmif_linattn_fold_f32 against an identity end_proj)."""
         part = self._partial(lin, name, x)
-        eye = self._pk.get_multi("eye", (), lambda: torch.eye(self.dim, device=x.device, dtype=torch.float32))
+        eye = self._pk.get_multi(f"eye:{x.device}", (), lambda: torch.eye(self.dim, device=x.device, dtype=torch.float32))
         w = torch.empty((x.shape[0], self.dim, self.dim), device=x.device, dtype=torch.float32)
         return ops.linattn_fold(part, eye, w, wofs=0, kofs=0, scale=self.scale, heads=self.num_heads)
 

@@ -617,6 +617,202 @@ __global__ __launch_bounds__(256) void wgrad3x3_split_kernel(const Wg3K p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wgrad3x3_split_kernel with the staging taken off the multiplying waves: 8 waves = a STAGING team (global loads, 3-way
+// split, pixel-pair packing, LDS stores - and the bias sums) and an MFMA team (fragment reads + the 108 MFMAs of a tile),
+// two LDS tile buffers in ping-pong, ONE workgroup barrier per tile:
+//     staging:  store(0) | store(1) | store(2) | ...
+//     MFMA:              | mult(0)  | mult(1)  | ...
+// In the one-team kernel the split phase (0.4 ms of a 1.52 ms call) and the tail of the loads were serial to the MFMA phase
+// (0.83 ms).  Tiles are 4 x 32 pixels here (two 80 KB buffers fill the 160 KB of LDS): a wave of the MFMA team owns one tile
+// row, the halo is 8 x 36 pixels.  Everything else - pair-packed planes, dword windows for the three horizontal taps, strips,
+// partial slabs, reduce - is the one-team kernel's.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
+  constexpr int DIL = 2, TH = 4, TW = 32, HH = TH + 2 * DIL, HWD = TW + 2 * DIL;
+  constexpr int YPAIRS = TH * TW / 2;    // 64
+  constexpr int XROWP = HWD / 2;         // 18 pairs per halo row
+  constexpr int XPAIRS = HH * XROWP;     // 144
+  constexpr int YJ = YPAIRS * 8 / 256;   // 2 units per staging thread
+  constexpr int XJ = (XPAIRS * 8 + 255) / 256;  // 5
+  constexpr int BUF = 3 * YPAIRS * 32 + 3 * XPAIRS * 32;  // dwords per tile buffer (79 872 bytes)
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint32_t* bufs = reinterpret_cast<uint32_t*>(smem);
+  const int tid = threadIdx.x, team = tid >> 8, t256 = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
+  const int r = lane & 31, h = lane >> 5;
+  const int chunk = blockIdx.x % p.nchunks, strip = blockIdx.x / p.nchunks;
+  const int ntile = blockIdx.y;
+  const int c0 = chunk * 32, n0 = ntile * 32;
+  const int t_begin = strip * p.tiles_per_strip;
+  const int t_end = min(t_begin + p.tiles_per_strip, p.tiles_total);
+  const bool want_bias = p.bias_partial != nullptr && chunk == 0;
+  const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+  f32x4 bsum = zero4;
+
+  if (team == 1) {
+    // ---------------- staging team ----------------
+    f32x4 ry[2 * YJ], rx[2 * XJ];
+    unsigned okbits = 0;
+    auto gload = [&](int tile) {  // unconditional loads from clamped addresses (see the one-team kernel)
+      const int tx = tile % p.tiles_x;
+      const int ty = (tile / p.tiles_x) % p.tiles_y;
+      const int b = tile / (p.tiles_x * p.tiles_y);
+      const int x0 = tx * TW, y0 = ty * TH;
+      const long long img = (long long)b * p.H * p.W;
+      okbits = 0;
+#pragma unroll
+      for (int j = 0; j < YJ; ++j) {
+        const int u = t256 + 256 * j;
+        const int pair = u >> 3, q = (u & 7) * 4;
+        const int gy = y0 + (pair >> 4), gx = x0 + 2 * (pair & 15);
+        const int cy = min(gy, p.H - 1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int cx = min(gx + e, p.W - 1);
+          ry[2 * j + e] = *reinterpret_cast<const f32x4*>(p.dy + (img + (long long)cy * p.W + cx) * p.ldy + n0 + q);
+          okbits |= (unsigned)(gy < p.H && gx + e < p.W) << (2 * j + e);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) {
+        const int u = min(t256 + 256 * j, XPAIRS * 8 - 1);
+        const int pair = u >> 3, q = (u & 7) * 4;
+        const int hy = pair / XROWP, hx = 2 * (pair - hy * XROWP);
+        const int gy = y0 - DIL + hy, gx = x0 - DIL + hx;
+        const int cy = min(max(gy, 0), p.H - 1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int cx = min(max(gx + e, 0), p.W - 1);
+          rx[2 * j + e] = *reinterpret_cast<const f32x4*>(p.in + (img + (long long)cy * p.W + cx) * p.lda + c0 + q);
+          okbits |= (unsigned)((unsigned)gy < (unsigned)p.H && (unsigned)(gx + e) < (unsigned)p.W) << (16 + 2 * j + e);
+        }
+      }
+    };
+    auto put = [&](uint32_t* base, int npairs, int unit, const f32x4 v0, const f32x4 v1) {
+      u32x4 w0, w1, w2;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint32_t a, b, d;
+        wg_split3(v0[c], v1[c], a, b, d);
+        w0[c] = a; w1[c] = b; w2[c] = d;
+      }
+      uint32_t* dst = base + unit * 4;
+      *reinterpret_cast<u32x4*>(dst) = w0;
+      *reinterpret_cast<u32x4*>(dst + npairs * 32) = w1;
+      *reinterpret_cast<u32x4*>(dst + 2 * npairs * 32) = w2;
+    };
+    auto sstore = [&](uint32_t* Ys) {
+      uint32_t* Xs = Ys + 3 * YPAIRS * 32;
+#pragma unroll
+      for (int j = 0; j < YJ; ++j) {
+        const f32x4 v0 = (okbits >> (2 * j)) & 1 ? ry[2 * j] : zero4, v1 = (okbits >> (2 * j + 1)) & 1 ? ry[2 * j + 1] : zero4;
+        put(Ys, YPAIRS, t256 + 256 * j, v0, v1);
+        if (want_bias) bsum += v0 + v1;
+      }
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) {
+        const int u = t256 + 256 * j;
+        const f32x4 v0 = (okbits >> (16 + 2 * j)) & 1 ? rx[2 * j] : zero4, v1 = (okbits >> (17 + 2 * j)) & 1 ? rx[2 * j + 1] : zero4;
+        if (u < XPAIRS * 8) put(Xs, XPAIRS, u, v0, v1);
+      }
+    };
+    if (t_begin < t_end) gload(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      sstore(bufs + ((tile - t_begin) & 1) * BUF);
+      if (tile + 1 < t_end) gload(tile + 1);
+      __syncthreads();  // tile's buffer is complete; the MFMA team has left the other buffer
+    }
+  } else {
+    // ---------------- MFMA team: wave w owns tile row w ----------------
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      __syncthreads();
+      const uint32_t* Ys = bufs + ((tile - t_begin) & 1) * BUF;
+      const uint32_t* Xs = Ys + 3 * YPAIRS * 32;
+      auto read_a = [&](int it, u32x4* a) {  // it = 3 ks + ky
+        const int ks = it / 3;
+        const uint32_t* ya = Ys + (wave * 16 + 8 * ks + 4 * h) * 32 + r;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[pl][i] = ya[(pl * YPAIRS + i) * 32];
+      };
+      auto read_b = [&](int it, uint32_t (*b6)[6]) {
+        const int ks = it / 3, ky = it % 3;
+        const uint32_t* xa = Xs + ((wave + ky * DIL) * XROWP + 8 * ks + 4 * h) * 32 + r;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int i = 0; i < 6; ++i) b6[pl][i] = xa[(pl * XPAIRS + i) * 32];
+      };
+      u32x4 a[2][3];
+      uint32_t b6[2][3][6];
+      read_a(0, a[0]);
+      read_b(0, b6[0]);
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int cb = it & 1, ca = (it / 3) & 1, ky = it % 3;
+        if (it + 1 < 6) {
+          if ((it + 1) % 3 == 0) read_a(it + 1, a[((it + 1) / 3) & 1]);
+          read_b(it + 1, b6[cb ^ 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int pl = PB[t];
+            const u32x4 bw = u32x4{b6[cb][pl][kx], b6[cb][pl][kx + 1], b6[cb][pl][kx + 2], b6[cb][pl][kx + 3]};
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ca][PA[t]]),
+                                                                       __builtin_bit_cast(bf16x8, bw), acc[ky * 3 + kx], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // combine the MFMA team's four waves tap by tap through LDS (all 512 threads take the barriers and share the summation)
+  float* red = smem;  // [4][32][33]
+  float* out = p.partial + (long long)strip * p.N * p.Kp;
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+    if (team == 0) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int n = (v & 3) + 8 * (v >> 2) + 4 * h;
+        red[(wave * 32 + n) * 33 + r] = acc[t][v];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 512) {
+      const int n = i >> 5, c = i & 31;
+      const float s4 = (red[(0 * 32 + n) * 33 + c] + red[(1 * 32 + n) * 33 + c]) +
+                       (red[(2 * 32 + n) * 33 + c] + red[(3 * 32 + n) * 33 + c]);
+      if (n0 + n < p.N) out[(long long)(n0 + n) * p.Kp + t * p.Cin + c0 + c] = s4;
+    }
+  }
+  if (want_bias) {
+    __syncthreads();
+    f32x4* rb = reinterpret_cast<f32x4*>(smem);
+    if (team == 1) rb[t256] = bsum;
+    __syncthreads();
+    if (tid < 8) {
+      f32x4 sacc = rb[tid];
+      for (int i = 1; i < 32; ++i) sacc += rb[tid + 8 * i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n0 + tid * 4 + e < p.N) p.bias_partial[(long long)strip * p.N + n0 + tid * 4 + e] = sacc[e];
+    }
+  }
+}
+
 // sum over chunks (fp64) and scatter from the packed [N][Kp] (tap-major, channel-minor) order into the
 // parameter's own layout: OIHW for convs; element (n, k) -> dw[n*sn + k*sk] for dense problems.
 // accumulate != 0: grad += value.
@@ -887,7 +1083,27 @@ static int wgrad_impl(const SegmifIgemm* d, const float* dy, int ldy, int64_t dy
       const bool fp32_only = mode_env && !strcmp(mode_env, "fp32");
       const char* dbg_env = getenv("SEGMIF_WG3_DBG");
       w.dbg = dbg_env ? atoi(dbg_env) : 0;
-      if (d->dil == 2 && !fp32_only && k.yvec && d->N % 32 == 0) {
+      const bool one_team = mode_env && !strcmp(mode_env, "split1");  // the one-team bf16x6 kernel (8 x 32 tiles)
+      if (d->dil == 2 && !fp32_only && !one_team && k.yvec && d->N % 32 == 0) {
+        // two teams, 4 x 32 pixel tiles: re-derive the tile grid and the strips for that tile height
+        w.tiles_y = (d->H + 3) / 4;
+        w.tiles_total = w.B * w.tiles_x * w.tiles_y;
+        long long strips2 = strips;
+        if (strips2 > w.tiles_total) strips2 = w.tiles_total;
+        w.tiles_per_strip = (int)((w.tiles_total + strips2 - 1) / strips2);
+        strips = (w.tiles_total + w.tiles_per_strip - 1) / w.tiles_per_strip;  // never more than the workspace was sized for
+        w.bias_partial = dbias ? workspace + strips * d->N * k.Kp : nullptr;
+        grid = dim3((unsigned)(strips * w.nchunks), (unsigned)ntiles_n);
+        constexpr size_t smem2 = (size_t)2 * (3 * 64 * 32 + 3 * 144 * 32) * sizeof(uint32_t);
+        static segmif::PerDeviceFlag raised_flag4;
+        bool& raised4 = raised_flag4.here();
+        if (!raised4) {
+          hipError_t e4 = hipFuncSetAttribute((const void*)wgrad3x3_split2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+          if (e4 != hipSuccess) return (int)e4;
+          raised4 = true;
+        }
+        hipLaunchKernelGGL(wgrad3x3_split2_kernel, grid, dim3(512), smem2, s, w);
+      } else if (d->dil == 2 && !fp32_only && k.yvec && d->N % 32 == 0) {
         constexpr size_t smem_split = (size_t)(3 * 128 * 32 + 3 * 216 * 32) * sizeof(uint32_t);
         static segmif::PerDeviceFlag raised_flag3;
         bool& raised3 = raised_flag3.here();

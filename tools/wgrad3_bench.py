@@ -28,8 +28,9 @@ for cin in (64, 128, 192):
         return (time.perf_counter() - t0) / 5
 
     base = {}
-    for name, env in (("fp32", {"SEGMIF_WGRAD3X3": "fp32"}), ("bf16x6", {}), ("no-mfma", {"SEGMIF_WG3_DBG": "1"}),
-                      ("no-split", {"SEGMIF_WG3_DBG": "2"}), ("no-loads", {"SEGMIF_WG3_DBG": "4"}),
-                      ("mfma-only", {"SEGMIF_WG3_DBG": "6"}), ("loads-only", {"SEGMIF_WG3_DBG": "3"})):
+    one = {"SEGMIF_WGRAD3X3": "split1"}
+    for name, env in (("fp32", {"SEGMIF_WGRAD3X3": "fp32"}), ("two-team", {}), ("one-team", one), ("no-mfma", {**one, "SEGMIF_WG3_DBG": "1"}),
+                      ("no-split", {**one, "SEGMIF_WG3_DBG": "2"}), ("no-loads", {**one, "SEGMIF_WG3_DBG": "4"}),
+                      ("mfma-only", {**one, "SEGMIF_WG3_DBG": "6"}), ("loads-only", {**one, "SEGMIF_WG3_DBG": "3"})):
         dt = run(env)
         print(f"Cin {cin:4d} {name:10s} {dt * 1e3:8.3f} ms  {flops / dt / 1e12:7.1f} TF/s", flush=True)
