@@ -628,8 +628,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_split_kernel(const Wg3K p) {
 // row, the halo is 8 x 36 pixels.  Everything else - pair-packed planes, dword windows for the three horizontal taps, strips,
 // partial slabs, reduce - is the one-team kernel's.
 // ---------------------------------------------------------------------------------------------------
+template <int DIL>  // 2: DRDB convs (tap shift = one dword); 1: conv2 / conv21 (tap shift = half a dword: the middle tap is a funnel shift)
 __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
-  constexpr int DIL = 2, TH = 4, TW = 32, HH = TH + 2 * DIL, HWD = TW + 2 * DIL;
+  constexpr int TH = 4, TW = 32, HH = TH + 2 * DIL, HWD = TW + 2 * DIL;
+  constexpr int NB = DIL == 2 ? 6 : 5;   // dwords of a halo row a lane reads per (k-step, vertical tap)
   constexpr int YPAIRS = TH * TW / 2;    // 64
   constexpr int XROWP = HWD / 2;         // 18 pairs per halo row
   constexpr int XPAIRS = HH * XROWP;     // 144
@@ -744,16 +746,16 @@ __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) a[pl][i] = ya[(pl * YPAIRS + i) * 32];
       };
-      auto read_b = [&](int it, uint32_t (*b6)[6]) {
+      auto read_b = [&](int it, uint32_t (*b6)[NB]) {
         const int ks = it / 3, ky = it % 3;
         const uint32_t* xa = Xs + ((wave + ky * DIL) * XROWP + 8 * ks + 4 * h) * 32 + r;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-          for (int i = 0; i < 6; ++i) b6[pl][i] = xa[(pl * XPAIRS + i) * 32];
+          for (int i = 0; i < NB; ++i) b6[pl][i] = xa[(pl * XPAIRS + i) * 32];
       };
       u32x4 a[2][3];
-      uint32_t b6[2][3][6];
+      uint32_t b6[2][3][NB];
       read_a(0, a[0]);
       read_b(0, b6[0]);
 #pragma unroll
@@ -769,7 +771,15 @@ __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             const int pl = PB[t];
-            const u32x4 bw = u32x4{b6[cb][pl][kx], b6[cb][pl][kx + 1], b6[cb][pl][kx + 2], b6[cb][pl][kx + 3]};
+            u32x4 bw;
+            if (DIL == 2) {  // halo pixels 2 kx + 0..7: dwords kx .. kx + 3
+              bw = u32x4{b6[cb][pl][kx], b6[cb][pl][kx + 1], b6[cb][pl][kx + 2], b6[cb][pl][kx + 3]};
+            } else if (kx != 1) {  // halo pixels kx + 0..7, kx even: dwords kx / 2 .. + 3
+              bw = u32x4{b6[cb][pl][kx / 2], b6[cb][pl][kx / 2 + 1], b6[cb][pl][kx / 2 + 2], b6[cb][pl][kx / 2 + 3]};
+            } else {  // halo pixels 1..8: (pixel 2i + 1, pixel 2i + 2) = high half of dword i, low half of dword i + 1
+#pragma unroll
+              for (int i = 0; i < 4; ++i) bw[i] = __builtin_amdgcn_alignbit(b6[cb][pl][i + 1], b6[cb][pl][i], 16);
+            }
             acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ca][PA[t]]),
                                                                        __builtin_bit_cast(bf16x8, bw), acc[ky * 3 + kx], 0, 0, 0);
           }
@@ -1083,8 +1093,8 @@ static int wgrad_impl(const SegmifIgemm* d, const float* dy, int ldy, int64_t dy
       const bool fp32_only = mode_env && !strcmp(mode_env, "fp32");
       const char* dbg_env = getenv("SEGMIF_WG3_DBG");
       w.dbg = dbg_env ? atoi(dbg_env) : 0;
-      const bool one_team = mode_env && !strcmp(mode_env, "split1");  // the one-team bf16x6 kernel (8 x 32 tiles)
-      if (d->dil == 2 && !fp32_only && !one_team && k.yvec && d->N % 32 == 0) {
+      const bool one_team = mode_env && !strcmp(mode_env, "split1");  // the one-team bf16x6 kernel (8 x 32 tiles, dilation 2)
+      if (!fp32_only && !(one_team && d->dil == 2) && k.yvec && d->N % 32 == 0) {
         // two teams, 4 x 32 pixel tiles: re-derive the tile grid and the strips for that tile height
         w.tiles_y = (d->H + 3) / 4;
         w.tiles_total = w.B * w.tiles_x * w.tiles_y;
@@ -1094,15 +1104,17 @@ static int wgrad_impl(const SegmifIgemm* d, const float* dy, int ldy, int64_t dy
         strips = (w.tiles_total + w.tiles_per_strip - 1) / w.tiles_per_strip;  // never more than the workspace was sized for
         w.bias_partial = dbias ? workspace + strips * d->N * k.Kp : nullptr;
         grid = dim3((unsigned)(strips * w.nchunks), (unsigned)ntiles_n);
-        constexpr size_t smem2 = (size_t)2 * (3 * 64 * 32 + 3 * 144 * 32) * sizeof(uint32_t);
-        static segmif::PerDeviceFlag raised_flag4;
-        bool& raised4 = raised_flag4.here();
+        const int xpairs = (4 + 2 * d->dil) * (32 + 2 * d->dil) / 2;
+        const size_t smem2 = (size_t)2 * (3 * 64 * 32 + 3 * xpairs * 32) * sizeof(uint32_t);
+        auto fn2 = d->dil == 2 ? wgrad3x3_split2_kernel<2> : wgrad3x3_split2_kernel<1>;
+        static segmif::PerDeviceFlag raised_flag4[2];
+        bool& raised4 = raised_flag4[d->dil == 2].here();
         if (!raised4) {
-          hipError_t e4 = hipFuncSetAttribute((const void*)wgrad3x3_split2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+          hipError_t e4 = hipFuncSetAttribute((const void*)fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
           if (e4 != hipSuccess) return (int)e4;
           raised4 = true;
         }
-        hipLaunchKernelGGL(wgrad3x3_split2_kernel, grid, dim3(512), smem2, s, w);
+        hipLaunchKernelGGL(fn2, grid, dim3(512), smem2, s, w);
       } else if (d->dil == 2 && !fp32_only && k.yvec && d->N % 32 == 0) {
         constexpr size_t smem_split = (size_t)(3 * 128 * 32 + 3 * 216 * 32) * sizeof(uint32_t);
         static segmif::PerDeviceFlag raised_flag3;

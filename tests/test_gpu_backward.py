@@ -71,6 +71,7 @@ CONV_CASES = [
     (2, 10, 12, 1, 64, 3, 1, 1, 1, 2),  # conv1
     (1, 19, 45, 96, 64, 3, 1, 2, 2, 0),  # dilated, odd width, two 32-channel output tiles, three input chunks (bf16x6 wgrad)
     (3, 40, 70, 160, 32, 3, 1, 2, 2, 1),  # DRDB Dcov4 geometry: several 8x32 tiles per strip, partial tiles on both edges
+    (2, 23, 37, 64, 32, 3, 1, 1, 1, 2),  # conv21 geometry, ragged: bf16x6 weight gradient at dilation 1 (funnel-shifted middle tap)
 ]
 
 
