@@ -569,6 +569,50 @@ class BatchedLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class BatchedLinear2Fn(torch.autograd.Function):
+    """y[b] = res[b] + [xa[b] | xb[b]] @ w[b]^T + bias: CrossPath's `x + end_proj(cat(z, v))` (core/model_fusion.py:357-360
+    with the contexts folded into a per-image weight) as ONE node - two-source GEMM with the residual in its epilogue, so
+    neither the 128-wide concatenation nor the separate add exists (they were 4 + 4 full-resolution aten passes per fusion
+    training step).  xa, xb: (B, n, Ka / Kb) rows views (channel slices of wider tensors are fine)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, w, bias, res):
+        N = w.shape[1]
+        ctx.save_for_backward(xa, xb, w)
+        ctx.has_bias = bias is not None
+        return ops.linear(xa, w.contiguous(), N, bias=bias, res=res, x2=xb, batched_weight=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, xb, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, n, Ka = xa.shape
+        Kb = xb.shape[2]
+        K, N = Ka + Kb, w.shape[1]
+        dxa = dxb = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dx = ops.linear(dy, w.transpose(1, 2).contiguous(), K, batched_weight=True)
+            dxa, dxb = dx[..., :Ka], dx[..., Ka:]
+        want_b = ctx.has_bias and ctx.needs_input_grad[3]
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty((B, N, K), device=dy.device, dtype=torch.float32)
+            db = _bias_out(want_b, N, dy)
+            for src, k0, kk, bias_out in ((xa, 0, Ka, db), (xb, Ka, Kb, None)):
+                d = _lib.SegmifIgemm()
+                d.in_ = src.data_ptr()
+                d.M, d.N, d.K, d.lda = n, N, kk, src.stride(1)
+                d.H = d.W = d.OH = d.OW = 1
+                d.Cin = kk
+                d.KH = d.KW = d.stride = d.dil = 1
+                d.nz = B
+                d.in_zstride = src.stride(0)
+                d.out_zstride = N * K
+                _wgrad(d, dy, N, dw[:, :, k0:], dy_zstride=n * N, sn=K, sk=1, nz=B, db=bias_out)
+        elif want_b:
+            db = colsum(dy)
+        return dxa, dxb, dw, db, (dy if ctx.needs_input_grad[4] else None)
+
+
 class KvContextFn(torch.autograd.Function):
     """ctx_raw[b][h] = K^T V per head with [K | V] = y @ wkv^T (no bias): the N-reduction of the linear
     cross attention (core/model_fusion.py:281, 316-318).  Forward = fused projection + reduction kernel
@@ -835,6 +879,10 @@ def drdb(x, params):
 
 def batched_linear(x, w, bias=None):
     return BatchedLinearFn.apply(x, w, bias)
+
+
+def batched_linear2(xa, xb, w, bias=None, res=None):
+    return BatchedLinear2Fn.apply(xa, xb, w, bias, res)
 
 
 def kv_context(y, wkv):

@@ -369,8 +369,8 @@ class CrossPath(nn.Module):
             # Weff[b][n][h*d+i] = sum_j ctx[b][h][i][j] * Wend[n][ofs + h*d + j]
             weff = torch.cat((torch.einsum("bhij,nhj->bnhi", ctx_i, wz).reshape(B, C, C),
                               torch.einsum("bhij,nhj->bnhi", ctx3, wv).reshape(B, C, C)), dim=-1).float()
-            a = torch.cat((y[2], ui), dim=-1)
-            t = x + ag.batched_linear(a, weff, end.bias)
+            # x + [y3 | u_i] @ Weff^T + b as one node (two-source GEMM, residual in the epilogue: no cat, no separate add)
+            t = ag.batched_linear2(y[2], ui, weff, end.bias, x)
             norm = getattr(self, f"norm{i}")
             outs.append(ag.layernorm(t, norm.weight, norm.bias, norm.eps))
         return outs[0], outs[1]
