@@ -225,7 +225,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist.init()  # RCCL process group when WORLD_SIZE > 1; replicas only, no data-path collective
     torch.manual_seed(1234 + rank)  # per-rank RNG stream (nothing on the eval path draws from it; train-mode masks would)
 

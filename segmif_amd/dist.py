@@ -20,9 +20,14 @@ def init(backend=None):
     if world > 1 and not torch.distributed.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # SEGMIF_DIST_BACKEND=gloo: run the multi-process path on a box with fewer GPUs than ranks (ranks share devices,
+        # collectives go through gloo) - a functional rehearsal of the N > 1 control flow with the real kernels, not a
+        # measurement.  RCCL refuses two ranks on one GPU, so the production backend cannot be rehearsed that way.
+        backend = backend or os.environ.get("SEGMIF_DIST_BACKEND") or None
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         use_gpu = torch.cuda.is_available() and backend != "gloo"
         if use_gpu:
-            torch.cuda.set_device(local_rank)
             # RCCL must come up on every rank or on none: a per-rank fallback to another backend would leave the
             # ranks in different process groups and deadlock the first collective, so a failure here is fatal.
             torch.distributed.init_process_group(backend or "nccl", device_id=torch.device("cuda", local_rank))
