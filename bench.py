@@ -334,8 +334,8 @@ def main():
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_src = None, None
             mode = ops.conv3x3_mode()
-            peak = PEAK_FP32_MFMA_TFLOPS if mode == "fp32" else PEAK_BF16X6_TFLOPS
-            pmc_name = {"planes": f"r03_pmc_dominant_b{B}_planes.json" if os.path.exists(os.path.join(ROOT, "profiles", f"r03_pmc_dominant_b{B}_planes.json")) else f"r02_pmc_dominant_b{B}_planes.json", "bf16x6": f"r01_pmc_dominant_b{B}_bf16x6.json",
+            peak = PEAK_FP32_MFMA_TFLOPS if mode == "fp32" else (PEAK_BF16X6_TFLOPS * 2.0 if mode == "planes16" else PEAK_BF16X6_TFLOPS)
+            pmc_name = {"planes16": f"r03_pmc_dominant_b{B}_planes16.json", "planes": f"r03_pmc_dominant_b{B}_planes.json" if os.path.exists(os.path.join(ROOT, "profiles", f"r03_pmc_dominant_b{B}_planes.json")) else f"r02_pmc_dominant_b{B}_planes.json", "bf16x6": f"r01_pmc_dominant_b{B}_bf16x6.json",
                         "fp32": "r01_pmc_dominant.json" if B == 8 else f"r01_pmc_dominant_b{B}.json"}[mode]
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and (H, W) == (480, 640):
@@ -344,15 +344,18 @@ def main():
                 traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(pmc)
             kernel = {"planes": "conv3x3_planes_kernel<2,false> (DRDB dilated 3x3 convs 1-4 on pre-split activations, bf16 MFMA x 6 "
                                 "split products, fp32-class; the fifth conv carries the DRDB's 1x1 tail and is a separate kernel)",
+                      "planes16": "conv3x3_planes_kernel<2,false,f16x3> (DRDB dilated 3x3 convs 1-4 on half-pair activations, f16 MFMA x 3 "
+                                  "split products, fp32-class inside the half's exponent range, guarded)",
                       "bf16x6": "conv3x3_split_kernel<32,2,8> (DRDB dilated 3x3 conv, bf16 MFMA x 6 split products, fp32-class)",
                       "fp32": "conv3x3_halo_kernel<32,8,2> (DRDB dilated 3x3 conv, fp32 MFMA)"}[mode]
             # algorithmic bytes per pixel of an average timed launch: planes mode reads Cin x 6 B (three bf16 planes) and
             # writes 32 x 6 B, Cin averaging 112 over Dcov1-4; the fp32 layouts read Cin x 4 B (average 128) + write 128 B
-            alg_bytes = (112 * 6 + 32 * 6 if mode == "planes" else 128 * 4 + 32 * 4) * float(B) * H * W
+            alg_bytes = (112 * 6 + 32 * 6 if mode == "planes" else 112 * 4 + 32 * 4 if mode == "planes16" else 128 * 4 + 32 * 4) * float(B) * H * W
             out["roofline"] = {
                 "kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "peak_basis": ("dense fp32 MFMA" if mode == "fp32" else "dense BF16 MFMA 2500 TFLOP/s / 6 products per "
-                               "fp32-equivalent MAC; achieved counts algorithmic fp32 flops"),
+                "peak_basis": ("dense fp32 MFMA" if mode == "fp32" else "dense F16 MFMA 2500 TFLOP/s / 3 products per fp32-equivalent "
+                               "MAC; achieved counts algorithmic fp32 flops" if mode == "planes16" else "dense BF16 MFMA 2500 "
+                               "TFLOP/s / 6 products per fp32-equivalent MAC; achieved counts algorithmic fp32 flops"),
                 "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                 "launches_timed": n, "avg_launch_ms": ms, "avg_launch_gflop": flops / 1e9,

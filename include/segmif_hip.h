@@ -94,9 +94,13 @@ typedef struct SegmifIgemm {
   /* optional second copy of the output as "planes" chunks (see segmif_planes_* below): conv output (B, OH, OW, N) with
    * N % 16 == 0 written as chunks [planes_chunk0, planes_chunk0 + N/16) of a planes buffer of planes_chunks chunk
    * images per batch element, geometry of segmif_planes_dims(OH, OW).  Needs the 16-byte epilogue (N, ldo multiples of 4,
-   * aligned out) and nz <= 1; conv1 of Fusion_Network3_ac hands its result to the first DRDB this way. */
+   * aligned out), nz <= 1 and a convolution (not a plain 1x1 / Linear problem); conv1 of Fusion_Network3_ac hands its
+   * result to the first DRDB this way.
+   * planes_f16 != 0: the buffer is an f16x3 one (segmif_planes16_*), max |output| is folded into *planes_amax. */
   void* planes_out;
   int32_t planes_chunks, planes_chunk0;
+  int32_t planes_f16;
+  uint32_t* planes_amax;   /* or NULL */
 } SegmifIgemm;
 
 int segmif_igemm_f32(const SegmifIgemm* desc, void* stream);
@@ -191,6 +195,27 @@ int segmif_planes_from_f32(const float* x, int ldx, void* planes, int B, int H, 
 int64_t segmif_planes_weight_bytes(int N, int Cin, int taps);
 int segmif_planes_pack_weight(const float* packed, int N, int Cin, int taps, int ldw, void* out, void* stream);
 int segmif_conv3x3_planes_bf16x6(const SegmifConvPlanes* desc, void* stream);
+
+/*
+ * "f16x3" planes: the same buffers, kernels and descriptor with HALF-precision pairs instead of bf16 triples -
+ * [b][chunk][Hp][Wp][plane 0..1][16] halves, x = p0 + 2^-11 p1 (p0 = RN16(x), p1 = RN16(2^11 (x - p0)): 23 significand
+ * bits + rounding, one bit short of fp32) - and weight rows scaled by a power of two into the half's range and stored as
+ * W0 | W - W0 | 2^-11 W0 followed by the N row factors (segmif_planes16_weight_bytes = the bf16 image + 4 N bytes).
+ * THREE MFMA products per fp32-equivalent MAC instead of six and 2/3 of the activation bytes, at the error level of
+ * the bf16x6 kernels (tests/test_gpu_kernels.py) - provided the activations lie in the half's exponent range: every
+ * producer (segmif_planes16_from_f32, the conv's own planes / fused-tail output) folds max |x| of what it wrote into
+ * *amax (atomic max on the IEEE bit pattern of a non-negative float; NULL = off).  The caller must read it back and
+ * re-run on the bf16x6 entry points when a value left [2^-13, 65504) (0 = an all-zero tensor is fine): above, a half
+ * overflows; below, the pair keeps fewer than 23 bits.  core/model_fusion.py does this per forward (ops.Planes16Guard).
+ * Same geometry (segmif_planes_dims), channel order and argument rules as the bf16 entry points above.
+ */
+int64_t segmif_planes16_bytes(int B, int H, int W, int chunks);
+int segmif_planes16_zero_border(void* planes, int B, int H, int W, int chunks, void* stream);
+int segmif_planes16_from_f32(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0, int nconv,
+                             uint32_t* amax, void* stream);
+int64_t segmif_planes16_weight_bytes(int N, int Cin, int taps);
+int segmif_planes16_pack_weight(const float* packed, int N, int Cin, int taps, int ldw, void* out, void* stream);
+int segmif_conv3x3_planes_f16x3(const SegmifConvPlanes* desc, uint32_t* amax, void* stream);
 
 /*
  * Weight gradient of the same problem: dW[n][k] = sum_m dY[m][n] * A(m,k), contraction over rows on
@@ -331,6 +356,8 @@ typedef struct SegmifCrossTail {
   float* out; int32_t ld3, ldi, ldo;
   int32_t B; int64_t N;
   void* planes_out; int32_t H, W, planes_chunks;   /* optional planes copy of out (NULL = off) */
+  int32_t planes_f16;                               /* != 0: an f16x3 buffer (segmif_planes16_*) */
+  uint32_t* planes_amax;                            /* f16x3: guard slot for max |out|, or NULL */
 } SegmifCrossTail;
 
 int segmif_crosspath_gram_blocks(int64_t N);

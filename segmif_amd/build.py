@@ -26,7 +26,7 @@ def _hipcc():
 
 def _digest():
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for f in SOURCES + ["igemm_common.h", "device_once.h", os.path.join(ROOT, "include", "segmif_hip.h")]:
+    for f in SOURCES + ["igemm_common.h", "device_once.h", "planes16.h", os.path.join(ROOT, "include", "segmif_hip.h")]:
         p = f if os.path.isabs(f) else os.path.join(CSRC, f)
         with open(p, "rb") as fh:
             h.update(fh.read())

@@ -125,14 +125,15 @@ class DRDB(nn.Module):
         if not preloaded:  # (a producer may already have written x as chunks 0..3, e.g. the CrossPath tail)
             planes.load_f32(x, 0)
         ch = self.in_ch
+        sfx, pack = ("h", ops.pack_weight_planes16) if planes.f16 else ("", ops.pack_weight_planes)
         for i in range(1, 6):
             conv = getattr(self, f"Dcov{i}")
-            wt = self._pk.get(f"p{i}", conv.weight, ops.pack_weight_planes)
+            wt = self._pk.get(f"p{i}{sfx}", conv.weight, pack)
             if i < 5:
                 ops.conv3x3_planes(planes, ch, wt, dil=2, bias=conv.bias, act=ops.ACT_RELU, out_chunk0=ch // 16,
                                    tag="drdb_dcov")
             else:
-                w1 = self._pk.get("p1x1", self.conv.weight, ops.pack_weight_planes)
+                w1 = self._pk.get(f"p1x1{sfx}", self.conv.weight, pack)
                 ops.conv3x3_planes(planes, ch, wt, dil=2, bias=conv.bias, act=ops.ACT_RELU,
                                    tail=(w1, self.conv.bias, x, out, ops.ACT_RELU), tag="drdb_tail")
             ch += self.growth
@@ -141,7 +142,7 @@ class DRDB(nn.Module):
     def planes_ok(self):
         """The planes kernels take 16-byte bias loads: parameters living at odd offsets of a flattened buffer fall back to
         the fp32-buffer DRDB (forward_buffer) instead of failing."""
-        return ops.conv3x3_mode() == "planes" and self.in_ch == 64 and self.growth == 32 \
+        return ops.conv3x3_mode() in ("planes", "planes16") and self.in_ch == 64 and self.growth == 32 \
             and ops.aligned16(self.conv.bias, *(getattr(self, f"Dcov{i}").bias for i in range(1, 6)))
 
     def _params(self):
@@ -160,7 +161,13 @@ class DRDB(nn.Module):
             return self.forward_train_nhwc(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
         B, _, H, W = x.shape
         if self.planes_ok():
-            return ops.as_nchw(self.forward_planes(ops.to_nhwc(x), ops.Planes(B, H, W, self.PLANES_CHUNKS, x.device)))
+            xh = ops.to_nhwc(x)
+            if ops.conv3x3_mode() == "planes16":  # f16x3, re-run on bf16 triples if a tensor left the half's range
+                guard = ops.Planes16Guard(x.device)
+                y = self.forward_planes(xh, ops.Planes(B, H, W, self.PLANES_CHUNKS, x.device, guard))
+                if guard.ok():
+                    return ops.as_nchw(y)
+            return ops.as_nchw(self.forward_planes(xh, ops.Planes(B, H, W, self.PLANES_CHUNKS, x.device)))
         buf = self.new_buffer(B, H, W, x.device)
         buf[..., :self.in_ch].copy_(x.permute(0, 2, 3, 1))
         return ops.as_nchw(self.forward_buffer(buf))
@@ -536,15 +543,18 @@ class Fusion_Network3_ac(nn.Module):
         return f.view(B, 1, H, W)
 
 
-    def _forward_eval_planes(self, ir, vis, seg1_fn, seg2_fn):
+    def _forward_eval_planes(self, ir, vis, seg1_fn, seg2_fn, _force_bf16=False):
         """_forward_eval with the four DRDBs on pre-split activations: two planes scratch buffers (one per
         modality, reused by DRDB1 -> DRDB3 and DRDB2 -> DRDB4), 64-channel fp32 tensors between the blocks."""
         B, _, H, W = ir.shape
         dev, slope = ir.device, self.relu.weight
         PRELU = ops.ACT_PRELU
+        # 'planes16': the DRDBs on half pairs (f16x3); the forward is repeated on the bf16x6 kernels if the guard saw a planes
+        # tensor outside the half's exponent range.
+        guard = ops.Planes16Guard(dev) if ops.conv3x3_mode() == "planes16" and not _force_bf16 else None
         xs, pls = [], []
         for x, conv, name in ((ir, self.conv1_ir, "conv1_ir"), (vis, self.conv1_vis, "conv1_vis")):
-            pls.append(ops.Planes(B, H, W, DRDB.PLANES_CHUNKS, dev))
+            pls.append(ops.Planes(B, H, W, DRDB.PLANES_CHUNKS, dev, guard))
             # conv1 writes its 64 channels as fp32 (the DRDB's residual input) and, split, as the DRDB's first four chunks
             xs.append(ops.conv2d(self._first_channel_nhwc(x), self._w(name), 64, 3, pad=1, bias=conv.bias, act=PRELU,
                                  prelu=slope, planes=pls[-1]))
@@ -557,6 +567,10 @@ class Fusion_Network3_ac(nn.Module):
         y1 = self.DRDB3.forward_planes(x1, pls[0], out=y1, preloaded=pre)
         y2 = self.DRDB4.forward_planes(x2, pls[1], out=y2, preloaded=pre)
         del pls, xs, x1, x2
+        if guard is not None and not guard.ok():
+            del y1, y2
+            self.planes16_fallbacks += 1
+            return self._forward_eval_planes(ir, vis, seg1_fn, seg2_fn, _force_bf16=True)
         seg = seg2_fn()
         cat = torch.empty((B, H, W, 128), device=dev, dtype=torch.float32)
         self.ffm.forward_nhwc(y1, y2, seg, out1=cat[..., :64], out2=cat[..., 64:])
@@ -564,6 +578,8 @@ class Fusion_Network3_ac(nn.Module):
         f = ops.conv2d(f, self._w3("conv21"), 32, 3, pad=1, bias=self.conv21.bias, act=PRELU, prelu=slope)
         f = self._conv22(f, slope)
         return f.view(B, 1, H, W)
+
+    planes16_fallbacks = 0  # forwards repeated on the bf16x6 kernels because the f16x3 range guard tripped
 
 
 class Network3(nn.Module):

@@ -29,11 +29,23 @@
 // fifth dilated conv: its input at a pixel is that conv's centre-tap fragment (chunks 0..11, already in
 // LDS) plus the 32 channels the conv itself produces (in the accumulators), so 12 + 24 extra MFMAs per
 // sub-tile replace a separate HBM-bound pass over the 224-channel buffer.
+//
+// Second operand format, F16 = true ("f16x3", segmif_planes16_* / segmif_conv3x3_planes_f16x3): an activation is a PAIR of
+// halves, x = x0 + 2^-11 l  with  x0 = RN16(x), l = RN16(2^11 (x - x0))  — 11 + 1 + 11 significand bits, within one bit
+// of fp32 for 2^-13 <= |x| < 65504 —, a weight row is scaled by a power of two 2^e(n) so that its largest entry lies in
+// [2^14, 2^15) and stored as three halves W0 = RN16(W), Wl = RN16(W - W0), W0s = 2^-11 W0; THREE products per fp32
+// product, x0 W0 + x0 Wl + l W0s, the epilogue multiplies by 2^-e(n).  Half the matrix work and 2/3 of the activation
+// bytes of bf16x6 at the same error level (tests/test_gpu_kernels.py holds both to the exact-fp32 MFMA kernel's error),
+// but only inside the half's exponent range: every producer records max |x| of what it wrote (atomic max on the bit
+// pattern, `amax`), and the host re-runs a forward whose planes left [2^-13, 65504) on the bf16x6 kernels.
+// LDS image: [pixel][64 B] = 4 pieces of 16 bytes (2 * plane + half); piece q of halo column c sits in slot
+// q ^ ((c >> 2) & 3), which puts the 16 lanes of a ds_read_b128 service group on 16 distinct slots of a bank row.
 #include <hip/hip_runtime.h>
 #include "device_once.h"
 #include <stdint.h>
 
 #include "igemm_common.h"
+#include "planes16.h"
 #include "segmif_hip.h"
 
 #ifndef PLANES_DBG
@@ -58,10 +70,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PB = 2;            // zero border of a planes image (pixels) = the largest dilation served
 constexpr int TH = 8, TW = 32;   // output patch of a workgroup
-constexpr int PXB = 96;          // bytes per pixel per chunk: 3 planes x 16 bf16
+constexpr int PXB = 96;          // bytes per pixel per chunk: 3 planes x 16 bf16 (also a weight row in both formats)
+constexpr int PXH = p16::PIXEL_BYTES;  // f16x3: bytes per pixel per chunk, 2 planes x 16 halves
+constexpr float LSCALE = p16::LSCALE;  // f16x3: the low half carries 2^11 x the residual
 constexpr int W3_BYTES = 9 * 32 * PXB;   // one chunk of 3x3 weights, 32 output channels
 constexpr int W1_BYTES = 64 * PXB;       // one chunk of the fused 1x1 weights, 64 output channels
 
@@ -94,6 +110,12 @@ __device__ __forceinline__ void split8(const float* y, u32x4& p0, u32x4& p1, u32
   }
 }
 
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_split(const u32x4& a, const u32x4& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 __host__ __device__ inline int sigma16(int j) { return (j & 3) + 4 * (j >> 3) + 8 * ((j >> 2) & 1); }
 
 struct PlanesConvK {
@@ -113,6 +135,9 @@ struct PlanesConvK {
   float* out1;
   int ldr, ldo1, act1;
   int tiles_x, tiles_y;
+  const float* wscale;        // f16x3: 2^-e(n) of the 32 conv rows / the 64 rows of the fused 1x1
+  const float* w1scale;
+  uint32_t* amax;             // f16x3: atomic max of the bit patterns of |conv output| (or null)
 };
 
 __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* lds_wave_base) {
@@ -130,10 +155,14 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
 // |lag| 0.28 of a period, both in their MFMA segment 68 % of the time, both issuing DMA into the 64 B/clk L1 path at
 // once the rest — profiles/r02_planes_timeline.txt); the barrier pins the phase.  Item i of team 0 is loaded in phase
 // 2i and multiplied in phase 2i + 1; team 1 runs one phase later and finds the weights of item i still in W[i & 1].
-template <int DIL, bool FUSE>
+template <int DIL, bool FUSE, bool F16>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_planes_kernel(const PlanesConvK p) {
   constexpr int HH = TH + 2 * DIL, HW = TW + 2 * DIL;
-  constexpr int UR = HW * 6;                      // 16-byte units per halo row
+  constexpr int PXA = F16 ? PXH : PXB;            // bytes per activation pixel per chunk
+  constexpr int UPP = PXA / 16;                   // 16-byte pieces per pixel
+  constexpr int NPA = F16 ? 2 : 3;                // activation planes
+  constexpr int NPROD = F16 ? 3 : 6;              // MFMA products per fp32 product
+  constexpr int UR = HW * UPP;                    // 16-byte units per halo row
   constexpr int A_UNITS = HH * UR;
   constexpr int A_INSTR = (A_UNITS + 63) / 64;    // wave-level DMA instructions (64 units each)
   constexpr int AJ = (A_INSTR + 3) / 4;
@@ -150,7 +179,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned char* As = smem_b + team * A_BYTES;                    // this team's halo
   unsigned char* Wsb = smem_b + 2 * A_BYTES;                      // [2][W3_BYTES], shared by the teams
   unsigned char* W1sb = Wsb + 2 * W3_BYTES;                       // [2][W1_BYTES] (FUSE)
-  unsigned char* Cst = W1sb + (FUSE ? 2 * W1_BYTES : 0);          // 512 B: bias[32], bias1[64], act slopes
+  unsigned char* Cst = W1sb + (FUSE ? 2 * W1_BYTES : 0);          // 512 B: bias[32], bias1[64], act slopes (+ 512 B f16x3: row scales)
 
   // patch pairs of this workgroup: XCD x (= blockIdx % 8 under round-robin dispatch) owns a contiguous range of
   // pairs and its workgroups stride through it together, so vertically adjacent patches meet in one L2
@@ -160,19 +189,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int q_lo = (int)((long long)npairs * xcd / nx), q_hi = (int)((long long)npairs * (xcd + 1) / nx);
   const int n_my = q_lo + jx < q_hi ? (q_hi - q_lo - jx + GX - 1) / GX : 0;
   const int n_items = n_my * p.nchunks;
-  const long long chunk_bytes = (long long)p.Hp * p.Wp * PXB;
+  const long long chunk_bytes = (long long)p.Hp * p.Wp * PXA;
 
-  // DMA slots of this lane relative to the patch origin.  LDS unit U (16 bytes, lane-linear) = halo pixel U / 6,
-  // sub-unit U % 6 = 2 * plane + half; it receives the source's half ^ f(halo column).  Kept in registers: a vector
-  // instruction of the loading team waits ~16 cycles for an issue slot beside the other team's MFMA stream.
+  // DMA slots of this lane relative to the patch origin.  LDS unit U (16 bytes, lane-linear) = halo pixel U / UPP,
+  // sub-unit U % UPP = 2 * plane + half; it receives the source's half ^ f(halo column) (f16x3: piece sub ^ g(halo
+  // column)).  Kept in registers: a vector instruction of the loading team waits ~16 cycles for an issue slot beside the
+  // other team's MFMA stream.
   uint32_t a_rel[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int u = (j * 4 + wave) * 64 + lane;
     const int hy = u / UR, rem = u - hy * UR;
-    const int hx = rem / 6, sub = rem - hx * 6;
-    const int f = (hx >> 3) & 1;
-    a_rel[j] = (uint32_t)((hy * p.Wp + hx) * PXB + (sub >> 1) * 32 + (((sub & 1) ^ f) * 16));
+    const int hx = rem / UPP, sub = rem - hx * UPP;
+    if constexpr (F16) {
+      a_rel[j] = (uint32_t)((hy * p.Wp + hx) * PXA + ((sub ^ ((hx >> 2) & 3)) * 16));
+    } else {
+      const int f = (hx >> 3) & 1;
+      a_rel[j] = (uint32_t)((hy * p.Wp + hx) * PXA + (sub >> 1) * 32 + (((sub & 1) ^ f) * 16));
+    }
   }
 
   struct Patch {
@@ -193,7 +227,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto stage = [&](const Patch& pt, int c) {
     {
       const unsigned char* __restrict__ ab = p.pin + ((long long)pt.b * p.in_total + c) * chunk_bytes +
-                                             ((long long)(pt.y0 + (PB - DIL)) * p.Wp + pt.x0 + (PB - DIL)) * PXB;
+                                             ((long long)(pt.y0 + (PB - DIL)) * p.Wp + pt.x0 + (PB - DIL)) * PXA;
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
         const int i = j * 4 + wave;
@@ -231,7 +265,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else if (tid == 96) v = p.act == SEGMIF_ACT_RELU ? 0.f : (p.act == SEGMIF_ACT_PRELU ? *p.prelu : 1.f);
     else v = p.act1 == SEGMIF_ACT_RELU ? 0.f : 1.f;
     reinterpret_cast<float*>(Cst)[tid] = v;
+  } else if (F16 && tid >= 128 && tid < 224) {  // row scales 2^-e(n): floats [128, 160) conv, [160, 224) fused 1x1
+    const int n = tid - 128;
+    reinterpret_cast<float*>(Cst)[tid] = n < 32 ? p.wscale[n] : (FUSE ? p.w1scale[n - 32] : 1.f);
   }
+  float amx = 0.f;  // f16x3: largest |output| this lane has split
 
   f32x16 acc[2], acc1[FUSE ? 2 : 1][2];
   auto zero_acc = [&]() {
@@ -252,15 +290,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ky + 1 of the first reads): a chunk is 12 steps (kx, m), halo row R0 + m * DIL at column offset kx * DIL
   // feeds sub-tile 0 with tap ky = m (m < 3) and sub-tile 1 with tap ky = m - 1 (m > 0).
   const int R0 = (DIL == 2) ? ((wave >> 1) * 4 + (wave & 1)) : 2 * wave;
-  const unsigned char* a_lane[3];
+  const unsigned char* a_lane[3][F16 ? 2 : 1];  // bf16: plane pl at + 32 pl; f16x3: a pointer per plane (slot q ^ g)
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) {
     const int col = kx * DIL + r;
-    a_lane[kx] = As + (R0 * HW + col) * PXB + ((h ^ ((col >> 3) & 1)) * 16);
+    if constexpr (F16) {
+      const int g = (col >> 2) & 3;
+      a_lane[kx][0] = As + (R0 * HW + col) * PXA + ((h ^ g) * 16);
+      a_lane[kx][1] = As + (R0 * HW + col) * PXA + (((2 + h) ^ g) * 16);
+    } else {
+      a_lane[kx][0] = As + (R0 * HW + col) * PXA + ((h ^ ((col >> 3) & 1)) * 16);
+    }
   }
   const int wsw = (h ^ (r >> 4)) * 16;
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first (activation plane)
-  constexpr int PW[6] = {0, 1, 2, 0, 1, 0};  // (weight plane)
+  // products, least significant first: (activation plane, weight plane).  bf16x6: x2 w0, x1 w1, x0 w2, x1 w0, x0 w1,
+  // x0 w0; f16x3: l W0s, x0 Wl, x0 W0
+  constexpr int PA[6] = {F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0, 0};
+  constexpr int PW[6] = {F16 ? 2 : 0, 1, F16 ? 0 : 2, 0, 1, 0};
 
   // A chunk = 9 balanced steps of 12 MFMAs, three per column offset kx, in which the two accumulators alternate:
   //   A: acc0 += W[1][kx] F1, acc1 += W[0][kx] F1      F_m = halo row R0 + m * DIL at column offset kx * DIL
@@ -272,27 +318,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto compute = [&](int slot) {
     const unsigned char* w_lane = Wsb + slot * W3_BYTES + r * PXB + wsw;
     const unsigned char* w1_lane = W1sb + slot * W1_BYTES + r * PXB + wsw;
-    bf16x8 Fa[2][3], Fb[3], Fc[2][3], W0[2][3], W1[2][3], W2[3];  // [kx & 1] where a fragment outlives its column
-    auto ld_f = [&](bf16x8* dst, int kx, int m) {
+    u32x4 Fa[2][NPA], Fb[NPA], Fc[2][NPA], W0[2][3], W1[2][3], W2[3];  // [kx & 1] where a fragment outlives its column
+    auto ld_f = [&](u32x4* dst, int kx, int m) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const bf16x8*>(a_lane[kx] + (m * DIL * HW) * PXB + pl * 32);
-    };
-    auto ld_w = [&](bf16x8* dst, int kx, int ky) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const bf16x8*>(w_lane + ((ky * 3 + kx) * 32) * PXB + pl * 32);
-    };
-    auto mm = [&](const bf16x8* wa, const bf16x8* fa, const bf16x8* wb, const bf16x8* fb) {
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[PW[t]], fa[PA[t]], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[PW[t]], fb[PA[t]], acc[1], 0, 0, 0);
+      for (int pl = 0; pl < NPA; ++pl) {
+        if constexpr (F16) dst[pl] = *reinterpret_cast<const u32x4*>(a_lane[kx][pl] + (m * DIL * HW) * PXA);
+        else dst[pl] = *reinterpret_cast<const u32x4*>(a_lane[kx][0] + (m * DIL * HW) * PXA + pl * 32);
       }
     };
-    auto fence = [&](int n) {  // one scheduling region per step: every MFMA is followed by one of the next step's reads
+    auto ld_w = [&](u32x4* dst, int kx, int ky) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const u32x4*>(w_lane + ((ky * 3 + kx) * 32) * PXB + pl * 32);
+    };
+    auto mm = [&](const u32x4* wa, const u32x4* fa, const u32x4* wb, const u32x4* fb) {
+#pragma unroll
+      for (int t = 0; t < NPROD; ++t) {
+        acc[0] = mfma_split<F16>(wa[PW[t]], fa[PA[t]], acc[0]);
+        acc[1] = mfma_split<F16>(wb[PW[t]], fb[PA[t]], acc[1]);
+      }
+    };
+    auto fence = [&](int n) {  // one scheduling region per step: every MFMA is followed by one (f16x3: up to two) of the next step's reads
 #pragma unroll
       for (int t = 0; t < n; ++t) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 2 : 1, 0);  // DS read
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -309,14 +358,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (FUSE && kx == 1) {  // centre tap of sub-tile 0: the 1x1 conv's input at this pixel
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          bf16x8 W1f[3];
+          u32x4 W1f[3];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) W1f[pl] = *reinterpret_cast<const bf16x8*>(w1_lane + (nt * 32) * PXB + pl * 32);
+          for (int pl = 0; pl < 3; ++pl) W1f[pl] = *reinterpret_cast<const u32x4*>(w1_lane + (nt * 32) * PXB + pl * 32);
 #pragma unroll
-          for (int t = 0; t < 6; ++t) acc1[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1f[PW[t]], Fa[c][PA[t]], acc1[0][nt], 0, 0, 0);
+          for (int t = 0; t < NPROD; ++t) acc1[0][nt] = mfma_split<F16>(W1f[PW[t]], Fa[c][PA[t]], acc1[0][nt]);
         }
       }
-      fence(FUSE && kx == 1 ? 24 : 12);
+      fence(FUSE && kx == 1 ? 4 * NPROD : 2 * NPROD);
       // step B; request step C's
       ld_f(Fc[0], kx, 0);
       ld_f(Fc[1], kx, 3);
@@ -324,14 +373,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (FUSE && kx == 1) {  // centre tap of sub-tile 1
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          bf16x8 W1f[3];
+          u32x4 W1f[3];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) W1f[pl] = *reinterpret_cast<const bf16x8*>(w1_lane + (nt * 32) * PXB + pl * 32);
+          for (int pl = 0; pl < 3; ++pl) W1f[pl] = *reinterpret_cast<const u32x4*>(w1_lane + (nt * 32) * PXB + pl * 32);
 #pragma unroll
-          for (int t = 0; t < 6; ++t) acc1[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1f[PW[t]], Fb[PA[t]], acc1[1][nt], 0, 0, 0);
+          for (int t = 0; t < NPROD; ++t) acc1[1][nt] = mfma_split<F16>(W1f[PW[t]], Fb[PA[t]], acc1[1][nt]);
         }
       }
-      fence(FUSE && kx == 1 ? 24 : 12);
+      fence(FUSE && kx == 1 ? 4 * NPROD : 2 * NPROD);
       // step C; request the next column's step A
       if (kx < 2) {
         ld_f(Fa[n], kx + 1, 1);
@@ -339,7 +388,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         ld_w(W0[n], kx + 1, 0);
       }
       mm(W0[c], Fc[0], W2, Fc[1]);
-      fence(12);
+      fence(2 * NPROD);
     }
   };
 
@@ -359,6 +408,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int e = 0; e < 4; ++e) bv[4 * g + e] = t[e];
     }
+    float sv[F16 ? 16 : 1];  // f16x3: 2^-e(n) of this lane's 16 output channels
+    if constexpr (F16) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(cst + 128 + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sv[4 * g + e] = t[e];
+      }
+    }
     const int ox = pt.x0 + r;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -367,8 +425,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       float y[16];
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const float t = acc[i][v] + bv[v];
+        const float t = F16 ? fmaf(acc[i][v], sv[F16 ? v : 0], bv[v]) : acc[i][v] + bv[v];
         y[v] = t >= 0.f ? t : nslope * t;
+      }
+      if constexpr (F16) {
+        const float mx = p16::abs_max8(y + 8, p16::abs_max8(y, 0.f));
+        amx = ok ? fmaxf(amx, mx) : amx;
       }
 #if PLANES_DBG & 32
       if (i == 0 && wave == 0 && lane == 0 && blockIdx.x < 256 && item < PLANES_TL_ITEMS) {
@@ -385,24 +447,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         u32x4 pl[3];
-        split8(y + 8 * q, pl[0], pl[1], pl[2]);
+        if constexpr (F16) {
+          p16::split8(y + 8 * q, pl[0], pl[1]);
+          pl[2] = pl[1];
+        } else {
+          split8(y + 8 * q, pl[0], pl[1], pl[2]);
+        }
         if (PLANES_DBG & 64) asm volatile("" ::"v"(pl[0]), "v"(pl[1]), "v"(pl[2]));
         if (p.pout && ok && !(PLANES_DBG & 64)) {
           unsigned char* dst = p.pout + ((long long)pt.b * p.out_total + p.out_chunk0 + q) * chunk_bytes +
-                               ((long long)(oy + PB) * p.Wp + ox + PB) * PXB + h * 16;
+                               ((long long)(oy + PB) * p.Wp + ox + PB) * PXA + h * 16;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(dst + k * 32) = pl[k];
+          for (int k = 0; k < NPA; ++k) *reinterpret_cast<u32x4*>(dst + k * 32) = pl[k];
         }
         if (FUSE) {  // 1x1 weights of the 16 channels just produced: chunk nchunks + q (re-read per sub-tile: L2 hits, keeps registers free)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
-            bf16x8 W1g[3];
+            u32x4 W1g[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-              W1g[k] = *reinterpret_cast<const bf16x8*>(p.w1 + z + ((long long)(p.nchunks + q) * 64 + nt * 32 + r) * PXB + k * 32 + wsw);
+              W1g[k] = *reinterpret_cast<const u32x4*>(p.w1 + z + ((long long)(p.nchunks + q) * 64 + nt * 32 + r) * PXB + k * 32 + wsw);
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
-              acc1[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1g[PW[t]], __builtin_bit_cast(bf16x8, pl[PA[t]]), acc1[i][nt], 0, 0, 0);
+            for (int t = 0; t < NPROD; ++t) acc1[i][nt] = mfma_split<F16>(W1g[PW[t]], pl[PA[t]], acc1[i][nt]);
           }
         }
       }
@@ -415,9 +481,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int n0 = nt * 32 + 8 * g + 4 * h;
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(cst + 32 + n0);
             f32x4 o;
+            f32x4 s1 = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (F16) s1 = *reinterpret_cast<const f32x4*>(cst + 160 + n0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float t = acc1[i][nt][4 * g + e] + b1[e];
+              const float t = F16 ? fmaf(acc1[i][nt][4 * g + e], s1[e], b1[e]) : acc1[i][nt][4 * g + e] + b1[e];
               o[e] = t >= 0.f ? t : nslope1 * t;
             }
             if (p.res) {
@@ -476,13 +544,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (team == 0) __syncthreads();
   }
+  if constexpr (F16) {
+    if (p.amax) p16::fold_max(p.amax, amx);
+  }
 }
 
-template <int DIL, bool FUSE>
+template <int DIL, bool FUSE, bool F16>
 int launch(const PlanesConvK& k, hipStream_t stream) {
-  constexpr int A_UNITS = (TH + 2 * DIL) * (TW + 2 * DIL) * 6;
-  constexpr size_t smem = 2 * ((size_t)((A_UNITS + 63) / 64) * 1024 + W3_BYTES + (FUSE ? W1_BYTES : 0)) + 512;
-  auto fn = conv3x3_planes_kernel<DIL, FUSE>;
+  constexpr int A_UNITS = (TH + 2 * DIL) * (TW + 2 * DIL) * (F16 ? PXH : PXB) / 16;
+  constexpr size_t smem = 2 * ((size_t)((A_UNITS + 63) / 64) * 1024 + W3_BYTES + (FUSE ? W1_BYTES : 0)) + (F16 ? 1024 : 512);
+  auto fn = conv3x3_planes_kernel<DIL, FUSE, F16>;
   static segmif::PerDeviceFlag raised_flag;  // idempotent attribute; benign race
   bool& raised = raised_flag.here();
   if (!raised) {
@@ -509,11 +580,15 @@ __device__ float planes_zero_bias[64];  // stands in for a NULL bias (static sto
 // ---- producers of the planes format ---------------------------------------------------------------
 
 // fp32 rows (pixel pitch ldx) -> planes chunks [chunk0, chunk0 + nconv).  One thread = (pixel, chunk, half).
+template <bool F16>
 __global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, unsigned char* __restrict__ planes, int B,
-                                       int H, int W, int Hp, int Wp, int total, int chunk0, int nconv) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                                       int H, int W, int Hp, int Wp, int total, int chunk0, int nconv, uint32_t* amax) {
+  constexpr int PXA = F16 ? PXH : PXB;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long npix = (long long)B * H * W;
-  if (idx >= npix * nconv * 2) return;
+  const bool live = idx < npix * nconv * 2;
+  if (!F16 && !live) return;
+  if (!live) idx = 0;  // f16x3: dead lanes of the last block still take part in the wave maximum below
   const int hf = (int)(idx & 1);
   const int ch = (int)((idx >> 1) % nconv);
   const long long pix = (idx >> 1) / nconv;
@@ -523,24 +598,34 @@ __global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, uns
   const float* src = x + pix * ldx + ch * 16 + 4 * hf;  // positions 8 hf + e <-> channels 4 hf + (e & 3) + 8 (e >> 2)
   const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 8);
   const float y[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  u32x4 p0, p1, p2;
-  split8(y, p0, p1, p2);
-  unsigned char* dst = planes + (((long long)b * total + chunk0 + ch) * Hp + yy + PB) * (long long)Wp * PXB + (long long)(xx + PB) * PXB + hf * 16;
-  *reinterpret_cast<u32x4*>(dst) = p0;
-  *reinterpret_cast<u32x4*>(dst + 32) = p1;
-  *reinterpret_cast<u32x4*>(dst + 64) = p2;
+  unsigned char* dst = planes + (((long long)b * total + chunk0 + ch) * Hp + yy + PB) * (long long)Wp * PXA + (long long)(xx + PB) * PXA + hf * 16;
+  if constexpr (F16) {
+    u32x4 p0, p1;
+    p16::split8(y, p0, p1);
+    if (live) {
+      *reinterpret_cast<u32x4*>(dst) = p0;
+      *reinterpret_cast<u32x4*>(dst + 32) = p1;
+    }
+    if (amax) p16::fold_max(amax, live ? p16::abs_max8(y, 0.f) : 0.f);
+  } else {
+    u32x4 p0, p1, p2;
+    split8(y, p0, p1, p2);
+    *reinterpret_cast<u32x4*>(dst) = p0;
+    *reinterpret_cast<u32x4*>(dst + 32) = p1;
+    *reinterpret_cast<u32x4*>(dst + 64) = p2;
+  }
 }
 
 // zero the border / round-up region of every chunk image: one block per padded row
-__global__ void planes_zero_border_kernel(unsigned char* __restrict__ planes, int H, int W, int Hp, int Wp) {
-  const int row = blockIdx.x;
-  u32x4* line = reinterpret_cast<u32x4*>(planes + ((long long)blockIdx.y * Hp + row) * (long long)Wp * PXB);
+__global__ void planes_zero_border_kernel(unsigned char* __restrict__ planes, int H, int W, int Hp, int Wp, int upp) {
+  const int row = blockIdx.x;  // upp = 16-byte pieces per pixel (6 | 4)
+  u32x4* line = reinterpret_cast<u32x4*>(planes + ((long long)blockIdx.y * Hp + row) * (long long)Wp * upp * 16);
   const u32x4 z = {0u, 0u, 0u, 0u};
   if (row < PB || row >= PB + H) {
-    for (int u = threadIdx.x; u < Wp * 6; u += blockDim.x) line[u] = z;
+    for (int u = threadIdx.x; u < Wp * upp; u += blockDim.x) line[u] = z;
   } else {
     const int right = Wp - (PB + W);
-    for (int u = threadIdx.x; u < (PB + right) * 6; u += blockDim.x) line[u < PB * 6 ? u : (PB + W) * 6 + (u - PB * 6)] = z;
+    for (int u = threadIdx.x; u < (PB + right) * upp; u += blockDim.x) line[u < PB * upp ? u : (PB + W) * upp + (u - PB * upp)] = z;
   }
 }
 
@@ -565,6 +650,42 @@ __global__ void planes_pack_weight_kernel(const float* __restrict__ w, int N, in
   dst[32] = (uint16_t)(p2 & 0xffffu);
 }
 
+// f16x3 weights.  Row scale: one wave per output row n finds max |w[n][.]| and stores 2^-e(n) with
+// 2^14 <= 2^e(n) max < 2^15 (e = 0 for an all-zero or vanishing row).
+__global__ void planes16_weight_scale_kernel(const float* __restrict__ w, int K, int ldw, float* __restrict__ inv_scale) {
+  const int n = blockIdx.x;
+  float mx = 0.f;
+  for (int k = threadIdx.x; k < K; k += 64) mx = fmaxf(mx, fabsf(w[(long long)n * ldw + k]));
+  mx = p16::wave_max(mx);
+  if (threadIdx.x == 0) {
+    int e = 0;
+    if (mx >= 1e-30f && mx <= 3e38f) e = 14 - (int)((__float_as_uint(mx) >> 23) - 127);
+    inv_scale[n] = ldexpf(1.f, -e);
+  }
+}
+
+// fp32 [N][ldw] (k = tap * Cin + c) -> [chunk][tap][n][96 B]: planes W0 | Wl | W0s of the scaled row, half-swapped rows
+__global__ void planes16_pack_weight_kernel(const float* __restrict__ w, int N, int Cin, int taps, int ldw, long long total,
+                                            const float* __restrict__ inv_scale, uint16_t* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx & 15);
+  long long t = idx >> 4;
+  const int n = (int)(t % N); t /= N;
+  const int tap = (int)(t % taps);
+  const int chunk = (int)(t / taps);
+  const float x = w[(long long)n * ldw + tap * Cin + chunk * 16 + sigma16(j)] * (1.f / inv_scale[n]);  // exact: power of two
+  const _Float16 w0 = (_Float16)x;
+  const _Float16 wl = (_Float16)(x - (float)w0);
+  const _Float16 ws = (_Float16)((float)w0 * (1.f / LSCALE));
+  const int f = (n >> 4) & 1;
+  const long long row = ((long long)chunk * taps + tap) * N + n;
+  uint16_t* dst = out + row * 48 + (((j >> 3) ^ f) * 8) + (j & 7);
+  dst[0] = __builtin_bit_cast(uint16_t, w0);
+  dst[16] = __builtin_bit_cast(uint16_t, wl);
+  dst[32] = __builtin_bit_cast(uint16_t, ws);
+}
+
 }  // namespace
 }  // namespace segmif
 
@@ -583,28 +704,48 @@ extern "C" int segmif_planes_dims(int H, int W, int* Hp, int* Wp) {
   return 0;
 }
 
-extern "C" int64_t segmif_planes_bytes(int B, int H, int W, int chunks) {
+static int64_t planes_bytes_impl(int B, int H, int W, int chunks, int pxa) {
   if (B <= 0 || H <= 0 || W <= 0 || chunks <= 0) return 0;
-  return (int64_t)B * chunks * planes_hp(H) * planes_wp(W) * PXB;
+  return (int64_t)B * chunks * planes_hp(H) * planes_wp(W) * pxa;
 }
 
-extern "C" int segmif_planes_zero_border(void* planes, int B, int H, int W, int chunks, void* stream) {
+static int planes_zero_border_impl(void* planes, int B, int H, int W, int chunks, int pxa, void* stream) {
   if (!planes || B <= 0 || H <= 0 || W <= 0 || chunks <= 0) return SEGMIF_EINVAL;
   const int Hp = planes_hp(H), Wp = planes_wp(W);
   hipLaunchKernelGGL(planes_zero_border_kernel, dim3((unsigned)Hp, (unsigned)(B * chunks)), dim3(256), 0, (hipStream_t)stream,
-                     (unsigned char*)planes, H, W, Hp, Wp);
+                     (unsigned char*)planes, H, W, Hp, Wp, pxa / 16);
   return (int)hipGetLastError();
 }
 
-extern "C" int segmif_planes_from_f32(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0,
-                                      int nconv, void* stream) {
+template <bool F16>
+static int planes_from_f32_impl(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0, int nconv,
+                                uint32_t* amax, void* stream) {
   if (!x || !planes || B <= 0 || H <= 0 || W <= 0 || nconv <= 0 || chunk0 < 0 || chunk0 + nconv > chunks || ldx % 4 ||
       ((uintptr_t)x & 15) || ldx < 16 * nconv)
     return SEGMIF_EINVAL;
   const long long n = (long long)B * H * W * nconv * 2;
-  hipLaunchKernelGGL(planes_from_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                     (unsigned char*)planes, B, H, W, planes_hp(H), planes_wp(W), chunks, chunk0, nconv);
+  hipLaunchKernelGGL(planes_from_f32_kernel<F16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     (unsigned char*)planes, B, H, W, planes_hp(H), planes_wp(W), chunks, chunk0, nconv, amax);
   return (int)hipGetLastError();
+}
+
+extern "C" int64_t segmif_planes_bytes(int B, int H, int W, int chunks) { return planes_bytes_impl(B, H, W, chunks, PXB); }
+extern "C" int64_t segmif_planes16_bytes(int B, int H, int W, int chunks) { return planes_bytes_impl(B, H, W, chunks, PXH); }
+
+extern "C" int segmif_planes_zero_border(void* planes, int B, int H, int W, int chunks, void* stream) {
+  return planes_zero_border_impl(planes, B, H, W, chunks, PXB, stream);
+}
+extern "C" int segmif_planes16_zero_border(void* planes, int B, int H, int W, int chunks, void* stream) {
+  return planes_zero_border_impl(planes, B, H, W, chunks, PXH, stream);
+}
+
+extern "C" int segmif_planes_from_f32(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0,
+                                      int nconv, void* stream) {
+  return planes_from_f32_impl<false>(x, ldx, planes, B, H, W, chunks, chunk0, nconv, nullptr, stream);
+}
+extern "C" int segmif_planes16_from_f32(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0,
+                                        int nconv, uint32_t* amax, void* stream) {
+  return planes_from_f32_impl<true>(x, ldx, planes, B, H, W, chunks, chunk0, nconv, amax, stream);
 }
 
 extern "C" int64_t segmif_planes_weight_bytes(int N, int Cin, int taps) {
@@ -620,7 +761,33 @@ extern "C" int segmif_planes_pack_weight(const float* packed, int N, int Cin, in
   return (int)hipGetLastError();
 }
 
+extern "C" int64_t segmif_planes16_weight_bytes(int N, int Cin, int taps) {
+  const int64_t image = segmif_planes_weight_bytes(N, Cin, taps);  // same 96-byte rows, then N floats: 2^-e(n)
+  return image ? image + (int64_t)N * 4 : 0;
+}
+
+extern "C" int segmif_planes16_pack_weight(const float* packed, int N, int Cin, int taps, int ldw, void* out, void* stream) {
+  if (!packed || !out || segmif_planes_weight_bytes(N, Cin, taps) == 0 || ldw < taps * Cin) return SEGMIF_EINVAL;
+  const long long total = (long long)N * Cin * taps;
+  float* inv_scale = reinterpret_cast<float*>((unsigned char*)out + total * 6);
+  hipLaunchKernelGGL(planes16_weight_scale_kernel, dim3((unsigned)N), dim3(64), 0, (hipStream_t)stream, packed, taps * Cin, ldw,
+                     inv_scale);
+  hipLaunchKernelGGL(planes16_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     packed, N, Cin, taps, ldw, total, inv_scale, (uint16_t*)out);
+  return (int)hipGetLastError();
+}
+
+static int conv3x3_planes_impl(const SegmifConvPlanes* d, bool f16, uint32_t* amax, void* stream);
+
 extern "C" int segmif_conv3x3_planes_bf16x6(const SegmifConvPlanes* d, void* stream) {
+  return conv3x3_planes_impl(d, false, nullptr, stream);
+}
+
+extern "C" int segmif_conv3x3_planes_f16x3(const SegmifConvPlanes* d, uint32_t* amax, void* stream) {
+  return conv3x3_planes_impl(d, true, amax, stream);
+}
+
+static int conv3x3_planes_impl(const SegmifConvPlanes* d, bool f16, uint32_t* amax, void* stream) {
   if (!d || !d->planes_in || !d->wt || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cin <= 0 || d->cin % 16) return SEGMIF_EINVAL;
   if (d->dil != 1 && d->dil != 2) return SEGMIF_EINVAL;
   if (d->act != SEGMIF_ACT_NONE && d->act != SEGMIF_ACT_RELU && d->act != SEGMIF_ACT_PRELU) return SEGMIF_EINVAL;
@@ -650,7 +817,10 @@ extern "C" int segmif_conv3x3_planes_bf16x6(const SegmifConvPlanes* d, void* str
   if (k.nchunks > k.in_total) return SEGMIF_EINVAL;
   if (k.pout && (k.out_chunk0 < 0 || k.out_chunk0 + 2 > k.out_total)) return SEGMIF_EINVAL;
   if (k.pout && k.pout == k.pin && k.out_chunk0 < k.nchunks) return SEGMIF_EINVAL;  // would overwrite its own input
-  if ((long long)k.Hp * k.Wp * PXB >= (1ll << 32)) return SEGMIF_EINVAL;
+  if ((long long)k.Hp * k.Wp * (f16 ? PXH : PXB) >= (1ll << 32)) return SEGMIF_EINVAL;
+  k.amax = amax;
+  k.wscale = reinterpret_cast<const float*>(k.wt + (long long)32 * d->cin * 9 * 6);  // f16x3 images end with the row scales
+  k.w1scale = d->w1 ? reinterpret_cast<const float*>((const unsigned char*)d->w1 + (long long)64 * (d->cin + 32) * 6) : nullptr;
   k.w1 = (const unsigned char*)d->w1;
   k.bias1 = d->bias1 ? d->bias1 : zero_bias;
   k.res = d->res;
@@ -664,6 +834,10 @@ extern "C" int segmif_conv3x3_planes_bf16x6(const SegmifConvPlanes* d, void* str
   k.tiles_x = (d->W + TW - 1) / TW;
   k.tiles_y = (d->H + TH - 1) / TH;
   hipStream_t s = (hipStream_t)stream;
-  if (d->dil == 2) return fuse ? launch<2, true>(k, s) : launch<2, false>(k, s);
-  return fuse ? launch<1, true>(k, s) : launch<1, false>(k, s);
+  if (f16) {
+    if (d->dil == 2) return fuse ? launch<2, true, true>(k, s) : launch<2, false, true>(k, s);
+    return fuse ? launch<1, true, true>(k, s) : launch<1, false, true>(k, s);
+  }
+  if (d->dil == 2) return fuse ? launch<2, true, false>(k, s) : launch<2, false, false>(k, s);
+  return fuse ? launch<1, true, false>(k, s) : launch<1, false, false>(k, s);
 }

@@ -29,7 +29,10 @@
 #include "device_once.h"
 #include <stdint.h>
 
+#include "planes16.h"
 #include "segmif_hip.h"
+
+namespace p16 = segmif::p16;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -294,12 +297,15 @@ struct TailK {
   const float* bend; const float* gamma; const float* beta;
   float* out;
   unsigned char* planes;              // optional split-bf16 copy of out (conv3x3_planes.hip format) or null
+  int pl_f16;                         // the copy is an f16x3 one (half pairs, 64 bytes per pixel; planes16.h)
+  uint32_t* pl_amax;                  // f16x3: guard slot for max |out| or null
   long long N;
   int ld3, ldi, ldo;
   int W, Hp, Wp, chunks;              // planes geometry (image width, padded dims, chunk images per batch element)
   float eps;
 };
 
+template <bool F16>  // F16: the planes copy is an f16x3 one (its own instantiation: the bf16 kernel sits at the register limit)
 __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* W3s = smem_raw;             // [64][WPB]
@@ -328,6 +334,7 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
 
   const long long ntiles = (p.N + 31) / 32;
   const long long stride = (long long)gridDim.x * CP_WAVES;
+  float pl_amx = 0.f;  // f16x3 planes copy: largest |out| this lane wrote
   auto load = [&](long long tt, const float* __restrict__ base, int ld, f32x4* dst) {  // a pixel's channels 8q + 4h .. +3
     const long long px = tt * 32 + r;
     const bool ok = tt < ntiles && px < p.N;
@@ -431,7 +438,21 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
         }
         if (ok) *reinterpret_cast<f32x4*>(outb + px * p.ldo + mt * 32 + 8 * g + 4 * h) = v;
       }
-    if (p.planes && ok) {  // positions 8h .. 8h+7 of chunk c = channels 16c + {4h..4h+3, 8+4h..8+4h+3}: this lane's o[8c .. 8c+7]
+    if constexpr (F16) {
+      if (ok) {
+        const int yy = (int)(px / p.W), xx = (int)(px - (long long)yy * p.W);
+        unsigned char* dst = p.planes + ((((long long)b * p.chunks) * p.Hp + yy + 2) * p.Wp + xx + 2) * p16::PIXEL_BYTES + h * 16;
+        const long long cstride = (long long)p.Hp * p.Wp * p16::PIXEL_BYTES;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          u32x4 hi, lo;
+          p16::split8(o + 8 * c, hi, lo);
+          *reinterpret_cast<u32x4*>(dst + c * cstride) = hi;
+          *reinterpret_cast<u32x4*>(dst + c * cstride + 32) = lo;
+          pl_amx = p16::abs_max8(o + 8 * c, pl_amx);
+        }
+      }
+    } else if (p.planes && ok) {  // (F16 implies a planes buffer) positions 8h .. 8h+7 of chunk c = channels 16c + {4h..4h+3, 8+4h..8+4h+3}: this lane's o[8c .. 8c+7]
       const int yy = (int)(px / p.W), xx = (int)(px - (long long)yy * p.W);
       unsigned char* dst = p.planes + ((((long long)b * p.chunks) * p.Hp + yy + 2) * p.Wp + xx + 2) * 96 + h * 16;
       const long long cstride = (long long)p.Hp * p.Wp * 96;
@@ -452,6 +473,9 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
   for (; t < ntiles; t += 2 * stride) {
     tile(t, a3, ai, b3, bi);
     if (t + stride < ntiles) tile(t + stride, b3, bi, a3, ai);
+  }
+  if constexpr (F16) {
+    if (p.pl_amax) p16::fold_max(p.pl_amax, pl_amx);
   }
 }
 
@@ -501,6 +525,8 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
   k.x3 = d->x3; k.xi = d->xi; k.w3 = d->w3; k.b3 = d->b3; k.wi = d->wi; k.bi = d->bi; k.weff = d->weff;
   k.bend = d->bend; k.gamma = d->ln_gamma; k.beta = d->ln_beta; k.out = d->out;
   k.planes = (unsigned char*)d->planes_out;
+  k.pl_f16 = k.planes ? d->planes_f16 : 0;
+  k.pl_amax = k.pl_f16 ? d->planes_amax : nullptr;
   k.N = d->N; k.ld3 = d->ld3; k.ldi = d->ldi; k.ldo = d->ldo;
   k.W = 0; k.Hp = 0; k.Wp = 0; k.chunks = 0;
   if (k.planes) {
@@ -518,10 +544,12 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
   static segmif::PerDeviceFlag raised_flag;
   bool& raised = raised_flag.here();
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)crosspath_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)crosspath_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)crosspath_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
-  hipLaunchKernelGGL(crosspath_tail_kernel, dim3((unsigned)wgs, (unsigned)d->B), dim3(512), smem, (hipStream_t)stream, k);
+  if (k.pl_f16) hipLaunchKernelGGL(crosspath_tail_kernel<true>, dim3((unsigned)wgs, (unsigned)d->B), dim3(512), smem, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL(crosspath_tail_kernel<false>, dim3((unsigned)wgs, (unsigned)d->B), dim3(512), smem, (hipStream_t)stream, k);
   return (int)hipGetLastError();
 }

@@ -26,6 +26,7 @@
 
 #include "segmif_hip.h"
 #include "igemm_common.h"
+#include "planes16.h"
 
 
 using namespace segmif;
@@ -386,6 +387,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
     return y;
   };
   if (p.vec4) {
+    // the planes copy exists in the generic-gather instantiations only (a conv that asks for it is routed there: its one
+    // user is conv1 with Cin = 1); the dense and 16-channel-chunk conv tiles stay free of its registers (20-30 VGPRs)
+    constexpr bool PLANES = MODE == MODE_GENERIC;
+    const int pl_pitch = PLANES && p.pl_f16 ? p16::PIXEL_BYTES : 96;
+    float pl_amx = 0.f;  // f16x3 planes: largest |output| this lane wrote
     f32x4 rr[TM][TN][4];
     if (res) {
 #pragma unroll
@@ -405,12 +411,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
       const long long m = row_of(i);
       if (m >= p.M) continue;
       unsigned char* pl_px = nullptr;
-      if (p.planes) {  // output pixel m = (b, oy, ox) -> its 96-byte slot in chunk image 0 of batch element b
+      if (PLANES && p.planes) {  // output pixel m = (b, oy, ox) -> its 96-byte (f16x3: 64-byte) slot in chunk image 0 of batch element b
         const long long ohw = (long long)p.OH * p.OW;
         const long long b = m / ohw;
         const int rem = (int)(m - b * ohw);
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        pl_px = p.planes + ((((long long)b * p.pl_chunks + p.pl_chunk0) * p.pl_Hp + oy + 2) * p.pl_Wp + ox + 2) * 96 + eh * 16;
+        pl_px = p.planes + ((((long long)b * p.pl_chunks + p.pl_chunk0) * p.pl_Hp + oy + 2) * p.pl_Wp + ox + 2) * pl_pitch + eh * 16;
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
@@ -432,23 +438,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
             }
             *reinterpret_cast<f32x4*>(out + m * p.ldo + n) = y;
           }
-          if (p.planes && col_of(j, 2 * q) < p.N) {
+          if (PLANES && p.planes && col_of(j, 2 * q) < p.N) {
             // this lane's 8 of the chunk's 16 channels are positions 8 h .. 8 h + 7 of the chunk (sigma order): one
             // 16-byte store per plane
-            ig_u32x4 pp[3];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              uint32_t a, b, c;
-              ig_split3(yy[2 * e], yy[2 * e + 1], a, b, c);
-              pp[0][e] = a; pp[1][e] = b; pp[2][e] = c;
-            }
             const int chunk = (n0 + wn * WN + 32 * j) / 16 + q;
-            unsigned char* dst = pl_px + (long long)chunk * p.pl_Hp * p.pl_Wp * 96;
+            unsigned char* dst = pl_px + (long long)chunk * p.pl_Hp * p.pl_Wp * pl_pitch;
+            if (p.pl_f16) {
+              ig_u32x4 hi, lo;
+              p16::split8(yy, hi, lo);
+              *reinterpret_cast<ig_u32x4*>(dst) = hi;
+              *reinterpret_cast<ig_u32x4*>(dst + 32) = lo;
+              pl_amx = p16::abs_max8(yy, pl_amx);
+            } else {
+              ig_u32x4 pp[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) *reinterpret_cast<ig_u32x4*>(dst + k * 32) = pp[k];
+              for (int e = 0; e < 4; ++e) {
+                uint32_t a, b, c;
+                ig_split3(yy[2 * e], yy[2 * e + 1], a, b, c);
+                pp[0][e] = a; pp[1][e] = b; pp[2][e] = c;
+              }
+#pragma unroll
+              for (int k = 0; k < 3; ++k) *reinterpret_cast<ig_u32x4*>(dst + k * 32) = pp[k];
+            }
           }
         }
     }
+    if (PLANES && p.pl_amax) p16::fold_max(p.pl_amax, pl_amx);  // (kernel argument: uniform over the grid)
   } else {  // ragged N or unaligned views: element by element
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -664,6 +679,8 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   if (k.ln_gamma && !k.vec4) return SEGMIF_EINVAL;  // the fused LayerNorm epilogue only exists in its 16-byte form
   k.planes = (unsigned char*)d->planes_out;
   k.pl_Hp = k.pl_Wp = k.pl_chunks = k.pl_chunk0 = 0;
+  k.pl_f16 = k.planes ? d->planes_f16 : 0;
+  k.pl_amax = k.pl_f16 ? d->planes_amax : nullptr;
   if (k.planes) {
     int hp, wp;
     if (!k.vec4 || (d->N & 15) || nz > 1 || k.ln_gamma || d->planes_chunk0 < 0 || d->planes_chunk0 + d->N / 16 > d->planes_chunks ||
@@ -684,6 +701,10 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   }
   if (mode != MODE_GENERIC && (((uintptr_t)d->in & 15) || (d->in2 && ((uintptr_t)d->in2 & 15)))) mode = d->in2 ? -1 : MODE_GENERIC;
   if (mode < 0 || ((uintptr_t)d->wt & 15)) return SEGMIF_EINVAL;
+  if (k.planes) {  // the planes copy is a conv epilogue, compiled into the generic-gather tiles
+    if (mode == MODE_DENSE || mode == MODE_DENSE2) return SEGMIF_EINVAL;
+    mode = MODE_GENERIC;
+  }
   if (mode == MODE_GENERIC && (d->KH * d->KW * d->Cin != d->K)) return SEGMIF_EINVAL;
 
   const bool bk32_ok = (k.Kp % 32 == 0) && (mode != MODE_CONV || d->Cin % 32 == 0) &&

@@ -35,6 +35,8 @@ struct IgemmK {
   int ntm, ntn;
   unsigned char* planes;  // optional planes copy of the output (conv3x3_planes.hip format): chunks [pl_chunk0, pl_chunk0 + N/16)
   int pl_Hp, pl_Wp, pl_chunks, pl_chunk0;
+  int pl_f16;             // planes are f16x3 half pairs (64 bytes per pixel) instead of bf16 triples (96)
+  uint32_t* pl_amax;      // f16x3: guard slot receiving max |output| (planes16.h) or null
   int vec4;  // epilogue may use 16-byte accesses: N, ldo, ldr, z strides multiples of 4 and out / res / bias / ws 16-byte aligned
 };
 

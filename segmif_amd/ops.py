@@ -82,7 +82,7 @@ class SplitWeight:
         self.data, self.N, self.cin = data, N, cin
 
 
-_CONV3X3_MODES = ("planes", "bf16x6", "fp32")
+_CONV3X3_MODES = ("planes", "planes16", "bf16x6", "fp32")
 _conv3x3_mode = os.environ.get("SEGMIF_CONV3X3", "planes")
 if _conv3x3_mode not in _CONV3X3_MODES:
     raise RuntimeError(f"SEGMIF_CONV3X3 must be one of {_CONV3X3_MODES}, got {_conv3x3_mode!r}")
@@ -115,8 +115,9 @@ def conv3x3_mode():
 def set_conv3x3_mode(mode):
     """'bf16x6': 3x3 stride-1 convs with Cin % 16 == 0 run on the bf16 matrix pipe with 3-way split
     operands (fp32-class accuracy, 2.7x the fp32 MFMA rate); 'planes' (default): the same, and a DRDB in
-    inference keeps its activations pre-split in a planes buffer (csrc/conv3x3_planes.hip); 'fp32':
-    exact-fp32 MFMA everywhere."""
+    inference keeps its activations pre-split in a planes buffer (csrc/conv3x3_planes.hip); 'planes16': as 'planes' with
+    the DRDBs on half-precision pairs and three products per MAC (f16x3; guarded by Planes16Guard, falls back to
+    'planes' when an activation tensor leaves the half's exponent range); 'fp32': exact-fp32 MFMA everywhere."""
     global _conv3x3_mode
     if mode not in _CONV3X3_MODES:
         raise ValueError(f"mode must be one of {_CONV3X3_MODES}")
@@ -141,55 +142,98 @@ def pack_weight_split(w):
 def pack_conv3x3(w):
     """Packing for a stride-1 'same' 3x3 conv (dilation 1 or 2): the split image when the mode and the
     shape allow it, the fp32 packing otherwise.  Cache entries must be keyed on conv3x3_mode()."""
-    if _conv3x3_mode in ("bf16x6", "planes") and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and w.shape[1] % 16 == 0 \
+    if _conv3x3_mode in ("bf16x6", "planes", "planes16") and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and w.shape[1] % 16 == 0 \
             and 16 <= w.shape[0] <= 256:
         return pack_weight_split(w)
     return pack_weight(w)
 
 
+class Planes16Guard:
+    """Range bookkeeping of the f16x3 planes path: every producer launch folds max |x| of what it wrote into its own
+    slot (a device-side atomic max); ok() reads the slots back (one host sync) and tells whether every tensor stayed
+    inside [2^-13, 65504) - the range in which a half pair carries an fp32 value to within one bit.  All-zero tensors
+    pass; NaN / inf read as overflow."""
+    SLOTS = 64
+    LO, HI = 2.0 ** -13, 65504.0
+
+    def __init__(self, device):
+        self.amax = torch.zeros((self.SLOTS,), device=device, dtype=torch.int32)
+        self.used = 0
+
+    def slot(self):
+        if self.used >= self.SLOTS:
+            raise RuntimeError("Planes16Guard: out of slots")
+        self.used += 1
+        return self.amax.data_ptr() + 4 * (self.used - 1)
+
+    def maxima(self):
+        return self.amax[:self.used].cpu().view(torch.float32)
+
+    def ok(self):
+        m = self.maxima()
+        return bool(((m == 0) | ((m >= self.LO) & (m < self.HI))).all())
+
+
 class Planes:
     """A planes buffer (include/segmif_hip.h, segmif_planes_*): `chunks` 16-channel chunk images per batch
-    element, each activation stored as three bf16 planes, zero border already cleared."""
-    __slots__ = ("data", "B", "H", "W", "chunks")
+    element, each activation stored as three bf16 planes (guard=None) or, with a Planes16Guard, as a pair of
+    halves (f16x3); zero border already cleared."""
+    __slots__ = ("data", "B", "H", "W", "chunks", "guard")
 
-    def __init__(self, B, H, W, chunks, device):
+    def __init__(self, B, H, W, chunks, device, guard=None):
         lib = _lib.load()
-        self.B, self.H, self.W, self.chunks = B, H, W, chunks
-        self.data = torch.empty((lib.segmif_planes_bytes(B, H, W, chunks),), device=device, dtype=torch.uint8)
-        _lib.check(lib.segmif_planes_zero_border(self.data.data_ptr(), B, H, W, chunks, _stream()),
-                   "segmif_planes_zero_border")
+        self.B, self.H, self.W, self.chunks, self.guard = B, H, W, chunks, guard
+        nbytes, zero = (lib.segmif_planes_bytes, lib.segmif_planes_zero_border) if guard is None else \
+            (lib.segmif_planes16_bytes, lib.segmif_planes16_zero_border)
+        self.data = torch.empty((nbytes(B, H, W, chunks),), device=device, dtype=torch.uint8)
+        _lib.check(zero(self.data.data_ptr(), B, H, W, chunks, _stream()), "segmif_planes_zero_border")
+
+    @property
+    def f16(self):
+        return self.guard is not None
 
     def load_f32(self, x, chunk0=0):
         """x: (B, H, W, C) rows view, C % 16 == 0 -> chunks [chunk0, chunk0 + C/16)."""
         _, C, ldx = rows_view(x, "x")
         if tuple(x.shape[:3]) != (self.B, self.H, self.W) or C % 16:
             raise RuntimeError(f"planes: x shape {tuple(x.shape)} does not fit ({self.B}, {self.H}, {self.W}, 16k)")
-        _lib.check(_lib.load().segmif_planes_from_f32(x.data_ptr(), ldx, self.data.data_ptr(), self.B, self.H, self.W,
-                                                      self.chunks, chunk0, C // 16, _stream()), "segmif_planes_from_f32")
+        lib = _lib.load()
+        if self.guard is None:
+            _lib.check(lib.segmif_planes_from_f32(x.data_ptr(), ldx, self.data.data_ptr(), self.B, self.H, self.W,
+                                                  self.chunks, chunk0, C // 16, _stream()), "segmif_planes_from_f32")
+        else:
+            _lib.check(lib.segmif_planes16_from_f32(x.data_ptr(), ldx, self.data.data_ptr(), self.B, self.H, self.W,
+                                                    self.chunks, chunk0, C // 16, self.guard.slot(), _stream()),
+                       "segmif_planes16_from_f32")
         return self
 
 
 class PlanesWeight:
-    """segmif_planes_pack_weight image of a 3x3 (taps = 9, N = 32) or 1x1 (taps = 1, N = 64) weight."""
-    __slots__ = ("data", "N", "cin", "taps")
+    """segmif_planes_pack_weight (f16: segmif_planes16_pack_weight) image of a 3x3 (taps = 9, N = 32) or 1x1 (taps = 1,
+    N = 64) weight."""
+    __slots__ = ("data", "N", "cin", "taps", "f16")
 
-    def __init__(self, data, N, cin, taps):
-        self.data, self.N, self.cin, self.taps = data, N, cin, taps
+    def __init__(self, data, N, cin, taps, f16=False):
+        self.data, self.N, self.cin, self.taps, self.f16 = data, N, cin, taps, f16
 
 
-def pack_weight_planes(w):
-    """OIHW 3x3 / 1x1 conv weight (or a Linear weight) -> PlanesWeight."""
+def pack_weight_planes(w, f16=False):
+    """OIHW 3x3 / 1x1 conv weight (or a Linear weight) -> PlanesWeight (f16: the f16x3 image with its row scales)."""
     N, cin = w.shape[0], w.shape[1]
     taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
     packed = pack_weight(w)
     lib = _lib.load()
-    nbytes = lib.segmif_planes_weight_bytes(N, cin, taps)
+    nbytes = (lib.segmif_planes16_weight_bytes if f16 else lib.segmif_planes_weight_bytes)(N, cin, taps)
     if nbytes <= 0:
         raise RuntimeError(f"planes packing needs N % 32 == 0, Cin % 16 == 0, 3x3 or 1x1; got {tuple(w.shape)}")
     out = torch.empty((nbytes,), device=w.device, dtype=torch.uint8)
-    _lib.check(lib.segmif_planes_pack_weight(packed.data_ptr(), N, cin, taps, packed.shape[1], out.data_ptr(), _stream()),
-               "segmif_planes_pack_weight")
-    return PlanesWeight(out, N, cin, taps)
+    fn = lib.segmif_planes16_pack_weight if f16 else lib.segmif_planes_pack_weight
+    _lib.check(fn(packed.data_ptr(), N, cin, taps, packed.shape[1], out.data_ptr(), _stream()), "segmif_planes_pack_weight")
+    return PlanesWeight(out, N, cin, taps, f16)
+
+
+def pack_weight_planes16(w):
+    return pack_weight_planes(w, f16=True)
 
 
 def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None, out_chunk0=None, out=None, tail=None,
@@ -198,7 +242,7 @@ def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None,
     out_chunk0: write the result as chunks [out_chunk0, out_chunk0 + 2) of the same buffer; out: optional fp32
     (B, H, W, 32) rows view; tail = (w1 PlanesWeight(64, cin + 32, 1), bias1, res, out1, act1): the fused 1x1 conv
     out1 = res + act1(W1 . [input | result] + bias1)."""
-    if not isinstance(wt, PlanesWeight) or (wt.N, wt.cin, wt.taps) != (32, cin, 9):
+    if not isinstance(wt, PlanesWeight) or (wt.N, wt.cin, wt.taps, wt.f16) != (32, cin, 9, planes.f16):
         raise RuntimeError("conv3x3_planes: weight image does not fit")
     d = _lib.SegmifConvPlanes()
     d.planes_in, d.wt = planes.data.data_ptr(), wt.data.data_ptr()
@@ -216,7 +260,7 @@ def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None,
         d.out, d.ldo = out.data_ptr(), ldo
     if tail is not None:
         w1, bias1, res, out1, act1 = tail
-        if not isinstance(w1, PlanesWeight) or (w1.N, w1.cin, w1.taps) != (64, cin + 32, 1):
+        if not isinstance(w1, PlanesWeight) or (w1.N, w1.cin, w1.taps, w1.f16) != (64, cin + 32, 1, planes.f16):
             raise RuntimeError("conv3x3_planes: tail weight image does not fit")
         _, c1, ldo1 = rows_view(out1, "out1")
         if tuple(out1.shape) != (planes.B, planes.H, planes.W, 64):
@@ -229,9 +273,13 @@ def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None,
                 raise RuntimeError("conv3x3_planes: res shape mismatch")
             d.res, d.ldr = res.data_ptr(), ldr
     lib = _lib.load()
+    amax = planes.guard.slot() if planes.f16 else None
 
     def go():
-        _lib.check(lib.segmif_conv3x3_planes_bf16x6(ctypes.byref(d), _stream()), "segmif_conv3x3_planes_bf16x6")
+        if planes.f16:
+            _lib.check(lib.segmif_conv3x3_planes_f16x3(ctypes.byref(d), amax, _stream()), "segmif_conv3x3_planes_f16x3")
+        else:
+            _lib.check(lib.segmif_conv3x3_planes_bf16x6(ctypes.byref(d), _stream()), "segmif_conv3x3_planes_bf16x6")
 
     if _timer is not None and tag is not None and tag == _timer.tag:
         _timer.bracket(go, 2.0 * planes.B * planes.H * planes.W * 32 * 9 * cin)
@@ -493,6 +541,8 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
         if isinstance(wt, SplitWeight) or (planes.B, planes.H, planes.W) != (B, OH, OW):
             raise RuntimeError("conv2d: planes output needs fp32-packed weights and a planes buffer of the output geometry")
         d.planes_out, d.planes_chunks, d.planes_chunk0 = planes.data.data_ptr(), planes.chunks, planes_chunk0
+        if planes.f16:
+            d.planes_f16, d.planes_amax = 1, planes.guard.slot()
     _igemm(d, tag, dev=x.device)
     return out
 
@@ -757,6 +807,8 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
         if hw is None or hw[0] * hw[1] != N or (planes.B, planes.H, planes.W) != (B, hw[0], hw[1]):
             raise RuntimeError("crosspath_tail: planes geometry does not match the tokens")
         d.planes_out, d.H, d.W, d.planes_chunks = planes.data.data_ptr(), hw[0], hw[1], planes.chunks
+        if planes.f16:
+            d.planes_f16, d.planes_amax = 1, planes.guard.slot()
     _side("cp_tail", lambda: _lib.check(_lib.load().segmif_crosspath_tail_f32(ctypes.byref(d), _stream()),
                                         "segmif_crosspath_tail_f32"), (768.0 + (384.0 if planes is not None else 0.0)) * B * N)
     return out

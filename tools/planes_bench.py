@@ -36,7 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--only", type=int, default=0, help="one Cin only (PMC passes)")
-    ap.add_argument("--kernel", default="both", choices=["both", "planes", "split"])
+    ap.add_argument("--kernel", default="both", choices=["both", "planes", "split", "planes16", "planes+16"])
     ap.add_argument("--fill", default="randn", choices=["randn", "zeros", "relu", "ones"], help="activation data (DVFS probe)")
     args = ap.parse_args()
     B, H, W = args.batch, 480, 640
@@ -49,16 +49,21 @@ def main():
     elif args.fill == "ones":
         buf.fill_(1.0)
     pl = ops.Planes(B, H, W, 14, dev).load_f32(buf[..., :192])
+    guard = ops.Planes16Guard(dev)
+    guard.slot = lambda: guard.amax.data_ptr()  # a benchmark re-launches forever: one shared slot
+    pl16 = ops.Planes(B, H, W, 14, dev, guard).load_f32(buf[..., :192])
     bias = torch.randn(32, device=dev)
     peak = 2500.0 / 6
     for cin in ((args.only,) if args.only else (64, 96, 128, 160, 192)):
         w = torch.randn(32, cin, 3, 3, device=dev) * 0.05
-        wsplit, wpl = ops.pack_weight_split(w), ops.pack_weight_planes(w)
+        wsplit, wpl, wpl16 = ops.pack_weight_split(w), ops.pack_weight_planes(w), ops.pack_weight_planes16(w)
         fns = {}
         if args.kernel in ("both", "split"):
             fns["split(r1)"] = lambda: ops.conv2d(buf[..., :cin], wsplit, 32, 3, pad=2, dil=2, bias=bias, act=1, out=buf[..., 192:224])
-        if args.kernel in ("both", "planes"):
+        if args.kernel in ("both", "planes", "planes+16"):
             fns["planes"] = lambda: ops.conv3x3_planes(pl, cin, wpl, dil=2, bias=bias, act=1, out_chunk0=12)
+        if args.kernel in ("planes16", "planes+16"):
+            fns["planes16"] = lambda: ops.conv3x3_planes(pl16, cin, wpl16, dil=2, bias=bias, act=1, out_chunk0=12)
         flops = 2.0 * B * H * W * 32 * 9 * cin
         for k, (med, mn) in time_all(fns).items():
             tf = flops / med / 1e9
@@ -78,10 +83,15 @@ def main():
         ops.conv2d(buf[..., :cin], wsplit, 32, 3, pad=2, dil=2, bias=bias, act=1, out=buf[..., 192:224])
         ops.linear(buf, w1pk, 64, bias=b1, act=1, res=x64, out=out)
 
+    wpl16, w1pl16 = ops.pack_weight_planes16(w), ops.pack_weight_planes16(w1)
     fns = {"split + 1x1 gemm (r1)": r1,
            "planes fused tail": lambda: ops.conv3x3_planes(pl, cin, wpl, dil=2, bias=bias, act=1, tail=(w1pl, b1, x64, out, 1)),
+           "planes16 fused tail": lambda: ops.conv3x3_planes(pl16, cin, wpl16, dil=2, bias=bias, act=1, tail=(w1pl16, b1, x64, out, 1)),
            "planes_from_f32 64ch": lambda: pl.load_f32(x64, 0),
+           "planes16_from_f32 64ch": lambda: pl16.load_f32(x64, 0),
            "1x1 gemm 224->64 alone": lambda: ops.linear(buf, w1pk, 64, bias=b1, act=1, res=x64, out=out)}
+    if args.kernel in ("planes16", "planes+16"):
+        fns.pop("split + 1x1 gemm (r1)"), fns.pop("1x1 gemm 224->64 alone")
     for k, (med, mn) in time_all(fns).items():
         print(f"tail B{B} {k:26s} median {med:7.3f} ms (min {mn:7.3f})", flush=True)
     # whole DRDB, both paths, through the module
@@ -97,7 +107,10 @@ def main():
         ops.set_conv3x3_mode(prev)
 
     with torch.no_grad():
-        fns = {"DRDB bf16x6 (r1)": drdb_r1, "DRDB planes": lambda: blk.forward_planes(x, pl, out=out)}
+        fns = {"DRDB bf16x6 (r1)": drdb_r1, "DRDB planes": lambda: blk.forward_planes(x, pl, out=out),
+               "DRDB planes16": lambda: blk.forward_planes(x, pl16, out=out)}
+        if args.kernel in ("planes16", "planes+16"):
+            fns.pop("DRDB bf16x6 (r1)")
         for k, (med, mn) in time_all(fns, rounds=5, iters=2).items():
             print(f"drdb B{B} {k:20s} median {med:7.3f} ms (min {mn:7.3f})", flush=True)
 
