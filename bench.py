@@ -273,6 +273,20 @@ def main():
 
     elapsed = dist.max_over_ranks(elapsed)
 
+    # for continuity with rounds 1-2: the same step with the fusion net's planes as bf16 triples (6 products per MAC)
+    elapsed_bf16 = None
+    if ops.conv3x3_mode() == "planes16" and not args.graph and not args.no_extras:
+        prev_mode = ops.set_conv3x3_mode("planes")
+        with torch.no_grad():
+            step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            elapsed_bf16 = dist.max_over_ranks(time.perf_counter() - t0)
+        ops.set_conv3x3_mode(prev_mode)
+
     # beside the headline, never in it: the same step with the two encoder stages whose outputs forward_fusion() discards
     # (the reference computes and drops them, core/mix_transformer.py:358-375) not computed - identical results
     enc = seg.denoise_net.encoder
@@ -307,7 +321,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if all_fp32 else "f32 (large contractions: fp32-equivalent 3-way bf16 split, 6 MFMA products; see arithmetic_modes)",
+            "dtype": "f32" if all_fp32 else (
+                "f32 (large contractions on split operands, fp32-class: the fusion net's 3x3 convs as half pairs x 3 f16 MFMA "
+                "products under a range guard, the rest as bf16 triples x 6 products; see arithmetic_modes)"
+                if ops.conv3x3_mode() == "planes16" else
+                "f32 (large contractions: fp32-equivalent 3-way bf16 split, 6 MFMA products; see arithmetic_modes)"),
+            "f16x3_range_fallbacks": int(getattr(fus, "planes16_fallbacks", 0)),
             "conv3x3_mode": ops.conv3x3_mode(),
             "arithmetic_modes": {"conv3x3": ops.conv3x3_mode(), "linear": ops.linear_mode(), "crosspath": ops.crosspath_mode(),
                                  "attention": ops.attention_mode()},
@@ -359,7 +378,16 @@ def main():
                 "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                 "launches_timed": n, "avg_launch_ms": ms, "avg_launch_gflop": flops / 1e9,
+                # the same launch against the memory side (planes16 sits near the ridge: 112 flop per algorithmic byte
+                # against 833 TFLOP/s / 8 TB/s = 104)
+                "hbm_side": {"algorithmic_GBps": alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "peak_GBps": 8000.0,
+                             "frac": alg_bytes / (ms * 1e-3) / 8e12 if ms > 0 else 0.0},
             }
+        if elapsed_bf16 is not None:
+            out["with_bf16x6_planes"] = {
+                "value": pairs / elapsed_bf16, "ms_per_step": 1000.0 * elapsed_bf16 / args.steps,
+                "note": "the same step with SEGMIF_CONV3X3=planes (rounds 1-2 arithmetic: bf16 triples, six products per MAC, no "
+                        "range guard needed) - what a forward falls back to when the f16x3 guard trips"}
         if elapsed_dse is not None:
             out["without_discarded_encoder_stages"] = {
                 "value": pairs / elapsed_dse, "ms_per_step": 1000.0 * elapsed_dse / args.steps,

@@ -567,15 +567,33 @@ class Fusion_Network3_ac(nn.Module):
         y1 = self.DRDB3.forward_planes(x1, pls[0], out=y1, preloaded=pre)
         y2 = self.DRDB4.forward_planes(x2, pls[1], out=y2, preloaded=pre)
         del pls, xs, x1, x2
-        if guard is not None and not guard.ok():
-            del y1, y2
-            self.planes16_fallbacks += 1
-            return self._forward_eval_planes(ir, vis, seg1_fn, seg2_fn, _force_bf16=True)
         seg = seg2_fn()
         cat = torch.empty((B, H, W, 128), device=dev, dtype=torch.float32)
-        self.ffm.forward_nhwc(y1, y2, seg, out1=cat[..., :64], out2=cat[..., 64:])
-        f = ops.conv2d(cat, self._w3("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)
-        f = ops.conv2d(f, self._w3("conv21"), 32, 3, pad=1, bias=self.conv21.bias, act=PRELU, prelu=slope)
+        if pre and ops.aligned16(self.conv2.bias, self.conv21.bias):
+            # conv2 (128 -> 64) and conv21 (64 -> 32) on the planes kernel as well: the second interaction's tails write the
+            # concatenated tensor pre-split (chunks 0-7), conv2 = two 32-channel launches appending chunks 8-11, conv21
+            # reads those and hands fp32 rows to the conv22 stencil
+            pc = ops.Planes(B, H, W, 12, dev, guard)
+            self.ffm.forward_nhwc(y1, y2, seg, out1=cat[..., :64], out2=cat[..., 64:], planes1=pc, planes2=pc.at(4))
+            del cat, y1, y2
+            sfx, pack = ("h", ops.pack_weight_planes16) if pc.f16 else ("", ops.pack_weight_planes)
+            for half in (0, 1):
+                rows = slice(32 * half, 32 * half + 32)
+                wt = self._pk.get(f"conv2:p{half}{sfx}", self.conv2.weight, lambda w, rows=rows: pack(w[rows]))
+                ops.conv3x3_planes(pc, 128, wt, dil=1, bias=self.conv2.bias[rows], act=PRELU, prelu=slope, out_chunk0=8 + 2 * half)
+            f = torch.empty((B, H, W, 32), device=dev, dtype=torch.float32)
+            ops.conv3x3_planes(pc.at(8), 64, self._pk.get(f"conv21:p{sfx}", self.conv21.weight, pack), dil=1,
+                               bias=self.conv21.bias, act=PRELU, prelu=slope, out=f)
+            del pc
+        else:
+            self.ffm.forward_nhwc(y1, y2, seg, out1=cat[..., :64], out2=cat[..., 64:])
+            del y1, y2
+            f = ops.conv2d(cat, self._w3("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)
+            f = ops.conv2d(f, self._w3("conv21"), 32, 3, pad=1, bias=self.conv21.bias, act=PRELU, prelu=slope)
+        if guard is not None and not guard.ok():  # one read-back per forward, after the last producer of half pairs
+            del f
+            self.planes16_fallbacks += 1
+            return self._forward_eval_planes(ir, vis, seg1_fn, seg2_fn, _force_bf16=True)
         f = self._conv22(f, slope)
         return f.view(B, 1, H, W)
 

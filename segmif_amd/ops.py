@@ -83,7 +83,7 @@ class SplitWeight:
 
 
 _CONV3X3_MODES = ("planes", "planes16", "bf16x6", "fp32")
-_conv3x3_mode = os.environ.get("SEGMIF_CONV3X3", "planes")
+_conv3x3_mode = os.environ.get("SEGMIF_CONV3X3", "planes16")
 if _conv3x3_mode not in _CONV3X3_MODES:
     raise RuntimeError(f"SEGMIF_CONV3X3 must be one of {_CONV3X3_MODES}, got {_conv3x3_mode!r}")
 
@@ -114,10 +114,11 @@ def conv3x3_mode():
 
 def set_conv3x3_mode(mode):
     """'bf16x6': 3x3 stride-1 convs with Cin % 16 == 0 run on the bf16 matrix pipe with 3-way split
-    operands (fp32-class accuracy, 2.7x the fp32 MFMA rate); 'planes' (default): the same, and a DRDB in
-    inference keeps its activations pre-split in a planes buffer (csrc/conv3x3_planes.hip); 'planes16': as 'planes' with
-    the DRDBs on half-precision pairs and three products per MAC (f16x3; guarded by Planes16Guard, falls back to
-    'planes' when an activation tensor leaves the half's exponent range); 'fp32': exact-fp32 MFMA everywhere."""
+    operands (fp32-class accuracy, 2.7x the fp32 MFMA rate); 'planes': the same, and the fusion net's DRDBs and closing
+    convs in inference keep their activations pre-split in a planes buffer (csrc/conv3x3_planes.hip); 'planes16' (default):
+    as 'planes' with half-precision pairs and three products per MAC (f16x3, the same error class at half the matrix
+    work; guarded by Planes16Guard: a forward whose planes leave the half's exponent range is repeated in 'planes');
+    'fp32': exact-fp32 MFMA everywhere.  Training always uses the bf16x6 / fp32 kernels."""
     global _conv3x3_mode
     if mode not in _CONV3X3_MODES:
         raise ValueError(f"mode must be one of {_CONV3X3_MODES}")
@@ -178,11 +179,11 @@ class Planes:
     """A planes buffer (include/segmif_hip.h, segmif_planes_*): `chunks` 16-channel chunk images per batch
     element, each activation stored as three bf16 planes (guard=None) or, with a Planes16Guard, as a pair of
     halves (f16x3); zero border already cleared."""
-    __slots__ = ("data", "B", "H", "W", "chunks", "guard")
+    __slots__ = ("data", "B", "H", "W", "chunks", "guard", "first")
 
     def __init__(self, B, H, W, chunks, device, guard=None):
         lib = _lib.load()
-        self.B, self.H, self.W, self.chunks, self.guard = B, H, W, chunks, guard
+        self.B, self.H, self.W, self.chunks, self.guard, self.first = B, H, W, chunks, guard, 0
         nbytes, zero = (lib.segmif_planes_bytes, lib.segmif_planes_zero_border) if guard is None else \
             (lib.segmif_planes16_bytes, lib.segmif_planes16_zero_border)
         self.data = torch.empty((nbytes(B, H, W, chunks),), device=device, dtype=torch.uint8)
@@ -192,11 +193,32 @@ class Planes:
     def f16(self):
         return self.guard is not None
 
+    def at(self, chunk0):
+        """The same buffer addressed from chunk image `chunk0` on: producers and consumers number chunks relative to the
+        base pointer they are given (the per-batch-element stride stays `chunks` images)."""
+        if not 0 <= chunk0 < self.chunks:
+            raise RuntimeError(f"planes: chunk {chunk0} outside a buffer of {self.chunks}")
+        v = object.__new__(Planes)
+        v.B, v.H, v.W, v.chunks, v.guard, v.first = self.B, self.H, self.W, self.chunks, self.guard, self.first + chunk0
+        v.data = self.data[chunk0 * self.chunk_bytes:]
+        return v
+
+    def need(self, n, what):
+        """n chunk images counted from this view's base must exist (the C side only knows the buffer's total)."""
+        if self.first + n > self.chunks:
+            raise RuntimeError(f"{what}: needs {n} chunk images from chunk {self.first} of a {self.chunks}-chunk planes buffer")
+
+    @property
+    def chunk_bytes(self):
+        hp, wp = (self.H + 7) // 8 * 8 + 4, (self.W + 31) // 32 * 32 + 4
+        return hp * wp * (64 if self.f16 else 96)
+
     def load_f32(self, x, chunk0=0):
         """x: (B, H, W, C) rows view, C % 16 == 0 -> chunks [chunk0, chunk0 + C/16)."""
         _, C, ldx = rows_view(x, "x")
         if tuple(x.shape[:3]) != (self.B, self.H, self.W) or C % 16:
             raise RuntimeError(f"planes: x shape {tuple(x.shape)} does not fit ({self.B}, {self.H}, {self.W}, 16k)")
+        self.need(chunk0 + C // 16, "planes.load_f32")
         lib = _lib.load()
         if self.guard is None:
             _lib.check(lib.segmif_planes_from_f32(x.data_ptr(), ldx, self.data.data_ptr(), self.B, self.H, self.W,
@@ -244,6 +266,7 @@ def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None,
     out1 = res + act1(W1 . [input | result] + bias1)."""
     if not isinstance(wt, PlanesWeight) or (wt.N, wt.cin, wt.taps, wt.f16) != (32, cin, 9, planes.f16):
         raise RuntimeError("conv3x3_planes: weight image does not fit")
+    planes.need(max(cin // 16, (out_chunk0 + 2) if out_chunk0 is not None else 0), "conv3x3_planes")
     d = _lib.SegmifConvPlanes()
     d.planes_in, d.wt = planes.data.data_ptr(), wt.data.data_ptr()
     d.B, d.H, d.W, d.cin, d.dil = planes.B, planes.H, planes.W, cin, dil
@@ -540,6 +563,7 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
     if planes is not None:
         if isinstance(wt, SplitWeight) or (planes.B, planes.H, planes.W) != (B, OH, OW):
             raise RuntimeError("conv2d: planes output needs fp32-packed weights and a planes buffer of the output geometry")
+        planes.need(planes_chunk0 + N // 16, "conv2d planes output")
         d.planes_out, d.planes_chunks, d.planes_chunk0 = planes.data.data_ptr(), planes.chunks, planes_chunk0
         if planes.f16:
             d.planes_f16, d.planes_amax = 1, planes.guard.slot()
@@ -806,6 +830,7 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
     if planes is not None:
         if hw is None or hw[0] * hw[1] != N or (planes.B, planes.H, planes.W) != (B, hw[0], hw[1]):
             raise RuntimeError("crosspath_tail: planes geometry does not match the tokens")
+        planes.need(4, "crosspath_tail planes output")
         d.planes_out, d.H, d.W, d.planes_chunks = planes.data.data_ptr(), hw[0], hw[1], planes.chunks
         if planes.f16:
             d.planes_f16, d.planes_amax = 1, planes.guard.slot()

@@ -41,15 +41,22 @@ class PairForward:
         if ops.launch_timer_active():
             raise RuntimeError("disable the launch timer before graph capture")
         self._static = [t.clone() for t in (ir, vis, mask3)]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):  # packs weights, raises LDS limits, warms the allocator
-                self.eager(*self._static)
-        torch.cuda.current_stream().wait_stream(side)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self._graph):
-            self._out = self.eager(*self._static)
+        # the f16x3 planes path ends a forward with a host read-back of its range guard, which a captured graph cannot hold:
+        # a graph is recorded on the guard-free bf16x6 planes kernels
+        prev = ops.set_conv3x3_mode("planes") if ops.conv3x3_mode() == "planes16" else None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(warmup):  # packs weights, raises LDS limits, warms the allocator
+                    self.eager(*self._static)
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self._graph):
+                self._out = self.eager(*self._static)
+        finally:
+            if prev is not None:
+                ops.set_conv3x3_mode(prev)
         return self
 
     def replay(self, ir=None, vis=None, mask3=None):

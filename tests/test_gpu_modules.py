@@ -151,9 +151,10 @@ def test_crosspath_in_both_modes(net_b1, fus, golden_dir):
 
 
 def test_fusion_net_in_all_conv3x3_modes(net_b1, fus, golden_dir):
-    """The 3x3 convs have three modes (planes, default: bf16x6 arithmetic with the DRDBs on pre-split
-    activations and the fused 1x1 tail; bf16x6: split operands made on the fly; fp32: exact-fp32 MFMA): all
-    must meet the same reference fixtures, and agree with each other far inside the parity tolerance."""
+    """The 3x3 convs have four modes (planes16, default: the DRDBs and closing convs on pre-split half pairs, three f16
+    products per MAC, range-guarded; planes: the same on bf16 triples, six products; bf16x6: split operands made on the
+    fly; fp32: exact-fp32 MFMA): all must meet the same reference fixtures, and agree with each other far inside the
+    parity tolerance."""
     from segmif_amd import ops
     g = load(golden_dir, "fusion_blocks.npz")
     gp = load(golden_dir, "pair_b1_64x96.npz")
@@ -163,7 +164,7 @@ def test_fusion_net_in_all_conv3x3_modes(net_b1, fus, golden_dir):
     try:
         with torch.no_grad():
             out0, out1 = net_b1.denoise_net.encoder.forward_fusion(mask)
-            for mode in ("planes", "bf16x6", "fp32"):
+            for mode in ("planes16", "planes", "bf16x6", "fp32"):
                 ops.set_conv3x3_mode(mode)
                 y = fus.DRDB1(torch.from_numpy(g["drdb_x"]).cuda())
                 assert rel(y, g["drdb_y"]) < TIGHT, mode
@@ -172,7 +173,7 @@ def test_fusion_net_in_all_conv3x3_modes(net_b1, fus, golden_dir):
                 outs[mode] = (y, yf)
     finally:
         ops.set_conv3x3_mode(prev)
-    for mode in ("planes", "bf16x6"):
+    for mode in ("planes16", "planes", "bf16x6"):
         assert rel(outs[mode][0], outs["fp32"][0].cpu()) < 2e-6, mode
         assert rel(outs[mode][1], outs["fp32"][1].cpu()) < 5e-6, mode
 
