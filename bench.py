@@ -326,7 +326,7 @@ def main():
                 "products under a range guard, the rest as bf16 triples x 6 products; see arithmetic_modes)"
                 if ops.conv3x3_mode() == "planes16" else
                 "f32 (large contractions: fp32-equivalent 3-way bf16 split, 6 MFMA products; see arithmetic_modes)"),
-            "f16x3_range_fallbacks": int(getattr(fus, "planes16_fallbacks", 0)),
+            "f16x3_range_fallbacks": ops.range_fallbacks(),
             "conv3x3_mode": ops.conv3x3_mode(),
             "arithmetic_modes": {"conv3x3": ops.conv3x3_mode(), "linear": ops.linear_mode(), "crosspath": ops.crosspath_mode(),
                                  "attention": ops.attention_mode()},

@@ -144,6 +144,13 @@ typedef struct SegmifGemmSplit {
 int64_t segmif_gemm_split_weight_bytes(int N, int K);
 int segmif_gemm_split_pack(const float* w, int N, int K, int ldw, void* out, void* stream);
 int segmif_gemm_split_f32(const SegmifGemmSplit* desc, void* stream);
+/* The same GEMM with f16x3 arithmetic (half pairs x three products, see segmif_planes16_* below): A is split in the kernel,
+ * max |A| of the staged rows is folded into *amax (NULL = off) - the caller must re-run on segmif_gemm_split_f32 when it
+ * left [2^-13, 65504); `w` is the segmif_gemm_split16_pack image (the bf16 image's layout with scaled half planes, then
+ * one float 2^-e(n) per padded output column). */
+int64_t segmif_gemm_split16_weight_bytes(int N, int K);
+int segmif_gemm_split16_pack(const float* w, int N, int K, int ldw, void* out, void* stream);
+int segmif_gemm_split16_f32(const SegmifGemmSplit* desc, uint32_t* amax, void* stream);
 
 /*
  * "Planes" activations: the bf16x6 operand split done ONCE by the producer instead of in every

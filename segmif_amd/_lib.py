@@ -75,6 +75,9 @@ SIGNATURES = {
     "segmif_gemm_split_weight_bytes": (c_int64, [c_int, c_int]),
     "segmif_gemm_split_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "segmif_gemm_split_f32": (c_int, [POINTER(SegmifGemmSplit), c_void_p]),
+    "segmif_gemm_split16_weight_bytes": (c_int64, [c_int, c_int]),
+    "segmif_gemm_split16_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "segmif_gemm_split16_f32": (c_int, [POINTER(SegmifGemmSplit), c_void_p, c_void_p]),
     "segmif_planes_dims": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "segmif_planes_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "segmif_planes_zero_border": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -101,7 +101,7 @@ def _gemm(x, w_nk, N, bias=None, act=ACT_NONE):
     # (measured at 8 images per step: with the per-call weight packing the bf16x6 GEMM only pays for the full-resolution
     # problems of the fusion net; the encoder's Linears - at most 153 600 rows - are 2.5 ms per step faster on the fp32 tiles)
     if rows >= TRAIN_SPLIT_MIN_ROWS and ops.linear_wants_split(rows, N, K):
-        return ops.linear_auto(x, ops.pack_linear(w_nk), N, bias=bias, act=act)
+        return ops.linear_auto(x, ops.pack_linear(w_nk, half=False), N, bias=bias, act=act)
     wt = w_nk if (K % 16 == 0 and w_nk.is_contiguous()) else ops.pack_weight(w_nk)
     return ops.linear(x, wt, N, bias=bias, act=act)
 

@@ -162,12 +162,10 @@ class DRDB(nn.Module):
         B, _, H, W = x.shape
         if self.planes_ok():
             xh = ops.to_nhwc(x)
-            if ops.conv3x3_mode() == "planes16":  # f16x3, re-run on bf16 triples if a tensor left the half's range
-                guard = ops.Planes16Guard(x.device)
-                y = self.forward_planes(xh, ops.Planes(B, H, W, self.PLANES_CHUNKS, x.device, guard))
-                if guard.ok():
-                    return ops.as_nchw(y)
-            return ops.as_nchw(self.forward_planes(xh, ops.Planes(B, H, W, self.PLANES_CHUNKS, x.device)))
+            # 'planes16': half pairs inside a guarded scope; repeated on bf16 triples if a tensor left the half's range
+            return ops.as_nchw(ops.run_guarded(
+                lambda: self.forward_planes(xh, ops.Planes(B, H, W, self.PLANES_CHUNKS, x.device, ops.active_guard())),
+                x.device, enabled=ops.conv3x3_mode() == "planes16"))
         buf = self.new_buffer(B, H, W, x.device)
         buf[..., :self.in_ch].copy_(x.permute(0, 2, 3, 1))
         return ops.as_nchw(self.forward_buffer(buf))
@@ -543,15 +541,24 @@ class Fusion_Network3_ac(nn.Module):
         return f.view(B, 1, H, W)
 
 
-    def _forward_eval_planes(self, ir, vis, seg1_fn, seg2_fn, _force_bf16=False):
-        """_forward_eval with the four DRDBs on pre-split activations: two planes scratch buffers (one per
-        modality, reused by DRDB1 -> DRDB3 and DRDB2 -> DRDB4), 64-channel fp32 tensors between the blocks."""
+    def _forward_eval_planes(self, ir, vis, seg1_fn, seg2_fn):
+        """_forward_eval with the four DRDBs and the closing convs on pre-split activations.  In 'planes16' mode the body
+        runs in a guarded scope (its own, or the caller's - segmif_amd.pipeline.PairForward opens one around the whole pair
+        forward): half pairs while a guard is active, and the scope repeats the forward on bf16 triples if a planes tensor
+        left the half's exponent range."""
+        before = ops.range_fallbacks()
+        out = ops.run_guarded(lambda: self._eval_planes_body(ir, vis, seg1_fn, seg2_fn), ir.device,
+                              enabled=ops.conv3x3_mode() == "planes16")
+        self.planes16_fallbacks += ops.range_fallbacks() - before
+        return out
+
+    def _eval_planes_body(self, ir, vis, seg1_fn, seg2_fn):
+        """Two planes scratch buffers (one per modality, reused by DRDB1 -> DRDB3 and DRDB2 -> DRDB4), 64-channel fp32
+        tensors between the blocks; a third buffer for the concatenated tensor and conv2's output."""
         B, _, H, W = ir.shape
         dev, slope = ir.device, self.relu.weight
         PRELU = ops.ACT_PRELU
-        # 'planes16': the DRDBs on half pairs (f16x3); the forward is repeated on the bf16x6 kernels if the guard saw a planes
-        # tensor outside the half's exponent range.
-        guard = ops.Planes16Guard(dev) if ops.conv3x3_mode() == "planes16" and not _force_bf16 else None
+        guard = ops.active_guard() if ops.conv3x3_mode() == "planes16" else None  # half pairs iff a guarded scope is running
         xs, pls = [], []
         for x, conv, name in ((ir, self.conv1_ir, "conv1_ir"), (vis, self.conv1_vis, "conv1_vis")):
             pls.append(ops.Planes(B, H, W, DRDB.PLANES_CHUNKS, dev, guard))
@@ -590,10 +597,6 @@ class Fusion_Network3_ac(nn.Module):
             del y1, y2
             f = ops.conv2d(cat, self._w3("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)
             f = ops.conv2d(f, self._w3("conv21"), 32, 3, pad=1, bias=self.conv21.bias, act=PRELU, prelu=slope)
-        if guard is not None and not guard.ok():  # one read-back per forward, after the last producer of half pairs
-            del f
-            self.planes16_fallbacks += 1
-            return self._forward_eval_planes(ir, vis, seg1_fn, seg2_fn, _force_bf16=True)
         f = self._conv22(f, slope)
         return f.view(B, 1, H, W)
 

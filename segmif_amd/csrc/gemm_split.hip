@@ -11,6 +11,11 @@
 // LDS rows are [K half][plane][16 bf16] = 192 bytes + 16 of padding: 13 sixteen-byte slots per row, so the 16 lanes of
 // a ds_read_b128 service group land on 16 distinct slots.  53 KB per workgroup: three workgroups share a CU and cover
 // each other's staging phases.
+//
+// F16 = true ("f16x3", segmif_gemm_split16_*; the format and its range guard are described in conv3x3_planes.hip /
+// planes16.h): A is split into half pairs (144-byte LDS rows: 2 K halves x 2 planes x 32 B + 16), the weight image keeps
+// its 208-byte rows with the planes W0 | W - W0 | 2^-11 W0 of the row scaled by 2^e(n), three products per MAC, the
+// epilogue multiplies by 2^-e(n); max |A| of what a workgroup staged is folded into the guard slot.
 #include <hip/hip_runtime.h>
 #include "device_once.h"
 #include <stdint.h>
@@ -18,11 +23,14 @@
 #include <string.h>
 
 #include "igemm_common.h"
+#include "planes16.h"
 #include "segmif_hip.h"
 
 namespace segmif {
 namespace {
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -44,6 +52,7 @@ __device__ unsigned long long gemm_timeline[1024][16][8];
 constexpr int GBM = 128, GBN = 128, GBK = 32;
 constexpr int GPITCH = 208;                   // bytes per LDS row
 constexpr int GTILE = GBM * GPITCH;           // 26 624 bytes = 26 DMA instructions of 1 KB
+constexpr int GPITCH_H = 144;                 // f16x3: bytes per LDS row of A (9 sixteen-byte slots: odd, conflict-free)
 
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
   f32x2 v = {a, b};
@@ -70,12 +79,24 @@ struct GemmSplitK {
   int N, K, lda, ldo, ldr, act;
   int ntm, ntn;
   int epi;  // 1: the output leaves through LDS (rows written 256 contiguous bytes at a time), 0: straight from the accumulators
+  const float* wscale;  // f16x3: 2^-e(n) per (padded) output column
+  uint32_t* amax;       // f16x3: guard slot for max |A| (or null)
 };
 
+template <bool F16>
+__device__ __forceinline__ f32x16 gemm_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16>
 __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
+  constexpr int APITCH = F16 ? GPITCH_H : GPITCH;   // LDS row of A
+  constexpr int AHALF = F16 ? 64 : 96;              // bytes per K half of an A row
+  constexpr int NPA = F16 ? 2 : 3, NPROD = F16 ? 3 : 6;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
   unsigned char* As = smem_g;
-  unsigned char* Bs = smem_g + GTILE;
+  unsigned char* Bs = smem_g + GBM * APITCH;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -102,9 +123,10 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
     const int row = (tid >> 3) + 32 * j;
     a_ok[j] = m0 + row < p.M;
     a_ptr[j] = p.a + (a_ok[j] ? (m0 + row) : 0) * (long long)p.lda + kq * 4;
-    a_dst[j] = row * GPITCH + (kq >> 2) * 96 + (kq & 3) * 8;
+    a_dst[j] = row * APITCH + (kq >> 2) * AHALF + (kq & 3) * 8;
   }
   f32x4 ra[4];
+  float amx = 0.f;  // f16x3: largest |A| this lane has split
   auto gload = [&](int ks) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(a_ptr[j] + ks * GBK);
@@ -113,12 +135,21 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x4 x = a_ok[j] ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-      uint32_t p0a, p1a, p2a, p0b, p1b, p2b;
-      split3(x[0], x[1], p0a, p1a, p2a);
-      split3(x[2], x[3], p0b, p1b, p2b);
-      *reinterpret_cast<u32x2*>(As + a_dst[j]) = u32x2{p0a, p0b};
-      *reinterpret_cast<u32x2*>(As + a_dst[j] + 32) = u32x2{p1a, p1b};
-      *reinterpret_cast<u32x2*>(As + a_dst[j] + 64) = u32x2{p2a, p2b};
+      if constexpr (F16) {
+        uint32_t ha, la, hb, lb;
+        p16::split2(x[0], x[1], ha, la);
+        p16::split2(x[2], x[3], hb, lb);
+        *reinterpret_cast<u32x2*>(As + a_dst[j]) = u32x2{ha, hb};
+        *reinterpret_cast<u32x2*>(As + a_dst[j] + 32) = u32x2{la, lb};
+        amx = fmaxf(fmaxf(amx, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
+      } else {
+        uint32_t p0a, p1a, p2a, p0b, p1b, p2b;
+        split3(x[0], x[1], p0a, p1a, p2a);
+        split3(x[2], x[3], p0b, p1b, p2b);
+        *reinterpret_cast<u32x2*>(As + a_dst[j]) = u32x2{p0a, p0b};
+        *reinterpret_cast<u32x2*>(As + a_dst[j] + 32) = u32x2{p1a, p1b};
+        *reinterpret_cast<u32x2*>(As + a_dst[j] + 64) = u32x2{p2a, p2b};
+      }
     }
   };
   const unsigned char* __restrict__ wt = p.w + (long long)nt * nks * GTILE + lane * 16;
@@ -141,10 +172,11 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-  const unsigned char* a_lane = As + (wm * 64 + r) * GPITCH + h * 16;
+  const unsigned char* a_lane = As + (wm * 64 + r) * APITCH + h * 16;
   const unsigned char* b_lane = Bs + (wn * 64 + r) * GPITCH + h * 16;
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first
-  constexpr int PW[6] = {0, 1, 2, 0, 1, 0};
+  // products, least significant first (A plane, W plane): bf16x6 a2 w0, a1 w1, a0 w2, a1 w0, a0 w1, a0 w0; f16x3 l W0s, a0 Wl, a0 W0
+  constexpr int PA[6] = {F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0, 0};
+  constexpr int PW[6] = {F16 ? 2 : 0, 1, F16 ? 0 : 2, 0, 1, 0};
 
   // Single-buffered on purpose: three workgroups per CU cover each other's staging phases.  (An 8-wave, LDS
   // double-buffered variant with one barrier per step at one workgroup per CU measured 10 % slower over the encoder's
@@ -160,21 +192,20 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
     if (more) gload(ks + 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 fa[2][3], fb[2][3];
+      u32x4 fa[2][NPA], fb[2][3];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-          fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_lane + i * 32 * GPITCH + s * 96 + pl * 32);
-          fb[i][pl] = *reinterpret_cast<const bf16x8*>(b_lane + i * 32 * GPITCH + s * 96 + pl * 32);
+          if (pl < NPA) fa[i][pl] = *reinterpret_cast<const u32x4*>(a_lane + i * 32 * APITCH + s * AHALF + pl * 32);
+          fb[i][pl] = *reinterpret_cast<const u32x4*>(b_lane + i * 32 * GPITCH + s * 96 + pl * 32);
         }
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][PW[t]], fa[i][PA[t]], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = gemm_mfma<F16>(fb[j][PW[t]], fa[i][PA[t]], acc[i][j]);
     }
     GEMM_TL(ks, 1);
     __syncthreads();  // every wave is done reading this step's tiles
@@ -191,6 +222,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
     GEMM_TL(ks, 6);
   }
   GEMM_TL(15, 7);
+  if constexpr (F16) {
+    if (p.amax) p16::fold_max(p.amax, amx);
+  }
 
   // ---- epilogue: bias + activation (+ residual).  The products run transposed (weights as the MFMA's row operand), so a
   // lane owns one output row and its registers 4g .. 4g+3 are four consecutive columns: 16-byte stores, a quarter of the
@@ -211,6 +245,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
           const int cl = j * 32 + 8 * g + 4 * h;
           const int n = n0 + wn * 64 + cl;
           f32x4 y = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if constexpr (F16) y *= *reinterpret_cast<const f32x4*>(p.wscale + n);  // (the scale array covers the padded columns)
           if (p.bias && n < p.N) y += *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -247,6 +282,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
         const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
         if (n >= p.N) continue;  // N % 4 == 0: a group of four is inside or outside as a whole
         f32x4 y = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if constexpr (F16) y *= *reinterpret_cast<const f32x4*>(p.wscale + n);
         if (p.bias) y += *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -282,6 +318,42 @@ __global__ void gemm_split_pack_kernel(const float* __restrict__ w, int N, int K
   if (kk < 8) out[(((long long)nt * nks + ks) * GBM + row) * (GPITCH / 2) + 96 + kk] = 0;  // the 16 padding bytes
 }
 
+// f16x3 weights: row scale 2^-e(n) (2^14 <= 2^e max|w[n][.]| < 2^15; 1 for vanishing rows and for the padding rows)
+__global__ void gemm_split16_scale_kernel(const float* __restrict__ w, int N, int K, int ldw, float* __restrict__ inv_scale) {
+  const int n = blockIdx.x;  // grid = padded N
+  float mx = 0.f;
+  if (n < N)
+    for (int k = threadIdx.x; k < K; k += 64) mx = fmaxf(mx, fabsf(w[(long long)n * ldw + k]));
+  mx = p16::wave_max(mx);
+  if (threadIdx.x == 0) {
+    int e = 0;
+    if (mx >= 1e-30f && mx <= 3e38f) e = 14 - (int)((__float_as_uint(mx) >> 23) - 127);
+    inv_scale[n] = ldexpf(1.f, -e);
+  }
+}
+
+// same image as gemm_split_pack_kernel with the planes W0 | W - W0 | 2^-11 W0 of the scaled row (halves)
+__global__ void gemm_split16_pack_kernel(const float* __restrict__ w, int N, int K, int ldw, int nks, long long total,
+                                         const float* __restrict__ inv_scale, uint16_t* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int kk = (int)(idx & 31);
+  long long t = idx >> 5;
+  const int row = (int)(t & 127); t >>= 7;
+  const int ks = (int)(t % nks);
+  const int nt = (int)(t / nks);
+  const int n = nt * GBN + row, k = ks * GBK + kk;
+  const float x = (n < N && k < K) ? w[(long long)n * ldw + k] * (1.f / inv_scale[n]) : 0.f;  // exact: power of two
+  const _Float16 w0 = (_Float16)x;
+  const _Float16 wl = (_Float16)(x - (float)w0);
+  const _Float16 ws = (_Float16)((float)w0 * (1.f / p16::LSCALE));
+  uint16_t* dst = out + (((long long)nt * nks + ks) * GBM + row) * (GPITCH / 2) + (kk >> 4) * 48 + (kk & 15);
+  dst[0] = __builtin_bit_cast(uint16_t, w0);
+  dst[16] = __builtin_bit_cast(uint16_t, wl);
+  dst[32] = __builtin_bit_cast(uint16_t, ws);
+  if (kk < 8) out[(((long long)nt * nks + ks) * GBM + row) * (GPITCH / 2) + 96 + kk] = 0;  // the 16 padding bytes
+}
+
 }  // namespace
 }  // namespace segmif
 
@@ -307,7 +379,31 @@ extern "C" int segmif_gemm_split_pack(const float* w, int N, int K, int ldw, voi
   return (int)hipGetLastError();
 }
 
-extern "C" int segmif_gemm_split_f32(const SegmifGemmSplit* d, void* stream) {
+extern "C" int64_t segmif_gemm_split16_weight_bytes(int N, int K) {
+  const int64_t image = segmif_gemm_split_weight_bytes(N, K);  // + one float per padded output column: 2^-e(n)
+  return image ? image + (int64_t)((N + GBN - 1) / GBN) * GBN * 4 : 0;
+}
+
+extern "C" int segmif_gemm_split16_pack(const float* w, int N, int K, int ldw, void* out, void* stream) {
+  if (!w || !out || segmif_gemm_split_weight_bytes(N, K) == 0 || ldw < K) return SEGMIF_EINVAL;
+  const int nks = K / GBK, npad = (N + GBN - 1) / GBN * GBN;
+  const long long total = (long long)(npad / GBN) * nks * GBM * GBK;
+  float* inv_scale = reinterpret_cast<float*>((unsigned char*)out + segmif_gemm_split_weight_bytes(N, K));
+  hipLaunchKernelGGL(gemm_split16_scale_kernel, dim3((unsigned)npad), dim3(64), 0, (hipStream_t)stream, w, N, K, ldw, inv_scale);
+  hipLaunchKernelGGL(gemm_split16_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, K,
+                     ldw, nks, total, inv_scale, (uint16_t*)out);
+  return (int)hipGetLastError();
+}
+
+static int gemm_split_impl(const SegmifGemmSplit* d, bool f16, uint32_t* amax, void* stream);
+
+extern "C" int segmif_gemm_split_f32(const SegmifGemmSplit* d, void* stream) { return gemm_split_impl(d, false, nullptr, stream); }
+
+extern "C" int segmif_gemm_split16_f32(const SegmifGemmSplit* d, uint32_t* amax, void* stream) {
+  return gemm_split_impl(d, true, amax, stream);
+}
+
+static int gemm_split_impl(const SegmifGemmSplit* d, bool f16, uint32_t* amax, void* stream) {
   if (!d || !d->a || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % GBK) return SEGMIF_EINVAL;
   if (d->lda < d->K || (d->lda & 3) || ((uintptr_t)d->a & 15) || ((uintptr_t)d->w & 15)) return SEGMIF_EINVAL;
   if (d->act == SEGMIF_ACT_PRELU && !d->prelu) return SEGMIF_EINVAL;
@@ -322,14 +418,20 @@ extern "C" int segmif_gemm_split_f32(const SegmifGemmSplit* d, void* stream) {
   }
   k.ntm = (int)((d->M + GBM - 1) / GBM);
   k.ntn = (d->N + GBN - 1) / GBN;
-  constexpr size_t smem = 2 * (size_t)GTILE;
+  k.amax = f16 ? amax : nullptr;
+  k.wscale = reinterpret_cast<const float*>(k.w + segmif_gemm_split_weight_bytes(d->N, d->K));  // (f16x3 images only)
+  constexpr size_t smem = 2 * (size_t)GTILE, smem16 = (size_t)GBM * GPITCH_H + GTILE;
+  static_assert(smem16 >= 4 * 32 * 68 * sizeof(float), "the LDS epilogue tile must fit");
   static segmif::PerDeviceFlag raised_flag;
   bool& raised = raised_flag.here();
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
-  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)((long long)k.ntm * k.ntn)), dim3(256), smem, (hipStream_t)stream, k);
+  const dim3 grid((unsigned)((long long)k.ntm * k.ntn));
+  if (f16) hipLaunchKernelGGL(gemm_split_kernel<true>, grid, dim3(256), smem16, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL(gemm_split_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, k);
   return (int)hipGetLastError();
 }

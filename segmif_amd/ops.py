@@ -154,7 +154,7 @@ class Planes16Guard:
     slot (a device-side atomic max); ok() reads the slots back (one host sync) and tells whether every tensor stayed
     inside [2^-13, 65504) - the range in which a half pair carries an fp32 value to within one bit.  All-zero tensors
     pass; NaN / inf read as overflow."""
-    SLOTS = 64
+    SLOTS = 1024
     LO, HI = 2.0 ** -13, 65504.0
 
     def __init__(self, device):
@@ -173,6 +173,43 @@ class Planes16Guard:
     def ok(self):
         m = self.maxima()
         return bool(((m == 0) | ((m >= self.LO) & (m < self.HI))).all())
+
+
+_guard = None          # the Planes16Guard of the running guarded scope (run_guarded), or None
+_suppress = 0          # > 0 while a scope is being repeated on the bf16x6 kernels: nested scopes must not open a guard
+_range_fallbacks = 0   # guarded scopes repeated on the bf16x6 kernels
+
+
+def active_guard():
+    return _guard
+
+
+def range_fallbacks():
+    return _range_fallbacks
+
+
+def run_guarded(fn, device, enabled=True):
+    """Run fn() with the f16x3 kernels available: inside, active_guard() hands every producer of half pairs its range slot.
+    One read-back at the end; if a tensor left the half's exponent range, fn() runs again without a guard, i.e. on the
+    bf16x6 kernels.  Nested calls join the outer scope (which does the checking); fn must be repeatable."""
+    global _guard, _range_fallbacks, _suppress
+    if _guard is not None or _suppress or not enabled:
+        return fn()
+    _guard = Planes16Guard(device)
+    try:
+        out = fn()
+        ok = _guard.ok()
+    finally:
+        _guard = None
+    if ok:
+        return out
+    del out
+    _range_fallbacks += 1
+    _suppress += 1
+    try:
+        return fn()
+    finally:
+        _suppress -= 1
 
 
 class Planes:
@@ -311,15 +348,16 @@ def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None,
 
 
 class GemmSplitWeight:
-    """segmif_gemm_split_pack image of an (N, K) Linear weight (bf16x6 dense GEMM, csrc/gemm_split.hip)."""
-    __slots__ = ("data", "N", "K")
+    """segmif_gemm_split_pack image of an (N, K) Linear weight (bf16x6 dense GEMM, csrc/gemm_split.hip); half: the
+    segmif_gemm_split16_pack image of the same weight (f16x3) or None."""
+    __slots__ = ("data", "N", "K", "half")
 
-    def __init__(self, data, N, K):
-        self.data, self.N, self.K = data, N, K
+    def __init__(self, data, N, K, half=None):
+        self.data, self.N, self.K, self.half = data, N, K, half
 
 
-_LINEAR_MODES = ("bf16x6", "fp32")
-_linear_mode = os.environ.get("SEGMIF_LINEAR", "bf16x6")
+_LINEAR_MODES = ("f16x3", "bf16x6", "fp32")
+_linear_mode = os.environ.get("SEGMIF_LINEAR", "f16x3")
 if _linear_mode not in _LINEAR_MODES:
     raise RuntimeError(f"SEGMIF_LINEAR must be one of {_LINEAR_MODES}, got {_linear_mode!r}")
 GEMM_SPLIT_MIN_ROWS = 2048  # below this the 128-row tiles leave the chip idle; the fp32 tiles with split-K win
@@ -329,27 +367,33 @@ def linear_mode():
     return _linear_mode
 
 
-def pack_linear(w):
-    """(N, K) Linear weight -> (fp32 packing, GemmSplitWeight or None).  Cache entries must be keyed on linear_mode()."""
+def pack_linear(w, half=None):
+    """(N, K) Linear weight -> (fp32 packing, GemmSplitWeight or None).  Cache entries must be keyed on linear_mode().
+    half: also build the f16x3 image (default: when linear_mode() is 'f16x3'; training passes False - it re-packs per step
+    and never runs under a range guard)."""
     packed = pack_weight(w)
     N, K = w.shape[0], w.shape[1]
-    if _linear_mode != "bf16x6" or w.dim() != 2 or K % 32 or N < 32:
+    if _linear_mode == "fp32" or w.dim() != 2 or K % 32 or N < 32:
         return packed, None
     lib = _lib.load()
+    wc = w.detach().contiguous()
     out = torch.empty((lib.segmif_gemm_split_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
-    _lib.check(lib.segmif_gemm_split_pack(w.detach().contiguous().data_ptr(), N, K, K, out.data_ptr(), _stream()),
-               "segmif_gemm_split_pack")
-    return packed, GemmSplitWeight(out, N, K)
+    _lib.check(lib.segmif_gemm_split_pack(wc.data_ptr(), N, K, K, out.data_ptr(), _stream()), "segmif_gemm_split_pack")
+    img16 = None
+    if _linear_mode == "f16x3" if half is None else half:
+        img16 = torch.empty((lib.segmif_gemm_split16_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
+        _lib.check(lib.segmif_gemm_split16_pack(wc.data_ptr(), N, K, K, img16.data_ptr(), _stream()), "segmif_gemm_split16_pack")
+    return packed, GemmSplitWeight(out, N, K, img16)
 
 
 def linear_wants_split(rows, N, K):
     """The size rule of linear_auto, for callers that would rather not build a split weight image they will not use."""
-    return _linear_mode == "bf16x6" and rows >= GEMM_SPLIT_MIN_ROWS and N >= 128 and N % 4 == 0 and K % 32 == 0
+    return _linear_mode != "fp32" and rows >= GEMM_SPLIT_MIN_ROWS and N >= 128 and N % 4 == 0 and K % 32 == 0
 
 
 def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):
-    """out = res + act(x @ W^T + bias) with packs = pack_linear(W): the bf16x6 GEMM for tall problems, the fp32 tiles
-    (with split-K) for short ones."""
+    """out = res + act(x @ W^T + bias) with packs = pack_linear(W): the split-operand GEMM for tall problems (f16x3 inside
+    a guarded scope when the weight carries its half image, bf16x6 otherwise), the fp32 tiles (with split-K) for short ones."""
     packed, split = packs
     rows, K, lda = rows_view(x, "x")
     # (N < 128 would leave half of the 128-column tile idle: measured slower than the fp32 64-column tiles)
@@ -366,8 +410,9 @@ def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):
     orow, oc, ldo = rows_view(out, "out")
     if orow != rows or oc != N or (split.N, split.K) != (N, K):
         raise RuntimeError(f"linear_auto: shapes do not fit (rows {rows}/{orow}, N {N}/{oc}, weight {split.N}x{split.K})")
+    use16 = split.half is not None and _guard is not None
     d = _lib.SegmifGemmSplit()
-    d.a, d.w, d.out = x.data_ptr(), split.data.data_ptr(), out.data_ptr()
+    d.a, d.w, d.out = x.data_ptr(), (split.half if use16 else split.data).data_ptr(), out.data_ptr()
     d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
     d.M, d.N, d.K, d.lda, d.ldo, d.act = rows, N, K, lda, ldo, act
     if res is not None:
@@ -375,7 +420,10 @@ def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):
         if rc != N or rrow != rows:
             raise RuntimeError("residual shape mismatch")
         d.res, d.ldr = res.data_ptr(), ldr
-    _lib.check(_lib.load().segmif_gemm_split_f32(ctypes.byref(d), _stream()), "segmif_gemm_split_f32")
+    if use16:
+        _lib.check(_lib.load().segmif_gemm_split16_f32(ctypes.byref(d), _guard.slot(), _stream()), "segmif_gemm_split16_f32")
+    else:
+        _lib.check(_lib.load().segmif_gemm_split_f32(ctypes.byref(d), _stream()), "segmif_gemm_split_f32")
     return out
 
 

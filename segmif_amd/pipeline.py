@@ -23,7 +23,12 @@ class PairForward:
         self._static = None
 
     def eager(self, ir, vis, mask3):
-        """-> (fused RGB (B,3,H,W), labels int32 (B,H,W))."""
+        """-> (fused RGB (B,3,H,W), labels int32 (B,H,W)).  One guarded scope around the whole pair forward: the encoder's
+        tall GEMMs and the fusion net's 3x3 convs run on f16x3 operands, their range slots are read back once at the end and
+        a pair whose activations left the half's exponent range is computed again on the bf16x6 kernels."""
+        return ops.run_guarded(lambda: self._eager_body(ir, vis, mask3), ir.device)
+
+    def _eager_body(self, ir, vis, mask3):
         enc = self.seg.denoise_net.encoder
         if self.commute_resize:  # conv3 / conv4 (1x1) before the bilinear resize: same function (SURVEY §8(f) N4)
             y_f = self.fus.forward_from_features(ir, vis, *enc.forward_fusion_features(mask3))
@@ -44,16 +49,17 @@ class PairForward:
         # the f16x3 planes path ends a forward with a host read-back of its range guard, which a captured graph cannot hold:
         # a graph is recorded on the guard-free bf16x6 planes kernels
         prev = ops.set_conv3x3_mode("planes") if ops.conv3x3_mode() == "planes16" else None
+        eager = self._eager_body  # (no guarded scope either: the encoder's GEMMs stay on bf16 triples)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(warmup):  # packs weights, raises LDS limits, warms the allocator
-                    self.eager(*self._static)
+                    eager(*self._static)
             torch.cuda.current_stream().wait_stream(side)
             self._graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(self._graph):
-                self._out = self.eager(*self._static)
+                self._out = eager(*self._static)
         finally:
             if prev is not None:
                 ops.set_conv3x3_mode(prev)
