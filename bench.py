@@ -273,10 +273,10 @@ def main():
 
     elapsed = dist.max_over_ranks(elapsed)
 
-    # for continuity with rounds 1-2: the same step with the fusion net's planes as bf16 triples (6 products per MAC)
+    # for continuity with rounds 1-2: the same step on bf16 triples throughout (6 products per MAC, no range guard)
     elapsed_bf16 = None
     if ops.conv3x3_mode() == "planes16" and not args.graph and not args.no_extras:
-        prev_mode = ops.set_conv3x3_mode("planes")
+        prev_mode, prev_lin = ops.set_conv3x3_mode("planes"), ops.set_linear_mode("bf16x6" if ops.linear_mode() == "f16x3" else ops.linear_mode())
         with torch.no_grad():
             step()
             fence()
@@ -286,6 +286,7 @@ def main():
             fence()
             elapsed_bf16 = dist.max_over_ranks(time.perf_counter() - t0)
         ops.set_conv3x3_mode(prev_mode)
+        ops.set_linear_mode(prev_lin)
 
     # beside the headline, never in it: the same step with the two encoder stages whose outputs forward_fusion() discards
     # (the reference computes and drops them, core/mix_transformer.py:358-375) not computed - identical results
@@ -322,8 +323,8 @@ def main():
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if all_fp32 else (
-                "f32 (large contractions on split operands, fp32-class: the fusion net's 3x3 convs as half pairs x 3 f16 MFMA "
-                "products under a range guard, the rest as bf16 triples x 6 products; see arithmetic_modes)"
+                "f32 (large contractions on split operands, fp32-class: the fusion net's 3x3 convs and the encoder's tall GEMMs as "
+                "half pairs x 3 f16 MFMA products under a range guard, the rest as bf16 triples x 6 products; see arithmetic_modes)"
                 if ops.conv3x3_mode() == "planes16" else
                 "f32 (large contractions: fp32-equivalent 3-way bf16 split, 6 MFMA products; see arithmetic_modes)"),
             "f16x3_range_fallbacks": ops.range_fallbacks(),
@@ -344,9 +345,12 @@ def main():
             # per GPU: executed FLOPs (N4 removes part of the textbook count) and, beside it, the textbook figure
             out["whole_path_tflops"] = value * (gf - gflop_removed_by_n4(H, W)) / 1000.0 / world
             out["whole_path_tflops_textbook_order"] = value * gf / 1000.0 / world
-            # the whole path against the bf16x6 ceiling (every large contraction of the path runs there; the rest - fp32-MFMA
-            # patch embeds / sr convs, bandwidth-bound row kernels - only lowers the figure)
-            out["whole_path_frac"] = None if all_fp32 else out["whole_path_tflops"] / PEAK_BF16X6_TFLOPS
+            # the whole path against the split-operand ceiling of its arithmetic: 2500 / 3 for the default (the fusion net's convs
+            # and the encoder's GEMMs on f16x3; attention / CrossPath still issue six bf16 products, fp32-MFMA patch embeds and
+            # bandwidth-bound row kernels only lower the figure), 2500 / 6 in the bf16x6 modes
+            ceiling = PEAK_BF16X6_TFLOPS * (2.0 if ops.conv3x3_mode() == "planes16" else 1.0)
+            out["whole_path_frac"] = None if all_fp32 else out["whole_path_tflops"] / ceiling
+            out["whole_path_ceiling_tflops"] = None if all_fp32 else ceiling
             out["gflop_per_pair"] = {"executed": gf - gflop_removed_by_n4(H, W), "textbook_order": gf}
         if timer is not None:
             n, ms, flops = timer.summary()
@@ -386,8 +390,8 @@ def main():
         if elapsed_bf16 is not None:
             out["with_bf16x6_planes"] = {
                 "value": pairs / elapsed_bf16, "ms_per_step": 1000.0 * elapsed_bf16 / args.steps,
-                "note": "the same step with SEGMIF_CONV3X3=planes (rounds 1-2 arithmetic: bf16 triples, six products per MAC, no "
-                        "range guard needed) - what a forward falls back to when the f16x3 guard trips"}
+                "note": "the same step with SEGMIF_CONV3X3=planes SEGMIF_LINEAR=bf16x6 (rounds 1-2 arithmetic: bf16 triples, six "
+                        "products per MAC, no range guard needed) - what a pair falls back to when the f16x3 guard trips"}
         if elapsed_dse is not None:
             out["without_discarded_encoder_stages"] = {
                 "value": pairs / elapsed_dse, "ms_per_step": 1000.0 * elapsed_dse / args.steps,

@@ -188,11 +188,17 @@ def range_fallbacks():
     return _range_fallbacks
 
 
-def run_guarded(fn, device, enabled=True):
-    """Run fn() with the f16x3 kernels available: inside, active_guard() hands every producer of half pairs its range slot.
+def f16x3_enabled():
+    return _conv3x3_mode == "planes16" or _linear_mode == "f16x3"
+
+
+def run_guarded(fn, device, enabled=None):
+    """Run fn() with the f16x3 kernels available (enabled=None: if a mode asks for them): inside, active_guard() hands every producer of half pairs its range slot.
     One read-back at the end; if a tensor left the half's exponent range, fn() runs again without a guard, i.e. on the
     bf16x6 kernels.  Nested calls join the outer scope (which does the checking); fn must be repeatable."""
     global _guard, _range_fallbacks, _suppress
+    if enabled is None:
+        enabled = f16x3_enabled()
     if _guard is not None or _suppress or not enabled:
         return fn()
     _guard = Planes16Guard(device)
@@ -365,6 +371,17 @@ GEMM_SPLIT_MIN_ROWS = 2048  # below this the 128-row tiles leave the chip idle; 
 
 def linear_mode():
     return _linear_mode
+
+
+def set_linear_mode(mode):
+    """'f16x3' (default): tall nn.Linear problems on the split-operand GEMM, with half pairs and three products per MAC
+    inside a guarded scope (run_guarded) and bf16 triples / six products outside one; 'bf16x6': always bf16 triples;
+    'fp32': the exact-fp32 MFMA tiles.  Weight caches are keyed on the mode."""
+    global _linear_mode
+    if mode not in _LINEAR_MODES:
+        raise ValueError(f"mode must be one of {_LINEAR_MODES}")
+    prev, _linear_mode = _linear_mode, mode
+    return prev
 
 
 def pack_linear(w, half=None):
