@@ -56,6 +56,117 @@ def test_struct_layout_matches_c(lib, tmp_path):
     assert got == want
 
 
+def test_struct_layout_of_the_f16x3_fields_matches_c(lib, tmp_path):
+    """The descriptors that grew f16x3 fields (planes_f16 / planes_amax): size and the new fields' offsets against gcc."""
+    from segmif_amd._lib import SegmifConvPlanes, SegmifCrossTail, SegmifGemmSplit, SegmifIgemm
+    src = tmp_path / "layout16.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "segmif_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(SegmifIgemm),offsetof(SegmifIgemm,planes_f16),offsetof(SegmifIgemm,planes_amax),'
+                   'sizeof(SegmifCrossTail),offsetof(SegmifCrossTail,planes_f16),offsetof(SegmifCrossTail,planes_amax),'
+                   'sizeof(SegmifConvPlanes),sizeof(SegmifGemmSplit));return 0;}')
+    exe = tmp_path / "layout16"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(SegmifIgemm), SegmifIgemm.planes_f16.offset, SegmifIgemm.planes_amax.offset,
+            ctypes.sizeof(SegmifCrossTail), SegmifCrossTail.planes_f16.offset, SegmifCrossTail.planes_amax.offset,
+            ctypes.sizeof(SegmifConvPlanes), ctypes.sizeof(SegmifGemmSplit)]
+    assert got == want
+
+
+def test_f16x3_entry_points_size_rules_and_rejections_without_a_gpu(lib):
+    """segmif_planes16_* / segmif_gemm_split16_*: buffer sizes (4 bytes per activation instead of 6; weight images = the bf16
+    images + one float per output row) and EINVAL on null / malformed arguments - no kernel is launched."""
+    from segmif_amd._lib import SegmifConvPlanes, SegmifGemmSplit
+    assert lib.segmif_planes16_bytes(2, 13, 45, 6) * 3 == lib.segmif_planes_bytes(2, 13, 45, 6) * 2
+    assert lib.segmif_planes16_bytes(2, 13, 45, 6) == 2 * 6 * 20 * 68 * 64
+    assert lib.segmif_planes16_bytes(0, 13, 45, 6) == 0
+    assert lib.segmif_planes16_weight_bytes(32, 64, 9) == lib.segmif_planes_weight_bytes(32, 64, 9) + 4 * 32
+    assert lib.segmif_planes16_weight_bytes(48, 64, 9) == 0 and lib.segmif_planes16_weight_bytes(32, 24, 9) == 0
+    assert lib.segmif_gemm_split16_weight_bytes(320, 320) == lib.segmif_gemm_split_weight_bytes(320, 320) + 4 * 384
+    assert lib.segmif_gemm_split16_weight_bytes(320, 48) == 0
+    assert lib.segmif_planes16_zero_border(None, 1, 8, 32, 4, None) == -22
+    assert lib.segmif_planes16_from_f32(None, 64, None, 1, 8, 32, 4, 0, 4, None, None) == -22
+    assert lib.segmif_planes16_pack_weight(None, 32, 64, 9, 576, None, None) == -22
+    assert lib.segmif_gemm_split16_pack(None, 320, 320, 320, None, None) == -22
+    assert lib.segmif_conv3x3_planes_f16x3(ctypes.byref(SegmifConvPlanes()), None, None) == -22
+    assert lib.segmif_gemm_split16_f32(ctypes.byref(SegmifGemmSplit()), None, None) == -22
+
+
+def test_guarded_scope_logic_on_the_host():
+    """ops.run_guarded without a GPU (the guard's slots are an ordinary tensor): a scope whose slots stay inside
+    [2^-13, 65504) returns its first result; one whose producer reports an overflow, a vanishing tensor or a NaN is run again
+    with no guard active (nested scopes included) and counted; nested scopes join the outer one; all-zero tensors pass."""
+    from segmif_amd import ops
+
+    def producer(value):  # what a kernel does with its slot: atomic max on the bit pattern
+        g = ops.active_guard()
+        if g is None:
+            return "bf16x6"
+        ptr_index = (g.slot() - g.amax.data_ptr()) // 4
+        g.amax[ptr_index] = int(torch.tensor([value], dtype=torch.float32).view(torch.int32))
+        return "f16x3"
+
+    base = ops.range_fallbacks()
+    assert ops.run_guarded(lambda: producer(1.0), "cpu", enabled=True) == "f16x3"
+    assert ops.run_guarded(lambda: producer(0.0), "cpu", enabled=True) == "f16x3"            # an all-zero tensor
+    assert ops.run_guarded(lambda: producer(1.0), "cpu", enabled=False) == "bf16x6"          # modes that never ask
+    assert ops.range_fallbacks() == base and ops.active_guard() is None
+    for k, bad in enumerate((65504.0, 7.0e4, float("inf"), float("nan"), 2.0 ** -14, 1.0e-30)):
+        calls = []
+
+        def body(bad=bad, calls=calls):
+            calls.append(ops.active_guard() is not None)
+            first = ops.run_guarded(lambda: producer(3.0), "cpu", enabled=True)              # nested: joins / is suppressed
+            return first, producer(bad)
+
+        assert ops.run_guarded(body, "cpu", enabled=True) == ("bf16x6", "bf16x6"), bad
+        assert calls == [True, False] and ops.range_fallbacks() == base + k + 1 and ops.active_guard() is None
+    with pytest.raises(ZeroDivisionError):  # an exception inside a scope must not leave a guard behind
+        ops.run_guarded(lambda: 1 / 0, "cpu", enabled=True)
+    assert ops.active_guard() is None
+    g = ops.Planes16Guard("cpu")
+    slots = {g.slot() for _ in range(g.SLOTS + 5)}
+    assert len(slots) == g.SLOTS and g.used == g.SLOTS  # past the end the last slot is shared
+
+
+def test_f16x3_operand_format_in_numpy():
+    """The f16x3 format's definition restated in numpy (the kernels' split: planes16.h; the weight scale:
+    planes16_pack_weight / gemm_split16_pack): a half pair carries an fp32 value to 2^-23 relative for 2^-12 <= |x| < 65504
+    and to 2^-36 absolute below; three products with fp32 accumulation stay within 1.5x of a plain fp32 chain's error
+    against fp64 over a K = 1008 contraction (relative to each output's conditioning)."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(200000) * 10.0 ** rng.uniform(-7, 4.5, 200000)).astype(np.float32)
+    x = x[np.abs(x) < 65504]
+    hi = x.astype(np.float16)
+    lo = ((x - hi.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+    back = hi.astype(np.float64) + lo.astype(np.float64) / 2048
+    err = np.abs(back - x.astype(np.float64))
+    big = np.abs(x) >= 2.0 ** -12
+    assert (err[big] / np.abs(x[big])).max() <= 2.0 ** -23 and err[~big].max() <= 2.0 ** -36
+
+    def mm32(a, b):
+        return a.astype(np.float32) @ b.astype(np.float32)
+
+    M, K, N = 512, 1008, 32
+    a = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    w = (0.03 * rng.standard_normal((K, N)) * 10.0 ** rng.uniform(-2, 1, (1, N))).astype(np.float32)
+    e = 14 - np.floor(np.log2(np.abs(w).max(axis=0, keepdims=True)))  # the pack kernels: 14 - ilogb(max |w[n][.]|)
+    W = (w * np.exp2(e)).astype(np.float32)
+    assert (np.abs(W).max(axis=0) >= 2.0 ** 14).all() and (np.abs(W).max(axis=0) < 2.0 ** 15).all()
+    W0 = W.astype(np.float16)
+    Wl = (W - W0.astype(np.float32)).astype(np.float16)
+    W0s = (W0.astype(np.float32) * np.float32(2.0 ** -11)).astype(np.float16)
+    a0 = a.astype(np.float16)
+    al = ((a - a0.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+    y = ((mm32(al, W0s) + mm32(a0, Wl)) + mm32(a0, W0)) * np.exp2(-e).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64)
+    cond = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64)
+    e16 = (np.abs(y - ref) / cond).max()
+    e32 = (np.abs(mm32(a, w) - ref) / cond).max()
+    assert e16 <= 1.5 * e32 and e16 < 4e-7, (e16, e32)
+
+
 def test_invalid_descriptors_are_rejected_without_a_gpu(lib):
     from segmif_amd._lib import SegmifIgemm
     d = SegmifIgemm()

@@ -19,14 +19,14 @@ def bf16x6(x, w):
     return acc
 def fp16x3(x, w):
     # weights: per output channel power-of-two scale so max|W| ~ 2^14
-    mx = np.abs(w).max(axis=0, keepdims=True); s = np.floor(14 - np.log2(np.maximum(mx, 1e-30))).clip(-60, 60)
+    mx = np.abs(w).max(axis=0, keepdims=True); s = (14 - np.floor(np.log2(np.maximum(mx, 1e-30)))).clip(-60, 60)
     W = (w * np.exp2(s)).astype(np.float32)
     W0 = W.astype(np.float16); Wl = (W - W0.astype(np.float32)).astype(np.float16); W0s = (W0.astype(np.float32) * 2.0**-11).astype(np.float16)
     x0 = x.astype(np.float16); l = ((x - x0.astype(np.float32)) * 2048.0).astype(np.float16)
     acc = mm32(x0, Wl) + mm32(l, W0s); acc = acc + mm32(x0, W0)
     return (acc * np.exp2(-s)).astype(np.float32)
 def fp16x3_two_acc(x, w):
-    mx = np.abs(w).max(axis=0, keepdims=True); s = np.floor(14 - np.log2(np.maximum(mx, 1e-30))).clip(-60, 60)
+    mx = np.abs(w).max(axis=0, keepdims=True); s = (14 - np.floor(np.log2(np.maximum(mx, 1e-30)))).clip(-60, 60)
     W = (w * np.exp2(s)).astype(np.float32)
     W0 = W.astype(np.float16); Wl = ((W - W0.astype(np.float32)) * 2048.0).astype(np.float16)
     x0 = x.astype(np.float16); l = ((x - x0.astype(np.float32)) * 2048.0).astype(np.float16)
