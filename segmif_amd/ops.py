@@ -901,7 +901,8 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
         if planes.f16:
             d.planes_f16, d.planes_amax = 1, planes.guard.slot()
     _side("cp_tail", lambda: _lib.check(_lib.load().segmif_crosspath_tail_f32(ctypes.byref(d), _stream()),
-                                        "segmif_crosspath_tail_f32"), (768.0 + (384.0 if planes is not None else 0.0)) * B * N)
+                                        "segmif_crosspath_tail_f32"),
+          (768.0 + (0.0 if planes is None else 256.0 if planes.f16 else 384.0)) * B * N)  # + the planes copy: 4 | 6 B per element
     return out
 
 
