@@ -219,6 +219,25 @@ def run_guarded(fn, device, enabled=None):
         _suppress -= 1
 
 
+def install_guard(guard):
+    """Low-level: make `guard` (or None) the active one WITHOUT run_guarded's read-back, returning the previous one - for a
+    caller that does the read-back itself later (pipeline.PairForward records a hipGraph this way and checks after replay)."""
+    global _guard
+    prev, _guard = _guard, guard
+    return prev
+
+
+def run_unguarded(fn):
+    """fn() on the bf16x6 kernels, counted as a range fallback (the repeat half of run_guarded for such a caller)."""
+    global _range_fallbacks, _suppress
+    _range_fallbacks += 1
+    _suppress += 1
+    try:
+        return fn()
+    finally:
+        _suppress -= 1
+
+
 class Planes:
     """A planes buffer (include/segmif_hip.h, segmif_planes_*): `chunks` 16-channel chunk images per batch
     element, each activation stored as three bf16 planes (guard=None) or, with a Planes16Guard, as a pair of

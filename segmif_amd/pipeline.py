@@ -20,6 +20,7 @@ class PairForward:
         self.commute_resize = commute_resize
         self.uint8_roundtrip = uint8_roundtrip
         self._graph = None
+        self._graph_guard = None
         self._static = None
 
     def eager(self, ir, vis, mask3):
@@ -46,23 +47,32 @@ class PairForward:
         if ops.launch_timer_active():
             raise RuntimeError("disable the launch timer before graph capture")
         self._static = [t.clone() for t in (ir, vis, mask3)]
-        # the f16x3 planes path ends a forward with a host read-back of its range guard, which a captured graph cannot hold:
-        # a graph is recorded on the guard-free bf16x6 planes kernels
-        prev = ops.set_conv3x3_mode("planes") if ops.conv3x3_mode() == "planes16" else None
-        eager = self._eager_body  # (no guarded scope either: the encoder's GEMMs stay on bf16 triples)
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(warmup):  # packs weights, raises LDS limits, warms the allocator
-                    eager(*self._static)
-            torch.cuda.current_stream().wait_stream(side)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self._graph):
-                self._out = eager(*self._static)
-        finally:
-            if prev is not None:
-                ops.set_conv3x3_mode(prev)
+        # The f16x3 kernels need a range guard, and a captured graph cannot hold run_guarded's host read-back: the graph gets
+        # a guard of its own whose slots are cleared by a memset node at its start and filled by its kernels; replay() reads
+        # them back after the launch and computes the pair again, eagerly on the bf16x6 kernels, if one tripped.
+        guard = ops.Planes16Guard(ir.device) if ops.f16x3_enabled() else None
+
+        def body():
+            if guard is None:
+                return self._eager_body(*self._static)
+            guard.used = 0
+            guard.amax.zero_()
+            prev = ops.install_guard(guard)
+            try:
+                return self._eager_body(*self._static)
+            finally:
+                ops.install_guard(prev)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):  # packs weights, raises LDS limits, warms the allocator
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self._graph):
+            self._out = body()
+        self._graph_guard = guard
         return self
 
     def replay(self, ir=None, vis=None, mask3=None):
@@ -72,6 +82,9 @@ class PairForward:
             if src is not None and src.data_ptr() != dst.data_ptr():
                 dst.copy_(src)
         self._graph.replay()
+        if self._graph_guard is not None and not self._graph_guard.ok():  # (one small read-back per replay)
+            with torch.no_grad():
+                return ops.run_unguarded(lambda: self._eager_body(*self._static))
         return self._out
 
     def __call__(self, ir, vis, mask3):

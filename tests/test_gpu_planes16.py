@@ -352,3 +352,42 @@ def test_full_size_b3_pair_on_f16x3_planes_vs_reference_checksum(ops, golden_dir
     ref_labels = torch.from_numpy(g["labels"]).long()
     stable = torch.from_numpy(g["margin_f16"].astype(np.float32)) > 1e-3
     assert torch.equal(labels.cpu().long().reshape(ref_labels.shape)[stable], ref_labels[stable])
+
+
+def test_pair_forward_graph_replay_carries_its_own_guard(ops, golden_dir):
+    """PairForward.capture with the f16x3 defaults: the graph owns a range guard (cleared by a memset node, filled by the
+    recorded kernels), replay() returns what the eager guarded forward returns - bit for bit, also for new inputs copied into
+    the static buffers - and an input that drives an activation past 65504 comes back as the eager bf16x6 result."""
+    import segmif_amd.core as core
+    from segmif_amd.pipeline import PairForward
+    if not ops.f16x3_enabled():
+        pytest.skip("f16x3 modes are switched off")
+    fus = _build(core.Fusion_Network3_ac)
+    net = _build(core.Network3, "mit_b1", 9, pretrained=None)
+    gp = _load(golden_dir, "pair_b1_64x96.npz")
+    ir, vis, mask = (torch.from_numpy(gp[k]).cuda() for k in ("ir", "vis", "mask"))
+
+    def same(a, b):
+        return bool(((a == b) | (a.isnan() & b.isnan())).all())
+
+    pipe = PairForward(net, fus)
+    with torch.no_grad():
+        fused_e, labels_e = pipe.eager(ir, vis, mask)
+    assert _rel(fused_e, gp["fused"]) < 5 * TIGHT
+    pipe.capture(ir, vis, mask)
+    assert pipe._graph_guard is not None and pipe._graph_guard.used > 0
+    fused_g, labels_g = pipe(ir, vis, mask)
+    assert same(fused_g, fused_e) and torch.equal(labels_g, labels_e)
+    ir2, vis2, mask2 = (t.flip(-1).contiguous() for t in (ir, vis, mask))
+    with torch.no_grad():
+        fused_e2, labels_e2 = pipe.eager(ir2, vis2, mask2)
+    fused_g2, labels_g2 = pipe(ir2, vis2, mask2)
+    assert same(fused_g2, fused_e2) and torch.equal(labels_g2, labels_e2) and not same(fused_g2, fused_e)
+    before = ops.range_fallbacks()
+    big = ir * 1.0e6
+    fused_gb, _ = pipe(big, vis, mask)
+    fused_gb = fused_gb.clone()
+    assert ops.range_fallbacks() == before + 1
+    with torch.no_grad():
+        fused_eb, _ = pipe.eager(big, vis, mask)
+    assert ops.range_fallbacks() == before + 2 and same(fused_gb, fused_eb)
