@@ -43,6 +43,7 @@
 #include <hip/hip_runtime.h>
 #include "device_once.h"
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "igemm_common.h"
 #include "planes16.h"
@@ -155,9 +156,12 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
 // |lag| 0.28 of a period, both in their MFMA segment 68 % of the time, both issuing DMA into the 64 B/clk L1 path at
 // once the rest — profiles/r02_planes_timeline.txt); the barrier pins the phase.  Item i of team 0 is loaded in phase
 // 2i and multiplied in phase 2i + 1; team 1 runs one phase later and finds the weights of item i still in W[i & 1].
-template <int DIL, bool FUSE, bool F16>
+// SUB = sub-tiles (patch rows) per wave: 2 (a team's patch is 8 x 32) or 4 (16 x 32; EXPERIMENTAL, see compute4 below).
+template <int DIL, bool FUSE, bool F16, int SUB = 2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_planes_kernel(const PlanesConvK p) {
-  constexpr int HH = TH + 2 * DIL, HW = TW + 2 * DIL;
+  static_assert(SUB == 2 || (SUB == 4 && !FUSE), "four sub-tiles per wave: plain conv only (the fused tail's accumulators do not fit)");
+  constexpr int THS = 4 * SUB;                    // patch rows of a team
+  constexpr int HH = THS + 2 * DIL, HW = TW + 2 * DIL;
   constexpr int PXA = F16 ? PXH : PXB;            // bytes per activation pixel per chunk
   constexpr int UPP = PXA / 16;                   // 16-byte pieces per pixel
   constexpr int NPA = F16 ? 2 : 3;                // activation planes
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     t.valid = pt < npatch;
     const int pc = t.valid ? pt : npatch - 1;
     t.x0 = (pc % p.tiles_x) * TW;
-    t.y0 = ((pc / p.tiles_x) % p.tiles_y) * TH;
+    t.y0 = ((pc / p.tiles_x) % p.tiles_y) * THS;
     t.b = pc / (p.tiles_x * p.tiles_y);
     return t;
   };
@@ -271,10 +275,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   float amx = 0.f;  // f16x3: largest |output| this lane has split
 
-  f32x16 acc[2], acc1[FUSE ? 2 : 1][2];
+  f32x16 acc[SUB], acc1[FUSE ? 2 : 1][2];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < SUB; ++i)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
 #pragma unroll
@@ -289,7 +293,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // The wave's two sub-tiles are patch rows R0 and R0 + DIL (tap ky of the second reads the halo row tap
   // ky + 1 of the first reads): a chunk is 12 steps (kx, m), halo row R0 + m * DIL at column offset kx * DIL
   // feeds sub-tile 0 with tap ky = m (m < 3) and sub-tile 1 with tap ky = m - 1 (m > 0).
-  const int R0 = (DIL == 2) ? ((wave >> 1) * 4 + (wave & 1)) : 2 * wave;
+  // (SUB = 4: rows R0 + s * DIL, s = 0..3; halo row R0 + m * DIL feeds sub-tile s with tap ky = m - s)
+  const int R0 = (DIL == 2) ? ((wave >> 1) * (2 * SUB) + (wave & 1)) : SUB * wave;
   const unsigned char* a_lane[3][F16 ? 2 : 1];  // bf16: plane pl at + 32 pl; f16x3: a pointer per plane (slot q ^ g)
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) {
@@ -345,6 +350,67 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       __builtin_amdgcn_sched_barrier(0);
     };
+    if constexpr (SUB == 4) {
+      // EXPERIMENTAL (built and compiled, not yet run on hardware; selected only by SEGMIF_PLANES_SUB=4): four sub-tiles per
+      // wave.  Per column offset kx the six halo rows F_m (m = 0..5) meet the three taps W_ky in five groups whose MFMAs
+      // never repeat an accumulator back to back:
+      //   G1  m=1: acc0 += W1 F1, acc1 += W0 F1            G4  m=4: acc2 += W2 F4, acc3 += W1 F4
+      //   G2  m=2: acc0 += W2 F2, acc1 += W1 F2, acc2 += W0 F2
+      //   G3  m=3: acc1 += W2 F3, acc2 += W1 F3, acc3 += W0 F3   G5  m=0 / m=5: acc0 += W0 F0, acc3 += W2 F5
+      // 36 MFMAs (x NPROD / 3) against 12 + 9 fragment reads per kx (two sub-tiles: 18 against 17): the LDS port is the
+      // limiter of the two-sub-tile kernel on f16x3 operands.  A group's operands are requested while the
+      // previous group multiplies; the weights of the next kx arrive during G5 into the other half of Wk.
+      u32x4 F[3][NPA], Wk[2][3][3];  // F: rotating fragment sets; Wk[kx & 1][ky][plane]
+      auto g2 = [&](int sa, const u32x4* wa, const u32x4* fa, int sb, const u32x4* wb, const u32x4* fb) {
+#pragma unroll
+        for (int t = 0; t < NPROD; ++t) {
+          acc[sa] = mfma_split<F16>(wa[PW[t]], fa[PA[t]], acc[sa]);
+          acc[sb] = mfma_split<F16>(wb[PW[t]], fb[PA[t]], acc[sb]);
+        }
+      };
+      auto g3 = [&](int sa, const u32x4* wa, int sb, const u32x4* wb, int sc, const u32x4* wc, const u32x4* f) {
+#pragma unroll
+        for (int t = 0; t < NPROD; ++t) {
+          acc[sa] = mfma_split<F16>(wa[PW[t]], f[PA[t]], acc[sa]);
+          acc[sb] = mfma_split<F16>(wb[PW[t]], f[PA[t]], acc[sb]);
+          acc[sc] = mfma_split<F16>(wc[PW[t]], f[PA[t]], acc[sc]);
+        }
+      };
+      ld_f(F[0], 0, 1);
+      ld_w(Wk[0][1], 0, 1);
+      ld_w(Wk[0][0], 0, 0);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int c = kx & 1, n = c ^ 1;
+        // G1 (F[0] = F_1, W0, W1 on hand); request G2's
+        ld_f(F[1], kx, 2);
+        ld_w(Wk[c][2], kx, 2);
+        g2(0, Wk[c][1], F[0], 1, Wk[c][0], F[0]);
+        fence(2 * NPROD);
+        // G2 (F[1] = F_2); request G3's
+        ld_f(F[2], kx, 3);
+        g3(0, Wk[c][2], 1, Wk[c][1], 2, Wk[c][0], F[1]);
+        fence(3 * NPROD);
+        // G3 (F[2] = F_3); request G4's
+        ld_f(F[0], kx, 4);
+        g3(1, Wk[c][2], 2, Wk[c][1], 3, Wk[c][0], F[2]);
+        fence(3 * NPROD);
+        // G4 (F[0] = F_4); request G5's
+        ld_f(F[1], kx, 0);
+        ld_f(F[2], kx, 5);
+        g2(2, Wk[c][2], F[0], 3, Wk[c][1], F[0]);
+        fence(2 * NPROD);
+        // G5 (F[1] = F_0, F[2] = F_5); request the next column's G1
+        if (kx < 2) {
+          ld_f(F[0], kx + 1, 1);
+          ld_w(Wk[n][1], kx + 1, 1);
+          ld_w(Wk[n][0], kx + 1, 0);
+        }
+        g2(0, Wk[c][0], F[1], 3, Wk[c][2], F[2]);
+        fence(2 * NPROD);
+      }
+      return;
+    }
     ld_f(Fa[0], 0, 1);
     ld_w(W1[0], 0, 1);
     ld_w(W0[0], 0, 0);
@@ -419,7 +485,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const int ox = pt.x0 + r;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < SUB; ++i) {
       const int oy = pt.y0 + R0 + i * DIL;
       const bool ok = pt.valid && oy < p.H && ox < p.W;
       float y[16];
@@ -549,11 +615,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-template <int DIL, bool FUSE, bool F16>
-int launch(const PlanesConvK& k, hipStream_t stream) {
-  constexpr int A_UNITS = (TH + 2 * DIL) * (TW + 2 * DIL) * (F16 ? PXH : PXB) / 16;
+template <int DIL, bool FUSE, bool F16, int SUB = 2>
+int launch(PlanesConvK k, hipStream_t stream) {
+  constexpr int A_UNITS = (4 * SUB + 2 * DIL) * (TW + 2 * DIL) * (F16 ? PXH : PXB) / 16;
   constexpr size_t smem = 2 * ((size_t)((A_UNITS + 63) / 64) * 1024 + W3_BYTES + (FUSE ? W1_BYTES : 0)) + (F16 ? 1024 : 512);
-  auto fn = conv3x3_planes_kernel<DIL, FUSE, F16>;
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  k.tiles_y = (k.H + 4 * SUB - 1) / (4 * SUB);
+  auto fn = conv3x3_planes_kernel<DIL, FUSE, F16, SUB>;
   static segmif::PerDeviceFlag raised_flag;  // idempotent attribute; benign race
   bool& raised = raised_flag.here();
   if (!raised) {
@@ -835,6 +903,9 @@ static int conv3x3_planes_impl(const SegmifConvPlanes* d, bool f16, uint32_t* am
   k.tiles_y = (d->H + TH - 1) / TH;
   hipStream_t s = (hipStream_t)stream;
   if (f16) {
+    // EXPERIMENTAL, opt-in and unmeasured: four sub-tiles per wave (16 x 32 patches) for the plain conv; needs whole patches
+    static const bool sub4 = [] { const char* e = getenv("SEGMIF_PLANES_SUB"); return e && e[0] == '4'; }();
+    if (sub4 && !fuse && d->H % 16 == 0) return d->dil == 2 ? launch<2, false, true, 4>(k, s) : launch<1, false, true, 4>(k, s);
     if (d->dil == 2) return fuse ? launch<2, true, true>(k, s) : launch<2, false, true>(k, s);
     return fuse ? launch<1, true, true>(k, s) : launch<1, false, true>(k, s);
   }

@@ -391,3 +391,31 @@ def test_pair_forward_graph_replay_carries_its_own_guard(ops, golden_dir):
     with torch.no_grad():
         fused_eb, _ = pipe.eager(big, vis, mask)
     assert ops.range_fallbacks() == before + 2 and same(fused_gb, fused_eb)
+
+
+@pytest.mark.skipif(os.environ.get("SEGMIF_PLANES_SUB") != "4",
+                    reason="opt-in: the four-sub-tile variant of the f16x3 conv is selected by SEGMIF_PLANES_SUB=4 at process start")
+@pytest.mark.parametrize("case", [(2, 32, 40, 64, 2), (1, 16, 70, 192, 2), (1, 48, 33, 96, 1), (3, 16, 32, 128, 2)])
+def test_conv3x3_planes_f16x3_four_subtiles(ops, case):
+    """EXPERIMENTAL kernel variant (conv3x3_planes_kernel<.., SUB = 4>: 16 x 32 patches, four sub-tiles per wave): the same
+    yardsticks as test_conv3x3_planes_f16x3 on heights that are whole 16-row patches.  Run as
+        SEGMIF_PLANES_SUB=4 python -m pytest tests/test_gpu_planes16.py -k four_subtiles"""
+    B, H, W, Cin, d = case
+    x, w, b = rnd(B, Cin, H, W, seed=13), rnd(32, Cin, 3, 3, seed=14), rnd(32, seed=15)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=d, dilation=d)).permute(0, 2, 3, 1)
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y32 = ops.conv2d(xh, ops.pack_weight(w.cuda()), 32, 3, pad=d, dil=d, bias=b.cuda(), act=1, tile=10)
+    guard = ops.Planes16Guard("cuda")
+    pl = ops.Planes(B, H, W, Cin // 16 + 2, "cuda", guard).load_f32(xh)
+    out = torch.full((B, H, W, 40), 7.0, device="cuda")
+    ops.conv3x3_planes(pl, Cin, ops.pack_weight_planes16(w.cuda()), dil=d, bias=b.cuda(), act=1, out_chunk0=Cin // 16,
+                       out=out[..., :32])
+    e, e32 = err(out[..., :32], ref), err(y32, ref)
+    assert e < TOL and e <= 2.0 * e32 + 1e-7, (e, e32)
+    assert float((out[..., 32:] - 7).abs().max()) == 0
+    got, raw = _decode(pl, Cin // 16, 2)
+    assert float((got - ref).abs().max() / ref.abs().max()) < TOL
+    mask = torch.ones_like(raw, dtype=torch.bool)
+    mask[:, :, 2:2 + H, 2:2 + W] = False
+    assert float(raw[mask].abs().max()) == 0.0
+    assert guard.ok()
