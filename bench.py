@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step (288 GB of HBM: ~100 GB at 64; +3-5 % over 32, flat beyond: profiles/r02_bench_batch_sweep.txt)")
+    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step (288 GB of HBM: ~100 GB at 64; +3-5 %% over 32, flat beyond: profiles/r02_bench_batch_sweep.txt)")
     ap.add_argument("--backbone", default="mit_b3")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
