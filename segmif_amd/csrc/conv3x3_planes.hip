@@ -156,7 +156,8 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
 // |lag| 0.28 of a period, both in their MFMA segment 68 % of the time, both issuing DMA into the 64 B/clk L1 path at
 // once the rest — profiles/r02_planes_timeline.txt); the barrier pins the phase.  Item i of team 0 is loaded in phase
 // 2i and multiplied in phase 2i + 1; team 1 runs one phase later and finds the weights of item i still in W[i & 1].
-// SUB = sub-tiles (patch rows) per wave: 2 (a team's patch is 8 x 32) or 4 (16 x 32; EXPERIMENTAL, see compute4 below).
+// SUB = sub-tiles (patch rows) per wave: 2 (a team's patch is 8 x 32) or 4 (16 x 32: the plain f16x3 conv on heights that
+// are whole 16-row patches - 0.58 fragment reads per MFMA instead of 0.94, halo overhead 1.41x instead of 1.69x).
 template <int DIL, bool FUSE, bool F16, int SUB = 2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_planes_kernel(const PlanesConvK p) {
   static_assert(SUB == 2 || (SUB == 4 && !FUSE), "four sub-tiles per wave: plain conv only (the fused tail's accumulators do not fit)");
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (SUB == 4) {
-      // EXPERIMENTAL (built and compiled, not yet run on hardware; selected only by SEGMIF_PLANES_SUB=4): four sub-tiles per
-      // wave.  Per column offset kx the six halo rows F_m (m = 0..5) meet the three taps W_ky in five groups whose MFMAs
+      // Four sub-tiles per wave (r4: measured 355 -> 378 TFLOP/s at Cin 192, B 16; 3.55 -> 3.33 ms per 64-image launch).
+      // Per column offset kx the six halo rows F_m (m = 0..5) meet the three taps W_ky in five groups whose MFMAs
       // never repeat an accumulator back to back:
       //   G1  m=1: acc0 += W1 F1, acc1 += W0 F1            G4  m=4: acc2 += W2 F4, acc3 += W1 F4
       //   G2  m=2: acc0 += W2 F2, acc1 += W1 F2, acc2 += W0 F2
@@ -903,8 +904,9 @@ static int conv3x3_planes_impl(const SegmifConvPlanes* d, bool f16, uint32_t* am
   k.tiles_y = (d->H + TH - 1) / TH;
   hipStream_t s = (hipStream_t)stream;
   if (f16) {
-    // EXPERIMENTAL, opt-in and unmeasured: four sub-tiles per wave (16 x 32 patches) for the plain conv; needs whole patches
-    static const bool sub4 = [] { const char* e = getenv("SEGMIF_PLANES_SUB"); return e && e[0] == '4'; }();
+    // plain conv on heights that are whole 16-row patches: four sub-tiles per wave (16 x 32 patches; +5..6 % over two,
+    // profiles/r04_planes_sub4_ab.txt).  SEGMIF_PLANES_SUB=2 (read once per process) keeps the two-sub-tile kernel for A/B runs.
+    static const bool sub4 = [] { const char* e = getenv("SEGMIF_PLANES_SUB"); return !(e && e[0] == '2'); }();
     if (sub4 && !fuse && d->H % 16 == 0) return d->dil == 2 ? launch<2, false, true, 4>(k, s) : launch<1, false, true, 4>(k, s);
     if (d->dil == 2) return fuse ? launch<2, true, true>(k, s) : launch<2, false, true>(k, s);
     return fuse ? launch<1, true, true>(k, s) : launch<1, false, true>(k, s);

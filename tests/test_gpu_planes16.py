@@ -393,13 +393,11 @@ def test_pair_forward_graph_replay_carries_its_own_guard(ops, golden_dir):
     assert ops.range_fallbacks() == before + 2 and same(fused_gb, fused_eb)
 
 
-@pytest.mark.skipif(os.environ.get("SEGMIF_PLANES_SUB") != "4",
-                    reason="opt-in: the four-sub-tile variant of the f16x3 conv is selected by SEGMIF_PLANES_SUB=4 at process start")
 @pytest.mark.parametrize("case", [(2, 32, 40, 64, 2), (1, 16, 70, 192, 2), (1, 48, 33, 96, 1), (3, 16, 32, 128, 2)])
 def test_conv3x3_planes_f16x3_four_subtiles(ops, case):
-    """EXPERIMENTAL kernel variant (conv3x3_planes_kernel<.., SUB = 4>: 16 x 32 patches, four sub-tiles per wave): the same
-    yardsticks as test_conv3x3_planes_f16x3 on heights that are whole 16-row patches.  Run as
-        SEGMIF_PLANES_SUB=4 python -m pytest tests/test_gpu_planes16.py -k four_subtiles"""
+    """conv3x3_planes_kernel<.., SUB = 4> (16 x 32 patches, four sub-tiles per wave: the default for the plain f16x3 conv on
+    heights that are whole 16-row patches): the same yardsticks as test_conv3x3_planes_f16x3, whose ragged heights keep
+    covering the two-sub-tile kernel."""
     B, H, W, Cin, d = case
     x, w, b = rnd(B, Cin, H, W, seed=13), rnd(32, Cin, 3, 3, seed=14), rnd(32, seed=15)
     ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=d, dilation=d)).permute(0, 2, 3, 1)
