@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SEGMIF_ABI_VERSION 1
+#define SEGMIF_ABI_VERSION 2
 #define SEGMIF_EINVAL (-22)
 #define SEGMIF_ENOSYS (-38)
 
@@ -96,11 +96,13 @@ typedef struct SegmifIgemm {
    * images per batch element, geometry of segmif_planes_dims(OH, OW).  Needs the 16-byte epilogue (N, ldo multiples of 4,
    * aligned out), nz <= 1 and a convolution (not a plain 1x1 / Linear problem); conv1 of Fusion_Network3_ac hands its
    * result to the first DRDB this way.
-   * planes_f16 != 0: the buffer is an f16x3 one (segmif_planes16_*), max |output| is folded into *planes_amax. */
+   * planes_f16 != 0: the buffer is an f16x3 one (segmif_planes16_*), max |output| is folded into planes_amax[image]
+   * (planes_amax_images == B: one range slot per batch element) or into planes_amax[0] (planes_amax_images <= 1). */
   void* planes_out;
   int32_t planes_chunks, planes_chunk0;
   int32_t planes_f16;
   uint32_t* planes_amax;   /* or NULL */
+  int32_t planes_amax_images;
 } SegmifIgemm;
 
 int segmif_igemm_f32(const SegmifIgemm* desc, void* stream);
@@ -145,12 +147,13 @@ int64_t segmif_gemm_split_weight_bytes(int N, int K);
 int segmif_gemm_split_pack(const float* w, int N, int K, int ldw, void* out, void* stream);
 int segmif_gemm_split_f32(const SegmifGemmSplit* desc, void* stream);
 /* The same GEMM with f16x3 arithmetic (half pairs x three products, see segmif_planes16_* below): A is split in the kernel,
- * max |A| of the staged rows is folded into *amax (NULL = off) - the caller must re-run on segmif_gemm_split_f32 when it
- * left [2^-13, 65504); `w` is the segmif_gemm_split16_pack image (the bf16 image's layout with scaled half planes, then
- * one float 2^-e(n) per padded output column). */
+ * max |A| of the staged rows is folded into the range slots amax[0 .. amax_images) (NULL = off): the M rows are
+ * amax_images whole images of M / amax_images rows, image i reports to amax[i] (amax_images = 1: one slot) - the caller
+ * must re-run the images whose slot left [2^-13, 65504) on segmif_gemm_split_f32; `w` is the segmif_gemm_split16_pack
+ * image (the bf16 image's layout with scaled half planes, then one float 2^-e(n) per padded output column). */
 int64_t segmif_gemm_split16_weight_bytes(int N, int K);
 int segmif_gemm_split16_pack(const float* w, int N, int K, int ldw, void* out, void* stream);
-int segmif_gemm_split16_f32(const SegmifGemmSplit* desc, uint32_t* amax, void* stream);
+int segmif_gemm_split16_f32(const SegmifGemmSplit* desc, uint32_t* amax, int amax_images, void* stream);
 
 /*
  * "Planes" activations: the bf16x6 operand split done ONCE by the producer instead of in every
@@ -211,18 +214,20 @@ int segmif_conv3x3_planes_bf16x6(const SegmifConvPlanes* desc, void* stream);
  * THREE MFMA products per fp32-equivalent MAC instead of six and 2/3 of the activation bytes, at the error level of
  * the bf16x6 kernels (tests/test_gpu_kernels.py) - provided the activations lie in the half's exponent range: every
  * producer (segmif_planes16_from_f32, the conv's own planes / fused-tail output) folds max |x| of what it wrote into
- * *amax (atomic max on the IEEE bit pattern of a non-negative float; NULL = off).  The caller must read it back and
- * re-run on the bf16x6 entry points when a value left [2^-13, 65504) (0 = an all-zero tensor is fine): above, a half
- * overflows; below, the pair keeps fewer than 23 bits.  core/model_fusion.py does this per forward (ops.Planes16Guard).
+ * a range slot (atomic max on the IEEE bit pattern of a non-negative float - NaN compares above inf; NULL = off):
+ * amax[b] for batch element b when amax_images == B, amax[0] when amax_images == 1.  The caller must read the slots
+ * back and re-run, on the bf16x6 entry points, the images whose value left [2^-13, 65504) (0 = an all-zero tensor is
+ * fine): above, a half overflows; below, the pair keeps fewer than 23 bits.  segmif_amd.ops.run_guarded does this once
+ * per pair forward, per image (ops.Planes16Guard).
  * Same geometry (segmif_planes_dims), channel order and argument rules as the bf16 entry points above.
  */
 int64_t segmif_planes16_bytes(int B, int H, int W, int chunks);
 int segmif_planes16_zero_border(void* planes, int B, int H, int W, int chunks, void* stream);
 int segmif_planes16_from_f32(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0, int nconv,
-                             uint32_t* amax, void* stream);
+                             uint32_t* amax, int amax_images, void* stream);
 int64_t segmif_planes16_weight_bytes(int N, int Cin, int taps);
 int segmif_planes16_pack_weight(const float* packed, int N, int Cin, int taps, int ldw, void* out, void* stream);
-int segmif_conv3x3_planes_f16x3(const SegmifConvPlanes* desc, uint32_t* amax, void* stream);
+int segmif_conv3x3_planes_f16x3(const SegmifConvPlanes* desc, uint32_t* amax, int amax_images, void* stream);
 
 /*
  * Weight gradient of the same problem: dW[n][k] = sum_m dY[m][n] * A(m,k), contraction over rows on
@@ -364,7 +369,8 @@ typedef struct SegmifCrossTail {
   int32_t B; int64_t N;
   void* planes_out; int32_t H, W, planes_chunks;   /* optional planes copy of out (NULL = off) */
   int32_t planes_f16;                               /* != 0: an f16x3 buffer (segmif_planes16_*) */
-  uint32_t* planes_amax;                            /* f16x3: guard slot for max |out|, or NULL */
+  uint32_t* planes_amax;                            /* f16x3: range slot(s) for max |out|, or NULL */
+  int32_t planes_amax_images;                       /* == B: planes_amax[image]; <= 1: planes_amax[0] */
 } SegmifCrossTail;
 
 int segmif_crosspath_gram_blocks(int64_t N);

@@ -29,7 +29,7 @@ class SegmifIgemm(ctypes.Structure):
         ("workspace", c_void_p), ("workspace_floats", c_int64),
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
         ("planes_out", c_void_p), ("planes_chunks", c_int32), ("planes_chunk0", c_int32),
-        ("planes_f16", c_int32), ("planes_amax", c_void_p),
+        ("planes_f16", c_int32), ("planes_amax", c_void_p), ("planes_amax_images", c_int32),
     ]
 
 
@@ -57,7 +57,7 @@ class SegmifCrossTail(ctypes.Structure):
         ("out", c_void_p), ("ld3", c_int32), ("ldi", c_int32), ("ldo", c_int32),
         ("B", c_int32), ("N", c_int64),
         ("planes_out", c_void_p), ("H", c_int32), ("W", c_int32), ("planes_chunks", c_int32),
-        ("planes_f16", c_int32), ("planes_amax", c_void_p),
+        ("planes_f16", c_int32), ("planes_amax", c_void_p), ("planes_amax_images", c_int32),
     ]
 
 
@@ -77,7 +77,7 @@ SIGNATURES = {
     "segmif_gemm_split_f32": (c_int, [POINTER(SegmifGemmSplit), c_void_p]),
     "segmif_gemm_split16_weight_bytes": (c_int64, [c_int, c_int]),
     "segmif_gemm_split16_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "segmif_gemm_split16_f32": (c_int, [POINTER(SegmifGemmSplit), c_void_p, c_void_p]),
+    "segmif_gemm_split16_f32": (c_int, [POINTER(SegmifGemmSplit), c_void_p, c_int, c_void_p]),
     "segmif_planes_dims": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "segmif_planes_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "segmif_planes_zero_border": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -87,10 +87,10 @@ SIGNATURES = {
     "segmif_conv3x3_planes_bf16x6": (c_int, [POINTER(SegmifConvPlanes), c_void_p]),
     "segmif_planes16_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "segmif_planes16_zero_border": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "segmif_planes16_from_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "segmif_planes16_from_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "segmif_planes16_weight_bytes": (c_int64, [c_int, c_int, c_int]),
     "segmif_planes16_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "segmif_conv3x3_planes_f16x3": (c_int, [POINTER(SegmifConvPlanes), c_void_p, c_void_p]),
+    "segmif_conv3x3_planes_f16x3": (c_int, [POINTER(SegmifConvPlanes), c_void_p, c_int, c_void_p]),
     "segmif_crosspath_gram_blocks": (c_int, [c_int64]),
     "segmif_crosspath_gram_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "segmif_crosspath_fold_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -190,7 +190,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.restype = res
         fn.argtypes = args
-    if lib.segmif_abi_version() != 1:
+    if lib.segmif_abi_version() != 2:
         raise HipLibraryMissing("libsegmif_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

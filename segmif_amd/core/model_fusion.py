@@ -515,7 +515,7 @@ class Fusion_Network3_ac(nn.Module):
         B, _, H, W = ir.shape
         dev, slope = ir.device, self.relu.weight
         PRELU = ops.ACT_PRELU
-        if self.DRDB1.planes_ok():
+        if all(d.planes_ok() for d in (self.DRDB1, self.DRDB2, self.DRDB3, self.DRDB4)):
             return self._forward_eval_planes(ir, vis, seg1_fn, seg2_fn)
         bufs = []
         for x, conv, drdb in ((ir, self.conv1_ir, self.DRDB1), (vis, self.conv1_vis, self.DRDB2)):

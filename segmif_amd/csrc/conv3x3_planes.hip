@@ -138,7 +138,8 @@ struct PlanesConvK {
   int tiles_x, tiles_y;
   const float* wscale;        // f16x3: 2^-e(n) of the 32 conv rows / the 64 rows of the fused 1x1
   const float* w1scale;
-  uint32_t* amax;             // f16x3: atomic max of the bit patterns of |conv output| (or null)
+  uint32_t* amax;             // f16x3: range slots of max |conv output| (or null), one per image when amax_images == B
+  int amax_images;            // 1: every image reports to amax[0]
 };
 
 __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* lds_wave_base) {
@@ -274,7 +275,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int n = tid - 128;
     reinterpret_cast<float*>(Cst)[tid] = n < 32 ? p.wscale[n] : (FUSE ? p.w1scale[n - 32] : 1.f);
   }
-  float amx = 0.f;  // f16x3: largest |output| this lane has split
+  uint32_t amx = 0u;  // f16x3: largest |output| this lane has split for image amx_b (p16::absmax_pk patterns)
+  int amx_b = 0;
 
   f32x16 acc[SUB], acc1[FUSE ? 2 : 1][2];
   auto zero_acc = [&]() {
@@ -468,6 +470,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // cycles measured) in a phase the other team is waiting on, and per-element "pointer ? load : 0" code cost 5 000.
     const float* cst = reinterpret_cast<const float*>(Cst);
     const float nslope = cst[96];
+    if constexpr (F16) {  // per-image range slots: hand in the running maximum when the patch sequence moves to another image
+      const int pb = p.amax_images > 1 ? pt.b : 0;  // (wave-uniform)
+      if (pb != amx_b) {
+        if (p.amax) p16::fold_pat(p.amax, amx_b, amx_b, amx);
+        amx = 0u;
+        amx_b = pb;
+      }
+    }
     float bv[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -495,10 +505,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float t = F16 ? fmaf(acc[i][v], sv[F16 ? v : 0], bv[v]) : acc[i][v] + bv[v];
         y[v] = t >= 0.f ? t : nslope * t;
       }
-      if constexpr (F16) {
-        const float mx = p16::abs_max8(y + 8, p16::abs_max8(y, 0.f));
-        amx = ok ? fmaxf(amx, mx) : amx;
-      }
 #if PLANES_DBG & 32
       if (i == 0 && wave == 0 && lane == 0 && blockIdx.x < 256 && item < PLANES_TL_ITEMS) {
         asm volatile("" ::"v"(y[0]), "v"(y[15]));
@@ -517,6 +523,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (F16) {
           p16::split8(y + 8 * q, pl[0], pl[1]);
           pl[2] = pl[1];
+          const uint32_t mx = p16::absmax_pk4(amx, pl[0]);
+          amx = ok ? mx : amx;
         } else {
           split8(y + 8 * q, pl[0], pl[1], pl[2]);
         }
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (team == 0) __syncthreads();
   }
   if constexpr (F16) {
-    if (p.amax) p16::fold_max(p.amax, amx);
+    if (p.amax) p16::fold_pat(p.amax, amx_b, amx_b, amx);
   }
 }
 
@@ -651,13 +659,14 @@ __device__ float planes_zero_bias[64];  // stands in for a NULL bias (static sto
 // fp32 rows (pixel pitch ldx) -> planes chunks [chunk0, chunk0 + nconv).  One thread = (pixel, chunk, half).
 template <bool F16>
 __global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, unsigned char* __restrict__ planes, int B,
-                                       int H, int W, int Hp, int Wp, int total, int chunk0, int nconv, uint32_t* amax) {
+                                       int H, int W, int Hp, int Wp, int total, int chunk0, int nconv, uint32_t* amax,
+                                       int amax_images) {
   constexpr int PXA = F16 ? PXH : PXB;
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long npix = (long long)B * H * W;
   const bool live = idx < npix * nconv * 2;
   if (!F16 && !live) return;
-  if (!live) idx = 0;  // f16x3: dead lanes of the last block still take part in the wave maximum below
+  if (!live) idx = npix * nconv * 2 - 1;  // f16x3: dead lanes of the last block still take part in the wave maximum below (as the last pixel)
   const int hf = (int)(idx & 1);
   const int ch = (int)((idx >> 1) % nconv);
   const long long pix = (idx >> 1) / nconv;
@@ -675,7 +684,10 @@ __global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, uns
       *reinterpret_cast<u32x4*>(dst) = p0;
       *reinterpret_cast<u32x4*>(dst + 32) = p1;
     }
-    if (amax) p16::fold_max(amax, live ? p16::abs_max8(y, 0.f) : 0.f);
+    if (amax) {  // a wave covers consecutive pixels: images of its first and last lane (conservative when it straddles two)
+      const int b_lo = __shfl(b, 0, 64), b_hi = __shfl(b, 63, 64);
+      p16::fold_pat(amax, amax_images > 1 ? b_lo : 0, amax_images > 1 ? b_hi : 0, live ? p16::absmax_pk4(0u, p0) : 0u);
+    }
   } else {
     u32x4 p0, p1, p2;
     split8(y, p0, p1, p2);
@@ -788,13 +800,13 @@ static int planes_zero_border_impl(void* planes, int B, int H, int W, int chunks
 
 template <bool F16>
 static int planes_from_f32_impl(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0, int nconv,
-                                uint32_t* amax, void* stream) {
+                                uint32_t* amax, int amax_images, void* stream) {
   if (!x || !planes || B <= 0 || H <= 0 || W <= 0 || nconv <= 0 || chunk0 < 0 || chunk0 + nconv > chunks || ldx % 4 ||
-      ((uintptr_t)x & 15) || ldx < 16 * nconv)
+      ((uintptr_t)x & 15) || ldx < 16 * nconv || (amax && amax_images != 1 && amax_images != B))
     return SEGMIF_EINVAL;
   const long long n = (long long)B * H * W * nconv * 2;
   hipLaunchKernelGGL(planes_from_f32_kernel<F16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                     (unsigned char*)planes, B, H, W, planes_hp(H), planes_wp(W), chunks, chunk0, nconv, amax);
+                     (unsigned char*)planes, B, H, W, planes_hp(H), planes_wp(W), chunks, chunk0, nconv, amax, amax_images);
   return (int)hipGetLastError();
 }
 
@@ -810,11 +822,11 @@ extern "C" int segmif_planes16_zero_border(void* planes, int B, int H, int W, in
 
 extern "C" int segmif_planes_from_f32(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0,
                                       int nconv, void* stream) {
-  return planes_from_f32_impl<false>(x, ldx, planes, B, H, W, chunks, chunk0, nconv, nullptr, stream);
+  return planes_from_f32_impl<false>(x, ldx, planes, B, H, W, chunks, chunk0, nconv, nullptr, 1, stream);
 }
 extern "C" int segmif_planes16_from_f32(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0,
-                                        int nconv, uint32_t* amax, void* stream) {
-  return planes_from_f32_impl<true>(x, ldx, planes, B, H, W, chunks, chunk0, nconv, amax, stream);
+                                        int nconv, uint32_t* amax, int amax_images, void* stream) {
+  return planes_from_f32_impl<true>(x, ldx, planes, B, H, W, chunks, chunk0, nconv, amax, amax_images, stream);
 }
 
 extern "C" int64_t segmif_planes_weight_bytes(int N, int Cin, int taps) {
@@ -846,17 +858,18 @@ extern "C" int segmif_planes16_pack_weight(const float* packed, int N, int Cin, 
   return (int)hipGetLastError();
 }
 
-static int conv3x3_planes_impl(const SegmifConvPlanes* d, bool f16, uint32_t* amax, void* stream);
+static int conv3x3_planes_impl(const SegmifConvPlanes* d, bool f16, uint32_t* amax, int amax_images, void* stream);
 
 extern "C" int segmif_conv3x3_planes_bf16x6(const SegmifConvPlanes* d, void* stream) {
-  return conv3x3_planes_impl(d, false, nullptr, stream);
+  return conv3x3_planes_impl(d, false, nullptr, 1, stream);
 }
 
-extern "C" int segmif_conv3x3_planes_f16x3(const SegmifConvPlanes* d, uint32_t* amax, void* stream) {
-  return conv3x3_planes_impl(d, true, amax, stream);
+extern "C" int segmif_conv3x3_planes_f16x3(const SegmifConvPlanes* d, uint32_t* amax, int amax_images, void* stream) {
+  return conv3x3_planes_impl(d, true, amax, amax_images, stream);
 }
 
-static int conv3x3_planes_impl(const SegmifConvPlanes* d, bool f16, uint32_t* amax, void* stream) {
+static int conv3x3_planes_impl(const SegmifConvPlanes* d, bool f16, uint32_t* amax, int amax_images, void* stream) {
+  if (amax && amax_images != 1 && (!d || amax_images != d->B)) return SEGMIF_EINVAL;
   if (!d || !d->planes_in || !d->wt || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cin <= 0 || d->cin % 16) return SEGMIF_EINVAL;
   if (d->dil != 1 && d->dil != 2) return SEGMIF_EINVAL;
   if (d->act != SEGMIF_ACT_NONE && d->act != SEGMIF_ACT_RELU && d->act != SEGMIF_ACT_PRELU) return SEGMIF_EINVAL;
@@ -888,6 +901,7 @@ static int conv3x3_planes_impl(const SegmifConvPlanes* d, bool f16, uint32_t* am
   if (k.pout && k.pout == k.pin && k.out_chunk0 < k.nchunks) return SEGMIF_EINVAL;  // would overwrite its own input
   if ((long long)k.Hp * k.Wp * (f16 ? PXH : PXB) >= (1ll << 32)) return SEGMIF_EINVAL;
   k.amax = amax;
+  k.amax_images = amax_images;
   k.wscale = reinterpret_cast<const float*>(k.wt + (long long)32 * d->cin * 9 * 6);  // f16x3 images end with the row scales
   k.w1scale = d->w1 ? reinterpret_cast<const float*>((const unsigned char*)d->w1 + (long long)64 * (d->cin + 32) * 6) : nullptr;
   k.w1 = (const unsigned char*)d->w1;

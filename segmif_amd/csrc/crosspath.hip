@@ -298,7 +298,8 @@ struct TailK {
   float* out;
   unsigned char* planes;              // optional split-bf16 copy of out (conv3x3_planes.hip format) or null
   int pl_f16;                         // the copy is an f16x3 one (half pairs, 64 bytes per pixel; planes16.h)
-  uint32_t* pl_amax;                  // f16x3: guard slot for max |out| or null
+  uint32_t* pl_amax;                  // f16x3: range slot(s) for max |out| or null
+  int pl_amax_images;                 // > 1: slot index = image (blockIdx.y)
   long long N;
   int ld3, ldi, ldo;
   int W, Hp, Wp, chunks;              // planes geometry (image width, padded dims, chunk images per batch element)
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
 
   const long long ntiles = (p.N + 31) / 32;
   const long long stride = (long long)gridDim.x * CP_WAVES;
-  float pl_amx = 0.f;  // f16x3 planes copy: largest |out| this lane wrote
+  uint32_t pl_amx = 0u;  // f16x3 planes copy: largest |out| this lane wrote (p16::absmax_pk patterns)
   auto load = [&](long long tt, const float* __restrict__ base, int ld, f32x4* dst) {  // a pixel's channels 8q + 4h .. +3
     const long long px = tt * 32 + r;
     const bool ok = tt < ntiles && px < p.N;
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
           p16::split8(o + 8 * c, hi, lo);
           *reinterpret_cast<u32x4*>(dst + c * cstride) = hi;
           *reinterpret_cast<u32x4*>(dst + c * cstride + 32) = lo;
-          pl_amx = p16::abs_max8(o + 8 * c, pl_amx);
+          pl_amx = p16::absmax_pk4(pl_amx, hi);
         }
       }
     } else if (p.planes && ok) {  // (F16 implies a planes buffer) positions 8h .. 8h+7 of chunk c = channels 16c + {4h..4h+3, 8+4h..8+4h+3}: this lane's o[8c .. 8c+7]
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
     if (t + stride < ntiles) tile(t + stride, b3, bi, a3, ai);
   }
   if constexpr (F16) {
-    if (p.pl_amax) p16::fold_max(p.pl_amax, pl_amx);
+    if (p.pl_amax) p16::fold_pat(p.pl_amax, p.pl_amax_images > 1 ? b : 0, p.pl_amax_images > 1 ? b : 0, pl_amx);
   }
 }
 
@@ -527,6 +528,8 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
   k.planes = (unsigned char*)d->planes_out;
   k.pl_f16 = k.planes ? d->planes_f16 : 0;
   k.pl_amax = k.pl_f16 ? d->planes_amax : nullptr;
+  k.pl_amax_images = d->planes_amax_images;
+  if (k.pl_amax && k.pl_amax_images > 1 && k.pl_amax_images != d->B) return SEGMIF_EINVAL;
   k.N = d->N; k.ld3 = d->ld3; k.ldi = d->ldi; k.ldo = d->ldo;
   k.W = 0; k.Hp = 0; k.Wp = 0; k.chunks = 0;
   if (k.planes) {

@@ -80,7 +80,8 @@ struct GemmSplitK {
   int ntm, ntn;
   int epi;  // 1: the output leaves through LDS (rows written 256 contiguous bytes at a time), 0: straight from the accumulators
   const float* wscale;  // f16x3: 2^-e(n) per (padded) output column
-  uint32_t* amax;       // f16x3: guard slot for max |A| (or null)
+  uint32_t* amax;       // f16x3: range slots for max |A| (or null): slot row / amax_rows
+  long long amax_rows;  // rows per image (M when every row reports to amax[0])
 };
 
 template <bool F16>
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
     a_dst[j] = row * APITCH + (kq >> 2) * AHALF + (kq & 3) * 8;
   }
   f32x4 ra[4];
-  float amx = 0.f;  // f16x3: largest |A| this lane has split
+  uint32_t amx = 0u;  // f16x3: largest |A| this lane has split (p16::absmax_pk patterns)
   auto gload = [&](int ks) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(a_ptr[j] + ks * GBK);
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
         p16::split2(x[2], x[3], hb, lb);
         *reinterpret_cast<u32x2*>(As + a_dst[j]) = u32x2{ha, hb};
         *reinterpret_cast<u32x2*>(As + a_dst[j] + 32) = u32x2{la, lb};
-        amx = fmaxf(fmaxf(amx, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
+        amx = p16::absmax_pk(p16::absmax_pk(amx, ha), hb);
       } else {
         uint32_t p0a, p1a, p2a, p0b, p1b, p2b;
         split3(x[0], x[1], p0a, p1a, p2a);
@@ -223,7 +224,10 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
   }
   GEMM_TL(15, 7);
   if constexpr (F16) {
-    if (p.amax) p16::fold_max(p.amax, amx);
+    if (p.amax) {  // the tile's rows m0 .. m0 + 127 may straddle images: it reports to each (conservative)
+      const long long m1 = m0 + GBM - 1 < p.M ? m0 + GBM - 1 : p.M - 1;
+      p16::fold_pat(p.amax, (int)(m0 / p.amax_rows), (int)(m1 / p.amax_rows), amx);
+    }
   }
 
   // ---- epilogue: bias + activation (+ residual).  The products run transposed (weights as the MFMA's row operand), so a
@@ -395,15 +399,16 @@ extern "C" int segmif_gemm_split16_pack(const float* w, int N, int K, int ldw, v
   return (int)hipGetLastError();
 }
 
-static int gemm_split_impl(const SegmifGemmSplit* d, bool f16, uint32_t* amax, void* stream);
+static int gemm_split_impl(const SegmifGemmSplit* d, bool f16, uint32_t* amax, int amax_images, void* stream);
 
-extern "C" int segmif_gemm_split_f32(const SegmifGemmSplit* d, void* stream) { return gemm_split_impl(d, false, nullptr, stream); }
+extern "C" int segmif_gemm_split_f32(const SegmifGemmSplit* d, void* stream) { return gemm_split_impl(d, false, nullptr, 1, stream); }
 
-extern "C" int segmif_gemm_split16_f32(const SegmifGemmSplit* d, uint32_t* amax, void* stream) {
-  return gemm_split_impl(d, true, amax, stream);
+extern "C" int segmif_gemm_split16_f32(const SegmifGemmSplit* d, uint32_t* amax, int amax_images, void* stream) {
+  return gemm_split_impl(d, true, amax, amax_images, stream);
 }
 
-static int gemm_split_impl(const SegmifGemmSplit* d, bool f16, uint32_t* amax, void* stream) {
+static int gemm_split_impl(const SegmifGemmSplit* d, bool f16, uint32_t* amax, int amax_images, void* stream) {
+  if (amax && (amax_images < 1 || !d || d->M % amax_images)) return SEGMIF_EINVAL;  // whole images: M = images x rows per image
   if (!d || !d->a || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % GBK) return SEGMIF_EINVAL;
   if (d->lda < d->K || (d->lda & 3) || ((uintptr_t)d->a & 15) || ((uintptr_t)d->w & 15)) return SEGMIF_EINVAL;
   if (d->act == SEGMIF_ACT_PRELU && !d->prelu) return SEGMIF_EINVAL;
@@ -412,13 +417,12 @@ static int gemm_split_impl(const SegmifGemmSplit* d, bool f16, uint32_t* amax, v
   GemmSplitK k;
   k.a = d->a; k.w = (const unsigned char*)d->w; k.bias = d->bias; k.res = d->res; k.prelu = d->prelu; k.out = d->out;
   k.M = d->M; k.N = d->N; k.K = d->K; k.lda = d->lda; k.ldo = d->ldo; k.ldr = d->ldr; k.act = d->act;
-  {
-    const char* e = getenv("SEGMIF_GEMM_EPI");  // "direct": stores straight from the accumulators (round 2)
-    k.epi = (e && !strcmp(e, "direct")) ? 0 : 1;
-  }
+  static const bool epi_direct = [] { const char* e = getenv("SEGMIF_GEMM_EPI"); return e && !strcmp(e, "direct"); }();
+  k.epi = epi_direct ? 0 : 1;  // "direct" (read once per process): stores straight from the accumulators (round 2)
   k.ntm = (int)((d->M + GBM - 1) / GBM);
   k.ntn = (d->N + GBN - 1) / GBN;
   k.amax = f16 ? amax : nullptr;
+  k.amax_rows = d->M / (amax && amax_images > 1 ? amax_images : 1);
   k.wscale = reinterpret_cast<const float*>(k.w + segmif_gemm_split_weight_bytes(d->N, d->K));  // (f16x3 images only)
   constexpr size_t smem = 2 * (size_t)GTILE, smem16 = (size_t)GBM * GPITCH_H + GTILE;
   static_assert(smem16 >= 4 * 32 * 68 * sizeof(float), "the LDS epilogue tile must fit");

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
     // user is conv1 with Cin = 1); the dense and 16-channel-chunk conv tiles stay free of its registers (20-30 VGPRs)
     constexpr bool PLANES = MODE == MODE_GENERIC;
     const int pl_pitch = PLANES && p.pl_f16 ? p16::PIXEL_BYTES : 96;
-    float pl_amx = 0.f;  // f16x3 planes: largest |output| this lane wrote
+    uint32_t pl_amx = 0u;  // f16x3 planes: largest |output| this lane wrote (p16::absmax_pk patterns)
     f32x4 rr[TM][TN][4];
     if (res) {
 #pragma unroll
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
               p16::split8(yy, hi, lo);
               *reinterpret_cast<ig_u32x4*>(dst) = hi;
               *reinterpret_cast<ig_u32x4*>(dst + 32) = lo;
-              pl_amx = p16::abs_max8(yy, pl_amx);
+              pl_amx = p16::absmax_pk4(pl_amx, hi);
             } else {
               ig_u32x4 pp[3];
 #pragma unroll
@@ -463,7 +463,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
           }
         }
     }
-    if (PLANES && p.pl_amax) p16::fold_max(p.pl_amax, pl_amx);  // (kernel argument: uniform over the grid)
+    if (PLANES && p.pl_amax) {  // (kernel argument: uniform over the grid) this wave's rows -> their images' range slots
+      const long long ohw = (long long)p.OH * p.OW;
+      const long long ma = m0 + wm * WM, mb = ma + TM * 32 - 1 < p.M ? ma + TM * 32 - 1 : p.M - 1;
+      if (ma < p.M) p16::fold_pat(p.pl_amax, p.pl_amax_images > 1 ? (int)(ma / ohw) : 0, p.pl_amax_images > 1 ? (int)(mb / ohw) : 0, pl_amx);
+    }
   } else {  // ragged N or unaligned views: element by element
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -681,6 +685,8 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   k.pl_Hp = k.pl_Wp = k.pl_chunks = k.pl_chunk0 = 0;
   k.pl_f16 = k.planes ? d->planes_f16 : 0;
   k.pl_amax = k.pl_f16 ? d->planes_amax : nullptr;
+  k.pl_amax_images = d->planes_amax_images > 1 ? d->planes_amax_images : 1;
+  if (k.pl_amax && k.pl_amax_images > 1 && (long long)k.pl_amax_images * d->OH * d->OW != d->M) return SEGMIF_EINVAL;
   if (k.planes) {
     int hp, wp;
     if (!k.vec4 || (d->N & 15) || nz > 1 || k.ln_gamma || d->planes_chunk0 < 0 || d->planes_chunk0 + d->N / 16 > d->planes_chunks ||

@@ -36,7 +36,8 @@ struct IgemmK {
   unsigned char* planes;  // optional planes copy of the output (conv3x3_planes.hip format): chunks [pl_chunk0, pl_chunk0 + N/16)
   int pl_Hp, pl_Wp, pl_chunks, pl_chunk0;
   int pl_f16;             // planes are f16x3 half pairs (64 bytes per pixel) instead of bf16 triples (96)
-  uint32_t* pl_amax;      // f16x3: guard slot receiving max |output| (planes16.h) or null
+  uint32_t* pl_amax;      // f16x3: range slots receiving max |output| (planes16.h) or null
+  int pl_amax_images;     // > 1: one slot per image (M = images x OH x OW), else everything reports to pl_amax[0]
   int vec4;  // epilogue may use 16-byte accesses: N, ldo, ldr, z strides multiples of 4 and out / res / bias / ws 16-byte aligned
 };
 

@@ -36,26 +36,49 @@ __device__ __forceinline__ void split8(const float* y, u4& hi, u4& lo) {
   }
 }
 
-__device__ __forceinline__ float abs_max8(const float* y, float m) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(y[e]));
-  return m;
+// ---- range bookkeeping -----------------------------------------------------------------------------------------------
+// A producer tracks the largest magnitude it wrote on the HIGH halves' bit patterns (|half| as a 15-bit unsigned integer is
+// monotone in magnitude; +inf = 0x7c00, every NaN lies above it), two halves per operation (v_and_b32 + v_pk_max_u16 - the
+// same count as one v_max_f32 per value, and unlike v_max_f32 an integer maximum cannot drop a NaN).  Values beyond the
+// half's range have already become inf in the conversion, so the pattern carries exactly what the guard asks about.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t absmax_pk(uint32_t m, uint32_t halves) {
+  const us2 a = __builtin_bit_cast(us2, m), b = __builtin_bit_cast(us2, halves & 0x7fff7fffu);
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(a, b));
 }
 
-__device__ __forceinline__ float wave_max(float v) {
+__device__ __forceinline__ uint32_t absmax_pk4(uint32_t m, const u4& hi) {
+  return absmax_pk(absmax_pk(absmax_pk(absmax_pk(m, hi[0]), hi[1]), hi[2]), hi[3]);
+}
+
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
+    v = v > w ? v : w;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {  // (weights' row scales: finite by construction)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
 
-// Fold this wave's maximum (non-negative, or NaN) into the slot.  The plain load first: a tensor has a few hundred
-// thousand waves and all but a handful carry a value below the running maximum - one atomic per wave on a single
-// address serialises in the L2 (measured 10x on segmif_planes16_from_f32).
-__device__ __forceinline__ void fold_max(uint32_t* slot, float lane_value) {
-  const float m = wave_max(lane_value);
-  if ((threadIdx.x & 63) == 0) {
-    const uint32_t bits = __float_as_uint(m);  // monotonic for m >= 0; NaN reads as larger than inf
-    if (bits > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, bits);
+// Fold this wave's running maximum (absmax_pk patterns) into the range slots of images b_lo .. b_hi (a wave whose rows
+// straddle an image boundary reports to both: conservative).  A slot holds the IEEE bit pattern of a non-negative float
+// (or NaN: it compares above inf).  The plain load first: a tensor has a few hundred thousand waves and all but a handful
+// carry a value below the running maximum - one atomic per wave on a single address serialises in the L2 (measured 10x
+// on segmif_planes16_from_f32).
+__device__ __forceinline__ void fold_pat(uint32_t* slots, int b_lo, int b_hi, uint32_t pat) {
+  uint32_t v = (pat & 0xffffu) > (pat >> 16) ? (pat & 0xffffu) : (pat >> 16);
+  v = wave_umax(v);
+  if ((threadIdx.x & 63) == 0 && v) {
+    const uint32_t bits = __float_as_uint((float)__builtin_bit_cast(_Float16, (unsigned short)v));  // exact; NaN stays NaN
+    for (int b = b_lo; b <= b_hi; ++b)
+      if (bits > __atomic_load_n(slots + b, __ATOMIC_RELAXED)) atomicMax(slots + b, bits);
   }
 }
 

@@ -7,6 +7,8 @@ convs read from and write into concat buffers without copies.
 """
 import ctypes
 import os
+import threading
+import warnings
 
 import torch
 
@@ -150,92 +152,151 @@ def pack_conv3x3(w):
 
 
 class Planes16Guard:
-    """Range bookkeeping of the f16x3 planes path: every producer launch folds max |x| of what it wrote into its own
-    slot (a device-side atomic max); ok() reads the slots back (one host sync) and tells whether every tensor stayed
-    inside [2^-13, 65504) - the range in which a half pair carries an fp32 value to within one bit.  All-zero tensors
-    pass; NaN / inf read as overflow."""
+    """Range bookkeeping of the f16x3 path, PER IMAGE: every producer launch of half pairs folds max |x| of what it wrote
+    into its own row of slots, one slot per batch element (a device-side atomic max; a launch whose batch is not the
+    guard's reports to column 0 and stands for every image).  tripped() reads the rows back (one host sync) and says which
+    images left [2^-13, 65504) somewhere - the range in which a half pair carries an fp32 value to within one bit.  All-zero
+    tensors pass; inf and NaN read as overflow (the slots hold integer maxima of bit patterns: a NaN cannot be dropped)."""
     SLOTS = 1024
     LO, HI = 2.0 ** -13, 65504.0
 
-    def __init__(self, device):
-        self.amax = torch.zeros((self.SLOTS,), device=device, dtype=torch.int32)
+    def __init__(self, device, images=1):
+        self.images = max(1, int(images))
+        self.amax = torch.zeros((self.SLOTS, self.images), device=device, dtype=torch.int32)
         self.used = 0
+        self.whole = set()  # rows written by a launch that did not index by image
 
-    def slot(self):
-        """Device address of the next launch's range slot.  Past SLOTS launches the last slot is shared: the overflow check
-        stays exact (a maximum of maxima), only the vanishing-tensor check of those launches is pooled."""
+    def slot(self, images=None):
+        """-> (device address of the next launch's row of range slots, amax_images for the kernel).  images: the batch the
+        launch will index its slots by; anything but the guard's own count makes it a whole-batch row.  Past SLOTS launches
+        the last row is shared: the overflow check stays exact (a maximum of maxima), only the vanishing-tensor check of those
+        launches is pooled."""
         if self.used < self.SLOTS:
             self.used += 1
-        return self.amax.data_ptr() + 4 * (self.used - 1)
+        row = self.used - 1
+        per_image = images is not None and images == self.images and self.images > 1
+        if not per_image and self.images > 1:
+            self.whole.add(row)
+        return self.amax.data_ptr() + 4 * self.images * row, (self.images if per_image else 1)
+
+    def reset(self):
+        """Forget every launch (a recorded hipGraph re-fills the same rows on each replay)."""
+        self.used = 0
+        self.whole.clear()
+        self.amax.zero_()
 
     def maxima(self):
         return self.amax[:self.used].cpu().view(torch.float32)
 
-    def ok(self):
+    def tripped(self):
+        """-> bool tensor (images,): True where some tensor of that image left the half's range (or held inf / NaN)."""
         m = self.maxima()
-        return bool(((m == 0) | ((m >= self.LO) & (m < self.HI))).all())
+        bad = ~((m == 0) | ((m >= self.LO) & (m < self.HI)))  # NaN fails every comparison: bad
+        out = bad.any(0)
+        for row in self.whole:
+            if row < bad.shape[0] and bool(bad[row, 0]):
+                out[:] = True
+        return out
+
+    def ok(self):
+        return not bool(self.tripped().any())
 
 
-_guard = None          # the Planes16Guard of the running guarded scope (run_guarded), or None
-_suppress = 0          # > 0 while a scope is being repeated on the bf16x6 kernels: nested scopes must not open a guard
-_range_fallbacks = 0   # guarded scopes repeated on the bf16x6 kernels
+class _Scope(threading.local):
+    """Per-thread state of the guarded scopes: two threads running forwards in one process must not share a guard."""
+    guard = None     # the Planes16Guard of the running guarded scope (run_guarded), or None
+    suppress = 0     # > 0 while a scope is being repeated on the bf16x6 kernels: nested scopes must not open a guard
+
+
+_scope = _Scope()
+_stats_lock = threading.Lock()
+_stats = {"scopes": 0, "fallbacks": 0, "images": 0, "images_repeated": 0, "streak": 0, "warned": False}
+
+
+def _count(images, repeated):
+    with _stats_lock:
+        _stats["scopes"] += 1
+        _stats["images"] += images
+        _stats["images_repeated"] += repeated
+        if repeated:
+            _stats["fallbacks"] += 1
+            _stats["streak"] += 1
+            if _stats["streak"] >= 8 and not _stats["warned"]:
+                _stats["warned"] = True
+                warnings.warn("segmif_amd: the f16x3 range guard has tripped in 8 guarded forwards in a row - those images "
+                              "run twice (f16x3, then bf16x6).  Activations outside [2^-13, 65504): consider "
+                              "SEGMIF_CONV3X3=planes SEGMIF_LINEAR=bf16x6 for this model / data.", RuntimeWarning)
+        else:
+            _stats["streak"] = 0
 
 
 def active_guard():
-    return _guard
+    return _scope.guard
 
 
 def range_fallbacks():
-    return _range_fallbacks
+    """Guarded scopes in which at least one image was repeated on the bf16x6 kernels."""
+    return _stats["fallbacks"]
+
+
+def range_stats():
+    """-> dict: guarded scopes, scopes with a repeat, images seen, images repeated (f16x3_trip_rate = repeated / seen)."""
+    with _stats_lock:
+        d = {k: _stats[k] for k in ("scopes", "fallbacks", "images", "images_repeated")}
+    d["trip_rate"] = d["images_repeated"] / d["images"] if d["images"] else 0.0
+    return d
 
 
 def f16x3_enabled():
     return _conv3x3_mode == "planes16" or _linear_mode == "f16x3"
 
 
-def run_guarded(fn, device, enabled=None):
-    """Run fn() with the f16x3 kernels available (enabled=None: if a mode asks for them): inside, active_guard() hands every producer of half pairs its range slot.
-    One read-back at the end; if a tensor left the half's exponent range, fn() runs again without a guard, i.e. on the
-    bf16x6 kernels.  Nested calls join the outer scope (which does the checking); fn must be repeatable."""
-    global _guard, _range_fallbacks, _suppress
+def run_guarded(fn, device, enabled=None, images=1, redo=None):
+    """Run fn() with the f16x3 kernels available (enabled=None: if a mode asks for them): inside, active_guard() hands every
+    producer of half pairs its row of range slots, one slot per image.  One read-back at the end.  If images left the
+    half's exponent range: with redo given, `redo(out, idx)` recomputes just those batch elements (idx: LongTensor) on the
+    bf16x6 kernels and returns the patched result; without it (or when every image tripped) fn() runs again as a whole,
+    without a guard.  Nested calls join the outer scope (which does the checking); fn must be repeatable."""
     if enabled is None:
         enabled = f16x3_enabled()
-    if _guard is not None or _suppress or not enabled:
+    if _scope.guard is not None or _scope.suppress or not enabled:
         return fn()
-    _guard = Planes16Guard(device)
+    _scope.guard = guard = Planes16Guard(device, images)
     try:
         out = fn()
-        ok = _guard.ok()
+        bad = guard.tripped()
     finally:
-        _guard = None
-    if ok:
+        _scope.guard = None
+    nbad = int(bad.sum())
+    _count(guard.images, nbad)
+    if nbad == 0:
         return out
-    del out
-    _range_fallbacks += 1
-    _suppress += 1
+    _scope.suppress += 1
     try:
+        if redo is not None and nbad < guard.images:
+            return redo(out, bad.nonzero().flatten().to(device))
+        del out
         return fn()
     finally:
-        _suppress -= 1
+        _scope.suppress -= 1
 
 
 def install_guard(guard):
     """Low-level: make `guard` (or None) the active one WITHOUT run_guarded's read-back, returning the previous one - for a
     caller that does the read-back itself later (pipeline.PairForward records a hipGraph this way and checks after replay)."""
-    global _guard
-    prev, _guard = _guard, guard
+    prev, _scope.guard = _scope.guard, guard
     return prev
 
 
-def run_unguarded(fn):
-    """fn() on the bf16x6 kernels, counted as a range fallback (the repeat half of run_guarded for such a caller)."""
-    global _range_fallbacks, _suppress
-    _range_fallbacks += 1
-    _suppress += 1
+def run_unguarded(fn, images=1, repeated=None):
+    """fn() on the bf16x6 kernels, counted as a range fallback of `repeated` of `images` images (the repeat half of
+    run_guarded for such a caller)."""
+    _count(images, images if repeated is None else repeated)
+    _scope.suppress += 1
     try:
         return fn()
     finally:
-        _suppress -= 1
+        _scope.suppress -= 1
 
 
 class Planes:
@@ -287,8 +348,9 @@ class Planes:
             _lib.check(lib.segmif_planes_from_f32(x.data_ptr(), ldx, self.data.data_ptr(), self.B, self.H, self.W,
                                                   self.chunks, chunk0, C // 16, _stream()), "segmif_planes_from_f32")
         else:
+            amax, nimg = self.guard.slot(self.B)
             _lib.check(lib.segmif_planes16_from_f32(x.data_ptr(), ldx, self.data.data_ptr(), self.B, self.H, self.W,
-                                                    self.chunks, chunk0, C // 16, self.guard.slot(), _stream()),
+                                                    self.chunks, chunk0, C // 16, amax, nimg, _stream()),
                        "segmif_planes16_from_f32")
         return self
 
@@ -359,11 +421,11 @@ def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None,
                 raise RuntimeError("conv3x3_planes: res shape mismatch")
             d.res, d.ldr = res.data_ptr(), ldr
     lib = _lib.load()
-    amax = planes.guard.slot() if planes.f16 else None
+    amax, nimg = planes.guard.slot(planes.B) if planes.f16 else (None, 1)
 
     def go():
         if planes.f16:
-            _lib.check(lib.segmif_conv3x3_planes_f16x3(ctypes.byref(d), amax, _stream()), "segmif_conv3x3_planes_f16x3")
+            _lib.check(lib.segmif_conv3x3_planes_f16x3(ctypes.byref(d), amax, nimg, _stream()), "segmif_conv3x3_planes_f16x3")
         else:
             _lib.check(lib.segmif_conv3x3_planes_bf16x6(ctypes.byref(d), _stream()), "segmif_conv3x3_planes_bf16x6")
 
@@ -447,7 +509,8 @@ def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):
     orow, oc, ldo = rows_view(out, "out")
     if orow != rows or oc != N or (split.N, split.K) != (N, K):
         raise RuntimeError(f"linear_auto: shapes do not fit (rows {rows}/{orow}, N {N}/{oc}, weight {split.N}x{split.K})")
-    use16 = split.half is not None and _guard is not None
+    guard = _scope.guard
+    use16 = split.half is not None and guard is not None
     d = _lib.SegmifGemmSplit()
     d.a, d.w, d.out = x.data_ptr(), (split.half if use16 else split.data).data_ptr(), out.data_ptr()
     d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
@@ -458,7 +521,9 @@ def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):
             raise RuntimeError("residual shape mismatch")
         d.res, d.ldr = res.data_ptr(), ldr
     if use16:
-        _lib.check(_lib.load().segmif_gemm_split16_f32(ctypes.byref(d), _guard.slot(), _stream()), "segmif_gemm_split16_f32")
+        # rows of a (B, n, K) token tensor are B whole images: each reports to its own range slot
+        amax, nimg = guard.slot(x.shape[0] if x.dim() == 3 and rows == x.shape[0] * x.shape[1] else None)
+        _lib.check(_lib.load().segmif_gemm_split16_f32(ctypes.byref(d), amax, nimg, _stream()), "segmif_gemm_split16_f32")
     else:
         _lib.check(_lib.load().segmif_gemm_split_f32(ctypes.byref(d), _stream()), "segmif_gemm_split_f32")
     return out
@@ -651,7 +716,8 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
         planes.need(planes_chunk0 + N // 16, "conv2d planes output")
         d.planes_out, d.planes_chunks, d.planes_chunk0 = planes.data.data_ptr(), planes.chunks, planes_chunk0
         if planes.f16:
-            d.planes_f16, d.planes_amax = 1, planes.guard.slot()
+            d.planes_f16 = 1
+            d.planes_amax, d.planes_amax_images = planes.guard.slot(B)
     _igemm(d, tag, dev=x.device)
     return out
 
@@ -918,7 +984,8 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
         planes.need(4, "crosspath_tail planes output")
         d.planes_out, d.H, d.W, d.planes_chunks = planes.data.data_ptr(), hw[0], hw[1], planes.chunks
         if planes.f16:
-            d.planes_f16, d.planes_amax = 1, planes.guard.slot()
+            d.planes_f16 = 1
+            d.planes_amax, d.planes_amax_images = planes.guard.slot(B)
     _side("cp_tail", lambda: _lib.check(_lib.load().segmif_crosspath_tail_f32(ctypes.byref(d), _stream()),
                                         "segmif_crosspath_tail_f32"),
           (768.0 + (0.0 if planes is None else 256.0 if planes.f16 else 384.0)) * B * N)  # + the planes copy: 4 | 6 B per element

@@ -25,9 +25,18 @@ class PairForward:
 
     def eager(self, ir, vis, mask3):
         """-> (fused RGB (B,3,H,W), labels int32 (B,H,W)).  One guarded scope around the whole pair forward: the encoder's
-        tall GEMMs and the fusion net's 3x3 convs run on f16x3 operands, their range slots are read back once at the end and
-        a pair whose activations left the half's exponent range is computed again on the bf16x6 kernels."""
-        return ops.run_guarded(lambda: self._eager_body(ir, vis, mask3), ir.device)
+        tall GEMMs and the fusion net's 3x3 convs run on f16x3 operands, their range slots - one per pair - are read back once
+        at the end and exactly the pairs whose activations left the half's exponent range are computed again on the bf16x6
+        kernels (a pair's result does not depend on what else is in the batch)."""
+        return ops.run_guarded(lambda: self._eager_body(ir, vis, mask3), ir.device, images=ir.shape[0],
+                               redo=lambda out, idx: self._redo(out, idx, ir, vis, mask3))
+
+    def _redo(self, out, idx, ir, vis, mask3):
+        """Recompute the pairs `idx` (run_guarded has switched the f16x3 kernels off) and patch them into `out`."""
+        fused, labels = self._eager_body(ir.index_select(0, idx), vis.index_select(0, idx), mask3.index_select(0, idx))
+        out[0].index_copy_(0, idx, fused)
+        out[1].index_copy_(0, idx, labels)
+        return out
 
     def _eager_body(self, ir, vis, mask3):
         enc = self.seg.denoise_net.encoder
@@ -50,13 +59,12 @@ class PairForward:
         # The f16x3 kernels need a range guard, and a captured graph cannot hold run_guarded's host read-back: the graph gets
         # a guard of its own whose slots are cleared by a memset node at its start and filled by its kernels; replay() reads
         # them back after the launch and computes the pair again, eagerly on the bf16x6 kernels, if one tripped.
-        guard = ops.Planes16Guard(ir.device) if ops.f16x3_enabled() else None
+        guard = ops.Planes16Guard(ir.device, ir.shape[0]) if ops.f16x3_enabled() else None
 
         def body():
             if guard is None:
                 return self._eager_body(*self._static)
-            guard.used = 0
-            guard.amax.zero_()
+            guard.reset()
             prev = ops.install_guard(guard)
             try:
                 return self._eager_body(*self._static)
@@ -82,9 +90,17 @@ class PairForward:
             if src is not None and src.data_ptr() != dst.data_ptr():
                 dst.copy_(src)
         self._graph.replay()
-        if self._graph_guard is not None and not self._graph_guard.ok():  # (one small read-back per replay)
-            with torch.no_grad():
-                return ops.run_unguarded(lambda: self._eager_body(*self._static))
+        if self._graph_guard is not None:  # (one small read-back per replay)
+            bad = self._graph_guard.tripped()
+            nbad, n = int(bad.sum()), self._graph_guard.images
+            if nbad:
+                with torch.no_grad():
+                    if nbad == n:
+                        return ops.run_unguarded(lambda: self._eager_body(*self._static), images=n)
+                    idx = bad.nonzero().flatten().to(self._static[0].device)
+                    return ops.run_unguarded(lambda: self._redo(self._out, idx, *self._static), images=n, repeated=nbad)
+            else:
+                ops.run_unguarded(lambda: None, images=n, repeated=0)  # (statistics only)
         return self._out
 
     def __call__(self, ir, vis, mask3):

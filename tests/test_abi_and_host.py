@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, s), f"{s} declared in segmif_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.segmif_abi_version() == 1
+    assert lib.segmif_abi_version() == 2
     assert lib.segmif_igemm_num_tiles() == 15
     assert lib.segmif_linattn_num_blocks(307200) == 300
 
@@ -60,15 +60,17 @@ def test_struct_layout_of_the_f16x3_fields_matches_c(lib, tmp_path):
     """The descriptors that grew f16x3 fields (planes_f16 / planes_amax): size and the new fields' offsets against gcc."""
     from segmif_amd._lib import SegmifConvPlanes, SegmifCrossTail, SegmifGemmSplit, SegmifIgemm
     src = tmp_path / "layout16.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "segmif_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "segmif_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(SegmifIgemm),offsetof(SegmifIgemm,planes_f16),offsetof(SegmifIgemm,planes_amax),'
                    'sizeof(SegmifCrossTail),offsetof(SegmifCrossTail,planes_f16),offsetof(SegmifCrossTail,planes_amax),'
+                   'offsetof(SegmifIgemm,planes_amax_images),offsetof(SegmifCrossTail,planes_amax_images),'
                    'sizeof(SegmifConvPlanes),sizeof(SegmifGemmSplit));return 0;}')
     exe = tmp_path / "layout16"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(SegmifIgemm), SegmifIgemm.planes_f16.offset, SegmifIgemm.planes_amax.offset,
             ctypes.sizeof(SegmifCrossTail), SegmifCrossTail.planes_f16.offset, SegmifCrossTail.planes_amax.offset,
+            SegmifIgemm.planes_amax_images.offset, SegmifCrossTail.planes_amax_images.offset,
             ctypes.sizeof(SegmifConvPlanes), ctypes.sizeof(SegmifGemmSplit)]
     assert got == want
 
@@ -85,11 +87,11 @@ def test_f16x3_entry_points_size_rules_and_rejections_without_a_gpu(lib):
     assert lib.segmif_gemm_split16_weight_bytes(320, 320) == lib.segmif_gemm_split_weight_bytes(320, 320) + 4 * 384
     assert lib.segmif_gemm_split16_weight_bytes(320, 48) == 0
     assert lib.segmif_planes16_zero_border(None, 1, 8, 32, 4, None) == -22
-    assert lib.segmif_planes16_from_f32(None, 64, None, 1, 8, 32, 4, 0, 4, None, None) == -22
+    assert lib.segmif_planes16_from_f32(None, 64, None, 1, 8, 32, 4, 0, 4, None, 1, None) == -22
     assert lib.segmif_planes16_pack_weight(None, 32, 64, 9, 576, None, None) == -22
     assert lib.segmif_gemm_split16_pack(None, 320, 320, 320, None, None) == -22
-    assert lib.segmif_conv3x3_planes_f16x3(ctypes.byref(SegmifConvPlanes()), None, None) == -22
-    assert lib.segmif_gemm_split16_f32(ctypes.byref(SegmifGemmSplit()), None, None) == -22
+    assert lib.segmif_conv3x3_planes_f16x3(ctypes.byref(SegmifConvPlanes()), None, 1, None) == -22
+    assert lib.segmif_gemm_split16_f32(ctypes.byref(SegmifGemmSplit()), None, 1, None) == -22
 
 
 def test_guarded_scope_logic_on_the_host():
@@ -102,8 +104,9 @@ def test_guarded_scope_logic_on_the_host():
         g = ops.active_guard()
         if g is None:
             return "bf16x6"
-        ptr_index = (g.slot() - g.amax.data_ptr()) // 4
-        g.amax[ptr_index] = int(torch.tensor([value], dtype=torch.float32).view(torch.int32))
+        ptr, nimg = g.slot()
+        assert nimg == 1
+        g.amax.view(-1)[(ptr - g.amax.data_ptr()) // 4] = int(torch.tensor([value], dtype=torch.float32).view(torch.int32))
         return "f16x3"
 
     base = ops.range_fallbacks()
@@ -125,8 +128,73 @@ def test_guarded_scope_logic_on_the_host():
         ops.run_guarded(lambda: 1 / 0, "cpu", enabled=True)
     assert ops.active_guard() is None
     g = ops.Planes16Guard("cpu")
-    slots = {g.slot() for _ in range(g.SLOTS + 5)}
+    slots = {g.slot()[0] for _ in range(g.SLOTS + 5)}
     assert len(slots) == g.SLOTS and g.used == g.SLOTS  # past the end the last slot is shared
+
+
+def test_guarded_scope_repeats_only_the_images_that_tripped():
+    """Per-image range slots on the host: a producer that indexes its row by image marks single images; run_guarded hands
+    exactly those to `redo` (with the f16x3 kernels switched off) and keeps the others' first results; a launch that does
+    not index by image stands for the whole batch; when every image tripped the scope runs again as a whole."""
+    from segmif_amd import ops
+    B = 5
+
+    def bits(v):
+        return int(torch.tensor([v], dtype=torch.float32).view(torch.int32))
+
+    def producer(values, per_image=True):
+        g = ops.active_guard()
+        if g is None:
+            return ["bf16x6"] * B
+        ptr, nimg = g.slot(B if per_image else None)
+        row = (ptr - g.amax.data_ptr()) // (4 * g.images)
+        assert nimg == (B if per_image else 1) and g.images == B
+        for b, v in enumerate(values if per_image else values[:1]):
+            g.amax[row, b] = bits(v)
+        return ["f16x3"] * B
+
+    seen = []
+
+    def redo(out, idx):
+        assert ops.active_guard() is None
+        seen.append(idx.tolist())
+        for i in idx.tolist():
+            out[i] = "bf16x6"
+        return out
+
+    s0 = ops.range_stats()
+    out = ops.run_guarded(lambda: producer([1.0, 7.0e4, 0.5, float("nan"), 0.0]), "cpu", enabled=True, images=B, redo=redo)
+    assert out == ["f16x3", "bf16x6", "f16x3", "bf16x6", "f16x3"] and seen == [[1, 3]]
+    out = ops.run_guarded(lambda: producer([1.0, 2.0, 3.0, 4.0, 5.0]), "cpu", enabled=True, images=B, redo=redo)
+    assert out == ["f16x3"] * B and len(seen) == 1
+    out = ops.run_guarded(lambda: producer([1.0e-9], per_image=False), "cpu", enabled=True, images=B, redo=redo)
+    assert out == ["bf16x6"] * B and len(seen) == 1  # a whole-batch row: everything again, as one forward
+    out = ops.run_guarded(lambda: producer([float("inf")] * B), "cpu", enabled=True, images=B, redo=redo)
+    assert out == ["bf16x6"] * B and len(seen) == 1
+    s1 = ops.range_stats()
+    assert s1["scopes"] - s0["scopes"] == 4 and s1["fallbacks"] - s0["fallbacks"] == 3
+    assert s1["images"] - s0["images"] == 4 * B and s1["images_repeated"] - s0["images_repeated"] == 2 + B + B
+    assert 0.0 < s1["trip_rate"] <= 1.0
+
+
+def test_guard_state_is_per_thread():
+    """Two threads in guarded scopes at once each see their own guard (the state used to be module globals)."""
+    import threading
+    from segmif_amd import ops
+    seen, gate = {}, threading.Barrier(2)
+
+    def work(name):
+        def body():
+            gate.wait(timeout=30)
+            seen[name] = id(ops.active_guard())
+            gate.wait(timeout=30)
+            return name
+        assert ops.run_guarded(body, "cpu", enabled=True) == name
+
+    ts = [threading.Thread(target=work, args=(n,)) for n in ("a", "b")]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    assert len(seen) == 2 and seen["a"] != seen["b"] and ops.active_guard() is None
 
 
 def test_f16x3_operand_format_in_numpy():

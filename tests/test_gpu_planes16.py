@@ -77,7 +77,7 @@ def test_planes16_roundtrip_border_and_amax(ops):
     mask[:, :, 2:2 + H, 2:2 + W] = False
     assert float(raw[mask].abs().max()) == 0.0
     m = guard.maxima()
-    assert m.numel() == 1 and float(m[0]) == float(x[..., :C].abs().max())
+    assert m.numel() == 1 and float(m[0]) == float(x[..., :C].abs().max().half())  # (slots hold the HIGH half's pattern)
     assert guard.ok()
 
 
@@ -116,7 +116,7 @@ def test_conv3x3_planes_f16x3(ops, case):
     mask[:, :, 2:2 + H, 2:2 + W] = False
     assert float(raw[mask].abs().max()) == 0.0
     m = guard.maxima()
-    assert m.numel() == 2 and abs(float(m[1]) - float(ref.abs().max())) <= 1e-5 * float(ref.abs().max())
+    assert m.numel() == 2 and abs(float(m[1]) - float(ref.abs().max())) <= 2.0 ** -11 * float(ref.abs().max())
     assert guard.ok()
 
 
@@ -184,7 +184,7 @@ def test_conv2d_f16x3_planes_copy_of_the_output(ops, cin, H, W):
         ref.load_f32(y, chunk0=chunk0)
         assert torch.equal(pl.data, ref.data)
         m = guard.maxima()
-        assert m.numel() == 1 and float(m[0]) == float(y.abs().max())
+        assert m.numel() == 1 and float(m[0]) == float(y.abs().max().half())
 
 
 def test_crosspath_tail_f16x3_planes_copy(ops):
@@ -209,7 +209,7 @@ def test_crosspath_tail_f16x3_planes_copy(ops):
     ref.load_f32(out.view(B, H, W, 64), chunk0=0)
     assert torch.equal(pl.data, ref.data)
     m = guard.maxima()
-    assert m.numel() == 1 and float(m[0]) == float(out.abs().max())
+    assert m.numel() == 1 and float(m[0]) == float(out.abs().max().half())
 
 
 def _act_ref(y, act):
@@ -231,7 +231,8 @@ def test_gemm_split_f16x3(ops, M, N, K):
     wide[:, :K] = x.cuda()
     xv = wide[:, :K]
     assert ops.active_guard() is None
-    ops._guard = guard = ops.Planes16Guard("cuda")
+    guard = ops.Planes16Guard("cuda")
+    ops.install_guard(guard)
     try:
         for act, use_res in ((0, False), (3, True), (1, False)):
             ref = _act_ref(ref_lin, act)
@@ -245,9 +246,9 @@ def test_gemm_split_f16x3(ops, M, N, K):
         y = ops.linear_auto(xv, packs, N, bias=b.cuda())
         assert float(((y.double().cpu() - ref_lin).abs() / cond).max()) < 1e-6
     finally:
-        ops._guard = None
+        ops.install_guard(None)
     m = guard.maxima()
-    assert m.numel() == 4 and all(float(v) == float(x.abs().max()) for v in m)  # four launches of the half-pair kernel
+    assert m.numel() == 4 and all(float(v) == float(x.abs().max().half()) for v in m)  # four launches of the half-pair kernel
     assert guard.ok()
 
 

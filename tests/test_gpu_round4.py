@@ -1,0 +1,228 @@
+"""GPU parity tests added in round 4 (all through the C ABI):
+  * the f16x3 range guard PER IMAGE: producers report each batch element's max |x| to its own slot, a guarded pair forward
+    repeats exactly the pairs that left the half's exponent range (on bf16x6) and keeps the others' f16x3 results;
+  * the f16x3 default on NON-SYNTHETIC statistics (VERDICT r3 "weak" 1): uint8-quantised images with large exactly-black
+    regions, images scaled by 1/255 and by 4, saturated highlights, weights whose per-layer scales span 1e-3 .. 1e1 -
+    through PairForward, against the CPU oracle, with the guard's trip rate reported.
+Observed figures are appended to gpurun_out/parity_observed.json."""
+import json
+import os
+
+import pytest
+import torch
+
+import detweights as dw
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3    # BASELINE.json north_star: 1e-3 rel fp32
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def observed(name, value):
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        p = os.path.join(d, "parity_observed.json")
+        rec = json.load(open(p)) if os.path.exists(p) else {}
+        rec[name] = value
+        json.dump(rec, open(p, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from segmif_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def nets(ops):
+    from segmif_amd.core import Fusion_Network3_ac, Network3
+    seg, fus = Network3("mit_b1", 9, pretrained=None), Fusion_Network3_ac()
+    sd_seg, sd_fus = dw.load_det_weights(seg, seed=0), dw.load_det_weights(fus, seed=0)
+    return seg.cuda().eval(), fus.cuda().eval(), sd_seg, sd_fus
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def test_producers_report_per_image(ops):
+    """Every producer of half pairs folds max |x| into the slot of the image it belongs to: planes16_from_f32, the planes
+    conv's epilogue, conv1's planes epilogue (igemm), the CrossPath tail and the GEMM's A staging.  Image 1 of 3 carries an
+    overflow (or a NaN): only its column trips."""
+    B, H, W = 3, 16, 32
+    x = rnd(B, H, W, 64, seed=1)
+    x[1] *= 1.0e6
+    guard = ops.Planes16Guard("cuda", B)
+    pl = ops.Planes(B, H, W, 6, "cuda", guard).load_f32(x.cuda())
+    assert guard.tripped().tolist() == [False, True, False]
+    m = guard.maxima()
+    assert m.shape == (1, B) and float(m[0, 0]) == float(x[0].abs().max().half()) and float(m[0, 2]) == float(x[2].abs().max().half())
+    # conv epilogue: a weight that blows image 2's OUTPUT up (its input is fine)
+    x2 = rnd(B, H, W, 64, seed=2)
+    x2[2] *= 3.0e3
+    guard = ops.Planes16Guard("cuda", B)
+    pl = ops.Planes(B, H, W, 6, "cuda", guard).load_f32(x2.cuda())
+    w = rnd(32, 64, 3, 3, seed=3) * 2.0
+    ops.conv3x3_planes(pl, 64, ops.pack_weight_planes16(w.cuda()), dil=2, act=0, out_chunk0=4)
+    m = guard.maxima()
+    assert m.shape == (2, B) and guard.tripped().tolist() == [False, False, True], m
+    assert float(m[0, 2]) < 65504 <= float(m[1, 2]) or float(m[1, 2]) != float(m[1, 2])
+    # conv1-style igemm planes epilogue (Cin = 1)
+    img = rnd(B, H, W, 1, seed=4, lo=0.0, hi=1.0)
+    img[0] *= 1.0e7
+    guard = ops.Planes16Guard("cuda", B)
+    pl = ops.Planes(B, H, W, 6, "cuda", guard)
+    w1 = rnd(64, 1, 3, 3, seed=5)
+    ops.conv2d(img.cuda(), ops.pack_weight(w1.cuda()), 64, 3, pad=1, planes=pl)
+    assert guard.maxima().shape == (1, B) and guard.tripped().tolist() == [True, False, False]
+    # GEMM A staging: tokens (B, n, K); a NaN in image 1; a tile straddling images 0 | 1 may report it to both, never to 2
+    t = rnd(B, 1000, 64, seed=6)
+    t[1, 999, 5] = float("nan")
+    packs = ops.pack_linear(rnd(128, 64, seed=7).cuda(), half=True)
+    guard = ops.Planes16Guard("cuda", B)
+    prev = ops.install_guard(guard)
+    try:
+        ops.linear_auto(t.cuda(), packs, 128)
+    finally:
+        ops.install_guard(prev)
+    trip = guard.tripped().tolist()
+    assert trip[1] and not trip[0], trip  # (row 1999 lies in tile 15 = rows 1920 .. 2047: images 1 and 2)
+    t[1, 999, 5], t[1, 500, 5] = 0.0, float("inf")
+    guard = ops.Planes16Guard("cuda", B)
+    prev = ops.install_guard(guard)
+    try:
+        ops.linear_auto(t.cuda(), packs, 128)
+    finally:
+        ops.install_guard(prev)
+    assert guard.tripped().tolist() == [False, True, False]
+
+
+def _inputs(B, H, W, seed):
+    ir = dw.det_input(f"r4_ir{seed}", (B, 1, H, W))
+    vis = dw.det_input(f"r4_vis{seed}", (B, 3, H, W))
+    mask = dw.det_input(f"r4_mask{seed}", (B, 1, H, W)).repeat(1, 3, 1, 1)
+    return ir, vis, mask
+
+
+def test_pair_forward_repeats_only_the_tripped_pairs(ops, nets):
+    """B = 4 pairs, pair 2's infrared image scaled out of the half's range: the guarded forward marks pair 2 alone, repeats
+    it alone (bitwise equal to that pair run on the bf16x6 kernels by itself) and the other pairs keep the results they
+    have in a batch where nothing trips (bitwise)."""
+    from segmif_amd.pipeline import PairForward
+    seg, fus, _, _ = nets
+    pipe = PairForward(seg, fus)
+    ir, vis, mask = (t.cuda() for t in _inputs(4, 64, 96, 1))
+    s0 = ops.range_stats()
+    with torch.no_grad():
+        clean_f, clean_l = pipe.eager(ir, vis, mask)
+        assert ops.range_stats()["images_repeated"] == s0["images_repeated"]
+        hot = ir.clone()
+        hot[2] *= 1.0e6
+        got_f, got_l = pipe.eager(hot, vis, mask)
+        s1 = ops.range_stats()
+        assert s1["images_repeated"] - s0["images_repeated"] == 1 and s1["images"] - s0["images"] == 8
+        alone_f, alone_l = ops.run_unguarded(lambda: pipe._eager_body(hot[2:3], vis[2:3], mask[2:3]), images=0, repeated=0)
+    keep = [0, 1, 3]
+    assert torch.equal(got_f[keep], clean_f[keep]) and torch.equal(got_l[keep], clean_l[keep])
+    assert torch.equal(got_f[2:3], alone_f) and torch.equal(got_l[2:3], alone_l)
+    assert not torch.equal(got_f[2], clean_f[2])
+    # the same through a hipGraph replay (its guard is read back after the launch)
+    pipe.capture(ir, vis, mask)
+    rep_f, rep_l = pipe(hot, vis, mask)
+    assert torch.equal(rep_f, got_f) and torch.equal(rep_l, got_l)
+    rep_f, rep_l = pipe(ir, vis, mask)
+    assert torch.equal(rep_f, clean_f) and torch.equal(rep_l, clean_l)
+
+
+def _image_like(B, H, W, seed):
+    """Image-like inputs: uint8-quantised, >= 50 % exactly-black pixels in rectangles, saturated highlights."""
+    g = torch.Generator().manual_seed(seed)
+
+    def one(c):
+        x = torch.rand(B, c, H, W, generator=g)
+        x = torch.nn.functional.avg_pool2d(x, 5, 1, 2) * 1.6 - 0.2          # smooth, with clipped tails
+        x = (x.clamp(0, 1) * 255).floor() / 255                             # uint8 grid, saturated whites
+        m = torch.ones(B, 1, H, W)
+        for b in range(B):
+            m[b, :, : H // 2 + 3, :] = 0                                    # a black half ...
+            m[b, :, :, : W // 5] = 0                                        # ... and a black band: > 50 % zeros
+        return x * m
+
+    ir, vis, mask = one(1), one(3), one(1)
+    assert float((vis == 0).float().mean()) >= 0.5 and float((ir == 0).float().mean()) >= 0.5
+    return ir, vis, mask.repeat(1, 3, 1, 1)
+
+
+def _check_against_oracle(ops, pipe, sd_seg, sd_fus, ir, vis, mask, name):
+    import segmif_oracle as so
+    s0 = ops.range_stats()
+    with torch.no_grad():
+        fused, labels = pipe.eager(ir.cuda(), vis.cuda(), mask.cuda())
+        torch.cuda.synchronize()
+        ref = so.pair_forward(sd_seg, sd_fus, ir, vis, mask, "mit_b1", return_all=True)
+    s1 = ops.range_stats()
+    tripped = s1["images_repeated"] - s0["images_repeated"]
+    rf = ref["fused"].double()
+    assert torch.isfinite(rf).all(), "the oracle itself is not finite on this case"
+    e = float((fused.double().cpu() - rf).abs().max() / (rf.abs().max() + 1e-30))
+    stable = so.top2_margin(ref["logits"]) > 1e-3 * float(ref["logits"].abs().max())
+    same = bool(torch.equal(labels.cpu().long()[stable], ref["labels"][stable]))
+    observed(f"r4_stats_{name}", {"fused_rel_err": e, "pairs": int(ir.shape[0]), "pairs_repeated_on_bf16x6": tripped,
+                                 "labels_equal_above_margin": same, "stable_fraction": float(stable.float().mean())})
+    assert e < TOL, (name, e)
+    assert same, name
+    return tripped
+
+
+def test_f16x3_default_on_image_like_statistics(ops, nets):
+    """Parity and guard behaviour on inputs that are not U[0,1): (a) uint8-quantised images with >= 50 % exact zeros and
+    saturated highlights, (b) the same scaled by 1/255 (a caller that forgot the normalisation the other way) and by 4
+    (over-exposed), (c) a mixed batch.  Every case: fused image within 1e-3 of the oracle, labels exact above the margin,
+    and the number of pairs the guard sent to bf16x6 recorded."""
+    from segmif_amd.pipeline import PairForward
+    seg, fus, sd_seg, sd_fus = nets
+    pipe = PairForward(seg, fus)
+    ir, vis, mask = _image_like(3, 64, 96, 11)
+    trips = {"u8_black": _check_against_oracle(ops, pipe, sd_seg, sd_fus, ir, vis, mask, "u8_black"),
+             "x1_255": _check_against_oracle(ops, pipe, sd_seg, sd_fus, ir / 255, vis / 255, mask / 255, "x1_255"),
+             "x4": _check_against_oracle(ops, pipe, sd_seg, sd_fus, ir * 4, vis * 4, mask * 4, "x4")}
+    mixed = [torch.cat((a[:1], a[1:2] / 255, a[2:3] * 4)) for a in (ir, vis, mask)]
+    trips["mixed"] = _check_against_oracle(ops, pipe, sd_seg, sd_fus, *mixed, "mixed")
+    observed("r4_stats_trips", trips)
+
+
+def test_f16x3_default_with_per_layer_weight_scales(ops):
+    """Weights whose per-layer scale is drawn log-uniformly over 1e-3 .. 1e1 (trained nets are not hash-uniform): DRDB
+    outputs after many ReLUs can sit far below 2^-13 or grow large.  The guarded forward must still match the oracle -
+    through bf16x6 where the guard says so - and the trip count is recorded."""
+    from segmif_amd.core import Fusion_Network3_ac, Network3
+    from segmif_amd.pipeline import PairForward
+    ir, vis, mask = _inputs(2, 64, 96, 5)
+    done = 0
+    for seed in (1, 2, 3, 4, 5, 6):
+        seg, fus = Network3("mit_b1", 9, pretrained=None), Fusion_Network3_ac()
+        sd_seg, sd_fus = dw.load_det_weights(seg, seed=0), dw.load_det_weights(fus, seed=0)
+        g = torch.Generator().manual_seed(100 + seed)
+        for sd, net in ((sd_seg, seg), (sd_fus, fus)):
+            layers = sorted({k.rsplit(".", 1)[0] for k in sd if k.endswith(".weight") and sd[k].dim() >= 2})
+            for layer in layers:
+                s = 10.0 ** float(torch.rand(1, generator=g) * 4 - 3)
+                sd[layer + ".weight"] = sd[layer + ".weight"] * s
+            net.load_state_dict(sd)
+        seg, fus = seg.cuda().eval(), fus.cuda().eval()
+        import segmif_oracle as so
+        with torch.no_grad():
+            ref = so.pair_forward(sd_seg, sd_fus, ir, vis, mask, "mit_b1", return_all=True)
+        if not torch.isfinite(ref["fused"]).all() or not torch.isfinite(ref["logits"]).all():
+            continue  # (a draw that overflows fp32 in the reference arithmetic itself says nothing about f16x3)
+        t = _check_against_oracle(ops, PairForward(seg, fus), sd_seg, sd_fus, ir, vis, mask, f"wscale_seed{seed}")
+        observed(f"r4_stats_wscale_seed{seed}_trips", t)
+        done += 1
+    assert done >= 3, "too few finite draws: widen the seed list"

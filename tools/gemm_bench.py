@@ -31,15 +31,15 @@ if NO32:
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 tot = {"fp32": 0.0, "bf16x6": 0.0, "f16x3": 0.0}
 guard = ops.Planes16Guard("cuda")
-guard.slot = lambda: guard.amax.data_ptr()  # a benchmark re-launches forever: one shared slot
+guard.slot = lambda images=None: (guard.amax.data_ptr(), 1)  # a benchmark re-launches forever: one shared slot
 
 
 def in_scope(fn):
-    ops._guard = guard
+    ops.install_guard(guard)
     try:
         fn()
     finally:
-        ops._guard = None
+        ops.install_guard(None)
 
 
 for name, tok, C, reps in (("stage1", B * 19200, 64, 3), ("stage2", B * 4800, 128, 4), ("stage3", B * 1200, 320, 18), ("stage4", B * 300, 512, 3)):

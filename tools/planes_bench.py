@@ -50,7 +50,7 @@ def main():
         buf.fill_(1.0)
     pl = ops.Planes(B, H, W, 14, dev).load_f32(buf[..., :192])
     guard = ops.Planes16Guard(dev)
-    guard.slot = lambda: guard.amax.data_ptr()  # a benchmark re-launches forever: one shared slot
+    guard.slot = lambda images=None: (guard.amax.data_ptr(), 1)  # a benchmark re-launches forever: one shared slot
     pl16 = ops.Planes(B, H, W, 14, dev, guard).load_f32(buf[..., :192])
     bias = torch.randn(32, device=dev)
     peak = 2500.0 / 6
