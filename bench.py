@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (BASELINE configs [2] / [3])")
     ap.add_argument("--train-batch", type=int, default=8, help="samples per GPU per training step (config[2]: 8)")
     ap.add_argument("--train-steps", type=int, default=0, help="timed steps per training variant (0: min(--steps, 8))")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short timed legs of BASELINE configs [1] (mit_b1, batch 4) and [4] (mit_b5, batch 2, 1024x1024)")
+    ap.add_argument("--dry-collective", action="store_true", help="multi-GPU readiness check only: bring the process group up, run the collective "
+                    "self-test (world size the backend reports, checked rank-id collectives, one timed all-reduce) and print the gradient bucket "
+                    "plan of both training steps; nothing is benchmarked")
     return ap.parse_args()
 
 
@@ -112,8 +116,13 @@ def cpu_baseline(backbone, H, W):
                       f"pair, best of {len(times)} timed pairs ({', '.join(f'{t:.2f}' for t in times)} s)"}
 
 
-# algorithmic work of the two training steps, GFLOP per sample at 480x640
+# algorithmic work of the two training steps, GFLOP per sample at 480x640: the reference's autograd
+# forms every gradient, 3 x forward of the differentiated parts ...
 GFLOP_TRAIN = {("mit_b3", "seg"): 300.0, ("mit_b3", "fusion"): 2304.0}
+# ... and what the fusion step EXECUTES with FusionTrainer(seg_weight_grads=False) (default: train_fusion's optimizer holds the
+# fusion net only, train.py:316-327; nothing reads the segmentation net's .grad): its backward runs THROUGH the segmentation
+# net (input gradients, 1 x forward) without the weight gradients (another 1 x): 88.8 + 3 x 638.2 + 2 x 100.1
+GFLOP_TRAIN_EXECUTED = {("mit_b3", "fusion", False): 88.8 + 3 * 638.2 + 2 * 100.1}
 
 
 def train_leg(args, rank, world, seg, fus):
@@ -152,6 +161,7 @@ def train_leg(args, rank, world, seg, fus):
     red_seg = GradAllReducer([p for grp in g for p in grp]) if world > 1 else None
     red_fus = GradAllReducer(list(fus.parameters())) if world > 1 else None
     trainer = FusionTrainer(seg, fus, opt_fus, crit, iter_=2, reducer=red_fus, report_lap=True)
+    trainer_full = FusionTrainer(seg, fus, opt_fus, crit, iter_=2, reducer=red_fus, report_lap=False, seg_weight_grads=True)
 
     def timed(step, reducer):
         for _ in range(warm):
@@ -180,15 +190,26 @@ def train_leg(args, rank, world, seg, fus):
                                 ("fusion", lambda: trainer.step(ir3, vis3, mask3, labels), red_fus)):
             dt, loss, exposed_ms = timed(step, red)
             gf = GFLOP_TRAIN.get((args.backbone, name))
+            gfx = GFLOP_TRAIN_EXECUTED.get((args.backbone, name, False), gf)  # (the default fusion step skips the seg net's weight gradients)
             rec = {"ms_per_step": 1e3 * dt, "samples_per_s": world * B / dt, "loss": loss,
-                   "tflops_per_gpu": (gf * B / dt / 1e3) if gf and (H, W) == (480, 640) else None,
-                   "gflop_per_sample": gf, "allreduce_exposed_ms": exposed_ms,
+                   "tflops_per_gpu": (gfx * B / dt / 1e3) if gfx and (H, W) == (480, 640) else None,
+                   "gflop_per_sample": gf, "gflop_executed_per_sample": gfx, "allreduce_exposed_ms": exposed_ms,
                    "grad_bytes": red.gradient_bytes() if red is not None else
                    4 * sum(p.numel() for p in (fus.parameters() if name == "fusion" else [q for grp in g for q in grp])
                            if p.grad is not None)}
             if name == "fusion" and trainer.last_lap is not None:
                 rec["lap_loss2_reported"] = float(trainer.last_lap)
             out[f"{name}_{mode}"] = rec
+    # the reference's side effect reproduced: the fusion step also forming the segmentation net's weight gradients (3 x forward
+    # of everything differentiated: the full 2 304 GFLOP per sample), train mode
+    seg.train(True)
+    fus.train(True)
+    dt, loss, _ = timed(lambda: trainer_full.step(ir3, vis3, mask3, labels), red_fus)
+    gf = GFLOP_TRAIN.get((args.backbone, "fusion"))
+    out["fusion_train_with_seg_weight_grads"] = {
+        "ms_per_step": 1e3 * dt, "samples_per_s": world * B / dt, "loss": loss, "gflop_executed_per_sample": gf,
+        "tflops_per_gpu": (gf * B / dt / 1e3) if gf and (H, W) == (480, 640) else None,
+        "note": "FusionTrainer(seg_weight_grads=True): the .grad the reference accumulates on the segmentation net and never reads"}
     seg.eval()
     fus.eval()
     out["modes"] = {"train": "DropPath, Dropout2d(0.1), BatchNorm batch statistics active (BASELINE.md section 3)",
@@ -201,6 +222,62 @@ def train_leg(args, rank, world, seg, fus):
                              "overlap": "buckets launched from post-accumulate-grad hooks during backward"}
     out["peak_mem_GB"] = torch.cuda.max_memory_allocated() / 2 ** 30
     return out
+
+
+def config_leg(backbone, B, H, W, steps):
+    """A short timed forward leg of another BASELINE config (the same pair forward in the default arithmetic, inputs resident
+    in HBM, one warm-up pass that also packs the weights): pairs/s and the whole-path rate."""
+    import detweights as dw
+    from segmif_amd import dist, ops
+    from segmif_amd.core import Fusion_Network3_ac, Network3
+    from segmif_amd.pipeline import PairForward
+    seg, fus = Network3(backbone, 9, pretrained=None), Fusion_Network3_ac()
+    dw.load_det_weights(seg, seed=0)
+    dw.load_det_weights(fus, seed=0)
+    seg, fus = seg.cuda().eval(), fus.cuda().eval()
+    ir = dw.det_input("cfg_ir", (B, 1, H, W)).cuda()
+    vis = dw.det_input("cfg_vis", (B, 3, H, W)).cuda()
+    mask = dw.det_input("cfg_mask", (B, 1, H, W)).repeat(1, 3, 1, 1).cuda()
+    pipe = PairForward(seg, fus)
+    s0 = ops.range_stats()
+    with torch.no_grad():
+        for _ in range(2):
+            pipe(ir, vis, mask)
+        dist.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            labels = pipe(ir, vis, mask)[1]
+        dist.fence()
+        dt = (time.perf_counter() - t0) / steps
+    assert labels.shape == (B, H, W)
+    s1 = ops.range_stats()
+    gf = GFLOP_PER_PAIR.get((backbone, H, W))
+    rec = {"backbone": backbone, "height": H, "width": W, "pairs_per_step": B, "steps": steps, "warmup": 2,
+           "value": B / dt, "unit": "img-pairs/s", "ms_per_step": 1e3 * dt,
+           "f16x3_pairs_repeated": s1["images_repeated"] - s0["images_repeated"]}
+    if gf is not None:
+        rec["gflop_per_pair"] = {"executed": gf - gflop_removed_by_n4(H, W), "textbook_order": gf}
+        rec["whole_path_tflops"] = B / dt * (gf - gflop_removed_by_n4(H, W)) / 1e3
+    del pipe, seg, fus, ir, vis, mask, labels
+    torch.cuda.empty_cache()
+    return rec
+
+
+def dry_collective(args, rank, world):
+    """--dry-collective: what the first real multi-GPU run should print before anything is timed."""
+    from segmif_amd import dist
+    from segmif_amd.core import Fusion_Network3_ac, Network3
+    seg = Network3(args.backbone, 9, pretrained=None)
+    g = seg.denoise_net.get_param_groups()
+    sizes = {"seg_step (upper bound: parameters that receive no gradient are dropped at the first step)":
+             [p.numel() for grp in g for p in grp if p.requires_grad],
+             "fusion_step (upper bound, same rule: ffm2.* receives none)": [p.numel() for p in Fusion_Network3_ac().parameters()]}
+    rec = dist.collective_selftest(sizes)
+    rec["launch"] = {"WORLD_SIZE": world, "RANK": rank, "MASTER_ADDR": os.environ.get("MASTER_ADDR"),
+                     "MASTER_PORT": os.environ.get("MASTER_PORT"), "timeout_s": float(os.environ.get("SEGMIF_DIST_TIMEOUT", 300))}
+    if rank == 0:
+        print(json.dumps({"dry_collective": rec}), flush=True)
+    dist.shutdown()
 
 
 def self_launch(args, script=None, argv=None):
@@ -223,6 +300,9 @@ def main():
         self_launch(args)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.dry_collective:  # (works on any backend: SEGMIF_DIST_BACKEND=gloo exercises it without GPUs)
+        dist.init()
+        return dry_collective(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -272,6 +352,8 @@ def main():
     assert labels.shape == (B, H, W)
 
     elapsed = dist.max_over_ranks(elapsed)
+    trip = ops.range_stats()  # (warm-up + timed steps of the headline configuration)
+    trip["granularity"] = "one pair: range slots per image, only the pairs that tripped are repeated on bf16x6"
 
     # for continuity with rounds 1-2: the same step on bf16 triples throughout (6 products per MAC, no range guard)
     elapsed_bf16 = None
@@ -304,6 +386,17 @@ def main():
             elapsed_dse = dist.max_over_ranks(time.perf_counter() - t0)
         enc.skip_unused_fusion_stages = False
 
+    # the other single-GPU forward configs of BASELINE.json, short legs in the same arithmetic (never part of `value`)
+    configs = None
+    if world == 1 and not args.no_configs and not args.graph and (args.backbone, H, W) == ("mit_b3", 480, 640):
+        configs = {}
+        for key, cfg in (("config1_mit_b1_b4_480x640", ("mit_b1", 4, 480, 640)), ("config4_mit_b5_b2_1024x1024", ("mit_b5", 2, 1024, 1024)),
+                         ("mit_b1_b64_480x640", ("mit_b1", 64, 480, 640))):
+            try:
+                configs[key] = config_leg(*cfg, steps=3)
+            except Exception as exc:
+                configs[key] = {"error": f"{type(exc).__name__}: {exc}"}
+
     train = None
     if not args.no_train and not args.graph:
         del pipe, labels
@@ -328,6 +421,7 @@ def main():
                 if ops.conv3x3_mode() == "planes16" else
                 "f32 (large contractions: fp32-equivalent 3-way bf16 split, 6 MFMA products; see arithmetic_modes)"),
             "f16x3_range_fallbacks": ops.range_fallbacks(),
+            "f16x3_trip_rate": trip["trip_rate"], "f16x3_guard": trip,
             "conv3x3_mode": ops.conv3x3_mode(),
             "arithmetic_modes": {"conv3x3": ops.conv3x3_mode(), "linear": ops.linear_mode(), "crosspath": ops.crosspath_mode(),
                                  "attention": ops.attention_mode()},
@@ -364,7 +458,8 @@ def main():
             if os.path.exists(pmc) and (H, W) == (480, 640):
                 # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
                 rec = json.load(open(pmc))
-                traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(pmc)
+                traffic, traffic_src = rec["hbm_bytes_per_launch"], ("static record, not measured in this run: profiles/" + os.path.basename(pmc) +
+                                                                     " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.sh)")
             kernel = {"planes": "conv3x3_planes_kernel<2,false> (DRDB dilated 3x3 convs 1-4 on pre-split activations, bf16 MFMA x 6 "
                                 "split products, fp32-class; the fifth conv carries the DRDB's 1x1 tail and is a separate kernel)",
                       "planes16": "conv3x3_planes_kernel<2,false,f16x3> (DRDB dilated 3x3 convs 1-4 on half-pair activations, f16 MFMA x 3 "
@@ -411,6 +506,8 @@ def main():
                                "algorithmic_GB_per_launch": nbytes / 1e9, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
                                "frac_of_8TBps": nbytes / (ms * 1e-3) / 8e12}
             out["hbm_bound_kernels"] = hb
+        if configs is not None:
+            out["configs"] = configs
         if train is not None:
             out["train"] = train
         if world == 1 and not args.no_cpu_baseline:

@@ -523,6 +523,25 @@ int segmif_adamw_f32(const void* table, const int32_t* chunk_entry, const int64_
                      int chunk_elems, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2_sqrt,
                      void* stream);
 
+/*
+ * Gradient exchange of the data-parallel training steps behind the C ABI (SURVEY.md section 8(b) lists
+ * segmif_comm_{init, allreduce, destroy}; section 8(e): one fp32 sum / average all-reduce per step over RCCL / xGMI; the
+ * reference has no distributed code at all).  Thin entry points over RCCL for a host that is not Python - this
+ * repo's Python host uses torch.distributed (backend "nccl" IS RCCL) in segmif_amd/parallel.py and does not route through
+ * them.  librccl is looked up at first use (the copy the process already holds first), never at load time.
+ *   segmif_comm_available   0 when RCCL could be resolved (version = ncclGetVersion), SEGMIF_ENOSYS otherwise
+ *   segmif_comm_unique_id   rank 0 obtains the 128-byte rendezvous id; the host hands it to every rank by its own means
+ *   segmif_comm_init        one communicator per process / GPU (binds to the caller's current HIP device)
+ *   segmif_comm_allreduce_f32  recv = sum (average != 0: mean) over ranks of send, in place allowed, on `stream`
+ * Return 0, SEGMIF_EINVAL / SEGMIF_ENOSYS, or 1000 + ncclResult_t.
+ */
+int segmif_comm_available(int* version);
+int segmif_comm_unique_id(void* id, int64_t bytes /* >= 128 */);
+int segmif_comm_init(void** comm, int world, int rank, const void* id, int64_t bytes);
+int segmif_comm_world(void* comm, int* world, int* rank);
+int segmif_comm_allreduce_f32(void* comm, const float* send, float* recv, int64_t count, int average, void* stream);
+int segmif_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -319,6 +319,10 @@ class DwconvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, w, b, H, W):
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and h.shape[2] % 128:
+            # (the forward kernel takes any C % 4 == 0; say it here instead of an EINVAL from the backward launch)
+            raise RuntimeError(f"DWConv under autograd: the parameter-gradient kernel needs a channel count that is a multiple of "
+                               f"128 (every MiT hidden width is), got {h.shape[2]}")
         ctx.hw = (H, W)
         ctx.save_for_backward(h, w)
         return ops.dwconv3x3_bias(h, ops.pack_dw_weight(w), b, H, W)

@@ -444,8 +444,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_xt_kernel(const float* __restri
 
 template <bool GELU>
 static int launch_dwconv(const float* x, const float* w9, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
-  const char* e = getenv("SEGMIF_DWCONV_XT");  // diagnosis: 1 = the one-column kernel, 2 / 4 = columns per thread
-  const int xt = e ? atoi(e) : (W >= 16 ? 2 : 1);
+  static const int xt_env = [] { const char* e = getenv("SEGMIF_DWCONV_XT"); return e ? atoi(e) : 0; }();  // diagnosis (read once): 1 = the one-column kernel, 2 / 4 = columns per thread
+  const int xt = xt_env ? xt_env : (W >= 16 ? 2 : 1);
   if (xt >= 2) {
     const int XT = xt >= 4 ? 4 : 2;
     const long long per_row = (long long)((W + XT - 1) / XT) * (C >> 2);

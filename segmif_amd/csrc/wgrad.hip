@@ -22,6 +22,10 @@
 #include "igemm_common.h"
 #include "segmif_hip.h"
 
+#ifndef WG3_DBG
+#define WG3_DBG 0  // tuning aid (profiles/r03_wgrad3x3_phases.txt): 1 compiles the phase-skipping switches of wgrad3x3_split in
+#endif
+
 namespace segmif {
 namespace {
 
@@ -238,7 +242,7 @@ struct Wg3K {
   float* bias_partial;  // [strips][N] or null (only channel-chunk 0 blocks write it)
   int B, H, W, Cin, N, Kp, ldy, lda;
   int tiles_x, tiles_y, tiles_total, tiles_per_strip, nchunks, yvec;
-  int dbg;  // diagnosis only (SEGMIF_WG3_DBG): 1 skip the MFMA loop, 2 skip the split + LDS stores, 4 skip the global loads
+  int dbg;  // diagnosis only, builds with -DWG3_DBG=1 (SEGMIF_WG3_DBG): 1 skip the MFMA loop, 2 skip the split + LDS stores, 4 skip the global loads
 };
 
 template <int DIL, bool VEC>  // VEC: dY rows are 16-byte loadable and the block's 32 output channels all exist
@@ -532,10 +536,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_split_kernel(const Wg3K p) {
 
   if (t_begin < t_end) gload(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
-    if (!(p.dbg & 2)) sstore();
+    if (!(WG3_DBG && (p.dbg & 2))) sstore();
     __syncthreads();
-    if (tile + 1 < t_end && !(p.dbg & 4)) gload(tile + 1);
-    if (p.dbg & 1) { __syncthreads(); continue; }
+    if (tile + 1 < t_end && !(WG3_DBG && (p.dbg & 4))) gload(tile + 1);
+    if (WG3_DBG && (p.dbg & 1)) { __syncthreads(); continue; }
     // 12 steps per tile: (row of the wave's two, 16-pixel k-step, vertical tap); a step = 18 MFMAs on one 6-dword halo
     // window per plane (+ the dY fragment, re-read when the pixel run changes).  The LDS reads of step i + 1 are issued
     // BEFORE the MFMAs of step i (one wave per SIMD: nothing else hides their latency).
@@ -1089,11 +1093,16 @@ static int wgrad_impl(const SegmifIgemm* d, const float* dy, int ldy, int64_t dy
       dim3 grid((unsigned)(strips * w.nchunks), (unsigned)ntiles_n);
       const int HPd = (8 + 2 * d->dil) * (32 + 2 * d->dil);
       const size_t smem = (size_t)(256 * 32 + HPd * 32) * sizeof(float);
-      const char* mode_env = getenv("SEGMIF_WGRAD3X3");  // "fp32": the exact-fp32 kernel for dilation 2 as well
-      const bool fp32_only = mode_env && !strcmp(mode_env, "fp32");
-      const char* dbg_env = getenv("SEGMIF_WG3_DBG");
-      w.dbg = dbg_env ? atoi(dbg_env) : 0;
-      const bool one_team = mode_env && !strcmp(mode_env, "split1");  // the one-team bf16x6 kernel (8 x 32 tiles, dilation 2)
+      // SEGMIF_WGRAD3X3 (read once per process; a training step is ~3000 launches): "fp32" = the exact-fp32 kernel for
+      // dilation 2 as well, "split1" = the one-team bf16x6 kernel (8 x 32 tiles, dilation 2)
+      static const int mode = [] { const char* e = getenv("SEGMIF_WGRAD3X3"); return !e ? 0 : !strcmp(e, "fp32") ? 1 : !strcmp(e, "split1") ? 2 : 0; }();
+      const bool fp32_only = mode == 1, one_team = mode == 2;
+#if WG3_DBG
+      static const int dbg = [] { const char* e = getenv("SEGMIF_WG3_DBG"); return e ? atoi(e) : 0; }();
+      w.dbg = dbg;
+#else
+      w.dbg = 0;
+#endif
       if (!fp32_only && !(one_team && d->dil == 2) && k.yvec && d->N % 32 == 0) {
         // two teams, 4 x 32 pixel tiles: re-derive the tile grid and the strips for that tile height
         w.tiles_y = (d->H + 3) / 4;

@@ -2,8 +2,10 @@
 Fusionloss_grad3, :634-650 Sobelxy; pytorch_ssim/__init__.py:8-43) and LapLoss2 (lap_loss.py:100-118).
 
 On the GPU both objectives are fused HIP kernels, forward and backward (csrc/losses.hip + the separable blur of
-csrc/rowops.hip; autograd.FusionLossGrad3Fn / FusionLoss3Fn): SURVEY §8(f) N1.  The torch formulations below are what
-the CPU tests pin against the reference (tests/golden/losses.npz) and what non-fp32 / multi-channel inputs fall back to.
+csrc/rowops.hip; autograd.FusionLossGrad3Fn / FusionLoss3Fn): SURVEY §8(f) N1.  Device tensors the kernels do not cover
+(non-fp32, more than one channel, mismatched shapes) are REFUSED like everywhere else in the package - there is no torch /
+MIOpen fallback on the GPU.  The torch formulations below run on CPU tensors only: they are what the CPU tests pin against
+the reference (tests/golden/losses.npz).
 """
 import math
 
@@ -21,7 +23,9 @@ def ssim(img1, img2, window_size=11):
     """Gaussian-window SSIM averaged over the image (single channel per group).  On the GPU the five
     window convolutions (and their backward) run in the separable HIP blur kernel."""
     C = img1.shape[1]
-    if img1.is_cuda and window_size == 11 and img1.dtype == torch.float32:
+    if img1.is_cuda:
+        if window_size != 11 or img1.dtype != torch.float32 or img2.dtype != torch.float32 or not img2.is_cuda:
+            raise RuntimeError("segmif_amd.losses.ssim: the HIP blur kernel is the 11-tap float32 one (no torch fallback on the GPU)")
         from . import autograd as ag
         blur = ag.gauss_blur11
     else:
@@ -36,9 +40,16 @@ def ssim(img1, img2, window_size=11):
     return (((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2))).mean()
 
 
-def _hip_ok(generate_img, m):
-    return generate_img.is_cuda and generate_img.dtype == torch.float32 and m.dtype == torch.float32 \
-        and generate_img.shape == m.shape and generate_img.shape[1] == 1
+def _hip_ok(generate_img, *others):
+    """True: the fused HIP kernels take it; False: CPU tensors (the torch formulation, test infrastructure); a device
+    tensor the kernels do not cover raises - no library-convolution fallback on the GPU."""
+    ts = (generate_img,) + others
+    if not any(t.is_cuda for t in ts):
+        return False
+    if all(t.is_cuda and t.dtype == torch.float32 and t.shape == generate_img.shape for t in ts) and generate_img.shape[1] == 1:
+        return True
+    raise RuntimeError("segmif_amd.losses: the fused loss kernels take float32 single-channel device tensors of one shape, got "
+                       + ", ".join(f"{tuple(t.shape)} {t.dtype} {t.device.type}" for t in ts) + " (no torch fallback on the GPU)")
 
 
 def fusion_loss_grad3(generate_img, mask):
@@ -80,10 +91,9 @@ def lap_loss2(generate_img, ir, vis):
     """LapLoss2.forward (lap_loss.py:100-118): d_k(img) = img - G_k * img for the 3 / 5 / 7-tap sigma-2 Gaussians;
     10 (L1_3 + L1_5) + L1_7 with L1_k = mean |d_k(gen) - max(d_k(ir), d_k(vis))|.  Fusionloss_grad3 builds one and never
     evaluates it (core/loss.py:509); FusionTrainer(report_lap=True) reports it beside the loss (BASELINE config[2])."""
-    if generate_img.is_cuda and generate_img.dtype == torch.float32 and generate_img.shape[1] == 1 \
-            and ir.shape == generate_img.shape and vis.shape == generate_img.shape:
+    if _hip_ok(generate_img, ir, vis):
         from . import autograd as ag
-        return ag.LapLoss2Fn.apply(generate_img, ir.detach().float(), vis.detach().float())
+        return ag.LapLoss2Fn.apply(generate_img, ir.detach(), vis.detach())
     C = generate_img.shape[1]
     total = 0.0
     for size, coef in ((3, 10.0), (5, 10.0), (7, 1.0)):

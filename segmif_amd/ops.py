@@ -161,6 +161,8 @@ class Planes16Guard:
     LO, HI = 2.0 ** -13, 65504.0
 
     def __init__(self, device, images=1):
+        if os.environ.get("SEGMIF_GUARD_PER_IMAGE") == "0":  # A/B switch: one slot per launch, whole-batch repeats (round 3)
+            images = 1
         self.images = max(1, int(images))
         self.amax = torch.zeros((self.SLOTS, self.images), device=device, dtype=torch.int32)
         self.used = 0

@@ -16,6 +16,23 @@ import torch
 import torch.distributed as dist
 
 
+def plan_buckets(params, bucket_bytes):
+    """Reverse-order greedy packing of parameters into buckets of at most `bucket_bytes` (a single larger parameter gets a
+    bucket of its own) -> list of lists.  The one layout rule of the exchange: the hook path, the static path and
+    bench.py --dry-collective all use it."""
+    buckets, cur, size = [], [], 0
+    for p in reversed(list(params)):
+        nbytes = p.numel() * p.element_size()
+        if cur and size + nbytes > bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+        cur.append(p)
+        size += nbytes
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
 class GradAllReducer:
     def __init__(self, params, bucket_mb=25.0, process_group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -32,17 +49,8 @@ class GradAllReducer:
         self.exposed_wait_s = 0.0
 
     # ---- bucket layout ------------------------------------------------------------------------
-    def _build(self, active):
-        buckets, cur, size = [], [], 0
-        for p in reversed(active):
-            nbytes = p.numel() * p.element_size()
-            if cur and size + nbytes > self.bucket_bytes:
-                buckets.append(cur)
-                cur, size = [], 0
-            cur.append(p)
-            size += nbytes
-        if cur:
-            buckets.append(cur)
+    def _build(self, active, hooks=True):
+        buckets = plan_buckets(active, self.bucket_bytes)
         self._buckets = buckets
         self._flat = [torch.empty(sum(p.numel() for p in b), device=b[0].device, dtype=b[0].dtype) for b in buckets]
         self._where = {}
@@ -53,7 +61,7 @@ class GradAllReducer:
                 off += p.numel()
         for h in self._hooks:
             h.remove()
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in active]
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in active] if hooks else []
         self._reset()
 
     def _reset(self):
@@ -134,25 +142,17 @@ class GradAllReducer:
     def allreduce_static(self):
         """Exchange for a backward that autograd did not run this step (a replayed hipGraph: no hooks fire, and the
         gradients are the graph's static tensors, so p.grad must keep pointing at them): pack, all-reduce every bucket,
-        average, copy back in place.  Not overlapped with backward."""
+        average, copy back in place.  Not overlapped with backward.  A reducer used this way has the same bucket layout as
+        the hook path but no hooks: calling finish() on it afterwards raises ("buckets were not completed")."""
         if self._buckets is None:
-            active = [p for p in self.params if p.grad is not None]
-            buckets, cur, size = [], [], 0
-            for p in reversed(active):
-                nbytes = p.numel() * p.element_size()
-                if cur and size + nbytes > self.bucket_bytes:
-                    buckets.append(cur)
-                    cur, size = [], 0
-                cur.append(p)
-                size += nbytes
-            if cur:
-                buckets.append(cur)
-            self._buckets = buckets
-            self._flat = [torch.empty(sum(p.numel() for p in b), device=b[0].device, dtype=b[0].dtype) for b in buckets]
-            self._pending = [0] * len(buckets)
+            self._build([p for p in self.params if p.grad is not None], hooks=False)
+        for b in self._buckets:
+            for p in b:
+                if not p.grad.is_contiguous():  # view(-1) below must alias the gradient, not a temporary copy of it
+                    raise RuntimeError("GradAllReducer.allreduce_static needs contiguous gradients")
         handles = []
         for b, flat in zip(self._buckets, self._flat):
-            torch._foreach_copy_(list(flat.split([p.numel() for p in b])), [p.grad.reshape(-1) for p in b])
+            torch._foreach_copy_(list(flat.split([p.numel() for p in b])), [p.grad.view(-1) for p in b])
             if dist.is_initialized():
                 handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for h in handles:
@@ -161,7 +161,7 @@ class GradAllReducer:
         for b, flat in zip(self._buckets, self._flat):
             if self.world > 1:
                 flat.mul_(inv)
-            torch._foreach_copy_([p.grad.reshape(-1) for p in b], list(flat.split([p.numel() for p in b])))
+            torch._foreach_copy_([p.grad.view(-1) for p in b], list(flat.split([p.numel() for p in b])))
 
     def gradient_bytes(self):
         return sum(f.numel() * f.element_size() for f in (self._flat or []))

@@ -155,3 +155,49 @@ def test_bench_main_self_launches_when_no_launcher_set_world_size(monkeypatch):
     except SystemExit as e:
         assert e.code == 0
     assert called == {"gpus": 8}
+
+
+def test_bench_dry_collective_world_2_on_gloo():
+    """`bench.py --gpus 2 --dry-collective` under torch.distributed.run with the collectives on gloo:
+    rank 0 prints the world size the backend reports, the checked rank-id collectives, one timed all-reduce and the gradient
+    bucket plan of both training steps (178 MB / 3.9 MB before the first step drops the grad-less parameters)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["SEGMIF_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-collective"], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(line) for line in r.stdout.splitlines() if line.startswith('{"dry_collective"')]
+    assert len(lines) == 1
+    d = lines[0]["dry_collective"]
+    assert d["initialized"] and d["world_size"] == 2 and d["backend"] == "gloo" and d["rank_id_collectives_ok"]
+    assert d["allreduce_payload_bytes"] == 2 ** 20 and d["allreduce_ms"] > 0
+    plans = list(d["gradient_buckets"].values())
+    seg, fus = plans[0], plans[1]
+    assert seg["bytes"] == 4 * 44604873 and 7 <= seg["buckets"] <= 9 and sum(seg["bucket_bytes"]) == seg["bytes"]
+    assert fus["bytes"] == 4 * 1034370 and fus["buckets"] == 1
+    assert d["launch"]["WORLD_SIZE"] == 2 and d["launch"]["timeout_s"] == 300.0
+
+
+def _lonely_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from segmif_amd import dist
+    try:
+        dist.init(backend="gloo", timeout_s=5)
+        q.put("joined")
+    except RuntimeError as e:
+        q.put(str(e))
+
+
+def test_a_rank_that_never_joins_fails_with_a_message():
+    """WORLD_SIZE = 2 with only rank 0 present: init() gives up after its timeout and says which rank, where, and what to
+    check - it must not hang the job."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_lonely_worker, args=(_free_port(), q))
+    p.start()
+    msg = q.get(timeout=120)
+    p.join(60)
+    assert "rank 0/2" in msg and "could not join the process group within 5 s" in msg and "MASTER_ADDR" in msg, msg

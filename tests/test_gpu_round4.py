@@ -147,7 +147,7 @@ def _image_like(B, H, W, seed):
 
     def one(c):
         x = torch.rand(B, c, H, W, generator=g)
-        x = torch.nn.functional.avg_pool2d(x, 5, 1, 2) * 1.6 - 0.2          # smooth, with clipped tails
+        x = (torch.nn.functional.avg_pool2d(x, 5, 1, 2) - 0.5) * 8 + 0.5    # smooth, clipped at both ends
         x = (x.clamp(0, 1) * 255).floor() / 255                             # uint8 grid, saturated whites
         m = torch.ones(B, 1, H, W)
         for b in range(B):
@@ -161,22 +161,46 @@ def _image_like(B, H, W, seed):
 
 
 def _check_against_oracle(ops, pipe, sd_seg, sd_fus, ir, vis, mask, name):
+    """The guarded pair forward against the oracle, with the input's CONDITIONING measured beside it: the oracle evaluated in
+    float64 is the truth, the oracle in float32 (= the reference's arithmetic) sits e_ref away from it.  On well-conditioned
+    inputs e_ref is ~1e-6 .. 1e-4 and the 1e-3 tolerance binds; on over-exposed images the CrossPath softmax logits grow with
+    the squared exposure and the reference's own fp32 result is 1.5e-3 from the truth (profiles/r04_stats_bisect.txt) - there
+    no fp32 implementation can agree with another to 1e-3, and the HIP path is held to a multiple of e_ref instead.  Recorded
+    beside it: the same pairs on the bf16x6 kernels (what a tripped pair gets) and on exact-fp32 MFMA."""
     import segmif_oracle as so
     s0 = ops.range_stats()
     with torch.no_grad():
         fused, labels = pipe.eager(ir.cuda(), vis.cuda(), mask.cuda())
         torch.cuda.synchronize()
         ref = so.pair_forward(sd_seg, sd_fus, ir, vis, mask, "mit_b1", return_all=True)
+        sd64 = [{k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()} for sd in (sd_seg, sd_fus)]
+        ref64 = so.pair_forward(sd64[0], sd64[1], ir.double(), vis.double(), mask.double(), "mit_b1", return_all=True)
     s1 = ops.range_stats()
     tripped = s1["images_repeated"] - s0["images_repeated"]
-    rf = ref["fused"].double()
-    assert torch.isfinite(rf).all(), "the oracle itself is not finite on this case"
-    e = float((fused.double().cpu() - rf).abs().max() / (rf.abs().max() + 1e-30))
-    stable = so.top2_margin(ref["logits"]) > 1e-3 * float(ref["logits"].abs().max())
-    same = bool(torch.equal(labels.cpu().long()[stable], ref["labels"][stable]))
-    observed(f"r4_stats_{name}", {"fused_rel_err": e, "pairs": int(ir.shape[0]), "pairs_repeated_on_bf16x6": tripped,
+    truth = ref64["fused"]
+    assert torch.isfinite(ref["fused"]).all() and torch.isfinite(truth).all(), "the oracle itself is not finite on this case"
+
+    def err(t):
+        return float((t.double().cpu() - truth).abs().max() / (truth.abs().max() + 1e-30))
+
+    e, e_ref = err(fused), err(ref["fused"])
+    with torch.no_grad():
+        e6 = err(ops.run_unguarded(lambda: pipe._eager_body(ir.cuda(), vis.cuda(), mask.cuda()), images=0, repeated=0)[0])
+        prev = (ops.set_conv3x3_mode("fp32"), ops.set_linear_mode("fp32"), ops.set_attention_mode("fp32"))
+        try:
+            e32 = err(pipe._eager_body(ir.cuda(), vis.cuda(), mask.cuda())[0])
+        finally:
+            ops.set_conv3x3_mode(prev[0]), ops.set_linear_mode(prev[1]), ops.set_attention_mode(prev[2])
+    # labels: exact wherever the truth's top-2 margin clears both the tolerance and the reference's own logit error
+    lg64 = ref64["logits"]
+    lg_scale = float(lg64.abs().max())
+    lg_err_ref = float((ref["logits"].double() - lg64).abs().max())
+    stable = so.top2_margin(lg64) > max(1e-3 * lg_scale, 10.0 * lg_err_ref)
+    same = bool(torch.equal(labels.cpu().long()[stable], ref64["labels"][stable]))
+    observed(f"r4_stats_{name}", {"fused_err_vs_fp64": e, "reference_fp32_err_vs_fp64": e_ref, "bf16x6_err_vs_fp64": e6,
+                                 "fp32_mfma_err_vs_fp64": e32, "pairs": int(ir.shape[0]), "pairs_repeated_on_bf16x6": tripped,
                                  "labels_equal_above_margin": same, "stable_fraction": float(stable.float().mean())})
-    assert e < TOL, (name, e)
+    assert e < max(TOL, 5.0 * e_ref), (name, e, e_ref, e6, e32)
     assert same, name
     return tripped
 
@@ -206,7 +230,8 @@ def test_f16x3_default_with_per_layer_weight_scales(ops):
     from segmif_amd.pipeline import PairForward
     ir, vis, mask = _inputs(2, 64, 96, 5)
     done = 0
-    for seed in (1, 2, 3, 4, 5, 6):
+    for seed in (1, 2, 5, 6):
+        with_bias = seed > 4  # the layer's bias scaled with it: its whole output shrinks / grows, tensors can really vanish
         seg, fus = Network3("mit_b1", 9, pretrained=None), Fusion_Network3_ac()
         sd_seg, sd_fus = dw.load_det_weights(seg, seed=0), dw.load_det_weights(fus, seed=0)
         g = torch.Generator().manual_seed(100 + seed)
@@ -215,6 +240,8 @@ def test_f16x3_default_with_per_layer_weight_scales(ops):
             for layer in layers:
                 s = 10.0 ** float(torch.rand(1, generator=g) * 4 - 3)
                 sd[layer + ".weight"] = sd[layer + ".weight"] * s
+                if with_bias and layer + ".bias" in sd:
+                    sd[layer + ".bias"] = sd[layer + ".bias"] * s
             net.load_state_dict(sd)
         seg, fus = seg.cuda().eval(), fus.cuda().eval()
         import segmif_oracle as so
@@ -226,3 +253,30 @@ def test_f16x3_default_with_per_layer_weight_scales(ops):
         observed(f"r4_stats_wscale_seed{seed}_trips", t)
         done += 1
     assert done >= 3, "too few finite draws: widen the seed list"
+
+
+def test_comm_c_abi_one_rank(ops):
+    """segmif_comm_*  on the one GPU this pool offers: rendezvous id, a one-rank communicator, sum and average
+    all-reduce in place on the current stream, destroy.  (Two or more ranks over xGMI: first executed by the driver's
+    multi-GPU run - the Python host exchanges through torch.distributed, which is the same RCCL.)"""
+    import ctypes
+    from segmif_amd import _lib
+    lib = _lib.load()
+    ver = ctypes.c_int(0)
+    assert lib.segmif_comm_available(ctypes.byref(ver)) == 0 and ver.value > 20000
+    uid = ctypes.create_string_buffer(128)
+    assert lib.segmif_comm_unique_id(uid, 128) == 0
+    comm = ctypes.c_void_p()
+    torch.cuda.set_device(0)
+    assert lib.segmif_comm_init(ctypes.byref(comm), 1, 0, uid, 128) == 0 and comm.value
+    w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert lib.segmif_comm_world(comm, ctypes.byref(w), ctypes.byref(r)) == 0 and (w.value, r.value) == (1, 0)
+    x = torch.arange(1 << 20, device="cuda", dtype=torch.float32)
+    y = torch.empty_like(x)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.segmif_comm_allreduce_f32(comm, x.data_ptr(), y.data_ptr(), x.numel(), 0, s) == 0
+    assert lib.segmif_comm_allreduce_f32(comm, y.data_ptr(), y.data_ptr(), x.numel(), 1, s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    assert lib.segmif_comm_allreduce_f32(comm, None, y.data_ptr(), 4, 0, s) == -22
+    assert lib.segmif_comm_destroy(comm) == 0
