@@ -130,10 +130,10 @@ class Attention(nn.Module):
         lm = ops.linear_mode()
         q = ops.linear_auto(x, pk.get("q:" + lm, self.q.weight, ops.pack_linear), C, bias=self.q.bias)
         if self.sr_ratio > 1:
-            # (the LayerNorm stays a kernel of its own here: the reduced map has few rows and a long K, which the conv
-            # covers with split-K - and split-K partials cannot carry a fused row normalisation)
-            red = ops.conv2d(x.view(B, H, W, C), pk.get("sr", self.sr.weight, ops.pack_weight), C, self.sr_ratio,
-                             stride=self.sr_ratio, bias=self.sr.bias)
+            # kernel = stride: a GEMM over sr x sr patches, read in place by the split-operand kernel (r4; the fp32 tiles with
+            # split-K for the short / narrow ones).  The LayerNorm stays a kernel of its own: few rows, a long K.
+            red = ops.sr_conv_auto(x.view(B, H, W, C), pk.get("sr:" + lm, self.sr.weight, ops.pack_sr_conv), C, self.sr_ratio,
+                                   bias=self.sr.bias)
             red = red.view(B, -1, C)
             red = ops.layernorm(red, self.norm.weight, self.norm.bias, self.norm.eps, out=red)
         else:

@@ -492,6 +492,37 @@ def linear_wants_split(rows, N, K):
     return _linear_mode != "fp32" and rows >= GEMM_SPLIT_MIN_ROWS and N >= 128 and N % 4 == 0 and K % 32 == 0
 
 
+def _vec4(t):  # the split GEMM's 16-byte epilogue accesses
+    return t is None or (t.data_ptr() % 16 == 0 and (t.dim() < 2 or t.stride(-2) % 4 == 0))
+
+
+def _gemm_split(a_ptr, rows, K, lda, split, N, bias, act, res, out, images, patch=None):
+    """Launch of the split-operand GEMM (f16x3 inside a guarded scope when the weight carries its half image, bf16x6
+    otherwise).  images: how many whole images the rows are (their range slots), or None; patch = (sr, H, W) or None."""
+    orow, oc, ldo = rows_view(out, "out")
+    if orow != rows or oc != N or (split.N, split.K) != (N, K):
+        raise RuntimeError(f"split GEMM: shapes do not fit (rows {rows}/{orow}, N {N}/{oc}, weight {split.N}x{split.K})")
+    guard = _scope.guard
+    use16 = split.half is not None and guard is not None
+    d = _lib.SegmifGemmSplit()
+    d.a, d.w, d.out = a_ptr, (split.half if use16 else split.data).data_ptr(), out.data_ptr()
+    d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
+    d.M, d.N, d.K, d.lda, d.ldo, d.act = rows, N, K, lda, ldo, act
+    if patch is not None:
+        d.patch_sr, d.patch_H, d.patch_W = patch
+    if res is not None:
+        rrow, rc, ldr = rows_view(res, "res")
+        if rc != N or rrow != rows:
+            raise RuntimeError("residual shape mismatch")
+        d.res, d.ldr = res.data_ptr(), ldr
+    if use16:
+        amax, nimg = guard.slot(images if images and rows % images == 0 else None)
+        _lib.check(_lib.load().segmif_gemm_split16_f32(ctypes.byref(d), amax, nimg, _stream()), "segmif_gemm_split16_f32")
+    else:
+        _lib.check(_lib.load().segmif_gemm_split_f32(ctypes.byref(d), _stream()), "segmif_gemm_split_f32")
+    return out
+
+
 def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):
     """out = res + act(x @ W^T + bias) with packs = pack_linear(W): the split-operand GEMM for tall problems (f16x3 inside
     a guarded scope when the weight carries its half image, bf16x6 otherwise), the fp32 tiles (with split-K) for short ones."""
@@ -500,35 +531,45 @@ def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):
     # (N < 128 would leave half of the 128-column tile idle: measured slower than the fp32 64-column tiles)
     if split is None or rows < GEMM_SPLIT_MIN_ROWS or N < 128 or N % 4 or lda % 4 or x.data_ptr() % 16:
         return linear(x, packed, N, bias=bias, act=act, res=res, out=out)
-
-    def _vec4(t):  # the kernel's 16-byte epilogue accesses
-        return t is None or (t.data_ptr() % 16 == 0 and (t.dim() < 2 or t.stride(-2) % 4 == 0))
-
     if not (_vec4(out) and _vec4(res) and _vec4(bias)):
         return linear(x, packed, N, bias=bias, act=act, res=res, out=out)
     if out is None:
         out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
-    orow, oc, ldo = rows_view(out, "out")
-    if orow != rows or oc != N or (split.N, split.K) != (N, K):
-        raise RuntimeError(f"linear_auto: shapes do not fit (rows {rows}/{orow}, N {N}/{oc}, weight {split.N}x{split.K})")
-    guard = _scope.guard
-    use16 = split.half is not None and guard is not None
-    d = _lib.SegmifGemmSplit()
-    d.a, d.w, d.out = x.data_ptr(), (split.half if use16 else split.data).data_ptr(), out.data_ptr()
-    d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
-    d.M, d.N, d.K, d.lda, d.ldo, d.act = rows, N, K, lda, ldo, act
-    if res is not None:
-        rrow, rc, ldr = rows_view(res, "res")
-        if rc != N or rrow != rows:
-            raise RuntimeError("residual shape mismatch")
-        d.res, d.ldr = res.data_ptr(), ldr
-    if use16:
-        # rows of a (B, n, K) token tensor are B whole images: each reports to its own range slot
-        amax, nimg = guard.slot(x.shape[0] if x.dim() == 3 and rows == x.shape[0] * x.shape[1] else None)
-        _lib.check(_lib.load().segmif_gemm_split16_f32(ctypes.byref(d), amax, nimg, _stream()), "segmif_gemm_split16_f32")
-    else:
-        _lib.check(_lib.load().segmif_gemm_split_f32(ctypes.byref(d), _stream()), "segmif_gemm_split_f32")
-    return out
+    # rows of a (B, n, K) token tensor are B whole images: each reports to its own range slot
+    images = x.shape[0] if x.dim() == 3 and rows == x.shape[0] * x.shape[1] else None
+    return _gemm_split(x.data_ptr(), rows, K, lda, split, N, bias, act, res, out, images)
+
+
+def pack_sr_conv(w):
+    """(N, C, sr, sr) weight of a spatial-reduction conv (kernel = stride = sr) -> (fp32 packing for the igemm tiles,
+    GemmSplitWeight over K = sr * sr * C in (ky, kx, c) order, or None).  Cache entries must be keyed on linear_mode()."""
+    packed = pack_weight(w)
+    N, C, sr = w.shape[0], w.shape[1], w.shape[2]
+    K = sr * sr * C
+    if _linear_mode == "fp32" or w.dim() != 4 or w.shape[3] != sr or (sr * C) % 32 or N < 32 or packed.shape[1] != K:
+        return packed, None
+    lib = _lib.load()
+    out = torch.empty((lib.segmif_gemm_split_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.segmif_gemm_split_pack(packed.data_ptr(), N, K, K, out.data_ptr(), _stream()), "segmif_gemm_split_pack")
+    img16 = None
+    if _linear_mode == "f16x3":
+        img16 = torch.empty((lib.segmif_gemm_split16_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
+        _lib.check(lib.segmif_gemm_split16_pack(packed.data_ptr(), N, K, K, img16.data_ptr(), _stream()), "segmif_gemm_split16_pack")
+    return packed, GemmSplitWeight(out, N, K, img16)
+
+
+def sr_conv_auto(x, packs, N, sr, *, bias=None):
+    """The spatial-reduction conv of Attention (kernel = stride = sr, no padding) on a contiguous NHWC batch x (B, H, W, C)
+    -> (B, H // sr, W // sr, N): the split-operand GEMM reading its A rows straight out of the image (patch mode: no gather
+    pass) when the problem is tall and wide enough, the strided implicit-GEMM tiles otherwise."""
+    packed, split = packs
+    B, H, W, C = x.shape
+    OH, OW = H // sr, W // sr
+    rows = B * OH * OW
+    if split is None or rows < GEMM_SPLIT_MIN_ROWS or N < 128 or N % 4 or not x.is_contiguous() or x.data_ptr() % 16 or not _vec4(bias):
+        return conv2d(x, packed, N, sr, stride=sr, bias=bias)
+    out = torch.empty((B, OH, OW, N), device=x.device, dtype=torch.float32)
+    return _gemm_split(x.data_ptr(), rows, sr * sr * C, C, split, N, bias, ACT_NONE, None, out, B, patch=(sr, H, W))
 
 
 class LaunchTimer:

@@ -280,3 +280,41 @@ def test_comm_c_abi_one_rank(ops):
     assert torch.equal(x, y)
     assert lib.segmif_comm_allreduce_f32(comm, None, y.data_ptr(), 4, 0, s) == -22
     assert lib.segmif_comm_destroy(comm) == 0
+
+
+@pytest.mark.parametrize("B,H,W,C,sr", [(8, 33, 41, 320, 2), (3, 60, 80, 128, 4), (2, 120, 160, 64, 8)])
+def test_sr_conv_on_the_split_gemm(ops, B, H, W, C, sr):
+    """Attention's spatial-reduction conv (kernel = stride = sr; core/mix_transformer.py:73-75, :98-101) as the split-operand
+    GEMM in patch mode - A rows read straight out of the NHWC image, no gather pass - against fp64, beside the exact-fp32
+    implicit-GEMM tiles; sizes that are not multiples of sr drop the remainder like the conv does; C = 64 (N < 128) keeps the
+    fp32 tiles.  Both arithmetics (half pairs inside a guarded scope, bf16 triples outside) and the per-image range slots."""
+    import torch.nn.functional as F
+    x = rnd(B, H, W, C, seed=B + H) * 10.0 ** rnd(B, H, W, C, seed=C, lo=-3, hi=1)
+    w = rnd(C, C, sr, sr, seed=sr) * 0.05 * 10.0 ** rnd(C, 1, 1, 1, seed=5, lo=-2, hi=1)
+    b = rnd(C, seed=9)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=sr).permute(0, 2, 3, 1)
+    xc, packs = x.cuda(), ops.pack_sr_conv(w.cuda())
+    y32 = ops.conv2d(xc, packs[0], C, sr, stride=sr, bias=b.cuda())
+
+    def err(t):
+        return float((t.double().cpu() - ref).abs().max() / ref.abs().max())
+
+    e32 = err(y32)
+    y6 = ops.sr_conv_auto(xc, packs, C, sr, bias=b.cuda())
+    assert y6.shape == ref.shape and err(y6) < TOL and err(y6) <= 3.0 * e32 + 1e-7
+    guard = ops.Planes16Guard("cuda", B)
+    prev = ops.install_guard(guard)
+    try:
+        y16 = ops.sr_conv_auto(xc, packs, C, sr, bias=b.cuda())
+    finally:
+        ops.install_guard(prev)
+    assert err(y16) < TOL and err(y16) <= 3.0 * e32 + 1e-7, (err(y16), e32)
+    if C >= 128:
+        assert packs[1] is not None and not torch.equal(y16, y6) and not torch.equal(y6, y32)  # three different kernels ran
+        m = guard.maxima()
+        assert m.shape == (1, B)
+        used = x[:, : H // sr * sr, : W // sr * sr]  # the pixels the conv reads; a 128-row tile may straddle two images
+        per_img = used.abs().amax(dim=(1, 2, 3)).half().float()
+        assert all(float(m[0, i]) >= float(per_img[i]) for i in range(B)) and float(m.max()) == float(per_img.max())
+    else:
+        assert torch.equal(y16, y32)
