@@ -371,7 +371,8 @@ typedef struct SegmifCrossTail {
   const float* weff;                    /* (B, 64, 128) */
   const float* bend;                    /* end_proj bias [64] or NULL */
   const float* ln_gamma; const float* ln_beta; float ln_eps;
-  float* out; int32_t ld3, ldi, ldo;
+  float* out;                           /* may be NULL when planes_out is the only consumer (no fp32 copy is written) */
+  int32_t ld3, ldi, ldo;
   int32_t B; int64_t N;
   void* planes_out; int32_t H, W, planes_chunks;   /* optional planes copy of out (NULL = off) */
   int32_t planes_f16;                               /* != 0: an f16x3 buffer (segmif_planes16_*) */

@@ -322,7 +322,7 @@ class CrossPath(nn.Module):
                                    ln=(norm.weight, norm.bias, norm.eps), out=o))
         return outs[0], outs[1]
 
-    def forward_tokens_gram(self, x1, x2, seg, out1=None, out2=None, planes1=None, planes2=None, hw=None):
+    def forward_tokens_gram(self, x1, x2, seg, out1=None, out2=None, planes1=None, planes2=None, hw=None, planes_only=False):
         """forward_tokens without the 128-wide intermediates (csrc/crosspath.hip): K^T V = Wk (Y^T Y) Wv^T needs only the
         Gram matrix of each projected half, and each consumer recomputes the 64-wide half of channel_proj it needs.
         Three Gram passes + two fused tails instead of three GEMMs, three kv reductions and two two-source GEMMs.
@@ -345,7 +345,8 @@ class CrossPath(nn.Module):
             ops.crosspath_fold(g, kv.weight, end.weight, weff, wofs=0, kofs=0, scale=self.cross_attn2.scale)
             ops.crosspath_fold(g3, self.cross_attn.kv3.weight, end.weight, weff, wofs=C, kofs=C, scale=self.cross_attn.scale)
             outs.append(ops.crosspath_tail(seg, x, halves[2][0], bias[2][0], halves[i - 1][1], bias[i - 1][1], weff, end.bias,
-                                           (norm.weight, norm.bias, norm.eps), out=o, planes=pl, hw=hw))
+                                           (norm.weight, norm.bias, norm.eps), out=o, planes=pl, hw=hw,
+                                           planes_only=planes_only))
         return outs[0], outs[1]
 
     def gram_ok(self):
@@ -394,9 +395,10 @@ class FeatureFusionModule(nn.Module):
         self.cross = CrossPath(dim=dim, reduction=reduction, num_heads=num_heads)
         init_reference_style(self)
 
-    def forward_nhwc(self, x1, x2, seg, out1=None, out2=None, planes1=None, planes2=None):
+    def forward_nhwc(self, x1, x2, seg, out1=None, out2=None, planes1=None, planes2=None, planes_only=False):
         """NHWC in / out; out_i may be channel slices of wider buffers (e.g. a DRDB concat buffer); planes_i: optional
-        ops.Planes that also receive out_i pre-split (inference on the Gram path only)."""
+        ops.Planes that also receive out_i pre-split (inference on the Gram path only); planes_only: the planes are the only
+        output (returns None, None)."""
         B, H, W, C = x1.shape
         if wants_grad(self, x1, x2, seg):
             r1, r2 = self.cross.forward_tokens_train(x1.reshape(B, H * W, C), x2.reshape(B, H * W, C),
@@ -404,7 +406,10 @@ class FeatureFusionModule(nn.Module):
             return r1.view(B, H, W, C), r2.view(B, H, W, C)
         tok = lambda t: None if t is None else t.view(B, H * W, t.shape[-1])
         if self.cross.gram_ok():
-            r1, r2 = self.cross.forward_tokens_gram(tok(x1), tok(x2), tok(seg), tok(out1), tok(out2), planes1, planes2, (H, W))
+            r1, r2 = self.cross.forward_tokens_gram(tok(x1), tok(x2), tok(seg), tok(out1), tok(out2), planes1, planes2, (H, W),
+                                                    planes_only=planes_only)
+            if planes_only:
+                return None, None
         else:
             if planes1 is not None or planes2 is not None:
                 raise RuntimeError("planes outputs need the Gram CrossPath path")
@@ -575,14 +580,14 @@ class Fusion_Network3_ac(nn.Module):
         y2 = self.DRDB4.forward_planes(x2, pls[1], out=y2, preloaded=pre)
         del pls, xs, x1, x2
         seg = seg2_fn()
-        cat = torch.empty((B, H, W, 128), device=dev, dtype=torch.float32)
         if pre and ops.aligned16(self.conv2.bias, self.conv21.bias):
             # conv2 (128 -> 64) and conv21 (64 -> 32) on the planes kernel as well: the second interaction's tails write the
             # concatenated tensor pre-split (chunks 0-7), conv2 = two 32-channel launches appending chunks 8-11, conv21
             # reads those and hands fp32 rows to the conv22 stencil
             pc = ops.Planes(B, H, W, 12, dev, guard)
-            self.ffm.forward_nhwc(y1, y2, seg, out1=cat[..., :64], out2=cat[..., 64:], planes1=pc, planes2=pc.at(4))
-            del cat, y1, y2
+            # (r4: no fp32 copy of the concatenated tensor - nothing reads it: 10 GB of stores per 64-pair step)
+            self.ffm.forward_nhwc(y1, y2, seg, planes1=pc, planes2=pc.at(4), planes_only=True)
+            del y1, y2
             sfx, pack = ("h", ops.pack_weight_planes16) if pc.f16 else ("", ops.pack_weight_planes)
             for half in (0, 1):
                 rows = slice(32 * half, 32 * half + 32)
@@ -593,6 +598,7 @@ class Fusion_Network3_ac(nn.Module):
                                bias=self.conv21.bias, act=PRELU, prelu=slope, out=f)
             del pc
         else:
+            cat = torch.empty((B, H, W, 128), device=dev, dtype=torch.float32)
             self.ffm.forward_nhwc(y1, y2, seg, out1=cat[..., :64], out2=cat[..., 64:])
             del y1, y2
             f = ops.conv2d(cat, self._w3("conv2"), 64, 3, pad=1, bias=self.conv2.bias, act=PRELU, prelu=slope)

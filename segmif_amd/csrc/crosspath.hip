@@ -437,7 +437,7 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
           v[e] = o[mt * 16 + 4 * g + e] * rstd * ga[e] + bt[e];
           o[mt * 16 + 4 * g + e] = v[e];
         }
-        if (ok) *reinterpret_cast<f32x4*>(outb + px * p.ldo + mt * 32 + 8 * g + 4 * h) = v;
+        if (ok && p.out) *reinterpret_cast<f32x4*>(outb + px * p.ldo + mt * 32 + 8 * g + 4 * h) = v;
       }
     if constexpr (F16) {
       if (ok) {
@@ -518,7 +518,7 @@ extern "C" int segmif_crosspath_fold_f32(const double* partial, int nblk, const 
 }
 
 extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream) {
-  if (!d || !d->x3 || !d->xi || !d->w3 || !d->wi || !d->weff || !d->out || d->B <= 0 || d->N <= 0) return SEGMIF_EINVAL;
+  if (!d || !d->x3 || !d->xi || !d->w3 || !d->wi || !d->weff || (!d->out && !d->planes_out) || d->B <= 0 || d->N <= 0) return SEGMIF_EINVAL;  // (out may be NULL when the planes copy is the only consumer)
   if (d->ld3 < 64 || d->ldi < 64 || d->ldo < 64 || ((d->ld3 | d->ldi | d->ldo) & 3)) return SEGMIF_EINVAL;
   if (((uintptr_t)d->x3 | (uintptr_t)d->xi | (uintptr_t)d->w3 | (uintptr_t)d->wi | (uintptr_t)d->weff | (uintptr_t)d->out) & 15)
     return SEGMIF_EINVAL;

@@ -540,6 +540,9 @@ def linear_auto(x, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None):
     return _gemm_split(x.data_ptr(), rows, K, lda, split, N, bias, act, res, out, images)
 
 
+_SR_CONV_IGEMM = os.environ.get("SEGMIF_SR_CONV") == "igemm"  # A/B switch: the round-3 path (fp32 implicit-GEMM tiles)
+
+
 def pack_sr_conv(w):
     """(N, C, sr, sr) weight of a spatial-reduction conv (kernel = stride = sr) -> (fp32 packing for the igemm tiles,
     GemmSplitWeight over K = sr * sr * C in (ky, kx, c) order, or None).  Cache entries must be keyed on linear_mode()."""
@@ -566,7 +569,8 @@ def sr_conv_auto(x, packs, N, sr, *, bias=None):
     B, H, W, C = x.shape
     OH, OW = H // sr, W // sr
     rows = B * OH * OW
-    if split is None or rows < GEMM_SPLIT_MIN_ROWS or N < 128 or N % 4 or not x.is_contiguous() or x.data_ptr() % 16 or not _vec4(bias):
+    if split is None or rows < GEMM_SPLIT_MIN_ROWS or N < 128 or N % 4 or not x.is_contiguous() or x.data_ptr() % 16 or not _vec4(bias) \
+            or _SR_CONV_IGEMM:
         return conv2d(x, packed, N, sr, stride=sr, bias=bias)
     out = torch.empty((B, OH, OW, N), device=x.device, dtype=torch.float32)
     return _gemm_split(x.data_ptr(), rows, sr * sr * C, C, split, N, bias, ACT_NONE, None, out, B, patch=(sr, H, W))
@@ -995,19 +999,24 @@ def crosspath_fold(part, wkv, wend, weff, wofs, kofs, scale):
     return weff
 
 
-def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None, hw=None):
+def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None, hw=None, planes_only=False):
     """out = LN(x_i + weff_b @ [relu(w3 x_3 + b3) | relu(wi x_i + bi)] + bend): x3, xi (B, N, 64) rows views, w3 / wi
     contiguous (64, 64) slices, weff (B, 64, 128), ln = (gamma, beta, eps).  planes: optional ops.Planes that receives
-    out as chunks 0..3 (hw = (H, W) with H * W == N)."""
+    out as chunks 0..3 (hw = (H, W) with H * W == N); planes_only: write nothing else (the fp32 tensor has no reader:
+    the second interaction of Fusion_Network3_ac, whose consumers are the planes convs) and return None."""
     for t, nm in ((x3, "x3"), (xi, "xi")):
         _req(t, nm)
         if t.dim() != 3 or t.shape[2] != 64 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
             raise RuntimeError(f"crosspath_tail: {nm} must be a (B, N, 64) rows view")
     B, N, _ = xi.shape
-    if out is None:
-        out = torch.empty((B, N, 64), device=xi.device, dtype=torch.float32)
-    if tuple(out.shape) != (B, N, 64) or out.stride(2) != 1 or out.stride(0) != N * out.stride(1):
-        raise RuntimeError("crosspath_tail: out must be a (B, N, 64) rows view")
+    if planes_only:
+        if planes is None or out is not None:
+            raise RuntimeError("crosspath_tail: planes_only needs a planes buffer and no fp32 output")
+    else:
+        if out is None:
+            out = torch.empty((B, N, 64), device=xi.device, dtype=torch.float32)
+        if tuple(out.shape) != (B, N, 64) or out.stride(2) != 1 or out.stride(0) != N * out.stride(1):
+            raise RuntimeError("crosspath_tail: out must be a (B, N, 64) rows view")
     for t in (w3, wi):
         if tuple(_req(t, "w").shape) != (64, 64) or not t.is_contiguous():
             raise RuntimeError("crosspath_tail expects contiguous (64, 64) weight slices")
@@ -1020,7 +1029,7 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
     d.bi = _req(bi).data_ptr() if bi is not None else None
     d.bend = _req(bend).data_ptr() if bend is not None else None
     d.ln_gamma, d.ln_beta, d.ln_eps = _req(ln[0]).data_ptr(), _req(ln[1]).data_ptr(), float(ln[2])
-    d.out, d.ldo, d.B, d.N = out.data_ptr(), out.stride(1), B, N
+    d.out, d.ldo, d.B, d.N = (None, 64, B, N) if planes_only else (out.data_ptr(), out.stride(1), B, N)
     if planes is not None:
         if hw is None or hw[0] * hw[1] != N or (planes.B, planes.H, planes.W) != (B, hw[0], hw[1]):
             raise RuntimeError("crosspath_tail: planes geometry does not match the tokens")
@@ -1031,7 +1040,7 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
             d.planes_amax, d.planes_amax_images = planes.guard.slot(B)
     _side("cp_tail", lambda: _lib.check(_lib.load().segmif_crosspath_tail_f32(ctypes.byref(d), _stream()),
                                         "segmif_crosspath_tail_f32"),
-          (768.0 + (0.0 if planes is None else 256.0 if planes.f16 else 384.0)) * B * N)  # + the planes copy: 4 | 6 B per element
+          ((512.0 if planes_only else 768.0) + (0.0 if planes is None else 256.0 if planes.f16 else 384.0)) * B * N)  # + the planes copy: 4 | 6 B per element
     return out
 
 

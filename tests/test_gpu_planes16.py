@@ -210,6 +210,13 @@ def test_crosspath_tail_f16x3_planes_copy(ops):
     assert torch.equal(pl.data, ref.data)
     m = guard.maxima()
     assert m.numel() == 1 and float(m[0]) == float(out.abs().max().half())
+    # planes_only (r4): the same planes, no fp32 tensor written at all
+    pl2 = ops.Planes(B, H, W, 6, "cuda", ops.Planes16Guard("cuda"))
+    pl2.data.zero_()
+    assert ops.crosspath_tail(*args, planes=pl2, hw=(H, W), planes_only=True) is None
+    assert torch.equal(pl2.data, ref.data)
+    with pytest.raises(RuntimeError):
+        ops.crosspath_tail(*args, planes_only=True)
 
 
 def _act_ref(y, act):
