@@ -399,6 +399,11 @@ int segmif_seg_normalize_f32(const float* x_nchw, float* y_nhwc, int B, int H, i
 int segmif_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int64_t HW, int ldo, void* stream);
 int segmif_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int64_t HW, int ldx, void* stream);
 int segmif_fuse_ycrcb_f32(const float* vis_nchw, const float* yf, float* out_nchw, int B, int64_t HW, void* stream);
+/* RGB2YCrCb / YCrCb2RGB themselves (core/model_fusion.py:69-91, :93-111; called at train.py:355, :365) and their backward, on
+ * planar (B, 3, HW) images: mode 0 RGB -> YCrCb; mode 1 YCrCb -> RGB (ysrc != NULL supplies channel 0 from a (B, 1, HW)
+ * tensor: train.py:362-364's clone + slice assignment folded in); mode 2 backward of 0 (in = d/dYCrCb -> d/dRGB); mode 3
+ * backward of 1 (in = d/dRGB -> d/d[Y, Cr, Cb], nout = 1: d/dY only, (B, 1, HW)).  nout = 3 otherwise. */
+int segmif_color3_f32(const float* in, const float* ysrc, float* out, int B, int64_t HW, int mode, int nout, void* stream);
 /* argmax over C of NHWC logits -> int32 labels (test_segmentation.py:174); ties -> lowest index */
 int segmif_argmax_nhwc_i32(const float* x, int32_t* labels, int64_t rows, int C, int ldx, void* stream);
 /* conf[t*K + p] += #{i : label[i] == t, pred[i] == p}, both inside [0, K) (K <= 32) — the accumulation of

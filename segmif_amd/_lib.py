@@ -96,6 +96,7 @@ SIGNATURES = {
     "segmif_crosspath_fold_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_float, c_void_p]),
     "segmif_crosspath_tail_f32": (c_int, [POINTER(SegmifCrossTail), c_void_p]),
+    "segmif_color3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "segmif_comm_available": (c_int, [POINTER(c_int)]),
     "segmif_comm_unique_id": (c_int, [c_void_p, c_int64]),
     "segmif_comm_init": (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p, c_int64]),

@@ -837,6 +837,71 @@ class LapLoss2Fn(torch.autograd.Function):
 
 
 # functional front-ends ------------------------------------------------------------------------------
+def _color3(x, mode, ysrc=None, nout=3):
+    """segmif_color3_f32 on a contiguous (B, 3, H, W) fp32 device tensor (ysrc: (B, 1, H, W))."""
+    ops._req(x, "colour transform input")
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise RuntimeError(f"colour transform expects (B, 3, H, W), got {tuple(x.shape)}")
+    x = x.contiguous()
+    B, _, H, W = x.shape
+    y = None
+    if ysrc is not None:
+        y = ops._req(ysrc, "Y source").contiguous()
+        if tuple(y.shape) != (B, 1, H, W):
+            raise RuntimeError(f"Y source must be ({B}, 1, {H}, {W}), got {tuple(y.shape)}")
+    out = torch.empty((B, nout, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().segmif_color3_f32(x.data_ptr(), y.data_ptr() if y is not None else None, out.data_ptr(), B, H * W,
+                                             mode, nout, _stream()), "segmif_color3_f32")
+    return out
+
+
+class Rgb2YCrCbFn(torch.autograd.Function):
+    """RGB2YCrCb (core/model_fusion.py:69-91): one pointwise kernel each way (the map is affine: its backward is the
+    transposed matrix)."""
+
+    @staticmethod
+    def forward(ctx, rgb):
+        return _color3(rgb, 0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _color3(dy, 2)
+
+
+class YCrCb2RgbFn(torch.autograd.Function):
+    """YCrCb2RGB (core/model_fusion.py:93-111) of [y | ycc[:, 1:]] when y is given (train.py:362-365: the fused luminance
+    takes the place of the visible image's - no clone, no slice assignment, no cat), of ycc itself otherwise."""
+
+    @staticmethod
+    def forward(ctx, ycc, y):
+        ctx.has_y = y is not None
+        return _color3(ycc, 1, ysrc=y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        g_ycc = g_y = None
+        if ctx.has_y:
+            if ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]:
+                return None, _color3(dy, 3, nout=1)
+            g = _color3(dy, 3)
+            if ctx.needs_input_grad[1]:
+                g_y = g[:, 0:1].contiguous()
+            if ctx.needs_input_grad[0]:
+                g_ycc = g
+                g_ycc[:, 0:1] = 0  # channel 0 of ycc was not read
+        elif ctx.needs_input_grad[0]:
+            g_ycc = _color3(dy, 3)
+        return g_ycc, g_y
+
+
+def rgb2ycrcb(rgb):
+    return Rgb2YCrCbFn.apply(rgb)
+
+
+def ycrcb2rgb(ycc, y=None):
+    return YCrCb2RgbFn.apply(ycc, y)
+
+
 def linear(x, w, b=None, act=ACT_NONE, slope=None):
     if act == ACT_PRELU:  # the shared PReLU is a node of its own: its backward reads the pre-activation (PReluFn)
         return PReluFn.apply(LinearFn.apply(x, w, b, ACT_NONE, None), slope)

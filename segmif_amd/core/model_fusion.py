@@ -67,14 +67,23 @@ class WeTr(nn.Module):
 
 
 def RGB2YCrCb(input_im):
-    """(B,3,H,W) RGB -> YCrCb (ref :69-91). Pointwise plumbing on whatever device the input is on."""
+    """(B,3,H,W) RGB -> YCrCb (ref :69-91): one HIP kernel, with its backward (autograd.Rgb2YCrCbFn); CPU tensors take the
+    torch formulation below (test infrastructure: the CPU tests pin it against the reference)."""
+    if input_im.is_cuda:
+        return ag.rgb2ycrcb(input_im)
     R, G, B = input_im[:, 0:1], input_im[:, 1:2], input_im[:, 2:3]
     Y = 0.299 * R + 0.587 * G + 0.114 * B
     return torch.cat((Y, (R - Y) * 0.713 + 0.5, (B - Y) * 0.564 + 0.5), dim=1)
 
 
-def YCrCb2RGB(input_im):
-    """(B,3,H,W) YCrCb -> RGB (ref :93-111)."""
+def YCrCb2RGB(input_im, y=None):
+    """(B,3,H,W) YCrCb -> RGB (ref :93-111): one HIP kernel, with its backward (autograd.YCrCb2RgbFn).  y (B,1,H,W), an
+    extension of the reference signature: takes the place of channel 0 (train.py:362-365's clone + slice assignment).  CPU
+    tensors take the torch formulation below (test infrastructure)."""
+    if input_im.is_cuda:
+        return ag.ycrcb2rgb(input_im, y)
+    if y is not None:
+        input_im = torch.cat((y, input_im[:, 1:]), dim=1)
     mat = input_im.new_tensor([[1.0, 1.0, 1.0], [1.403, -0.714, 0.0], [0.0, -0.344, 1.773]])
     bias = input_im.new_tensor([0.0, -0.5, -0.5])
     flat = input_im.permute(0, 2, 3, 1).reshape(-1, 3)

@@ -234,6 +234,50 @@ __global__ __launch_bounds__(256) void fuse_ycrcb_kernel(const float* __restrict
   out[(b * 3 + 2) * HW + p] = fminf(fmaxf(bl, 0.f), 1.f);
 }
 
+// RGB2YCrCb / YCrCb2RGB (core/model_fusion.py:69-91, :93-111) and their backward, on planar (B, 3, HW) images.
+//   MODE 0  RGB -> YCrCb          Y = .299 R + .587 G + .114 B, Cr = (R - Y) .713 + .5, Cb = (B - Y) .564 + .5
+//   MODE 1  YCrCb -> RGB          ([Y, Cr, Cb] + [0, -.5, -.5]) M, M = [[1, 1, 1], [1.403, -.714, 0], [0, -.344, 1.773]], summed
+//                                 in aten mm order; ysrc != null supplies channel 0 from a (B, 1, HW) tensor instead
+//                                 (train.py:362-364: fused_ycbcr = vis.clone(); fused_ycbcr[:, 0:1] = fusion) - no clone, no cat
+//   MODE 2  backward of 0: in = d/dYCrCb -> d/dRGB          (both maps are affine: the backward is the transposed matrix)
+//   MODE 3  backward of 1: in = d/dRGB -> d/d[Y, Cr, Cb]; nout = 1 writes d/dY only (the gradient of `fusion`)
+template <int MODE>
+__global__ __launch_bounds__(256) void color3_kernel(const float* __restrict__ in, const float* __restrict__ ysrc,
+                                                     float* __restrict__ out, long long HW, long long total, int nout) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const long long b = idx / HW, p = idx - b * HW;
+  const float a = (MODE == 1 && ysrc) ? ysrc[idx] : in[(b * 3 + 0) * HW + p];
+  const float c1 = in[(b * 3 + 1) * HW + p], c2 = in[(b * 3 + 2) * HW + p];
+  float o0, o1, o2;
+  if (MODE == 0) {
+    o0 = 0.299f * a + 0.587f * c1 + 0.114f * c2;
+    o1 = (a - o0) * 0.713f + 0.5f;
+    o2 = (c2 - o0) * 0.564f + 0.5f;
+  } else if (MODE == 1) {
+    const float t0 = a + 0.0f, t1 = c1 + -0.5f, t2 = c2 + -0.5f;
+    o0 = t0 * 1.0f + t1 * 1.403f + t2 * 0.0f;
+    o1 = t0 * 1.0f + t1 * -0.714f + t2 * -0.344f;
+    o2 = t0 * 1.0f + t1 * 0.0f + t2 * 1.773f;
+  } else if (MODE == 2) {  // (a, c1, c2) = (dY, dCr, dCb); dCr reaches R directly and everything through Y
+    const float gy = a - 0.713f * c1 - 0.564f * c2;  // total gradient arriving at Y
+    o0 = 0.299f * gy + 0.713f * c1;
+    o1 = 0.587f * gy;
+    o2 = 0.114f * gy + 0.564f * c2;
+  } else {  // (a, c1, c2) = (dR, dG, dB): d t_i = sum_j d out_j M[i][j]
+    o0 = a + c1 + c2;
+    o1 = 1.403f * a - 0.714f * c1;
+    o2 = -0.344f * c1 + 1.773f * c2;
+  }
+  if (nout == 1) {
+    out[idx] = o0;
+  } else {
+    out[(b * 3 + 0) * HW + p] = o0;
+    out[(b * 3 + 1) * HW + p] = o1;
+    out[(b * 3 + 2) * HW + p] = o2;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 11-tap separable Gaussian blur with zero padding over (planes, H, W) images: the window of
 // pytorch_ssim (pytorch_ssim/__init__.py:8-17; an outer product, so the 2-D "same" convolution
@@ -595,6 +639,19 @@ extern "C" int segmif_fuse_ycrcb_f32(const float* vis, const float* yf, float* o
   const long long total = (long long)HW * B;
   hipLaunchKernelGGL(fuse_ycrcb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vis,
                      yf, out, (long long)HW, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_color3_f32(const float* in, const float* ysrc, float* out, int B, int64_t HW, int mode, int nout, void* stream) {
+  if (!in || !out || B <= 0 || HW <= 0 || mode < 0 || mode > 3 || (nout != 3 && !(nout == 1 && mode == 3)) || (ysrc && mode != 1))
+    return SEGMIF_EINVAL;
+  const long long total = (long long)HW * B;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) hipLaunchKernelGGL(color3_kernel<0>, grid, block, 0, s, in, ysrc, out, (long long)HW, total, nout);
+  else if (mode == 1) hipLaunchKernelGGL(color3_kernel<1>, grid, block, 0, s, in, ysrc, out, (long long)HW, total, nout);
+  else if (mode == 2) hipLaunchKernelGGL(color3_kernel<2>, grid, block, 0, s, in, ysrc, out, (long long)HW, total, nout);
+  else hipLaunchKernelGGL(color3_kernel<3>, grid, block, 0, s, in, ysrc, out, (long long)HW, total, nout);
   return (int)hipGetLastError();
 }
 

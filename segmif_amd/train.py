@@ -112,7 +112,7 @@ class FusionTrainer:
                 self.last_lap = losses.lap_loss2(fusion.detach(), ir, vis[:, 0:1])
         if self.iter_ > 1:
             loss1 = losses.fusion_loss_grad3(fusion, mask3)
-            fused_rgb = YCrCb2RGB(torch.cat((fusion, vis[:, 1:2], vis[:, 2:3]), dim=1))
+            fused_rgb = YCrCb2RGB(vis, fusion)  # (train.py:362-365: fused_ycbcr = vis.clone(); fused_ycbcr[:, 0:1] = fusion)
             if self.seg_weight_grads:
                 loss2 = self.seg._loss(fused_rgb, labels, self.crit)
             else:

@@ -320,3 +320,64 @@ def test_sr_conv_on_the_split_gemm(ops, B, H, W, C, sr):
         assert all(float(m[0, i]) >= float(per_img[i]) for i in range(B)) and float(m.max()) == float(per_img.max())
     else:
         assert torch.equal(y16, y32)
+
+
+def test_colour_transforms_on_the_hip_path(ops, golden_dir):
+    """RGB2YCrCb / YCrCb2RGB as HIP kernels with backward (closes SURVEY 8(a) row a15): values and gradients against records of
+    the reference's own functions and autograd (tests/golden/colour.npz), and train.py:362-365's composite - the fused
+    luminance in channel 0 - with the gradient of `fusion`; no aten op on the way (a CPU tensor takes the torch formulation)."""
+    import numpy as np
+    from segmif_amd.core.model_fusion import RGB2YCrCb, YCrCb2RGB
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "colour.npz")).items()}
+
+    def rel(a, b):
+        return float((a.detach().double().cpu() - b.double()).abs().max() / b.double().abs().max())
+
+    rgb = g["rgb"].cuda().requires_grad_(True)
+    ycc = RGB2YCrCb(rgb)
+    assert type(ycc.grad_fn).__name__ == "Rgb2YCrCbFnBackward" and rel(ycc, g["ycc"]) < 1e-6
+    (g_rgb,) = torch.autograd.grad((ycc * g["ct1"].cuda()).sum(), rgb)
+    assert rel(g_rgb, g["g_rgb"]) < 1e-6
+    y_in = g["ycc"].cuda().requires_grad_(True)
+    back = YCrCb2RGB(y_in)
+    assert rel(back, g["back"]) < 1e-6
+    (g_ycc,) = torch.autograd.grad((back * g["ct2"].cuda()).sum(), y_in)
+    assert rel(g_ycc, g["g_ycc"]) < 1e-6
+    fusion = g["fusion"].cuda().requires_grad_(True)
+    fused_rgb = YCrCb2RGB(g["ycc"].cuda(), fusion)
+    assert rel(fused_rgb, g["fused_rgb"]) < 1e-6
+    (g_fusion,) = torch.autograd.grad((fused_rgb * g["ct2"].cuda()).sum(), fusion)
+    assert g_fusion.shape == fusion.shape and rel(g_fusion, g["g_fusion"]) < 1e-6
+    # both inputs differentiable: channel 0 of the YCrCb tensor is not read, its gradient is zero
+    y2 = g["ycc"].cuda().requires_grad_(True)
+    out = YCrCb2RGB(y2, fusion)
+    ga, gb = torch.autograd.grad((out * g["ct2"].cuda()).sum(), (y2, fusion))
+    assert float(ga[:, 0].abs().max()) == 0.0 and rel(gb, g["g_fusion"]) < 1e-6 and rel(ga[:, 1:], g["g_ycc"][:, 1:]) < 1e-6
+
+
+def test_mit_b0_at_256x256_vs_reference(ops, golden_dir):
+    """BASELINE config[0] at its stated size: mit_b0 (head_dim 32, C = 32 .. 256), one 256 x 256 image, against the
+    reference's record - encoder features, forward_fusion, Network3 logits."""
+    import numpy as np
+    from segmif_amd.core import Network3
+    g = {k: v for k, v in np.load(os.path.join(golden_dir, "mit_b0_256x256.npz")).items()}
+    net = Network3("mit_b0", 9, pretrained=None)
+    dw.load_det_weights(net, seed=0)
+    net = net.cuda().eval()
+    x = dw.det_input("b0_256x256", (1, 3, 256, 256)).cuda()
+
+    def rel(a, b):
+        b = torch.as_tensor(b).double()
+        return float((a.detach().double().cpu() - b).abs().max() / b.abs().max())
+
+    with torch.no_grad():
+        feats = net.denoise_net.encoder(x)
+        o0, o1 = net.denoise_net.encoder.forward_fusion(x)
+        _, _, seg = net(x)
+    assert [tuple(f.shape) for f in feats] == [(1, 32, 64, 64), (1, 64, 32, 32), (1, 160, 16, 16), (1, 256, 8, 8)]
+    e = {"f1": rel(feats[0][:, :, ::3, 1::4], g["f1_sample"]), "f2": rel(feats[1], g["f2"]), "f3": rel(feats[2], g["f3"]),
+         "f4": rel(feats[3], g["f4"]), "fus0": rel(o0[:, :, 1::9, 2::11], g["fus0_sample"]),
+         "fus1": rel(o1[:, :, 1::9, 2::11], g["fus1_sample"]), "seg": rel(seg, g["seg"])}
+    observed("r4_mit_b0_256x256", e)
+    assert max(e.values()) < 1e-4, e
+    assert abs(float(o0.double().mean()) - float(g["fus0_mean"])) < 1e-5 and abs(float(feats[0].double().mean()) - float(g["f1_mean"])) < 1e-5

@@ -330,3 +330,46 @@ def test_config1_geometry_mit_b1_480x640_checksum(golden_dir, sd_fus):
     with torch.no_grad():
         r = so.pair_forward(sd, sd_fus, ir, vis, mask, "mit_b1", return_all=True)
     _check_samples(r, g, ("out0", "out1", "y_fused", "fused", "seg", "logits"))
+
+
+def test_colour_transforms_vs_reference(golden_dir):
+    """RGB2YCrCb / YCrCb2RGB (core/model_fusion.py:69-111) called on their own: the oracle's restatement, and the CPU path of
+    the product's functions (test infrastructure), against records of the reference's functions - values and autograd
+    gradients, and train.py:362-365's composite with the fused luminance in channel 0."""
+    g = load(golden_dir, "colour.npz")
+    rgb = torch.from_numpy(g["rgb"]).requires_grad_(True)
+    ct1, ct2 = torch.from_numpy(g["ct1"]), torch.from_numpy(g["ct2"])
+    for fwd, inv in ((so.rgb2ycrcb, so.ycrcb2rgb),):
+        ycc = fwd(rgb)
+        assert rel_err(ycc, g["ycc"]) < 1e-6
+        (g_rgb,) = torch.autograd.grad((ycc * ct1).sum(), rgb)
+        assert rel_err(g_rgb, g["g_rgb"]) < 1e-6
+        y_in = torch.from_numpy(g["ycc"]).requires_grad_(True)
+        back = inv(y_in)
+        assert rel_err(back, g["back"]) < 1e-6
+        (g_ycc,) = torch.autograd.grad((back * ct2).sum(), y_in)
+        assert rel_err(g_ycc, g["g_ycc"]) < 1e-6
+    from segmif_amd.core.model_fusion import RGB2YCrCb, YCrCb2RGB
+    fusion = torch.from_numpy(g["fusion"]).requires_grad_(True)
+    assert rel_err(RGB2YCrCb(rgb), g["ycc"]) < 1e-6
+    fused_rgb = YCrCb2RGB(torch.from_numpy(g["ycc"]), fusion)
+    assert rel_err(fused_rgb, g["fused_rgb"]) < 1e-6
+    (g_fusion,) = torch.autograd.grad((fused_rgb * ct2).sum(), fusion)
+    assert rel_err(g_fusion, g["g_fusion"]) < 1e-6
+
+
+def test_mit_b0_at_256x256(golden_dir):
+    """BASELINE config[0] at its stated size (mit_b0, one 256 x 256 image): encoder features, forward_fusion and Network3
+    logits of the oracle against the reference's record (oracle/make_golden_r4.py)."""
+    g = load(golden_dir, "mit_b0_256x256.npz")
+    sd = dw.det_state_dict(so.network3_shapes("mit_b0", 9), seed=0)
+    x = dw.det_input("b0_256x256", (1, 3, 256, 256))
+    feats = so.mit_forward_features(sd, "denoise_net.encoder.", x, "mit_b0")
+    assert [tuple(f.shape) for f in feats] == [(1, 32, 64, 64), (1, 64, 32, 32), (1, 160, 16, 16), (1, 256, 8, 8)]
+    assert rel_err(feats[0][:, :, ::3, 1::4], g["f1_sample"]) < TOL and abs(float(feats[0].double().mean()) - float(g["f1_mean"])) < 1e-6
+    for i in (1, 2, 3):
+        assert rel_err(feats[i], g[f"f{i + 1}"]) < TOL
+    o0, o1 = so.mit_forward_fusion(sd, "denoise_net.encoder.", x, "mit_b0")
+    assert rel_err(o0[:, :, 1::9, 2::11], g["fus0_sample"]) < TOL and rel_err(o1[:, :, 1::9, 2::11], g["fus1_sample"]) < TOL
+    assert abs(float(o0.double().mean()) - float(g["fus0_mean"])) < 1e-6 and abs(float(o1.double().mean()) - float(g["fus1_mean"])) < 1e-6
+    assert rel_err(so.network3_forward(sd, x, "mit_b0"), g["seg"]) < TOL
