@@ -536,6 +536,27 @@ int segmif_adamw_f32(const void* table, const int32_t* chunk_entry, const int64_
                      void* stream);
 
 /*
+ * Mix-FFN of a MiT block as ONE kernel (csrc/mixffn.hip), C = 64 | 128 (stages 1-2 of mit_b1 .. b5):
+ *     out = x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x)))))     core/mix_transformer.py:46-53, :376-387, :152-155
+ * on (B, H*W, C) tokens; a workgroup owns a 12 x 16 pixel tile, the 4C-wide hidden tensor stays in its LDS / registers.
+ * f16x3 arithmetic (half pairs x three products, see segmif_planes16_*): `wimg` is the segmif_mixffn_pack image of the fc1
+ * (4C, C) and fc2 (C, 4C) weights (segmif_mixffn_weight_bytes(C) bytes), dw_weight the depthwise weight as [9][4C] (tap-major);
+ * amax_a / amax_g: range slots of the two tensors the kernel splits (LN(x) and the GELU output), indexed by image when
+ * amax_images == B (NULL = off); the caller re-runs tripped images on the bf16x6 chain (segmif_layernorm_f32,
+ * segmif_gemm_split_f32, segmif_dwconv3x3_gelu_f32).  out must not alias x.
+ */
+typedef struct SegmifMixFfn {
+  const float* x; float* out; const void* wimg;
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  const float* b1; const float* dw_weight; const float* dw_bias; const float* b2;
+  int32_t B, H, W, C;
+  uint32_t* amax_a; uint32_t* amax_g; int32_t amax_images;
+} SegmifMixFfn;
+int64_t segmif_mixffn_weight_bytes(int C);
+int segmif_mixffn_pack(const float* w1 /* (4C, C) */, const float* w2 /* (C, 4C) */, int C, void* out, void* stream);
+int segmif_mixffn_f16x3(const SegmifMixFfn* desc, void* stream);
+
+/*
  * Gradient exchange of the data-parallel training steps behind the C ABI (SURVEY.md section 8(b) lists
  * segmif_comm_{init, allreduce, destroy}; section 8(e): one fp32 sum / average all-reduce per step over RCCL / xGMI; the
  * reference has no distributed code at all).  Thin entry points over RCCL for a host that is not Python - this

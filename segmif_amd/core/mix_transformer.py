@@ -68,6 +68,22 @@ class Mlp(nn.Module):
         h = ag.dwconv_gelu(h, self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W)
         return ag.linear(self.drop(h), self.fc2.weight, self.fc2.bias)
 
+    def fusable(self, x):
+        """True when norm2 + this Mlp + the residual can run as the one-kernel Mix-FFN (inference, C = 64 | 128, inside a
+        guarded f16x3 scope, 16-byte aligned parameters)."""
+        C = self.fc1.in_features
+        return ops.mixffn_fusable(C, self.fc1.out_features) and self.fc2.out_features == C and x.is_contiguous() \
+            and not (self.drop.p > 0 and self.training) and self.fc1.bias is not None and self.fc2.bias is not None \
+            and ops.aligned16(self.fc1.bias, self.fc2.bias, self.dwconv.dwconv.bias)
+
+    def forward_fused(self, x, norm, H, W):
+        """x + fc2(gelu(dwconv(fc1(norm(x))))) for tokens x (B, H*W, C): csrc/mixffn.hip."""
+        pk = self._pk
+        wimg = pk.get_multi("mixffn", (self.fc1.weight, self.fc2.weight), lambda: ops.pack_mixffn(self.fc1.weight, self.fc2.weight))
+        return ops.mixffn_fused(x, (norm.weight, norm.bias, norm.eps), wimg, self.fc1.bias,
+                                pk.get("dw", self.dwconv.dwconv.weight, ops.pack_dw_weight), self.dwconv.dwconv.bias,
+                                self.fc2.bias, H, W)
+
     def forward(self, x, H, W, residual=None):
         """x: (B, N, C) tokens.  Returns fc2(gelu(dwconv(fc1(x)))) (+ residual, written in place)."""
         if wants_grad(self, x):
@@ -176,6 +192,10 @@ class Block(nn.Module):
         xn = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         if not stochastic:
             x = self.attn(xn, H, W, residual=x)
+            if self.mlp.fusable(x):
+                # stages 1-2 inside a guarded scope: norm2 + fc1 + dwconv + GELU + fc2 + residual in ONE kernel, the hidden
+                # tensor never reaches HBM (csrc/mixffn.hip); returns a new token buffer (halo reads forbid in place)
+                return self.mlp.forward_fused(x, self.norm2, H, W)
             xn = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=xn)
             return self.mlp(xn, H, W, residual=x)
         # train-mode stochastic depth (timm DropPath): per-sample Bernoulli scaling of each branch

@@ -1,0 +1,475 @@
+// Mix-FFN of a MiT block in ONE kernel for the wide-image stages (C = 64 | 128: stages 1-2 of mit_b1 .. b5):
+//     out = x + fc2( GELU( dwconv3x3( fc1( LayerNorm(x) ) ) ) )        core/mix_transformer.py:46-53 (Mlp), :376-387 (DWConv),
+//                                                                       :152-155 (Block: norm2, mlp, residual)
+// Round 3 ran this as LayerNorm -> GEMM -> dwconv+GELU -> GEMM: the 4C-wide hidden tensor crossed HBM four times (315 MB
+// in, 1.26 GB out, 1.26 GB in / out, 1.26 GB in per 64 images at stage 1) and the three kernels sat at 3.2 - 4.4 TB/s:
+// 1.65 ms per block.  Here a workgroup owns a 12 x 16 pixel tile and the hidden tensor never leaves the CU:
+//
+//   A      the tile's 14 x 18 halo of tokens (252 -> 8 row blocks of 32) is loaded ONCE, normalised (LayerNorm in registers:
+//          a token's row is split over the two half-waves, one cross-half shuffle per statistic) and split into half pairs
+//          straight into MFMA operand registers (f16x3 format, planes16.h) - no LDS for A;
+//   per chunk of 32 hidden channels (4C / 32 chunks):
+//   P1     fc1 on the matrix pipe (weights by LDS-DMA, 3 products per MAC), + bias, zero outside the image (the dwconv's
+//          zero padding applies to the HIDDEN image) -> Hs[256 tokens][32] fp32 in LDS
+//   P2     depthwise 3x3 + bias + exact GELU on the vector ALU (a thread slides a 3 x 3 window of float4s down a column),
+//          result split into half pairs -> Gs (aliases Hs) in the B-operand layout of fc2
+//   P3     fc2 partial product over these 32 hidden channels into the output accumulators (registers)
+//   end    out = x + acc * 2^-e(n) + b2.
+// HBM traffic: x once (1.31x with the halo, mostly L2 hits), out once.  One workgroup of 8 waves per CU (72 KB of LDS at
+// C = 64, 111 KB at C = 128; ~200 registers per lane: the halo's operand fragments, the output accumulators and the
+// depthwise window live side by side).
+//
+// f16x3 only (half pairs, range slots for the two tensors the kernel splits: LN(x) and the GELU output); outside a guarded
+// scope, or for a pair the guard sends back, the host runs the round-3 chain on bf16x6.
+#include <hip/hip_runtime.h>
+#include "device_once.h"
+#include <stdint.h>
+
+#include "igemm_common.h"
+#include "planes16.h"
+#include "segmif_hip.h"
+
+namespace segmif {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int MF_TH = 12, MF_TW = 16;          // output tile (pixels)
+constexpr int MF_HH = MF_TH + 2, MF_HW = MF_TW + 2;
+constexpr int MF_NTOK = MF_HH * MF_HW;         // 252 halo tokens -> 8 row blocks
+constexpr int MF_NPX = MF_TH * MF_TW;          // 192 output pixels -> 6 row blocks
+constexpr int MF_HS_BYTES = 256 * 128;         // Hs: [256 tokens][32 ch] fp32, 16-byte slots swizzled by (token & 7)
+constexpr int MF_GP = 144;                     // Gs: bytes per pixel (32 hi halves | 32 lo halves | 16 pad); 9 slots: odd
+
+template <int C>
+struct MfGeom {
+  static constexpr int HID = 4 * C, NCH = HID / 32, KS = C / 16, CB = C / 32;
+  static constexpr int P1 = 6 * C + 16;        // W1s row pitch: 3 planes x C halves + 16 (an odd number of 16-byte slots)
+  static constexpr int W1B = 32 * P1;          // one chunk of fc1 weights: 32 hidden rows
+  static constexpr int P2 = 208;               // W2s row pitch: 3 planes x 32 halves + 16
+  static constexpr int W2B = C * P2;           // one chunk of fc2 weights: C output rows x 32 hidden columns
+  static constexpr int W1B_PAD = (W1B + 1023) / 1024 * 1024;
+  // constants (floats): gamma[C] beta[C] b2[C] s2[C] | b1[HID] s1[HID] dwb[HID] | dww[9][HID]
+  static constexpr int O_GAMMA = 0, O_BETA = C, O_B2 = 2 * C, O_S2 = 3 * C, O_B1 = 4 * C, O_S1 = O_B1 + HID, O_DWB = O_S1 + HID,
+                       O_DWW = O_DWB + HID, NCONST = O_DWW + 9 * HID;
+  static constexpr int SMEM = MF_HS_BYTES + W1B_PAD + W2B + NCONST * 4;
+};
+
+struct MixFfnK {
+  const float* x;             // (B, H*W, C) tokens, dense
+  float* out;                 // (B, H*W, C), must not alias x (halo tokens are read by neighbouring workgroups)
+  const unsigned char* wimg;  // [NCH][W1B_PAD] fc1 chunks | [NCH][W2B] fc2 chunks | s1[HID] | s2[C]   (segmif_mixffn_pack)
+  const float* gamma; const float* beta; float eps;
+  const float* b1; const float* dww; const float* dwb; const float* b2;  // dww: [9][HID] tap-major
+  int B, H, W, tiles_x, tiles_y;
+  uint32_t* amax_a;           // range slots of LN(x) and of the GELU output (or null); index = image when amax_images > 1
+  uint32_t* amax_g;
+  int amax_images;
+};
+
+__device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void mf_dma16(const unsigned char* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void mixffn_kernel(const MixFfnK p) {
+  using G = MfGeom<C>;
+  constexpr int T = 64 * NW;
+  constexpr int RBW = 8 / NW;                 // halo row blocks per wave in fc1 (2 | 1)
+  constexpr int RPT = MF_TH / (T / 128);      // output rows per thread in the depthwise phase (6 | 3)
+  constexpr int HALF = C / 2;                 // channels of a token held by one half-wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_m[];
+  unsigned char* Hs = smem_m;                               // also Gs
+  unsigned char* W1s = smem_m + MF_HS_BYTES;
+  unsigned char* W2s = W1s + G::W1B_PAD;
+  float* Cst = reinterpret_cast<float*>(W2s + G::W2B);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  int bid = blockIdx.x;
+  {  // XCD-aware remap: an XCD owns a contiguous run of tiles (neighbouring tiles share their halo rows in one L2)
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int tx = bid % p.tiles_x, ty = (bid / p.tiles_x) % p.tiles_y, b = bid / (p.tiles_x * p.tiles_y);
+  const int x0 = tx * MF_TW, y0 = ty * MF_TH;
+  const long long img = (long long)b * p.H * p.W;
+
+  const unsigned char* w1img = p.wimg;
+  const unsigned char* w2img = p.wimg + (long long)G::NCH * G::W1B_PAD;
+  // chunk j's weights -> LDS by LDS-DMA, each buffer single: W1s is free from the barrier after P1 on (chunk j + 1 is fetched
+  // under P2), W2s from the barrier that opens the next chunk on (chunk j + 1 is fetched under its own P1 / P2)
+  auto dma_w1 = [&](int j) {
+    const unsigned char* src = w1img + (long long)j * G::W1B_PAD + lane * 16;
+    for (int i = wave; i < G::W1B_PAD / 1024; i += NW) mf_dma16(src + i * 1024, W1s + i * 1024);
+  };
+  auto dma_w2 = [&](int j) {
+    const unsigned char* src = w2img + (long long)j * G::W2B + lane * 16;
+    for (int i = wave; i < G::W2B / 1024; i += NW) mf_dma16(src + i * 1024, W2s + i * 1024);
+  };
+  dma_w1(0);
+
+  // ---- constants -> LDS ------------------------------------------------------------------------------------------------
+  {
+    const float* s1g = reinterpret_cast<const float*>(p.wimg + (long long)G::NCH * (G::W1B_PAD + G::W2B));
+    const float* s2g = s1g + G::HID;
+    for (int i = tid; i < G::NCONST; i += T) {
+      float v;
+      if (i < G::O_BETA) v = p.gamma[i];
+      else if (i < G::O_B2) v = p.beta[i - G::O_BETA];
+      else if (i < G::O_S2) v = p.b2[i - G::O_B2];
+      else if (i < G::O_B1) v = s2g[i - G::O_S2];
+      else if (i < G::O_S1) v = p.b1[i - G::O_B1];
+      else if (i < G::O_DWB) v = s1g[i - G::O_S1];
+      else if (i < G::O_DWW) v = p.dwb[i - G::O_DWB];
+      else v = p.dww[i - G::O_DWW];
+      Cst[i] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- A: this wave's halo row blocks, LayerNorm, split -> operand registers ------------------------------------------
+  // MFMA contraction slot (step s, half h, element e) <-> channel HALF h + 8 s + e (the fc1 weight image is packed the same
+  // way), so a lane reads one contiguous run of HALF floats of its token.
+  u32x4 a_hi[RBW][G::KS], a_lo[RBW][G::KS];
+  bool tok_in[RBW];
+  int tok_id[RBW];
+  uint32_t amx_a = 0u, amx_g = 0u;
+#pragma unroll
+  for (int i = 0; i < RBW; ++i) {
+    const int tok = (wave + i * NW) * 32 + r;
+    tok_id[i] = tok;
+    const int hy = tok / MF_HW, hx = tok - hy * MF_HW;
+    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+    const bool in = tok < MF_NTOK && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    tok_in[i] = in;
+    const float* src = p.x + (img + (long long)(in ? gy : 0) * p.W + (in ? gx : 0)) * C + HALF * h;
+    f32x4 v[HALF / 4];
+#pragma unroll
+    for (int k = 0; k < HALF / 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + 4 * k);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < HALF / 4; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < HALF / 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[k][e] -= mean;
+        q += v[k][e] * v[k][e];
+      }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + p.eps);
+#pragma unroll
+    for (int s8 = 0; s8 < G::KS; ++s8) {
+      float y[8];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(Cst + G::O_GAMMA + HALF * h + 8 * s8 + 4 * k);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(Cst + G::O_BETA + HALF * h + 8 * s8 + 4 * k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[4 * k + e] = in ? v[2 * s8 + k][e] * rstd * ga[e] + be[e] : 0.f;
+      }
+      p16::split8(y, a_hi[i][s8], a_lo[i][s8]);
+      amx_a = p16::absmax_pk4(amx_a, a_hi[i][s8]);
+    }
+  }
+
+  // output jobs of this wave in fc2: column block cb (32 output channels), row blocks rb0 + i RSTEP (i < NJ, those < 6)
+  constexpr int NJ = (6 * G::CB + NW - 1) / NW, RSTEP = NW / G::CB;
+  const int cb = wave % G::CB, rb0 = wave / G::CB;
+  f32x16 acc2[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc2[i][v] = 0.f;
+
+  // depthwise phase geometry of this thread: channel quad q4, column xc, rows yb .. yb + RPT - 1 of the output tile
+  const int q4 = tid & 7, xc = (tid >> 3) & 15, yb = (tid >> 7) * RPT;
+
+  const unsigned char* w1_lane = W1s + r * G::P1 + h * 16;
+  const unsigned char* w2_lane = W2s + (32 * cb + r) * G::P2 + h * 16;
+
+  for (int j = 0; j < G::NCH; ++j) {
+    // ---- P1: fc1 for 32 hidden channels ---------------------------------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's fc1 weights have landed (issued under the previous P2)
+    __syncthreads();                                     // ... for every wave; the previous chunk's P3 is done with Gs and W2s
+    dma_w2(j);
+    f32x16 acc1[RBW];
+#pragma unroll
+    for (int i = 0; i < RBW; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc1[i][v] = 0.f;
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) {
+      u32x4 w[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const u32x4*>(w1_lane + pl * (2 * C) + s * 32);
+#pragma unroll
+      for (int i = 0; i < RBW; ++i) {  // products least significant first: l W0s, x0 Wl, x0 W0
+        acc1[i] = mfma16(w[2], a_lo[i][s], acc1[i]);
+        acc1[i] = mfma16(w[1], a_hi[i][s], acc1[i]);
+        acc1[i] = mfma16(w[0], a_hi[i][s], acc1[i]);
+      }
+    }
+    {  // + bias (x row scale), zero outside the image, -> Hs
+      f32x4 bb[4], ss[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bb[g] = *reinterpret_cast<const f32x4*>(Cst + G::O_B1 + 32 * j + 8 * g + 4 * h);
+        ss[g] = *reinterpret_cast<const f32x4*>(Cst + G::O_S1 + 32 * j + 8 * g + 4 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < RBW; ++i) {
+        const int tok = tok_id[i];
+        unsigned char* row = Hs + tok * 128;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = tok_in[i] ? fmaf(acc1[i][4 * g + e], ss[g][e], bb[g][e]) : 0.f;
+          *reinterpret_cast<f32x4*>(row + (((2 * g + h) ^ (tok & 7)) * 16)) = y;
+        }
+      }
+    }
+    __syncthreads();  // Hs complete; every wave is done with W1s
+    if (j + 1 < G::NCH) dma_w1(j + 1);
+
+    // ---- P2: depthwise 3x3 + bias + GELU over the output tile, 4 channels x RPT rows per thread -----------------------------
+    uint32_t g_hi[RPT][2], g_lo[RPT][2];
+    {
+      f32x4 wt[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(Cst + G::O_DWW + t * G::HID + 32 * j + 4 * q4);
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(Cst + G::O_DWB + 32 * j + 4 * q4);
+      f32x4 win[3][3];
+      auto ld_row = [&](int hy, f32x4* dst) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int tok = hy * MF_HW + xc + dx;
+          dst[dx] = *reinterpret_cast<const f32x4*>(Hs + tok * 128 + ((q4 ^ (tok & 7)) * 16));
+        }
+      };
+      ld_row(yb, win[0]);
+      ld_row(yb + 1, win[1]);
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        ld_row(yb + i + 2, win[2]);
+        f32x4 a = bias;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = fmaf(win[dy][dx][e], wt[dy * 3 + dx][e], a[e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = gelu_exact(a[e]);
+        p16::split2(a[0], a[1], g_hi[i][0], g_lo[i][0]);
+        p16::split2(a[2], a[3], g_hi[i][1], g_lo[i][1]);
+        const bool ok = y0 + yb + i < p.H && x0 + xc < p.W;
+        const uint32_t m = p16::absmax_pk(p16::absmax_pk(amx_g, g_hi[i][0]), g_hi[i][1]);
+        amx_g = ok ? m : amx_g;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          win[0][dx] = win[1][dx];
+          win[1][dx] = win[2][dx];
+        }
+      }
+    }
+    __syncthreads();  // every thread has read its Hs window: Gs may overwrite the region
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      unsigned char* px = Hs + ((yb + i) * MF_TW + xc) * MF_GP + q4 * 8;
+      *reinterpret_cast<u32x2*>(px) = u32x2{g_hi[i][0], g_hi[i][1]};
+      *reinterpret_cast<u32x2*>(px + 64) = u32x2{g_lo[i][0], g_lo[i][1]};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's fc2 weights (and the next chunk's fc1 weights) have landed
+    __syncthreads();  // Gs complete
+
+    // ---- P3: fc2 partial product over these 32 hidden channels ----------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 w[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const u32x4*>(w2_lane + pl * 64 + s * 32);
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) {
+        if (rb0 + RSTEP * i < 6) {  // (wave-uniform)
+          const unsigned char* px = Hs + ((rb0 + RSTEP * i) * 32 + r) * MF_GP + (2 * s + h) * 16;
+          const u32x4 ghi = *reinterpret_cast<const u32x4*>(px);
+          const u32x4 glo = *reinterpret_cast<const u32x4*>(px + 64);
+          acc2[i] = mfma16(w[2], glo, acc2[i]);
+          acc2[i] = mfma16(w[1], ghi, acc2[i]);
+          acc2[i] = mfma16(w[0], ghi, acc2[i]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: out = x + acc * 2^-e(n) + b2 ---------------------------------------------------------------------------
+  {
+    f32x4 bb[4], ss[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bb[g] = *reinterpret_cast<const f32x4*>(Cst + G::O_B2 + 32 * cb + 8 * g + 4 * h);
+      ss[g] = *reinterpret_cast<const f32x4*>(Cst + G::O_S2 + 32 * cb + 8 * g + 4 * h);
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      const int px = (rb0 + RSTEP * i) * 32 + r;
+      const int gy = y0 + px / MF_TW, gx = x0 + (px % MF_TW);
+      if (rb0 + RSTEP * i < 6 && gy < p.H && gx < p.W) {
+        const long long m = (img + (long long)gy * p.W + gx) * C + 32 * cb + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 xr = *reinterpret_cast<const f32x4*>(p.x + m + 8 * g);
+          f32x4 y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = xr[e] + fmaf(acc2[i][4 * g + e], ss[g][e], bb[g][e]);
+          *reinterpret_cast<f32x4*>(p.out + m + 8 * g) = y;
+        }
+      }
+    }
+  }
+  const int slot = p.amax_images > 1 ? b : 0;
+  if (p.amax_a) p16::fold_pat(p.amax_a, slot, slot, amx_a);
+  if (p.amax_g) p16::fold_pat(p.amax_g, slot, slot, amx_g);
+}
+
+// row scale 2^-e(n) of an (N, K) weight: 2^14 <= 2^e max |w[n][.]| < 2^15 (1 for a vanishing row)
+__global__ void mixffn_scale_kernel(const float* __restrict__ w, int K, float* __restrict__ inv_scale) {
+  const int n = blockIdx.x;
+  float mx = 0.f;
+  for (int k = threadIdx.x; k < K; k += 64) mx = fmaxf(mx, fabsf(w[(long long)n * K + k]));
+  mx = p16::wave_max(mx);
+  if (threadIdx.x == 0) {
+    int e = 0;
+    if (mx >= 1e-30f && mx <= 3e38f) e = 14 - (int)((__float_as_uint(mx) >> 23) - 127);
+    inv_scale[n] = ldexpf(1.f, -e);
+  }
+}
+
+__device__ __forceinline__ void mf_put3(unsigned char* row, int plane_bytes, int pos, float x) {
+  const _Float16 w0 = (_Float16)x;
+  const _Float16 wl = (_Float16)(x - (float)w0);
+  const _Float16 ws = (_Float16)((float)w0 * (1.f / p16::LSCALE));
+  reinterpret_cast<_Float16*>(row)[pos] = w0;
+  reinterpret_cast<_Float16*>(row + plane_bytes)[pos] = wl;
+  reinterpret_cast<_Float16*>(row + 2 * plane_bytes)[pos] = ws;
+}
+
+// fc1 (HID, C) -> [chunk][32 rows][P1]: planes W0 | Wl | W0s of the scaled row, position (s, h, e) <- channel C/2 h + 8 s + e
+template <int C>
+__global__ void mixffn_pack1_kernel(const float* __restrict__ w1, const float* __restrict__ s1, unsigned char* __restrict__ out) {
+  using G = MfGeom<C>;
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // one thread per (n, position)
+  if (idx >= G::HID * C) return;
+  const int n = idx / C, pos = idx - n * C;
+  const int s = pos >> 4, hh = (pos >> 3) & 1, e = pos & 7;
+  const int c = (C / 2) * hh + 8 * s + e;
+  const float x = w1[(long long)n * C + c] * (1.f / s1[n]);  // exact: power of two
+  unsigned char* row = out + (long long)(n >> 5) * G::W1B_PAD + (n & 31) * G::P1;
+  mf_put3(row, 2 * C, pos, x);
+  if (pos < 8) reinterpret_cast<uint16_t*>(row + 6 * C)[pos] = 0;  // the 16 padding bytes
+}
+
+// fc2 (C, HID) -> [chunk][C rows][P2]: position (s, h, e) of chunk j <- hidden channel 32 j + 16 s + 8 h + e
+template <int C>
+__global__ void mixffn_pack2_kernel(const float* __restrict__ w2, const float* __restrict__ s2, unsigned char* __restrict__ out) {
+  using G = MfGeom<C>;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= C * G::HID) return;
+  const int n = idx / G::HID, k = idx - n * G::HID;
+  const int j = k >> 5, pos = k & 31;
+  const float x = w2[(long long)n * G::HID + k] * (1.f / s2[n]);
+  unsigned char* row = out + (long long)j * G::W2B + n * G::P2;
+  mf_put3(row, 64, pos, x);
+  if (pos < 8) reinterpret_cast<uint16_t*>(row + 192)[pos] = 0;
+}
+
+template <int C>
+int64_t image_bytes() {
+  using G = MfGeom<C>;
+  return (int64_t)G::NCH * (G::W1B_PAD + G::W2B) + (int64_t)(G::HID + C) * 4;
+}
+
+template <int C>
+int pack(const float* w1, const float* w2, void* out, hipStream_t s) {
+  using G = MfGeom<C>;
+  unsigned char* o = (unsigned char*)out;
+  float* s1 = reinterpret_cast<float*>(o + (long long)G::NCH * (G::W1B_PAD + G::W2B));
+  float* s2 = s1 + G::HID;
+  hipError_t e = hipMemsetAsync(o, 0, (size_t)G::NCH * G::W1B_PAD, s);  // (the round-up of a fc1 chunk to whole DMA instructions)
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(mixffn_scale_kernel, dim3(G::HID), dim3(64), 0, s, w1, C, s1);
+  hipLaunchKernelGGL(mixffn_scale_kernel, dim3(C), dim3(64), 0, s, w2, G::HID, s2);
+  hipLaunchKernelGGL(mixffn_pack1_kernel<C>, dim3((G::HID * C + 255) / 256), dim3(256), 0, s, w1, s1, o);
+  hipLaunchKernelGGL(mixffn_pack2_kernel<C>, dim3((C * G::HID + 255) / 256), dim3(256), 0, s, w2, s2,
+                     o + (long long)G::NCH * G::W1B_PAD);
+  return (int)hipGetLastError();
+}
+
+template <int C, int NW>
+int launch(const MixFfnK& k, hipStream_t s) {
+  using G = MfGeom<C>;
+  static_assert(G::SMEM <= 160 * 1024, "LDS budget");
+  static_assert(MF_NPX * MF_GP <= MF_HS_BYTES, "Gs must fit the Hs region");
+  auto fn = mixffn_kernel<C, NW>;
+  static segmif::PerDeviceFlag raised_flag;
+  bool& raised = raised_flag.here();
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  const long long tiles = (long long)k.B * k.tiles_x * k.tiles_y;
+  hipLaunchKernelGGL(fn, dim3((unsigned)tiles), dim3(64 * NW), G::SMEM, s, k);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+}  // namespace segmif
+
+using namespace segmif;
+
+extern "C" int64_t segmif_mixffn_weight_bytes(int C) {
+  return C == 64 ? image_bytes<64>() : C == 128 ? image_bytes<128>() : 0;
+}
+
+extern "C" int segmif_mixffn_pack(const float* w1, const float* w2, int C, void* out, void* stream) {
+  if (!w1 || !w2 || !out || ((uintptr_t)out & 15)) return SEGMIF_EINVAL;
+  if (C == 64) return pack<64>(w1, w2, out, (hipStream_t)stream);
+  if (C == 128) return pack<128>(w1, w2, out, (hipStream_t)stream);
+  return SEGMIF_EINVAL;
+}
+
+extern "C" int segmif_mixffn_f16x3(const SegmifMixFfn* d, void* stream) {
+  if (!d || !d->x || !d->out || !d->wimg || !d->ln_gamma || !d->ln_beta || !d->b1 || !d->dw_weight || !d->dw_bias || !d->b2)
+    return SEGMIF_EINVAL;
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->x == d->out) return SEGMIF_EINVAL;
+  if (((uintptr_t)d->x | (uintptr_t)d->out | (uintptr_t)d->wimg) & 15) return SEGMIF_EINVAL;
+  if ((d->amax_a || d->amax_g) && d->amax_images != 1 && d->amax_images != d->B) return SEGMIF_EINVAL;
+  MixFfnK k;
+  k.x = d->x; k.out = d->out; k.wimg = (const unsigned char*)d->wimg;
+  k.gamma = d->ln_gamma; k.beta = d->ln_beta; k.eps = d->ln_eps;
+  k.b1 = d->b1; k.dww = d->dw_weight; k.dwb = d->dw_bias; k.b2 = d->b2;
+  k.B = d->B; k.H = d->H; k.W = d->W;
+  k.tiles_x = (d->W + MF_TW - 1) / MF_TW; k.tiles_y = (d->H + MF_TH - 1) / MF_TH;
+  k.amax_a = d->amax_a; k.amax_g = d->amax_g; k.amax_images = d->amax_images;
+  if ((long long)k.B * k.tiles_x * k.tiles_y >= (1ll << 31)) return SEGMIF_EINVAL;
+  if (d->C == 64) return launch<64, 8>(k, (hipStream_t)stream);
+  if (d->C == 128) return launch<128, 8>(k, (hipStream_t)stream);
+  return SEGMIF_EINVAL;
+}

@@ -576,6 +576,73 @@ def sr_conv_auto(x, packs, N, sr, *, bias=None):
     return _gemm_split(x.data_ptr(), rows, sr * sr * C, C, split, N, bias, ACT_NONE, None, out, B, patch=(sr, H, W))
 
 
+_MIXFFN = os.environ.get("SEGMIF_MIXFFN", "fused")  # "chain": round 3's LayerNorm -> GEMM -> dwconv+GELU -> GEMM everywhere (A/B switch)
+if _MIXFFN not in ("fused", "chain"):
+    raise RuntimeError(f"SEGMIF_MIXFFN must be 'fused' or 'chain', got {_MIXFFN!r}")
+
+
+def mixffn_mode():
+    return _MIXFFN
+
+
+def set_mixffn_mode(mode):
+    global _MIXFFN
+    if mode not in ("fused", "chain"):
+        raise ValueError("mode must be 'fused' or 'chain'")
+    prev, _MIXFFN = _MIXFFN, mode
+    return prev
+
+
+def mixffn_fusable(C, hidden):
+    """The one-kernel Mix-FFN (csrc/mixffn.hip) exists for C = 64 | 128 with the 4x hidden width, on f16x3 operands: it runs
+    inside a guarded scope only (the bf16x6 chain is what a tripped pair is repeated on)."""
+    return _MIXFFN == "fused" and C in (64, 128) and hidden == 4 * C and _linear_mode == "f16x3" and _scope.guard is not None
+
+
+def pack_mixffn(w1, w2):
+    """fc1 (4C, C) and fc2 (C, 4C) Linear weights -> the segmif_mixffn_pack image (uint8 tensor)."""
+    _req(w1, "fc1 weight"), _req(w2, "fc2 weight")
+    C = w1.shape[1]
+    if tuple(w1.shape) != (4 * C, C) or tuple(w2.shape) != (C, 4 * C):
+        raise RuntimeError(f"pack_mixffn: expected (4C, C) and (C, 4C) weights, got {tuple(w1.shape)} and {tuple(w2.shape)}")
+    lib = _lib.load()
+    nbytes = lib.segmif_mixffn_weight_bytes(C)
+    if nbytes <= 0:
+        raise RuntimeError(f"pack_mixffn: C must be 64 or 128, got {C}")
+    out = torch.empty((nbytes,), device=w1.device, dtype=torch.uint8)
+    _lib.check(lib.segmif_mixffn_pack(w1.detach().contiguous().data_ptr(), w2.detach().contiguous().data_ptr(), C, out.data_ptr(),
+                                      _stream()), "segmif_mixffn_pack")
+    return out
+
+
+def mixffn_fused(x, ln, wimg, b1, dw9, dwb, b2, H, W):
+    """out = x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))) in one launch: x contiguous tokens (B, H*W, C), ln = (gamma, beta,
+    eps), wimg = pack_mixffn(fc1.weight, fc2.weight), dw9 = pack_dw_weight(dwconv.weight) ([9][4C]).  Needs an active range
+    guard (two slot rows: the normalised tokens and the GELU output).  Returns a NEW tensor (halo tokens of x are read by
+    neighbouring workgroups, so the update cannot be in place)."""
+    _req(x, "x")
+    if x.dim() != 3 or not x.is_contiguous() or x.shape[1] != H * W:
+        raise RuntimeError("mixffn_fused expects contiguous (B, H*W, C) tokens")
+    guard = _scope.guard
+    if guard is None:
+        raise RuntimeError("mixffn_fused runs on f16x3 operands: call it inside ops.run_guarded (or install_guard)")
+    B, _, C = x.shape
+    if tuple(dw9.shape) != (9, 4 * C) or not dw9.is_contiguous() or wimg.dtype != torch.uint8:
+        raise RuntimeError("mixffn_fused: dw9 must be the contiguous [9][4C] packing, wimg the pack_mixffn image")
+    out = torch.empty_like(x)
+    d = _lib.SegmifMixFfn()
+    d.x, d.out, d.wimg = x.data_ptr(), out.data_ptr(), wimg.data_ptr()
+    d.ln_gamma, d.ln_beta, d.ln_eps = _req(ln[0]).data_ptr(), _req(ln[1]).data_ptr(), float(ln[2])
+    d.b1, d.dw_weight, d.dw_bias, d.b2 = _req(b1).data_ptr(), _req(dw9).data_ptr(), _req(dwb).data_ptr(), _req(b2).data_ptr()
+    d.B, d.H, d.W, d.C = B, H, W, C
+    d.amax_a, n1 = guard.slot(B)
+    d.amax_g, n2 = guard.slot(B)
+    d.amax_images = n1
+    _side("mixffn", lambda: _lib.check(_lib.load().segmif_mixffn_f16x3(ctypes.byref(d), _stream()), "segmif_mixffn_f16x3"),
+          8.0 * x.numel())
+    return out
+
+
 class LaunchTimer:
     """Brackets tagged kernel launches with HIP events on the launch stream (torch's current
     stream) so bench.py can report a kernel's average duration live.  `work` is whatever the caller wants averaged

@@ -381,3 +381,76 @@ def test_mit_b0_at_256x256_vs_reference(ops, golden_dir):
     observed("r4_mit_b0_256x256", e)
     assert max(e.values()) < 1e-4, e
     assert abs(float(o0.double().mean()) - float(g["fus0_mean"])) < 1e-5 and abs(float(feats[0].double().mean()) - float(g["f1_mean"])) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 30, 37, 64), (3, 12, 16, 64), (2, 17, 50, 128), (1, 60, 80, 128)])
+def test_mixffn_fused_kernel(ops, B, H, W, C):
+    """csrc/mixffn.hip: norm2 + fc1 + dwconv3x3 + GELU + fc2 + residual of a MiT block (core/mix_transformer.py:46-53,
+    :376-387, :152-155) in one launch, f16x3 operands - against fp64 (yardstick: the exact-fp32 chain LayerNorm -> GEMM ->
+    dwconv+GELU -> GEMM of round 3), on ragged sizes (partial tiles, image borders inside a tile), with the hidden image's
+    zero padding, x left untouched, and both range rows per image."""
+    import torch.nn.functional as F
+    hid = 4 * C
+    x = rnd(B, H * W, C, seed=C + H) * 10.0 ** rnd(B, H * W, 1, seed=3, lo=-1, hi=1)
+    gamma, beta = rnd(C, seed=4, lo=0.5, hi=1.5), rnd(C, seed=5) * 0.2
+    w1, b1 = rnd(hid, C, seed=6) * 0.2 * 10.0 ** rnd(hid, 1, seed=7, lo=-1, hi=0.5), rnd(hid, seed=8) * 0.3
+    wd, bd = rnd(hid, 1, 3, 3, seed=9) * 0.5, rnd(hid, seed=10) * 0.2
+    w2, b2 = rnd(C, hid, seed=11) * 0.1 * 10.0 ** rnd(C, 1, seed=12, lo=-1, hi=0.5), rnd(C, seed=13) * 0.3
+    eps = 1e-6
+    xd = x.double()
+    n = F.layer_norm(xd, (C,), gamma.double(), beta.double(), eps)
+    hdn = n @ w1.double().t() + b1.double()
+    img = hdn.transpose(1, 2).reshape(B, hid, H, W)
+    img = F.conv2d(img, wd.double(), bd.double(), padding=1, groups=hid)
+    g = F.gelu(img.flatten(2).transpose(1, 2))
+    ref = xd + g @ w2.double().t() + b2.double()
+
+    xc = x.cuda()
+    x_keep = xc.clone()
+    ln = (gamma.cuda(), beta.cuda(), eps)
+    dw9 = ops.pack_dw_weight(wd.cuda())
+    wimg = ops.pack_mixffn(w1.cuda(), w2.cuda())
+    guard = ops.Planes16Guard("cuda", B)
+    prev = ops.install_guard(guard)
+    try:
+        out = ops.mixffn_fused(xc, ln, wimg, b1.cuda(), dw9, bd.cuda(), b2.cuda(), H, W)
+    finally:
+        ops.install_guard(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(xc, x_keep) and out.data_ptr() != xc.data_ptr()
+    # the round-3 chain on exact-fp32 MFMA tiles
+    xn = ops.layernorm(xc, ln[0], ln[1], eps)
+    hh = ops.linear(xn, ops.pack_weight(w1.cuda()), hid, bias=b1.cuda())
+    hh = ops.dwconv3x3_gelu(hh, dw9, bd.cuda(), H, W)
+    chain = ops.linear(hh, ops.pack_weight(w2.cuda()), C, bias=b2.cuda(), res=xc)
+
+    def err(t):
+        return float((t.double().cpu() - ref).abs().max() / ref.abs().max())
+
+    e, e32 = err(out), err(chain)
+    observed(f"r4_mixffn_C{C}_{H}x{W}", {"fused_f16x3": e, "fp32_chain": e32})
+    assert e < TOL and e <= 3.0 * e32 + 2e-7, (e, e32)
+    m = guard.maxima()
+    assert m.shape == (2, B) and guard.ok()
+    assert all(abs(float(m[1, i]) - float(g[i].abs().max())) <= 2.0 ** -10 * float(g[i].abs().max()) for i in range(B))
+    assert all(float(m[0, i]) >= 0.999 * float(n[i].abs().max()) for i in range(B))
+
+
+def test_mixffn_fused_inside_the_encoder(ops, nets):
+    """A guarded mit_b1 pair forward takes the one-kernel Mix-FFN at stages 1-2; the same pairs with SEGMIF_MIXFFN=chain
+    (round 3's four launches) agree to the f16x3 / bf16x6 level, and the labels are the same above the margin."""
+    from segmif_amd.pipeline import PairForward
+    seg, fus, sd_seg, sd_fus = nets
+    pipe = PairForward(seg, fus)
+    ir, vis, mask = (t.cuda() for t in _inputs(2, 96, 128, 3))
+    with torch.no_grad():
+        f1, l1 = pipe.eager(ir, vis, mask)
+        prev = ops.set_mixffn_mode("chain")
+        try:
+            f0, l0 = pipe.eager(ir, vis, mask)
+        finally:
+            ops.set_mixffn_mode(prev)
+    d = float((f1 - f0).abs().max())
+    observed("r4_mixffn_pair_fused_vs_chain", {"max_abs_diff_fused_image": d, "labels_differ": int((l1 != l0).sum())})
+    assert not torch.equal(f1, f0) and d < 1e-4
+    assert int((l1 != l0).sum()) <= 0.001 * l0.numel()
