@@ -539,8 +539,9 @@ int segmif_adamw_f32(const void* table, const int32_t* chunk_entry, const int64_
  * Mix-FFN of a MiT block as ONE kernel (csrc/mixffn.hip), C = 64 | 128 (stages 1-2 of mit_b1 .. b5):
  *     out = x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x)))))     core/mix_transformer.py:46-53, :376-387, :152-155
  * on (B, H*W, C) tokens; a workgroup owns a 12 x 16 pixel tile, the 4C-wide hidden tensor stays in its LDS / registers.
- * f16x3 arithmetic (half pairs x three products, see segmif_planes16_*): `wimg` is the segmif_mixffn_pack image of the fc1
- * (4C, C) and fc2 (C, 4C) weights (segmif_mixffn_weight_bytes(C) bytes), dw_weight the depthwise weight as [9][4C] (tap-major);
+ * f16x3 arithmetic (half pairs x three products, see segmif_planes16_*): `wimg` is the segmif_mixffn_pack image
+ * (segmif_mixffn_weight_bytes(C) bytes) of everything per hidden channel - the fc1 (4C, C) and fc2 (C, 4C) weights, fc1's bias,
+ * the depthwise weight as [9][4C] (tap-major) and its bias -, one contiguous block per 32 hidden channels;
  * amax_a / amax_g: range slots of the two tensors the kernel splits (LN(x) and the GELU output), indexed by image when
  * amax_images == B (NULL = off); the caller re-runs tripped images on the bf16x6 chain (segmif_layernorm_f32,
  * segmif_gemm_split_f32, segmif_dwconv3x3_gelu_f32).  out must not alias x.
@@ -548,12 +549,13 @@ int segmif_adamw_f32(const void* table, const int32_t* chunk_entry, const int64_
 typedef struct SegmifMixFfn {
   const float* x; float* out; const void* wimg;
   const float* ln_gamma; const float* ln_beta; float ln_eps;
-  const float* b1; const float* dw_weight; const float* dw_bias; const float* b2;
+  const float* b2;   /* fc2 bias [C] */
   int32_t B, H, W, C;
   uint32_t* amax_a; uint32_t* amax_g; int32_t amax_images;
 } SegmifMixFfn;
 int64_t segmif_mixffn_weight_bytes(int C);
-int segmif_mixffn_pack(const float* w1 /* (4C, C) */, const float* w2 /* (C, 4C) */, int C, void* out, void* stream);
+int segmif_mixffn_pack(const float* w1 /* (4C, C) */, const float* b1, const float* dw9 /* [9][4C] */, const float* dw_bias,
+                       const float* w2 /* (C, 4C) */, int C, void* out, void* stream);
 int segmif_mixffn_f16x3(const SegmifMixFfn* desc, void* stream);
 
 /*

@@ -63,7 +63,7 @@ class SegmifCrossTail(ctypes.Structure):
 
 class SegmifMixFfn(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("wimg", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p),
-                ("ln_eps", c_float), ("b1", c_void_p), ("dw_weight", c_void_p), ("dw_bias", c_void_p), ("b2", c_void_p),
+                ("ln_eps", c_float), ("b2", c_void_p),
                 ("B", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32),
                 ("amax_a", c_void_p), ("amax_g", c_void_p), ("amax_images", c_int32)]
 
@@ -105,7 +105,7 @@ SIGNATURES = {
     "segmif_crosspath_tail_f32": (c_int, [POINTER(SegmifCrossTail), c_void_p]),
     "segmif_color3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "segmif_mixffn_weight_bytes": (c_int64, [c_int]),
-    "segmif_mixffn_pack": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "segmif_mixffn_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "segmif_mixffn_f16x3": (c_int, [POINTER(SegmifMixFfn), c_void_p]),
     "segmif_comm_available": (c_int, [POINTER(c_int)]),
     "segmif_comm_unique_id": (c_int, [c_void_p, c_int64]),

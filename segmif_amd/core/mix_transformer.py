@@ -78,11 +78,11 @@ class Mlp(nn.Module):
 
     def forward_fused(self, x, norm, H, W):
         """x + fc2(gelu(dwconv(fc1(norm(x))))) for tokens x (B, H*W, C): csrc/mixffn.hip."""
-        pk = self._pk
-        wimg = pk.get_multi("mixffn", (self.fc1.weight, self.fc2.weight), lambda: ops.pack_mixffn(self.fc1.weight, self.fc2.weight))
-        return ops.mixffn_fused(x, (norm.weight, norm.bias, norm.eps), wimg, self.fc1.bias,
-                                pk.get("dw", self.dwconv.dwconv.weight, ops.pack_dw_weight), self.dwconv.dwconv.bias,
-                                self.fc2.bias, H, W)
+        dw = self.dwconv.dwconv
+        srcs = (self.fc1.weight, self.fc1.bias, dw.weight, dw.bias, self.fc2.weight)
+        wimg = self._pk.get_multi("mixffn", srcs, lambda: ops.pack_mixffn(self.fc1.weight, self.fc1.bias, ops.pack_dw_weight(dw.weight),
+                                                                        dw.bias, self.fc2.weight))
+        return ops.mixffn_fused(x, (norm.weight, norm.bias, norm.eps), wimg, self.fc2.bias, H, W)
 
     def forward(self, x, H, W, residual=None):
         """x: (B, N, C) tokens.  Returns fc2(gelu(dwconv(fc1(x)))) (+ residual, written in place)."""

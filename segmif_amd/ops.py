@@ -599,27 +599,32 @@ def mixffn_fusable(C, hidden):
     return _MIXFFN == "fused" and C in (64, 128) and hidden == 4 * C and _linear_mode == "f16x3" and _scope.guard is not None
 
 
-def pack_mixffn(w1, w2):
-    """fc1 (4C, C) and fc2 (C, 4C) Linear weights -> the segmif_mixffn_pack image (uint8 tensor)."""
-    _req(w1, "fc1 weight"), _req(w2, "fc2 weight")
+def pack_mixffn(w1, b1, dw9, dwb, w2):
+    """fc1 (4C, C) weight + bias, depthwise weight as pack_dw_weight's [9][4C] + bias, fc2 (C, 4C) weight -> the
+    segmif_mixffn_pack image (uint8 tensor): one contiguous block per 32 hidden channels."""
+    for t, nm in ((w1, "fc1 weight"), (b1, "fc1 bias"), (dw9, "dw weight"), (dwb, "dw bias"), (w2, "fc2 weight")):
+        _req(t, nm)
     C = w1.shape[1]
-    if tuple(w1.shape) != (4 * C, C) or tuple(w2.shape) != (C, 4 * C):
-        raise RuntimeError(f"pack_mixffn: expected (4C, C) and (C, 4C) weights, got {tuple(w1.shape)} and {tuple(w2.shape)}")
+    if tuple(w1.shape) != (4 * C, C) or tuple(w2.shape) != (C, 4 * C) or tuple(dw9.shape) != (9, 4 * C) \
+            or b1.numel() != 4 * C or dwb.numel() != 4 * C:
+        raise RuntimeError(f"pack_mixffn: shapes do not fit C = {C}: {tuple(w1.shape)}, {tuple(w2.shape)}, {tuple(dw9.shape)}")
     lib = _lib.load()
     nbytes = lib.segmif_mixffn_weight_bytes(C)
     if nbytes <= 0:
         raise RuntimeError(f"pack_mixffn: C must be 64 or 128, got {C}")
-    out = torch.empty((nbytes,), device=w1.device, dtype=torch.uint8)
-    _lib.check(lib.segmif_mixffn_pack(w1.detach().contiguous().data_ptr(), w2.detach().contiguous().data_ptr(), C, out.data_ptr(),
-                                      _stream()), "segmif_mixffn_pack")
+    out = torch.zeros((nbytes,), device=w1.device, dtype=torch.uint8)
+    c = lambda t: t.detach().contiguous()
+    w1c, b1c, d9c, dbc, w2c = c(w1), c(b1), c(dw9), c(dwb), c(w2)
+    _lib.check(lib.segmif_mixffn_pack(w1c.data_ptr(), b1c.data_ptr(), d9c.data_ptr(), dbc.data_ptr(), w2c.data_ptr(), C,
+                                      out.data_ptr(), _stream()), "segmif_mixffn_pack")
     return out
 
 
-def mixffn_fused(x, ln, wimg, b1, dw9, dwb, b2, H, W):
+def mixffn_fused(x, ln, wimg, b2, H, W):
     """out = x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))) in one launch: x contiguous tokens (B, H*W, C), ln = (gamma, beta,
-    eps), wimg = pack_mixffn(fc1.weight, fc2.weight), dw9 = pack_dw_weight(dwconv.weight) ([9][4C]).  Needs an active range
-    guard (two slot rows: the normalised tokens and the GELU output).  Returns a NEW tensor (halo tokens of x are read by
-    neighbouring workgroups, so the update cannot be in place)."""
+    eps), wimg = pack_mixffn(...), b2 = fc2's bias.  Needs an active range guard (two slot rows: the normalised tokens and
+    the GELU output).  Returns a NEW tensor (halo tokens of x are read by neighbouring workgroups, so the update cannot be
+    in place)."""
     _req(x, "x")
     if x.dim() != 3 or not x.is_contiguous() or x.shape[1] != H * W:
         raise RuntimeError("mixffn_fused expects contiguous (B, H*W, C) tokens")
@@ -627,18 +632,19 @@ def mixffn_fused(x, ln, wimg, b1, dw9, dwb, b2, H, W):
     if guard is None:
         raise RuntimeError("mixffn_fused runs on f16x3 operands: call it inside ops.run_guarded (or install_guard)")
     B, _, C = x.shape
-    if tuple(dw9.shape) != (9, 4 * C) or not dw9.is_contiguous() or wimg.dtype != torch.uint8:
-        raise RuntimeError("mixffn_fused: dw9 must be the contiguous [9][4C] packing, wimg the pack_mixffn image")
+    lib = _lib.load()
+    if wimg.dtype != torch.uint8 or wimg.numel() != lib.segmif_mixffn_weight_bytes(C):
+        raise RuntimeError("mixffn_fused: wimg must be the pack_mixffn image for this C")
     out = torch.empty_like(x)
     d = _lib.SegmifMixFfn()
     d.x, d.out, d.wimg = x.data_ptr(), out.data_ptr(), wimg.data_ptr()
     d.ln_gamma, d.ln_beta, d.ln_eps = _req(ln[0]).data_ptr(), _req(ln[1]).data_ptr(), float(ln[2])
-    d.b1, d.dw_weight, d.dw_bias, d.b2 = _req(b1).data_ptr(), _req(dw9).data_ptr(), _req(dwb).data_ptr(), _req(b2).data_ptr()
+    d.b2 = _req(b2).data_ptr()
     d.B, d.H, d.W, d.C = B, H, W, C
     d.amax_a, n1 = guard.slot(B)
     d.amax_g, n2 = guard.slot(B)
     d.amax_images = n1
-    _side("mixffn", lambda: _lib.check(_lib.load().segmif_mixffn_f16x3(ctypes.byref(d), _stream()), "segmif_mixffn_f16x3"),
+    _side("mixffn", lambda: _lib.check(lib.segmif_mixffn_f16x3(ctypes.byref(d), _stream()), "segmif_mixffn_f16x3"),
           8.0 * x.numel())
     return out
 

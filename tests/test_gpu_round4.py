@@ -409,11 +409,11 @@ def test_mixffn_fused_kernel(ops, B, H, W, C):
     x_keep = xc.clone()
     ln = (gamma.cuda(), beta.cuda(), eps)
     dw9 = ops.pack_dw_weight(wd.cuda())
-    wimg = ops.pack_mixffn(w1.cuda(), w2.cuda())
+    wimg = ops.pack_mixffn(w1.cuda(), b1.cuda(), dw9, bd.cuda(), w2.cuda())
     guard = ops.Planes16Guard("cuda", B)
     prev = ops.install_guard(guard)
     try:
-        out = ops.mixffn_fused(xc, ln, wimg, b1.cuda(), dw9, bd.cuda(), b2.cuda(), H, W)
+        out = ops.mixffn_fused(xc, ln, wimg, b2.cuda(), H, W)
     finally:
         ops.install_guard(prev)
     torch.cuda.synchronize()
