@@ -328,6 +328,13 @@ int64_t segmif_sr_attention_split_workspace(int B, int heads, int Nk);
 int segmif_sr_attention_split_f32(const float* q, const float* k, const float* v, float* out, void* workspace,
                                   int B, int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo,
                                   float scale, void* stream);
+/* The same with f16x3 arithmetic (half pairs x three f16 MFMA products, see segmif_planes16_*): K and V^T are packed as
+ * scaled half planes with one power-of-two scale per (key tile, head, image), Q and the probabilities are split in registers.
+ * amax[image] (amax_images == B) or amax[0] (1) receives max |scale log2(e) Q| (NULL = off): the caller re-runs images whose
+ * slot left [2^-13, 65504) on segmif_sr_attention_split_f32.  Same workspace size. */
+int segmif_sr_attention_split16_f32(const float* q, const float* k, const float* v, float* out, void* workspace, int B,
+                                    int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo, float scale,
+                                    uint32_t* amax, int amax_images, void* stream);
 
 /*
  * Linear ("efficient") cross attention context, step 1: per (batch, head) partial sums of

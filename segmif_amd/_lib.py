@@ -143,6 +143,8 @@ SIGNATURES = {
     "segmif_sr_attention_split_workspace": (c_int64, [c_int, c_int, c_int]),
     "segmif_sr_attention_split_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                               c_int, c_int, c_int, c_float, c_void_p]),
+    "segmif_sr_attention_split16_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                              c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "segmif_linattn_num_blocks": (c_int, [c_int64]),
     "segmif_linattn_partial_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "segmif_linattn_kvpartial_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),

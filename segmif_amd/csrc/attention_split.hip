@@ -18,11 +18,24 @@
 // the accumulator registers 8 s .. 8 s + 7 of S^T (rows (v&3) + 8 (v>>2) + 4 h) ARE the 8 slots of step s - key
 // 16 s + 4 h + (j & 3) + 8 (j >> 2) again - so P feeds the second product without leaving its registers and the V
 // image is stored transposed in that key order.
+//
+// F16 = true ("f16x3", segmif_sr_attention_split16_f32; the format: csrc/conv3x3_planes.hip / planes16.h): THREE
+// v_mfma_f32_32x32x16_f16 per product instead of six.  K and V^T play the weights' role (three half planes W0 | W - W0 |
+// 2^-11 W0 of the values scaled by a power of two), Q and P the activations' (half pairs x = hi + 2^-11 lo, split in
+// registers).  The scale is per (key tile, head, image), found by the pack workgroup that writes the tile's image: the largest
+// |K| (|V|) of the tile lands in [2^14, 2^15).  2^-eK multiplies the tile's scores inside the exponent's fma (softmax needs
+// the scores' ABSOLUTE accuracy: a tile-wide scale gives the small ones at least the precision of the largest); 2^-eV is the
+// unit of the running output sums, which are rescaled - by an exact power of two - when a tile's unit differs from the
+// running one, together with the online softmax's own rescale.  Range slots: max |scaled Q| per image (P lies in [0, 1]; K
+// and V are in range by construction).
 #include <hip/hip_runtime.h>
 #include "device_once.h"
 #include <stdint.h>
 
+#include "planes16.h"
 #include "segmif_hip.h"
+
+namespace p16 = segmif::p16;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -30,6 +43,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -39,6 +53,8 @@ constexpr int VPITCH = 3 * 64 + 16;         // V^T image row (one head dimension
 constexpr int K_BYTES = KT * KPITCH;        // 12800
 constexpr int V_BYTES = 64 * VPITCH;        // 13312
 constexpr int IMG = 26624;                  // K image + V^T image, rounded up to 26 x 1 KB (one LDS-DMA wave instruction each)
+constexpr int O_TILE_SCALES = K_BYTES + V_BYTES;  // f16x3: floats 2^-eK, 2^-eV of the tile (in the round-up's slack)
+static_assert(O_TILE_SCALES + 8 <= IMG, "tile scales must fit the image");
 constexpr int PX6[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first: plane of the first operand ...
 constexpr int PY6[6] = {0, 1, 2, 0, 1, 0};  // ... and of the second
 
@@ -77,6 +93,40 @@ __device__ __forceinline__ f32x16 mma6(const u32x4* a, const u32x4* b, f32x16 ac
   for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a[PX6[t]]), op(b[PY6[t]]), acc, 0, 0, 0);
   return acc;
 }
+// f16x3: an activation operand is a half pair (hi, lo = 2^11 residual); products least significant first: lo W0s, hi Wl, hi W0
+struct Op2 {
+  u32x4 hi, lo;
+};
+__device__ __forceinline__ Op2 split8h(const f32x4 a, const f32x4 b) {
+  const float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  Op2 o;
+  p16::split8(y, o.hi, o.lo);
+  return o;
+}
+__device__ __forceinline__ f16x8 oph(const u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+__device__ __forceinline__ f32x16 mma3(const u32x4* w, const Op2& x, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oph(w[2]), oph(x.lo), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oph(w[1]), oph(x.hi), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oph(w[0]), oph(x.hi), acc, 0, 0, 0);
+  return acc;
+}
+// three half planes W0 | W - W0 | 2^-11 W0 of two adjacent scaled values -> one dword per plane
+__device__ __forceinline__ void split3h(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 w0 = {(_Float16)x0, (_Float16)x1};
+  const h2 wl = {(_Float16)(x0 - (float)w0[0]), (_Float16)(x1 - (float)w0[1])};
+  const h2 ws = {(_Float16)((float)w0[0] * (1.f / p16::LSCALE)), (_Float16)((float)w0[1] * (1.f / p16::LSCALE))};
+  p0 = __builtin_bit_cast(uint32_t, w0);
+  p1 = __builtin_bit_cast(uint32_t, wl);
+  p2 = __builtin_bit_cast(uint32_t, ws);
+}
+// power of two that brings mx into [2^14, 2^15) (1 for zero / non-finite input)
+__device__ __forceinline__ float pow2_scale(float mx) {
+  int e = 0;
+  if (mx >= 1e-30f && mx <= 3e38f) e = 14 - (int)((__float_as_uint(mx) >> 23) - 127);
+  return ldexpf(1.f, e);
+}
+
 __device__ __forceinline__ int slot_to_index(int pos) {  // position 16 s + 8 h + j -> 16 s + 4 h + (j & 3) + 8 (j >> 2)
   const int s = pos >> 4, hh = (pos >> 3) & 1, j = pos & 7;
   return 16 * s + 4 * hh + (j & 3) + 8 * (j >> 2);
@@ -87,6 +137,7 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
 }
 
 // One workgroup per (key tile, head, batch): the tile's K rows and V^T rows, split, in LDS-image order.
+template <bool F16>
 __global__ __launch_bounds__(256) void sr_attention_pack_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                                 unsigned char* __restrict__ img, int Nk, int ldkv, int ntiles) {
   const int kt = blockIdx.x, head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
@@ -94,25 +145,63 @@ __global__ __launch_bounds__(256) void sr_attention_pack_kernel(const float* __r
   const float* kb = k + (long long)b * Nk * ldkv + head * 64;
   const float* vb = v + (long long)b * Nk * ldkv + head * 64;
   unsigned char* dst = img + (((long long)b * heads + head) * ntiles + kt) * IMG;
-  for (int u = tid; u < KT * 32; u += 256) {  // K: row = key, positions pp, pp + 1 = adjacent head dimensions
+  // every thread's share stays in registers between the range pass and the split (KT * 32 / 256 = 4 K pairs, 4 V pairs)
+  f32x2 kv2[4], vv2[4];
+  float mk = 0.f, mv = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // K: row = key, positions pp, pp + 1 = adjacent head dimensions
+    const int u = tid + 256 * i;
     const int row = u >> 5, pp = 2 * (u & 31);
     const int key = kt * KT + row, d = slot_to_index(pp);
-    f32x2 val = {0.f, 0.f};
-    if (key < Nk) val = *reinterpret_cast<const f32x2*>(kb + (long long)key * ldkv + d);
+    kv2[i] = f32x2{0.f, 0.f};
+    if (key < Nk) kv2[i] = *reinterpret_cast<const f32x2*>(kb + (long long)key * ldkv + d);
+    mk = fmaxf(mk, fmaxf(fabsf(kv2[i][0]), fabsf(kv2[i][1])));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // V^T: row = head dimension, positions pp, pp + 1 = adjacent keys
+    const int u = tid + 256 * i;
+    const int d = u & 63, pp = 2 * (u >> 6);
+    const int key = kt * KT + slot_to_index(pp);
+    vv2[i][0] = key < Nk ? vb[(long long)key * ldkv + d] : 0.f;
+    vv2[i][1] = key + 1 < Nk ? vb[(long long)(key + 1) * ldkv + d] : 0.f;
+    mv = fmaxf(mv, fmaxf(fabsf(vv2[i][0]), fabsf(vv2[i][1])));
+  }
+  float sk = 1.f, sv = 1.f;
+  if constexpr (F16) {  // tile-wide power-of-two scales (a NaN in the tile: fmaxf drops it, the values themselves carry it on)
+    __shared__ float red[2][4];
+    mk = p16::wave_max(mk);
+    mv = p16::wave_max(mv);
+    if ((tid & 63) == 0) {
+      red[0][tid >> 6] = mk;
+      red[1][tid >> 6] = mv;
+    }
+    __syncthreads();
+    sk = pow2_scale(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
+    sv = pow2_scale(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+    if (tid == 0) {
+      reinterpret_cast<float*>(dst + O_TILE_SCALES)[0] = 1.f / sk;  // exact: powers of two
+      reinterpret_cast<float*>(dst + O_TILE_SCALES)[1] = 1.f / sv;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = tid + 256 * i;
+    const int row = u >> 5, pp = 2 * (u & 31);
     uint32_t a, bb, c;
-    split3(val[0], val[1], a, bb, c);
+    if constexpr (F16) split3h(kv2[i][0] * sk, kv2[i][1] * sk, a, bb, c);
+    else split3(kv2[i][0], kv2[i][1], a, bb, c);
     unsigned char* o = dst + row * KPITCH + pp * 2;
     *reinterpret_cast<uint32_t*>(o) = a;
     *reinterpret_cast<uint32_t*>(o + 128) = bb;
     *reinterpret_cast<uint32_t*>(o + 256) = c;
   }
-  for (int u = tid; u < 64 * 16; u += 256) {  // V^T: row = head dimension, positions pp, pp + 1 = adjacent keys
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = tid + 256 * i;
     const int d = u & 63, pp = 2 * (u >> 6);
-    const int key = kt * KT + slot_to_index(pp);
-    const float v0 = key < Nk ? vb[(long long)key * ldkv + d] : 0.f;
-    const float v1 = key + 1 < Nk ? vb[(long long)(key + 1) * ldkv + d] : 0.f;
     uint32_t a, bb, c;
-    split3(v0, v1, a, bb, c);
+    if constexpr (F16) split3h(vv2[i][0] * sv, vv2[i][1] * sv, a, bb, c);
+    else split3(vv2[i][0], vv2[i][1], a, bb, c);
     unsigned char* o = dst + K_BYTES + d * VPITCH + pp * 2;
     *reinterpret_cast<uint32_t*>(o) = a;
     *reinterpret_cast<uint32_t*>(o + 64) = bb;
@@ -121,9 +210,10 @@ __global__ __launch_bounds__(256) void sr_attention_pack_kernel(const float* __r
 }
 
 // Workgroup = 4 waves = 128 queries of one (batch, head); key tiles double-buffered in LDS (one barrier per tile).
+template <bool F16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sr_attention_split_kernel(const float* __restrict__ q, const unsigned char* __restrict__ img,
                                                                  float* __restrict__ out, int N, int Nk, int ldq, int ldo,
-                                                                 float scale, int ntiles) {
+                                                                 float scale, int ntiles, uint32_t* amax, int amax_images) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][IMG]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -140,7 +230,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   };
   stage(0, 0);
 
-  Op3 qp[4];  // the query row, split: K-step s = head dimensions 16 s + {4h .. 4h+3, 8 + 4h .. 8 + 4h+3}
+  // the query row, split: K-step s = head dimensions 16 s + {4h .. 4h+3, 8 + 4h .. 8 + 4h+3}
+  Op3 qp[F16 ? 1 : 4];
+  Op2 qh[F16 ? 4 : 1];
+  uint32_t amx = 0u;
   {
     const float* qrow = q + ((long long)b * N + (q_ok ? qi : 0)) * ldq + head * 64 + 4 * h;
 #pragma unroll
@@ -152,7 +245,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
       // softmax_e(scale q.k) = softmax_2((scale log2(e) q).k): one multiply per query element here, a bare v_exp_f32 per
       // score in the key loop
-      qp[s] = split8(lo * (scale * 1.44269504088896340736f), hi * (scale * 1.44269504088896340736f));
+      if constexpr (F16) {
+        qh[s] = split8h(lo * (scale * 1.44269504088896340736f), hi * (scale * 1.44269504088896340736f));
+        amx = p16::absmax_pk4(amx, qh[s].hi);
+      } else {
+        qp[s] = split8(lo * (scale * 1.44269504088896340736f), hi * (scale * 1.44269504088896340736f));
+      }
     }
   }
 
@@ -162,6 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  float vunit = 1.f;  // f16x3: the running output sums are in units of 2^-eV of the last tile taken (o_true = o * vunit)
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -170,6 +269,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (kt + 1 < ntiles) stage(kt + 1, cur ^ 1);  // buffer cur^1 was last read in iteration kt-1, before its closing barrier
     const unsigned char* Kt = smem + cur * IMG;
     const unsigned char* Vt = Kt + K_BYTES;
+    float kinv = 1.f, vinv = 1.f;
+    if constexpr (F16) {  // the tile's 2^-eK, 2^-eV (every lane reads the same two words)
+      kinv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(Kt + O_TILE_SCALES)));
+      vinv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(Kt + O_TILE_SCALES + 4)));
+    }
 
     // ---- S^T = K (scale log2(e) Q)^T: scores in the base-2 exponent domain -----------------------
     f32x16 s;
@@ -180,7 +284,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       u32x4 kf[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) kf[k] = *reinterpret_cast<const u32x4*>(Kt + r * KPITCH + k * 128 + (16 * st + 8 * h) * 2);
-      s = mma6(kf, qp[st].p, s);
+      if constexpr (F16) s = mma3(kf, qh[st], s);
+      else s = mma6(kf, qp[st].p, s);
     }
     // ---- per-lane online softmax over this lane's 16 keys (+ partner half) -----------------
     if ((kt + 1) * KT > Nk) {  // last, partial tile: keys past the end get no weight
@@ -194,35 +299,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if constexpr (F16) mx *= kinv;  // (kinv > 0: the maximum commutes with the tile's scale)
     const float m_new = fmaxf(m_run, mx);  // finite: every tile holds at least one valid key
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      s[e] = __builtin_amdgcn_exp2f(s[e] - m_new);
+      s[e] = F16 ? __builtin_amdgcn_exp2f(fmaf(s[e], kinv, -m_new)) : __builtin_amdgcn_exp2f(s[e] - m_new);
       psum += s[e];
     }
-    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {  // some lane's maximum moved: rescale the running sums
+    const bool unit_moved = F16 && vinv != vunit;  // (uniform)
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0 || unit_moved) {  // some lane's maximum (or the unit) moved: rescale the running sums
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
+      const float beta = F16 ? alpha * (vunit / vinv) : alpha;  // (a ratio of two powers of two: exact)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+        for (int e = 0; e < 16; ++e) o[dt][e] *= beta;
+      vunit = vinv;
     }
     l_run += psum;
     m_run = m_new;
     // ---- O^T += V^T P^T: registers 8 sp .. 8 sp + 7 of s are the K-slots (keys) of step sp ------------
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
-      const Op3 pk = split8(f32x4{s[8 * sp], s[8 * sp + 1], s[8 * sp + 2], s[8 * sp + 3]},
-                            f32x4{s[8 * sp + 4], s[8 * sp + 5], s[8 * sp + 6], s[8 * sp + 7]});
+      const f32x4 pa = {s[8 * sp], s[8 * sp + 1], s[8 * sp + 2], s[8 * sp + 3]};
+      const f32x4 pb = {s[8 * sp + 4], s[8 * sp + 5], s[8 * sp + 6], s[8 * sp + 7]};
+      Op3 pk;
+      Op2 ph;
+      if constexpr (F16) ph = split8h(pa, pb);
+      else pk = split8(pa, pb);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         u32x4 vf[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           vf[k] = *reinterpret_cast<const u32x4*>(Vt + (dt * 32 + r) * VPITCH + k * 64 + (16 * sp + 8 * h) * 2);
-        o[dt] = mma6(vf, pk.p, o[dt]);
+        if constexpr (F16) o[dt] = mma3(vf, ph, o[dt]);
+        else o[dt] = mma6(vf, pk.p, o[dt]);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt + 1 has landed
@@ -230,7 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
+  const float inv = vunit / l_tot;
   if (q_ok) {
     float* orow = out + ((long long)b * N + qi) * ldo + head * 64;
 #pragma unroll
@@ -241,6 +355,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) = w;
       }
   }
+  if constexpr (F16) {
+    if (amax) p16::fold_pat(amax, amax_images > 1 ? b : 0, amax_images > 1 ? b : 0, q_ok ? amx : 0u);
+  }
 }
 
 }  // namespace
@@ -250,25 +367,45 @@ extern "C" int64_t segmif_sr_attention_split_workspace(int B, int heads, int Nk)
   return (int64_t)B * heads * ((Nk + KT - 1) / KT) * IMG;
 }
 
-extern "C" int segmif_sr_attention_split_f32(const float* q, const float* k, const float* v, float* out, void* workspace, int B,
-                                             int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo, float scale,
-                                             void* stream) {
+static int sr_attention_split_impl(bool f16, const float* q, const float* k, const float* v, float* out, void* workspace, int B,
+                                   int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo, float scale, uint32_t* amax,
+                                   int amax_images, void* stream) {
   if (!q || !k || !v || !out || !workspace || B <= 0 || heads <= 0 || N <= 0 || Nk <= 0 || hd != 64) return SEGMIF_EINVAL;
   if ((ldq | ldo) & 3 || (ldkv & 1)) return SEGMIF_EINVAL;
   if (((uintptr_t)q | (uintptr_t)out | (uintptr_t)workspace) & 15) return SEGMIF_EINVAL;
   if (((uintptr_t)k | (uintptr_t)v) & 7) return SEGMIF_EINVAL;
+  if (amax && amax_images != 1 && amax_images != B) return SEGMIF_EINVAL;
   const int ntiles = (Nk + KT - 1) / KT;
   hipStream_t s = (hipStream_t)stream;
   static segmif::PerDeviceFlag raised_flag;
   bool& raised = raised_flag.here();
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)sr_attention_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
+    hipError_t e = hipFuncSetAttribute((const void*)sr_attention_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sr_attention_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
-  hipLaunchKernelGGL(sr_attention_pack_kernel, dim3((unsigned)ntiles, (unsigned)heads, (unsigned)B), dim3(256), 0, s, k, v,
-                     (unsigned char*)workspace, Nk, ldkv, ntiles);
-  hipLaunchKernelGGL(sr_attention_split_kernel, dim3((unsigned)((N + 127) / 128), (unsigned)heads, (unsigned)B), dim3(256),
-                     2 * IMG, s, q, (const unsigned char*)workspace, out, N, Nk, ldq, ldo, scale, ntiles);
+  const dim3 pgrid((unsigned)ntiles, (unsigned)heads, (unsigned)B), grid((unsigned)((N + 127) / 128), (unsigned)heads, (unsigned)B);
+  if (f16) {
+    hipLaunchKernelGGL(sr_attention_pack_kernel<true>, pgrid, dim3(256), 0, s, k, v, (unsigned char*)workspace, Nk, ldkv, ntiles);
+    hipLaunchKernelGGL(sr_attention_split_kernel<true>, grid, dim3(256), 2 * IMG, s, q, (const unsigned char*)workspace, out, N, Nk,
+                       ldq, ldo, scale, ntiles, amax, amax_images);
+  } else {
+    hipLaunchKernelGGL(sr_attention_pack_kernel<false>, pgrid, dim3(256), 0, s, k, v, (unsigned char*)workspace, Nk, ldkv, ntiles);
+    hipLaunchKernelGGL(sr_attention_split_kernel<false>, grid, dim3(256), 2 * IMG, s, q, (const unsigned char*)workspace, out, N, Nk,
+                       ldq, ldo, scale, ntiles, (uint32_t*)nullptr, 1);
+  }
   return (int)hipGetLastError();
+}
+
+extern "C" int segmif_sr_attention_split_f32(const float* q, const float* k, const float* v, float* out, void* workspace, int B,
+                                             int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo, float scale,
+                                             void* stream) {
+  return sr_attention_split_impl(false, q, k, v, out, workspace, B, heads, N, Nk, hd, ldq, ldkv, ldo, scale, nullptr, 1, stream);
+}
+
+extern "C" int segmif_sr_attention_split16_f32(const float* q, const float* k, const float* v, float* out, void* workspace, int B,
+                                               int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo, float scale,
+                                               uint32_t* amax, int amax_images, void* stream) {
+  return sr_attention_split_impl(true, q, k, v, out, workspace, B, heads, N, Nk, hd, ldq, ldkv, ldo, scale, amax, amax_images, stream);
 }

@@ -250,7 +250,7 @@ def range_stats():
 
 
 def f16x3_enabled():
-    return _conv3x3_mode == "planes16" or _linear_mode == "f16x3"
+    return _conv3x3_mode == "planes16" or _linear_mode == "f16x3" or _attention_mode == "f16x3"
 
 
 def run_guarded(fn, device, enabled=None, images=1, redo=None):
@@ -960,8 +960,8 @@ def upsum_act(base, srcs, OH, OW, bias=None, act=ACT_NONE, out=None):
     return out
 
 
-_ATTENTION_MODES = ("bf16x6", "fp32")
-_attention_mode = os.environ.get("SEGMIF_ATTENTION", "bf16x6")
+_ATTENTION_MODES = ("f16x3", "bf16x6", "fp32")
+_attention_mode = os.environ.get("SEGMIF_ATTENTION", "f16x3")
 if _attention_mode not in _ATTENTION_MODES:
     raise RuntimeError(f"SEGMIF_ATTENTION must be one of {_ATTENTION_MODES}, got {_attention_mode!r}")
 
@@ -971,8 +971,9 @@ def attention_mode():
 
 
 def set_attention_mode(mode):
-    """'bf16x6': csrc/attention_split.hip (head_dim 64; bf16 MFMA, six split products, fp32-class); 'fp32':
-    csrc/attention.hip (fp32 MFMA) everywhere.  head_dim 32 always runs the fp32 kernel."""
+    """'f16x3' (default): csrc/attention_split.hip on half pairs with three f16 MFMA products per MAC inside a guarded scope
+    (run_guarded), on bf16 triples / six products outside one; 'bf16x6': always bf16 triples (head_dim 64, fp32-class either
+    way); 'fp32': csrc/attention.hip (fp32 MFMA) everywhere.  head_dim 32 always runs the fp32 kernel."""
     global _attention_mode
     if mode not in _ATTENTION_MODES:
         raise ValueError(f"mode must be one of {_ATTENTION_MODES}")
@@ -991,8 +992,15 @@ def sr_attention(q, kv, heads, scale):
     out = torch.empty_like(q)
     kptr = kv.data_ptr()
     lib = _lib.load()
-    if hd == 64 and _attention_mode == "bf16x6" and N >= 1024:  # below that the K/V pack launch outweighs the matrix-pipe gain
+    if hd == 64 and _attention_mode != "fp32" and N >= 1024:  # below that the K/V pack launch outweighs the matrix-pipe gain
         ws = torch.empty((lib.segmif_sr_attention_split_workspace(B, heads, Nk),), device=q.device, dtype=torch.uint8)
+        guard = _scope.guard
+        if _attention_mode == "f16x3" and guard is not None:
+            amax, nimg = guard.slot(B)
+            _lib.check(lib.segmif_sr_attention_split16_f32(q.data_ptr(), kptr, kptr + 4 * C, out.data_ptr(), ws.data_ptr(), B, heads,
+                                                           N, Nk, hd, C, 2 * C, C, float(scale), amax, nimg, _stream()),
+                       "segmif_sr_attention_split16_f32")
+            return out
         _lib.check(lib.segmif_sr_attention_split_f32(q.data_ptr(), kptr, kptr + 4 * C, out.data_ptr(), ws.data_ptr(), B, heads, N,
                                                      Nk, hd, C, 2 * C, C, float(scale), _stream()),
                    "segmif_sr_attention_split_f32")

@@ -486,10 +486,10 @@ def test_bilinear(ops, B, IH, IW, OH, OW, C):
 @pytest.mark.parametrize("B,heads,N,Nk,hd", [(2, 2, 96, 6, 64), (1, 1, 19200, 300, 64), (2, 5, 1200, 300, 64),
                                              (1, 8, 300, 300, 64), (1, 2, 1024, 64, 32), (1, 1, 130, 1, 64),
                                              (1, 1, 4096, 1024, 64), (1, 5, 35, 35, 32)])
-@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "fp32"])
 def test_sr_attention(ops, B, heads, N, Nk, hd, mode):
-    """csrc/attention_split.hip (head_dim 64, bf16 MFMA x 6 split products) and csrc/attention.hip (fp32 MFMA) against
-    fp64 softmax attention; head_dim 32 runs the fp32 kernel in either mode."""
+    """csrc/attention_split.hip (head_dim 64: f16 MFMA x 3 split products inside a guarded scope, bf16 MFMA x 6 outside) and
+    csrc/attention.hip (fp32 MFMA) against fp64 softmax attention; head_dim 32 runs the fp32 kernel in every mode."""
     C = heads * hd
     q, kv = rnd(B, N, C, seed=26, lo=-2, hi=2), rnd(B, Nk, 2 * C, seed=27, lo=-2, hi=2)
     scale = hd ** -0.5
@@ -499,27 +499,50 @@ def test_sr_attention(ops, B, heads, N, Nk, hd, mode):
     ref = (torch.softmax(qh @ k.transpose(-2, -1) * scale, -1) @ v).transpose(1, 2).reshape(B, N, C)
     prev = ops.attention_mode()
     ops.set_attention_mode(mode)
+    guard = ops.Planes16Guard("cuda", B) if mode == "f16x3" else None
+    pg = ops.install_guard(guard)
     try:
         y = ops.sr_attention(q.cuda(), kv.cuda(), heads, scale)
+        y32 = y
+        if mode == "f16x3":
+            ops.install_guard(None)
+            ops.set_attention_mode("fp32")
+            y32 = ops.sr_attention(q.cuda(), kv.cuda(), heads, scale)
     finally:
+        ops.install_guard(pg)
         ops.set_attention_mode(prev)
     assert err(y, ref) < TOL
+    if mode == "f16x3" and hd == 64 and N >= 1024:
+        assert err(y, ref) <= 3.0 * err(y32, ref) + 1e-7, (err(y, ref), err(y32, ref))
+        m = guard.maxima()
+        want = (q.abs().amax(dim=(1, 2)) * (scale * 1.4426950408889634)).half().float()
+        assert m.shape == (1, B) and guard.ok() and all(abs(float(m[0, i]) - float(want[i])) <= 2.0 ** -10 * float(want[i]) for i in range(B))
 
 
-@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "fp32"])
 def test_sr_attention_large_logits(ops, mode):
-    """Online-softmax rescale path: one key dominates late in the sequence."""
-    B, heads, N, Nk, hd = 1, 1, 64, 100, 64
+    """Online-softmax rescale path: one key dominates late in the sequence; f16x3: also a value tile 1000x larger than the
+    others (the running sums change their power-of-two unit between tiles) and operands spanning 1e-3 .. 1e2."""
+    B, heads, N, Nk, hd = 1, 1, (2048 if mode == "f16x3" else 64), 100, 64
     q, kv = rnd(B, N, hd, seed=28), rnd(B, Nk, 2 * hd, seed=29)
     kv[:, 77, :hd] = 40.0 * q[0, 5]  # spike: row 5's max jumps at tile 2
+    if mode == "f16x3":
+        kv[:, 32:64, hd:] *= 1000.0
+        kv[:, :32, :hd] *= 1.0e-3
+        kv[:, 64:, hd:] *= 10.0 ** rnd(1, 36, 1, seed=30, lo=-3, hi=2)
     ref = torch.softmax(q.double() @ kv[..., :hd].double().transpose(-2, -1) * 0.125, -1) @ kv[..., hd:].double()
     prev = ops.attention_mode()
     ops.set_attention_mode(mode)
+    pg = ops.install_guard(ops.Planes16Guard("cuda", B) if mode == "f16x3" else None)
     try:
         y = ops.sr_attention(q.cuda(), kv.cuda(), heads, 0.125)
+        ops.install_guard(None)
+        ops.set_attention_mode("fp32")
+        y32 = ops.sr_attention(q.cuda(), kv.cuda(), heads, 0.125)
     finally:
+        ops.install_guard(pg)
         ops.set_attention_mode(prev)
-    assert err(y, ref) < TOL
+    assert err(y, ref) < TOL and err(y, ref) <= 3.0 * err(y32, ref) + 1e-7, (err(y, ref), err(y32, ref))
 
 
 @pytest.mark.parametrize("B,N", [(2, 3000), (1, 1024), (3, 37), (1, 70000)])
