@@ -385,6 +385,9 @@ typedef struct SegmifCrossTail {
   int32_t planes_f16;                               /* != 0: an f16x3 buffer (segmif_planes16_*) */
   uint32_t* planes_amax;                            /* f16x3: range slot(s) for max |out|, or NULL */
   int32_t planes_amax_images;                       /* == B: planes_amax[image]; <= 1: planes_amax[0] */
+  /* arith_f16 != 0: the kernel's own contractions on f16x3 operands (half pairs x three products; default: bf16 triples x six);
+   * arith_amax (or NULL) then receives max |x_3|, |x_i| of the pixels it split, indexed like planes_amax */
+  int32_t arith_f16; uint32_t* arith_amax; int32_t arith_amax_images;
 } SegmifCrossTail;
 
 int segmif_crosspath_gram_blocks(int64_t N);

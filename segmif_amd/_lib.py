@@ -58,6 +58,7 @@ class SegmifCrossTail(ctypes.Structure):
         ("B", c_int32), ("N", c_int64),
         ("planes_out", c_void_p), ("H", c_int32), ("W", c_int32), ("planes_chunks", c_int32),
         ("planes_f16", c_int32), ("planes_amax", c_void_p), ("planes_amax_images", c_int32),
+        ("arith_f16", c_int32), ("arith_amax", c_void_p), ("arith_amax_images", c_int32),
     ]
 
 

@@ -82,5 +82,20 @@ __device__ __forceinline__ void fold_pat(uint32_t* slots, int b_lo, int b_hi, ui
   }
 }
 
+// The same bookkeeping on fp32 values a kernel is ABOUT to split (when touching the split halves again would cost registers):
+// running maximum of |x| as an IEEE bit pattern - an integer maximum, so a NaN (any sign) is kept, not dropped.
+__device__ __forceinline__ uint32_t absmax_bits(uint32_t m, float a, float b) {
+  const uint32_t x = __float_as_uint(a) & 0x7fffffffu, y = __float_as_uint(b) & 0x7fffffffu;
+  const uint32_t t = x > y ? x : y;
+  return m > t ? m : t;  // (v_max3_u32)
+}
+__device__ __forceinline__ void fold_bits(uint32_t* slots, int b_lo, int b_hi, uint32_t bits) {
+  bits = wave_umax(bits);
+  if ((threadIdx.x & 63) == 0 && bits) {
+    for (int b = b_lo; b <= b_hi; ++b)
+      if (bits > __atomic_load_n(slots + b, __ATOMIC_RELAXED)) atomicMax(slots + b, bits);
+  }
+}
+
 }  // namespace p16
 }  // namespace segmif

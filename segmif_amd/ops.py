@@ -100,6 +100,21 @@ def crosspath_mode():
     return _crosspath_mode
 
 
+_CROSSPATH_ARITH = os.environ.get("SEGMIF_CROSSPATH_ARITH", "f16x3")  # "bf16x6": the Gram-path kernels' own contractions always on bf16 triples (A/B switch)
+if _CROSSPATH_ARITH not in ("f16x3", "bf16x6"):
+    raise RuntimeError(f"SEGMIF_CROSSPATH_ARITH must be 'f16x3' or 'bf16x6', got {_CROSSPATH_ARITH!r}")
+
+
+def set_crosspath_arith(mode):
+    """'f16x3' (default): inside a guarded scope crosspath_tail runs its contractions on half pairs x three products;
+    'bf16x6': bf16 triples x six everywhere."""
+    global _CROSSPATH_ARITH
+    if mode not in ("f16x3", "bf16x6"):
+        raise ValueError("mode must be 'f16x3' or 'bf16x6'")
+    prev, _CROSSPATH_ARITH = _CROSSPATH_ARITH, mode
+    return prev
+
+
 def set_crosspath_mode(mode):
     """'gram' (default): CrossPath in inference on the Gram-matrix kernels of csrc/crosspath.hip; 'gemm': round 1's
     channel_proj GEMMs + fused kv reductions + two-source end_proj GEMM."""
@@ -250,7 +265,7 @@ def range_stats():
 
 
 def f16x3_enabled():
-    return _conv3x3_mode == "planes16" or _linear_mode == "f16x3" or _attention_mode == "f16x3"
+    return _conv3x3_mode == "planes16" or _linear_mode == "f16x3" or _attention_mode == "f16x3" or _CROSSPATH_ARITH == "f16x3"
 
 
 def run_guarded(fn, device, enabled=None, images=1, redo=None):
@@ -1119,6 +1134,9 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
         if planes.f16:
             d.planes_f16 = 1
             d.planes_amax, d.planes_amax_images = planes.guard.slot(B)
+    if _CROSSPATH_ARITH == "f16x3" and _scope.guard is not None:  # the kernel's own contractions on f16x3 operands
+        d.arith_f16 = 1
+        d.arith_amax, d.arith_amax_images = _scope.guard.slot(B)
     _side("cp_tail", lambda: _lib.check(_lib.load().segmif_crosspath_tail_f32(ctypes.byref(d), _stream()),
                                         "segmif_crosspath_tail_f32"),
           ((512.0 if planes_only else 768.0) + (0.0 if planes is None else 256.0 if planes.f16 else 384.0)) * B * N)  # + the planes copy: 4 | 6 B per element

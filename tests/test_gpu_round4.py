@@ -454,3 +454,57 @@ def test_mixffn_fused_inside_the_encoder(ops, nets):
     observed("r4_mixffn_pair_fused_vs_chain", {"max_abs_diff_fused_image": d, "labels_differ": int((l1 != l0).sum())})
     assert not torch.equal(f1, f0) and d < 1e-4
     assert int((l1 != l0).sum()) <= 0.001 * l0.numel()
+
+
+def test_crosspath_tail_on_f16x3_arithmetic(ops):
+    """crosspath_tail_kernel<., A16>: inside a guarded scope the tail's own contractions (two channel_proj halves, the folded
+    end_proj) run on half pairs x three f16 products, the three weight matrices staged as power-of-two-scaled half planes -
+    against fp64, beside the bf16x6 arithmetic of the same kernel (yardstick), operands spanning 1e-3 .. 1e1 and weight rows
+    of very different magnitude, a ragged token count, per-image range slots for the pixels it split."""
+    import torch.nn.functional as F
+    B, H, W = 3, 13, 37
+    N = H * W
+    x3 = (rnd(B, N, 64, seed=71) * 10.0 ** rnd(B, N, 1, seed=1, lo=-3, hi=1)).cuda()
+    xi = (rnd(B, N, 224, seed=72) * 10.0 ** rnd(B, N, 1, seed=2, lo=-3, hi=1)).cuda()[..., :64]
+    w3, b3 = rnd(64, 64, seed=73) * 0.3 * 10.0 ** rnd(64, 1, seed=3, lo=-2, hi=0.5), rnd(64, seed=74) * 0.1
+    wi, bi = rnd(64, 64, seed=75) * 0.3 * 10.0 ** rnd(64, 1, seed=4, lo=-2, hi=0.5), rnd(64, seed=76) * 0.1
+    weff, bend = rnd(B, 64, 128, seed=77) * 0.2 * 10.0 ** rnd(B, 64, 1, seed=5, lo=-2, hi=0.5), rnd(64, seed=78) * 0.1
+    gm, bt = rnd(64, seed=79, lo=0.5, hi=1.5), rnd(64, seed=80)
+    t = torch.cat((F.relu(x3.cpu().double() @ w3.double().t() + b3.double()),
+                   F.relu(xi.cpu().double() @ wi.double().t() + bi.double())), dim=-1)
+    pre = xi.cpu().double() + torch.einsum("bnk,bok->bno", t, weff.double()) + bend.double()
+    ref = F.layer_norm(pre, (64,), gm.double(), bt.double(), 1e-5)
+    args = (x3, xi, w3.cuda(), b3.cuda(), wi.cuda(), bi.cuda(), weff.cuda(), bend.cuda(), (gm.cuda(), bt.cuda(), 1e-5))
+
+    def err(t_):
+        return float((t_.double().cpu() - ref).abs().max() / ref.abs().max())
+
+    out6 = ops.crosspath_tail(*args)                     # no guard: bf16 triples
+    guard = ops.Planes16Guard("cuda", B)
+    prev = ops.install_guard(guard)
+    try:
+        pl = ops.Planes(B, H, W, 6, "cuda", guard)
+        pl.data.zero_()
+        out16 = ops.crosspath_tail(*args, planes=pl, hw=(H, W))
+        old = ops.set_crosspath_arith("bf16x6")
+        try:
+            pl6 = ops.Planes(B, H, W, 6, "cuda", guard)
+            pl6.data.zero_()
+            out6g = ops.crosspath_tail(*args, planes=pl6, hw=(H, W))
+        finally:
+            ops.set_crosspath_arith(old)
+    finally:
+        ops.install_guard(prev)
+    assert torch.equal(out6g, out6) and not torch.equal(out16, out6)
+    e16, e6 = err(out16), err(out6)
+    observed("r4_crosspath_tail_arith", {"f16x3": e16, "bf16x6": e6})
+    assert e16 < TOL and e16 <= 3.0 * e6 + 2e-7, (e16, e6)
+    m = guard.maxima()  # rows: planes copy (f16x3 run), its arithmetic, planes copy (bf16x6-arithmetic run)
+    assert m.shape == (3, B) and guard.ok()
+    want = torch.maximum(x3.abs().amax(dim=(1, 2)), xi.abs().amax(dim=(1, 2))).cpu()
+    assert all(float(m[1, i]) == float(want[i]) for i in range(B))
+    # the planes copy of the f16x3 run is the split of ITS fp32 output
+    ref_pl = ops.Planes(B, H, W, 6, "cuda", ops.Planes16Guard("cuda"))
+    ref_pl.data.zero_()
+    ref_pl.load_f32(out16.view(B, H, W, 64), chunk0=0)
+    assert torch.equal(pl.data, ref_pl.data)
