@@ -340,7 +340,7 @@ def main():
         timer, side = None, {}
         if not args.no_kernel_timer:
             timer = ops.LaunchTimer("drdb_dcov")
-            side = {t: ops.LaunchTimer(t) for t in ("dwconv", "cp_gram", "cp_tail", "bilinear")}
+            side = {t: ops.LaunchTimer(t) for t in ("dwconv", "cp_gram", "cp_tail", "bilinear", "mixffn")}
             ops.set_launch_timer(timer, side)
         fence()
         t0 = time.perf_counter()
@@ -416,15 +416,16 @@ def main():
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if all_fp32 else (
-                "f32 (large contractions on split operands, fp32-class: the fusion net's 3x3 convs and the encoder's tall GEMMs as "
-                "half pairs x 3 f16 MFMA products under a range guard, the rest as bf16 triples x 6 products; see arithmetic_modes)"
+                "f32 (large contractions on split operands, fp32-class: the fusion net's 3x3 convs, the encoder's tall GEMMs, fused Mix-FFN "
+                "and attention and the CrossPath tail as half pairs x 3 f16 MFMA products under a per-pair range guard, the rest as bf16 "
+                "triples x 6 products; see arithmetic_modes)"
                 if ops.conv3x3_mode() == "planes16" else
                 "f32 (large contractions: fp32-equivalent 3-way bf16 split, 6 MFMA products; see arithmetic_modes)"),
             "f16x3_range_fallbacks": ops.range_fallbacks(),
             "f16x3_trip_rate": trip["trip_rate"], "f16x3_guard": trip,
             "conv3x3_mode": ops.conv3x3_mode(),
             "arithmetic_modes": {"conv3x3": ops.conv3x3_mode(), "linear": ops.linear_mode(), "crosspath": ops.crosspath_mode(),
-                                 "attention": ops.attention_mode()},
+                                 "attention": ops.attention_mode(), "mixffn": ops.mixffn_mode()},
             "data": "synthetic",
             "config": {"workload": f"{args.backbone} pair forward (forward_fusion + Fusion_Network3_ac + Network3 "
                                    f"+ x4 bilinear + argmax), {H}x{W}, {B} pairs per GPU per step, eval mode, "
@@ -452,7 +453,7 @@ def main():
             traffic, traffic_src = None, None
             mode = ops.conv3x3_mode()
             peak = PEAK_FP32_MFMA_TFLOPS if mode == "fp32" else (PEAK_BF16X6_TFLOPS * 2.0 if mode == "planes16" else PEAK_BF16X6_TFLOPS)
-            pmc_name = {"planes16": f"r03_pmc_dominant_b{B}_planes16.json", "planes": f"r03_pmc_dominant_b{B}_planes.json" if os.path.exists(os.path.join(ROOT, "profiles", f"r03_pmc_dominant_b{B}_planes.json")) else f"r02_pmc_dominant_b{B}_planes.json", "bf16x6": f"r01_pmc_dominant_b{B}_bf16x6.json",
+            pmc_name = {"planes16": f"r04_pmc_dominant_b{B}_planes16.json" if os.path.exists(os.path.join(ROOT, "profiles", f"r04_pmc_dominant_b{B}_planes16.json")) else f"r03_pmc_dominant_b{B}_planes16.json", "planes": f"r03_pmc_dominant_b{B}_planes.json" if os.path.exists(os.path.join(ROOT, "profiles", f"r03_pmc_dominant_b{B}_planes.json")) else f"r02_pmc_dominant_b{B}_planes.json", "bf16x6": f"r01_pmc_dominant_b{B}_bf16x6.json",
                         "fp32": "r01_pmc_dominant.json" if B == 8 else f"r01_pmc_dominant_b{B}.json"}[mode]
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and (H, W) == (480, 640):
@@ -462,7 +463,7 @@ def main():
                                                                      " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.sh)")
             kernel = {"planes": "conv3x3_planes_kernel<2,false> (DRDB dilated 3x3 convs 1-4 on pre-split activations, bf16 MFMA x 6 "
                                 "split products, fp32-class; the fifth conv carries the DRDB's 1x1 tail and is a separate kernel)",
-                      "planes16": "conv3x3_planes_kernel<2,false,f16x3> (DRDB dilated 3x3 convs 1-4 on half-pair activations, f16 MFMA x 3 "
+                      "planes16": "conv3x3_planes_kernel<2,false,f16x3,SUB=4> (DRDB dilated 3x3 convs 1-4 on half-pair activations, 16 x 32 patches, f16 MFMA x 3 "
                                   "split products, fp32-class inside the half's exponent range, guarded)",
                       "bf16x6": "conv3x3_split_kernel<32,2,8> (DRDB dilated 3x3 conv, bf16 MFMA x 6 split products, fp32-class)",
                       "fp32": "conv3x3_halo_kernel<32,8,2> (DRDB dilated 3x3 conv, fp32 MFMA)"}[mode]
@@ -497,7 +498,8 @@ def main():
             # bandwidth-bound kernels: algorithmic HBM bytes per launch / HIP-event time around the launch (peak 8 TB/s,
             # ~6.3 achievable: MI355X_MICROARCH.md)
             names = {"dwconv": "dwconv3x3_gelu_kernel (Mix-FFN middle)", "cp_gram": "crosspath_gram_kernel",
-                     "cp_tail": "crosspath_tail_kernel", "bilinear": "bilinear_kernel (forward_fusion / logits resize)"}
+                     "cp_tail": "crosspath_tail_kernel", "bilinear": "bilinear_kernel (forward_fusion / logits resize)",
+                     "mixffn": "mixffn_kernel (norm2 + fc1 + dwconv + GELU + fc2 + residual of a stage-1/2 block in one launch; bytes = x in + out)"}
             hb = {}
             for tag, t in side.items():
                 n, ms, nbytes = t.summary()
