@@ -292,9 +292,10 @@ def test_grad_allreducer_over_the_hip_backward_on_rccl():
 
 @gpu
 def test_config2_full_size_train_steps_property_run():
-    """BASELINE config[2] at its real size (mit_b3, 480x640): one segmentation step at batch 8 and one fusion step at
-    batch 2 (the oracle's CPU fusion forward bounds the batch here) — the losses the steps report equal the losses of the
-    CPU oracle's forward on the same weights and inputs, every gradient is finite, parameters move."""
+    """BASELINE config[2] at its real size (mit_b3, 480x640): one segmentation step at batch 8, one fusion step at batch 2
+    (the oracle's CPU fusion forward bounds the batch of DISTINCT pairs here) and the same fusion step at batch 8 (the two
+    pairs repeated four times) — the losses the steps report equal the losses of the CPU oracle's forward on the same weights
+    and inputs, every gradient is finite, parameters move, batch 8 reproduces batch 2's losses and gradients."""
     need_gpu()
     import torch.nn.functional as F
     import detweights as dw
@@ -351,3 +352,22 @@ def test_config2_full_size_train_steps_property_run():
     assert abs(tr.history[0][1] - float(l2)) < 2e-4 * abs(float(l2)), (tr.history[0][1], float(l2))
     assert abs(float(total) - float(ref_total)) < 2e-4 * abs(float(ref_total))
     assert all(torch.isfinite(p.grad).all() for p in fus.parameters() if p.grad is not None)
+    # --- the same step at config[2]'s batch of 8 (r4): the pair batch above repeated four times.  Every loss
+    # term is a mean over samples, so losses AND gradients must equal the batch-2 step's - checked against the same CPU oracle
+    # numbers - while the kernels run the batch-8 problem sizes the bench times.
+    g2 = [p.grad.detach().clone() if p.grad is not None else None for p in fus.parameters()]
+    dw.load_det_weights(net, seed=0)
+    dw.load_det_weights(fus, seed=0)
+    opt8 = PolyWarmupAdamW([{"params": fus.parameters(), "lr": 8e-5 / iter_, "weight_decay": 0.01}], **fus_kw(iter_))
+    tr8 = FusionTrainer(net, fus, opt8, crit, iter_=iter_)
+    rep = lambda t: t.repeat(4, *([1] * (t.dim() - 1))).cuda()
+    total8 = tr8.step(rep(ir3), rep(vis3), rep(mask3), rep(labels))
+    assert abs(tr8.history[0][0] - float(l1)) < 2e-4 * abs(float(l1)), (tr8.history[0][0], float(l1))
+    assert abs(tr8.history[0][1] - float(l2)) < 2e-4 * abs(float(l2)), (tr8.history[0][1], float(l2))
+    assert abs(float(total8) - float(ref_total)) < 2e-4 * abs(float(ref_total))
+    worst = 0.0
+    for p, g in zip(fus.parameters(), g2):
+        assert (p.grad is None) == (g is None)
+        if g is not None:
+            worst = max(worst, float((p.grad - g).abs().max() / (g.abs().max() + 1e-30)))
+    assert worst < 2e-3, worst  # (fp32 reductions over 4x the pixels in another order)
