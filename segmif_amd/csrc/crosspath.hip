@@ -433,9 +433,11 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
     }
     return a;
   };
-  // one 32-pixel tile; c3 / ci hold its rows of x_3 / x_i, the next tile's are requested into n3 / ni while it is
-  // computed (two register sets used alternately: no copies on the loop edge)
-  auto tile = [&](long long t, const f32x4* c3, const f32x4* ci, f32x4* n3, f32x4* ni) {
+  // one 32-pixel tile; c3 / ci hold its rows of x_3 / x_i.  The next tile's x_i rows are requested into ni while this one is
+  // computed (two register sets used alternately: ci is live until the residual add of the epilogue); the next tile's x_3 rows go
+  // back into c3 as soon as stage 1 has split them ((r4) three 32-register sets instead of four: the fourth made hipcc spill, and
+  // every spill reload is followed by s_waitcnt vmcnt(0) - which drains the prefetch it sits beside)
+  auto tile = [&](long long t, f32x4* c3, const f32x4* ci, f32x4* ni) {
     const long long px = t * 32 + r;
     const bool ok = px < p.N;
     int zo = 0;  // opaque zero in every LDS address below (see the Gram kernel): keeps ~200 registers of loop-invariant
@@ -461,8 +463,7 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
     // two passes: source 0 = x_3 -> y_3 half (W3, columns 0..63 of Weff), source 1 = x_i -> u_i half (Wi, columns 64..127)
 #pragma unroll
     for (int src = 0; src < 2; ++src) {
-      if (src == 0) load(t + stride, x3b, p.ld3, n3);
-      else load(t + stride, xib, p.ldi, ni);
+      if (src == 1) load(t + stride, xib, p.ldi, ni);
       const f32x4* xc = src == 0 ? c3 : ci;
       // stage 1 (transposed): T[c][px] = relu(sum_k W[c][k] x[px][k] + bias[c]); lane = pixel, register v = channel
       // (v&3) + 8 (v>>2) + 4h of the 32-row tile
@@ -492,6 +493,7 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
           else tt[nt] = mma6(wf, xs.p, tt[nt]);
         }
       }
+      if (src == 0) load(t + stride, x3b, p.ld3, c3);  // (its rows have been split: the registers take the next tile's)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         if constexpr (A16) {  // row scale 2^-e(c), bias, ReLU
@@ -606,13 +608,13 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
       }
     }
   };
-  f32x4 a3[8], ai[8], b3[8], bi[8];
+  f32x4 a3[8], ai[8], bi[8];
   long long t = (long long)blockIdx.x * CP_WAVES + wave;
   load(t, x3b, p.ld3, a3);
   load(t, xib, p.ldi, ai);
   for (; t < ntiles; t += 2 * stride) {
-    tile(t, a3, ai, b3, bi);
-    if (t + stride < ntiles) tile(t + stride, b3, bi, a3, ai);
+    tile(t, a3, ai, bi);
+    if (t + stride < ntiles) tile(t + stride, a3, bi, ai);
   }
   if constexpr (F16) {
     if (p.pl_amax) p16::fold_pat(p.pl_amax, p.pl_amax_images > 1 ? b : 0, p.pl_amax_images > 1 ? b : 0, pl_amx);

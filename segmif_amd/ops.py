@@ -100,14 +100,17 @@ def crosspath_mode():
     return _crosspath_mode
 
 
-_CROSSPATH_ARITH = os.environ.get("SEGMIF_CROSSPATH_ARITH", "f16x3")  # "bf16x6": the Gram-path kernels' own contractions always on bf16 triples (A/B switch)
+# The CrossPath tail's own contractions: "bf16x6" (default) or "f16x3" inside a guarded scope.  Measured equal-to-slower
+# (profiles/r04_crosspath_tail_arith_ab.txt): the kernel moves 896 B per pixel at 4.2 TB/s of mixed read / write traffic - it is bound
+# by HBM, not by its matrix work -, and the f16x3 instantiation spills ~30 registers.  Kept as a tested option.
+_CROSSPATH_ARITH = os.environ.get("SEGMIF_CROSSPATH_ARITH", "bf16x6")
 if _CROSSPATH_ARITH not in ("f16x3", "bf16x6"):
     raise RuntimeError(f"SEGMIF_CROSSPATH_ARITH must be 'f16x3' or 'bf16x6', got {_CROSSPATH_ARITH!r}")
 
 
 def set_crosspath_arith(mode):
-    """'f16x3' (default): inside a guarded scope crosspath_tail runs its contractions on half pairs x three products;
-    'bf16x6': bf16 triples x six everywhere."""
+    """'bf16x6' (default): bf16 triples x six products everywhere; 'f16x3': inside a guarded scope crosspath_tail runs its
+    contractions on half pairs x three products (no faster: the kernel is HBM-bound)."""
     global _CROSSPATH_ARITH
     if mode not in ("f16x3", "bf16x6"):
         raise ValueError("mode must be 'f16x3' or 'bf16x6'")

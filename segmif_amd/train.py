@@ -10,7 +10,7 @@ feed train.py:369-374's dynamic weights are averaged too so every rank applies i
 """
 import torch
 
-from . import losses
+from . import losses, ops
 from .core.model_fusion import RGB2YCrCb, YCrCb2RGB
 from .parallel import allreduce_scalar_mean
 
@@ -104,7 +104,17 @@ class FusionTrainer:
         ir = ir3[:, 0:1]
         vis = RGB2YCrCb(vis3)
         with torch.no_grad():
-            out0, out1 = self.seg.denoise_net.encoder.forward_fusion(mask3)
+            # (the frozen encoder pass is plain inference: a guarded scope puts it on the f16x3 kernels - fused Mix-FFN, half-pair
+            # GEMMs and attention -, per-image range slots, tripped images repeated on bf16x6)
+            enc = self.seg.denoise_net.encoder
+
+            def redo(out, idx):
+                sub = enc.forward_fusion(mask3.index_select(0, idx))
+                out[0].index_copy_(0, idx, sub[0])
+                out[1].index_copy_(0, idx, sub[1])
+                return out
+
+            out0, out1 = ops.run_guarded(lambda: enc.forward_fusion(mask3), mask3.device, images=mask3.shape[0], redo=redo)
         fusion = self.fus(ir, vis, out0, out1)
         self.opt.zero_grad(set_to_none=True)
         if self.report_lap:
