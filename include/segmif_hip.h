@@ -142,12 +142,13 @@ int segmif_conv3x3_split_pack(const float* packed, int N, int Cin, int ldw, void
 typedef struct SegmifGemmSplit {
   const float* a; const void* w; const float* bias; const float* res; const float* prelu; float* out;
   int64_t M; int32_t N, K, lda, ldo, ldr, act;
-  /* patch mode (patch_sr > 0): the spatial-reduction conv of Attention (core/mix_transformer.py:73-75, :98-101; kernel =
-   * stride = sr) as this GEMM with no gather pass: `a` is a dense NHWC image batch (B, patch_H, patch_W, C) with lda = C,
-   * row m = (b, oy, ox) of A is the sr x sr patch at (sr oy, sr ox) in (ky, kx, c) order - K = sr * sr * C, sr * C a multiple
-   * of 32, M = B * floor(patch_H / sr) * floor(patch_W / sr) - and `w` the image of the conv weight in the same order
-   * (segmif_pack_conv_weight's [N][Kp] rows).  0 = plain rows. */
-  int32_t patch_sr, patch_H, patch_W;
+  /* patch mode (patch_k > 0): a k x k convolution with stride patch_st and zero padding patch_pad as this GEMM with no gather
+   * pass - Attention's spatial-reduction conv (core/mix_transformer.py:73-75, :98-101; k = stride = sr, pad 0) and the
+   * overlapping patch embeds of stages 2-4 (:171-172; k 3, stride 2, pad 1).  `a` is a dense NHWC image batch
+   * (B, patch_H, patch_W, C) with lda = C, C % 32 == 0; row m = (b, oy, ox) of A is the patch at (st oy - pad, st ox - pad) in
+   * (ky, kx, c) order, taps outside the image read as zeros; K = k * k * C, M = B * OH * OW with OH = (H + 2 pad - k) / st + 1;
+   * `w` is the image of the conv weight in the same order (segmif_pack_conv_weight's [N][Kp] rows).  0 = plain rows. */
+  int32_t patch_k, patch_st, patch_pad, patch_H, patch_W;
 } SegmifGemmSplit;
 int64_t segmif_gemm_split_weight_bytes(int N, int K);
 int segmif_gemm_split_pack(const float* w, int N, int K, int ldw, void* out, void* stream);

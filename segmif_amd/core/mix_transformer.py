@@ -242,8 +242,14 @@ class OverlapPatchEmbed(nn.Module):
         xh = ops.to_nhwc(x)
         C = self.proj.out_channels
         fuse = ops.conv_ln_fusable(C)  # K1: bias + LayerNorm in the conv's epilogue where a row fits a wave tile (C = 64)
-        y = ops.conv2d(xh, self._pk.get("proj", self.proj.weight, ops.pack_weight), C, k, stride=self.stride, pad=k // 2,
-                       bias=self.proj.bias, ln=(self.norm.weight, self.norm.bias, self.norm.eps) if fuse else None)
+        if not fuse and self.proj.in_channels % 32 == 0:
+            # stages 2-4 (3 x 3, stride 2, 64 / 128 / 320 input channels): (r4) the split-operand GEMM in patch mode - rows read
+            # in place from the image, border taps as zeros - instead of the exact-fp32 implicit-GEMM tiles
+            y = ops.patch_conv_auto(xh.contiguous(), self._pk.get("proj:" + ops.linear_mode(), self.proj.weight, ops.pack_sr_conv), C, k,
+                                    self.stride, k // 2, bias=self.proj.bias)
+        else:
+            y = ops.conv2d(xh, self._pk.get("proj", self.proj.weight, ops.pack_weight), C, k, stride=self.stride, pad=k // 2,
+                           bias=self.proj.bias, ln=(self.norm.weight, self.norm.bias, self.norm.eps) if fuse else None)
         B, H, W, C = y.shape
         t = y.view(B, H * W, C)
         if not fuse:

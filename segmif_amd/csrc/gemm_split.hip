@@ -82,9 +82,10 @@ struct GemmSplitK {
   const float* wscale;  // f16x3: 2^-e(n) per (padded) output column
   uint32_t* amax;       // f16x3: range slots for max |A| (or null): slot row / amax_rows
   long long amax_rows;  // rows per image (M when every row reports to amax[0])
-  // patch mode (patch_sr > 0): A row (b, oy, ox) is the sr x sr patch of an NHWC image (pixel pitch lda) at (sr oy, sr ox),
-  // k = (ky, kx, c): ky selects an image row (pitch patch_W * lda), (kx, c) is one contiguous run of sr * C floats
-  int patch_sr, patch_H, patch_W, patch_OH, patch_OW, patch_seg;  // patch_seg = sr * C (a multiple of GBK)
+  // patch mode (patch_k > 0): a k x k convolution with stride patch_st and zero padding patch_pad over a dense NHWC image
+  // (pixel pitch lda = C, C % GBK == 0): A row (b, oy, ox) is the patch at (st oy - pad, st ox - pad), k = (ky, kx, c); a K step
+  // of GBK floats lies inside one tap (ky, kx), whose pixel is either inside the image or contributes zeros
+  int patch_k, patch_st, patch_pad, patch_H, patch_W, patch_OH, patch_OW;
 };
 
 template <bool F16>
@@ -122,17 +123,22 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
   const float* a_ptr[4];
   bool a_ok[4];
   int a_dst[4];
+  int a_iy[4] = {0, 0, 0, 0}, a_ix[4] = {0, 0, 0, 0};  // patch mode: image coordinates of the patch's top-left pixel
+  bool ra_ok[4] = {true, true, true, true};           // patch mode: the tap of the step held in ra[] lies inside the image
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int row = (tid >> 3) + 32 * j;
     a_ok[j] = m0 + row < p.M;
     const long long m = a_ok[j] ? (m0 + row) : 0;
-    if (p.patch_sr) {
+    if (p.patch_k) {
       const long long ohw = (long long)p.patch_OH * p.patch_OW;
       const long long b = m / ohw;
       const int rem = (int)(m - b * ohw);
       const int oy = rem / p.patch_OW, ox = rem - oy * p.patch_OW;
-      a_ptr[j] = p.a + ((b * p.patch_H + (long long)oy * p.patch_sr) * p.patch_W + (long long)ox * p.patch_sr) * p.lda + kq * 4;
+      a_iy[j] = oy * p.patch_st - p.patch_pad;
+      a_ix[j] = ox * p.patch_st - p.patch_pad;
+      // (pointer of the patch's top-left pixel: may lie outside the image - only dereferenced for taps that are inside)
+      a_ptr[j] = p.a + ((b * p.patch_H + a_iy[j]) * p.patch_W + a_ix[j]) * p.lda + kq * 4;
     } else {
       a_ptr[j] = p.a + m * (long long)p.lda + kq * 4;
     }
@@ -140,20 +146,29 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
   }
   f32x4 ra[4];
   uint32_t amx = 0u;  // f16x3: largest |A| this lane has split (p16::absmax_pk patterns)
-  const long long seg_pitch = (long long)p.patch_W * p.lda;  // patch mode: floats between two image rows
   auto gload = [&](int ks) {
-    long long ko = (long long)ks * GBK;
-    if (p.patch_sr) {  // (uniform) K step ks lies in image row ky = ks * GBK / patch_seg of the patch
-      const int ky = (ks * GBK) / p.patch_seg;
-      ko = ky * seg_pitch + (ks * GBK - ky * p.patch_seg);
+    if (p.patch_k) {  // (uniform) K step ks = tap (ky, kx), channels c0 .. c0 + GBK - 1
+      const int tap = (ks * GBK) / p.lda, c0 = ks * GBK - tap * p.lda;
+      const int ky = tap / p.patch_k, kx = tap - ky * p.patch_k;
+      const long long ko = ((long long)ky * p.patch_W + kx) * p.lda + c0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // unconditional load from a clamped address + a mask applied at the LDS store: a load under a divergent branch makes
+        // hipcc wait vmcnt(0) at the join, i.e. before the MFMAs it was issued to hide under (profiles/r03_wgrad3x3_phases.txt)
+        ra_ok[j] = (unsigned)(a_iy[j] + ky) < (unsigned)p.patch_H && (unsigned)(a_ix[j] + kx) < (unsigned)p.patch_W;
+        const float* src = ra_ok[j] ? a_ptr[j] + ko : p.a + kq * 4;
+        ra[j] = *reinterpret_cast<const f32x4*>(src);
+      }
+      return;
     }
+    const long long ko = (long long)ks * GBK;
 #pragma unroll
     for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(a_ptr[j] + ko);
   };
   auto a_store = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f32x4 x = a_ok[j] ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 x = (a_ok[j] && ra_ok[j]) ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (F16) {
         uint32_t ha, la, hb, lb;
         p16::split2(x[0], x[1], ha, la);
@@ -428,15 +443,16 @@ extern "C" int segmif_gemm_split16_f32(const SegmifGemmSplit* d, uint32_t* amax,
 static int gemm_split_impl(const SegmifGemmSplit* d, bool f16, uint32_t* amax, int amax_images, void* stream) {
   if (amax && (amax_images < 1 || !d || d->M % amax_images)) return SEGMIF_EINVAL;  // whole images: M = images x rows per image
   if (!d || !d->a || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % GBK) return SEGMIF_EINVAL;
-  const bool patch = d->patch_sr > 0;
+  const bool patch = d->patch_k > 0;
   if ((!patch && d->lda < d->K) || (d->lda & 3) || ((uintptr_t)d->a & 15) || ((uintptr_t)d->w & 15)) return SEGMIF_EINVAL;
-  int poh = 0, pow_ = 0, pseg = 0;
-  if (patch) {  // K = sr * sr * C with C = the channels read per pixel (<= lda), whole patches only (the conv floors)
-    const int sr = d->patch_sr;
-    if (d->patch_H < sr || d->patch_W < sr || d->K % (sr * sr)) return SEGMIF_EINVAL;
-    const int C = d->K / (sr * sr);
-    poh = d->patch_H / sr; pow_ = d->patch_W / sr; pseg = sr * C;
-    if (C != d->lda || pseg % GBK || d->M % ((long long)poh * pow_)) return SEGMIF_EINVAL;  // dense NHWC pixels: (kx, c) runs are contiguous
+  int poh = 0, pow_ = 0;
+  if (patch) {  // K = k * k * C, C = lda a multiple of GBK (a K step never straddles two taps)
+    const int kk = d->patch_k, st = d->patch_st, pad = d->patch_pad;
+    if (st < 1 || pad < 0 || pad >= kk || d->patch_H + 2 * pad < kk || d->patch_W + 2 * pad < kk || d->K != kk * kk * d->lda || d->lda % GBK)
+      return SEGMIF_EINVAL;
+    poh = (d->patch_H + 2 * pad - kk) / st + 1;
+    pow_ = (d->patch_W + 2 * pad - kk) / st + 1;
+    if (d->M % ((long long)poh * pow_)) return SEGMIF_EINVAL;
   }
   if (d->act == SEGMIF_ACT_PRELU && !d->prelu) return SEGMIF_EINVAL;
   if (d->res && (d->ldr <= 0 || (d->ldr & 3) || ((uintptr_t)d->res & 15))) return SEGMIF_EINVAL;
@@ -448,8 +464,8 @@ static int gemm_split_impl(const SegmifGemmSplit* d, bool f16, uint32_t* amax, i
   k.epi = epi_direct ? 0 : 1;  // "direct" (read once per process): stores straight from the accumulators (round 2)
   k.ntm = (int)((d->M + GBM - 1) / GBM);
   k.ntn = (d->N + GBN - 1) / GBN;
-  k.patch_sr = patch ? d->patch_sr : 0; k.patch_H = d->patch_H; k.patch_W = d->patch_W;
-  k.patch_OH = poh; k.patch_OW = pow_; k.patch_seg = pseg;
+  k.patch_k = patch ? d->patch_k : 0; k.patch_st = d->patch_st; k.patch_pad = d->patch_pad;
+  k.patch_H = d->patch_H; k.patch_W = d->patch_W; k.patch_OH = poh; k.patch_OW = pow_;
   k.amax = f16 ? amax : nullptr;
   k.amax_rows = d->M / (amax && amax_images > 1 ? amax_images : 1);
   k.wscale = reinterpret_cast<const float*>(k.w + segmif_gemm_split_weight_bytes(d->N, d->K));  // (f16x3 images only)

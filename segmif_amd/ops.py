@@ -527,7 +527,7 @@ def _gemm_split(a_ptr, rows, K, lda, split, N, bias, act, res, out, images, patc
     d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
     d.M, d.N, d.K, d.lda, d.ldo, d.act = rows, N, K, lda, ldo, act
     if patch is not None:
-        d.patch_sr, d.patch_H, d.patch_W = patch
+        d.patch_k, d.patch_st, d.patch_pad, d.patch_H, d.patch_W = patch
     if res is not None:
         rrow, rc, ldr = rows_view(res, "res")
         if rc != N or rrow != rows:
@@ -562,12 +562,13 @@ _SR_CONV_IGEMM = os.environ.get("SEGMIF_SR_CONV") == "igemm"  # A/B switch: the 
 
 
 def pack_sr_conv(w):
-    """(N, C, sr, sr) weight of a spatial-reduction conv (kernel = stride = sr) -> (fp32 packing for the igemm tiles,
-    GemmSplitWeight over K = sr * sr * C in (ky, kx, c) order, or None).  Cache entries must be keyed on linear_mode()."""
+    """(N, C, k, k) weight of a conv the split GEMM can take in patch mode (Attention's spatial-reduction conv: kernel =
+    stride; the overlapping patch embeds of stages 2-4) -> (fp32 packing for the igemm tiles, GemmSplitWeight over K = k * k * C
+    in (ky, kx, c) order, or None).  Cache entries must be keyed on linear_mode()."""
     packed = pack_weight(w)
-    N, C, sr = w.shape[0], w.shape[1], w.shape[2]
-    K = sr * sr * C
-    if _linear_mode == "fp32" or w.dim() != 4 or w.shape[3] != sr or (sr * C) % 32 or N < 32 or packed.shape[1] != K:
+    N, C, k = w.shape[0], w.shape[1], w.shape[2]
+    K = k * k * C
+    if _linear_mode == "fp32" or w.dim() != 4 or w.shape[3] != k or C % 32 or N < 32 or packed.shape[1] != K:
         return packed, None
     lib = _lib.load()
     out = torch.empty((lib.segmif_gemm_split_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
@@ -579,19 +580,24 @@ def pack_sr_conv(w):
     return packed, GemmSplitWeight(out, N, K, img16)
 
 
-def sr_conv_auto(x, packs, N, sr, *, bias=None):
-    """The spatial-reduction conv of Attention (kernel = stride = sr, no padding) on a contiguous NHWC batch x (B, H, W, C)
-    -> (B, H // sr, W // sr, N): the split-operand GEMM reading its A rows straight out of the image (patch mode: no gather
-    pass) when the problem is tall and wide enough, the strided implicit-GEMM tiles otherwise."""
+def patch_conv_auto(x, packs, N, k, stride, pad, *, bias=None):
+    """A k x k conv (stride, zero padding) on a contiguous NHWC batch x (B, H, W, C) -> (B, OH, OW, N): the split-operand GEMM
+    reading its A rows straight out of the image (patch mode: no gather pass, taps outside the image read as zeros) when the
+    problem is tall and wide enough and C % 32 == 0, the strided implicit-GEMM tiles otherwise."""
     packed, split = packs
     B, H, W, C = x.shape
-    OH, OW = H // sr, W // sr
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     rows = B * OH * OW
-    if split is None or rows < GEMM_SPLIT_MIN_ROWS or N < 128 or N % 4 or not x.is_contiguous() or x.data_ptr() % 16 or not _vec4(bias) \
-            or _SR_CONV_IGEMM:
-        return conv2d(x, packed, N, sr, stride=sr, bias=bias)
+    if split is None or rows < GEMM_SPLIT_MIN_ROWS or N < 128 or N % 4 or C % 32 or not x.is_contiguous() or x.data_ptr() % 16 \
+            or not _vec4(bias) or _SR_CONV_IGEMM:
+        return conv2d(x, packed, N, k, stride=stride, pad=pad, bias=bias)
     out = torch.empty((B, OH, OW, N), device=x.device, dtype=torch.float32)
-    return _gemm_split(x.data_ptr(), rows, sr * sr * C, C, split, N, bias, ACT_NONE, None, out, B, patch=(sr, H, W))
+    return _gemm_split(x.data_ptr(), rows, k * k * C, C, split, N, bias, ACT_NONE, None, out, B, patch=(k, stride, pad, H, W))
+
+
+def sr_conv_auto(x, packs, N, sr, *, bias=None):
+    """The spatial-reduction conv of Attention (kernel = stride = sr, no padding): patch_conv_auto(x, packs, N, sr, sr, 0)."""
+    return patch_conv_auto(x, packs, N, sr, sr, 0, bias=bias)
 
 
 _MIXFFN = os.environ.get("SEGMIF_MIXFFN", "fused")  # "chain": round 3's LayerNorm -> GEMM -> dwconv+GELU -> GEMM everywhere (A/B switch)

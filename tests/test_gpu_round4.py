@@ -282,40 +282,44 @@ def test_comm_c_abi_one_rank(ops):
     assert lib.segmif_comm_destroy(comm) == 0
 
 
-@pytest.mark.parametrize("B,H,W,C,sr", [(8, 33, 41, 320, 2), (8, 60, 80, 128, 4), (2, 120, 160, 64, 8)])
-def test_sr_conv_on_the_split_gemm(ops, B, H, W, C, sr):
-    """Attention's spatial-reduction conv (kernel = stride = sr; core/mix_transformer.py:73-75, :98-101) as the split-operand
-    GEMM in patch mode - A rows read straight out of the NHWC image, no gather pass - against fp64, beside the exact-fp32
-    implicit-GEMM tiles; sizes that are not multiples of sr drop the remainder like the conv does; C = 64 (N < 128) keeps the
-    fp32 tiles.  Both arithmetics (half pairs inside a guarded scope, bf16 triples outside) and the per-image range slots."""
+@pytest.mark.parametrize("B,H,W,C,N,k,st,pad", [(8, 33, 41, 320, 320, 2, 2, 0), (8, 60, 80, 128, 128, 4, 4, 0),
+                                                 (2, 120, 160, 64, 64, 8, 8, 0), (4, 60, 81, 64, 128, 3, 2, 1),
+                                                 (3, 31, 40, 128, 320, 3, 2, 1), (5, 30, 40, 320, 512, 3, 2, 1)])
+def test_patch_convs_on_the_split_gemm(ops, B, H, W, C, N, k, st, pad):
+    """Attention's spatial-reduction conv (kernel = stride = sr; core/mix_transformer.py:73-75, :98-101) and the overlapping
+    patch embeds of stages 2-4 (3 x 3, stride 2, pad 1; :171-172) as the split-operand GEMM in patch mode - A rows read straight
+    out of the NHWC image, no gather pass, border taps as zeros - against fp64, beside the exact-fp32 implicit-GEMM tiles; odd
+    sizes (the conv floors / the last window hangs over the border); N = 64 keeps the fp32 tiles.  Both arithmetics (half pairs
+    inside a guarded scope, bf16 triples outside) and the per-image range slots."""
     import torch.nn.functional as F
     x = rnd(B, H, W, C, seed=B + H) * 10.0 ** rnd(B, H, W, C, seed=C, lo=-3, hi=1)
-    w = rnd(C, C, sr, sr, seed=sr) * 0.05 * 10.0 ** rnd(C, 1, 1, 1, seed=5, lo=-2, hi=1)
-    b = rnd(C, seed=9)
-    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=sr).permute(0, 2, 3, 1)
+    w = rnd(N, C, k, k, seed=k) * 0.05 * 10.0 ** rnd(N, 1, 1, 1, seed=5, lo=-2, hi=1)
+    b = rnd(N, seed=9)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=st, padding=pad).permute(0, 2, 3, 1)
     xc, packs = x.cuda(), ops.pack_sr_conv(w.cuda())
-    y32 = ops.conv2d(xc, packs[0], C, sr, stride=sr, bias=b.cuda())
+    y32 = ops.conv2d(xc, packs[0], N, k, stride=st, pad=pad, bias=b.cuda())
 
     def err(t):
         return float((t.double().cpu() - ref).abs().max() / ref.abs().max())
 
     e32 = err(y32)
-    y6 = ops.sr_conv_auto(xc, packs, C, sr, bias=b.cuda())
-    # (K = sr^2 C up to 2048 .. 4096: the split kernels' error grows faster with K than the fp32 tiles' - observed up to 5.3x)
+    y6 = ops.patch_conv_auto(xc, packs, N, k, st, pad, bias=b.cuda())
+    # (K = k^2 C up to 2048 .. 4096: the split kernels' error grows faster with K than the fp32 tiles' - observed up to 5.3x)
     assert y6.shape == ref.shape and err(y6) < TOL and err(y6) <= 8.0 * e32 + 1e-7, (err(y6), e32)
     guard = ops.Planes16Guard("cuda", B)
     prev = ops.install_guard(guard)
     try:
-        y16 = ops.sr_conv_auto(xc, packs, C, sr, bias=b.cuda())
+        y16 = ops.patch_conv_auto(xc, packs, N, k, st, pad, bias=b.cuda())
     finally:
         ops.install_guard(prev)
     assert err(y16) < TOL and err(y16) <= 8.0 * e32 + 1e-7, (err(y16), e32)
-    observed(f"r4_sr_conv_C{C}_sr{sr}", {"fp32_tiles": e32, "bf16x6": err(y6), "f16x3": err(y16)})
-    if C >= 128:
+    observed(f"r4_patch_conv_C{C}_N{N}_k{k}s{st}", {"fp32_tiles": e32, "bf16x6": err(y6), "f16x3": err(y16)})
+    if N >= 128:
         assert packs[1] is not None and not torch.equal(y16, y6) and not torch.equal(y6, y32)  # three different kernels ran
         m = guard.maxima()
         assert m.shape == (1, B)
-        used = x[:, : H // sr * sr, : W // sr * sr]  # the pixels the conv reads; a 128-row tile may straddle two images
+        oh, ow = ref.shape[1], ref.shape[2]
+        used = x[:, : min(H, (oh - 1) * st - pad + k), : min(W, (ow - 1) * st - pad + k)]  # the pixels the conv reads; a tile may straddle two images
         per_img = used.abs().amax(dim=(1, 2, 3)).half().float()
         assert all(float(m[0, i]) >= float(per_img[i]) for i in range(B)) and float(m.max()) == float(per_img.max())
     else:
