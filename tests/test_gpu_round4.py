@@ -284,7 +284,7 @@ def test_comm_c_abi_one_rank(ops):
 
 @pytest.mark.parametrize("B,H,W,C,N,k,st,pad", [(8, 33, 41, 320, 320, 2, 2, 0), (8, 60, 80, 128, 128, 4, 4, 0),
                                                  (2, 120, 160, 64, 64, 8, 8, 0), (4, 60, 81, 64, 128, 3, 2, 1),
-                                                 (3, 31, 40, 128, 320, 3, 2, 1), (5, 30, 40, 320, 512, 3, 2, 1)])
+                                                 (8, 31, 40, 128, 320, 3, 2, 1), (8, 30, 40, 320, 512, 3, 2, 1)])
 def test_patch_convs_on_the_split_gemm(ops, B, H, W, C, N, k, st, pad):
     """Attention's spatial-reduction conv (kernel = stride = sr; core/mix_transformer.py:73-75, :98-101) and the overlapping
     patch embeds of stages 2-4 (3 x 3, stride 2, pad 1; :171-172) as the split-operand GEMM in patch mode - A rows read straight
