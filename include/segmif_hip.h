@@ -202,6 +202,10 @@ typedef struct SegmifConvPlanes {
   const float* res;    /* [B*H*W][ldr] or NULL */
   float* out1;         /* [B*H*W][ldo1], 64 channels */
   int32_t ldr, ldo1, act1;
+  /* f16x3 fused tail with res == NULL: != 0 takes the residual from the conv's OWN input, chunks 0..3 of planes_in
+   * (x = hi + 2^-11 lo: the DRDB's input as its producer split it, 23 significand bits) - the fp32 copy of that tensor then
+   * needs no writer and no reader (core/model_fusion.py:157: out = conv(cat) + x).  Ignored by the bf16x6 entry point. */
+  int32_t res_from_planes;
 } SegmifConvPlanes;
 
 int segmif_planes_dims(int H, int W, int* Hp, int* Wp);

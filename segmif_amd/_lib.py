@@ -40,7 +40,7 @@ class SegmifConvPlanes(ctypes.Structure):
         ("B", c_int32), ("H", c_int32), ("W", c_int32), ("cin", c_int32), ("dil", c_int32),
         ("in_chunks", c_int32), ("out_chunks", c_int32), ("out_chunk0", c_int32), ("act", c_int32),
         ("w1", c_void_p), ("bias1", c_void_p), ("res", c_void_p), ("out1", c_void_p),
-        ("ldr", c_int32), ("ldo1", c_int32), ("act1", c_int32),
+        ("ldr", c_int32), ("ldo1", c_int32), ("act1", c_int32), ("res_from_planes", c_int32),
     ]
 
 

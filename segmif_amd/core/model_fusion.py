@@ -21,6 +21,10 @@ from . import mix_transformer
 from ._util import PackedCache, init_reference_style, require_device, wants_grad
 from .segformer_head import SegFormerHead
 
+import os
+
+_DRDB_RES_PLANES = os.environ.get("SEGMIF_DRDB_RES", "planes") != "fp32"
+
 __all__ = ["WeTr", "RGB2YCrCb", "YCrCb2RGB", "DRDB", "CrossAttention", "CrossAttention2", "CrossPath",
            "FeatureFusionModule", "Fusion_Network3_ac", "Network3", "Mean", "fuse_to_rgb"]
 
@@ -127,10 +131,14 @@ class DRDB(nn.Module):
     def forward_planes(self, x, planes, out=None, preloaded=False):
         """Inference on pre-split activations (csrc/conv3x3_planes.hip): x (B,H,W,64) fp32 rows view, planes a
         12-chunk ops.Planes scratch buffer.  Dcov1-4 read / append chunk images, Dcov5 also carries the closing
-        1x1 conv + ReLU + residual (ref :153-157), so the 224-channel concat is never materialised in fp32."""
-        B, H, W, _ = x.shape
+        1x1 conv + ReLU + residual (ref :153-157), so the 224-channel concat is never materialised in fp32.
+        x = None (r4; f16x3 planes already holding the input as chunks 0..3): the residual is read back from those chunks
+        (hi + 2^-11 lo), so the producer - conv1, the CrossPath tail - need not write an fp32 copy at all."""
+        B, H, W = planes.B, planes.H, planes.W
+        if x is None and not (preloaded and planes.f16):
+            raise RuntimeError("DRDB.forward_planes: x = None needs f16x3 planes preloaded with the input")
         if out is None:
-            out = torch.empty((B, H, W, self.in_ch), device=x.device, dtype=torch.float32)
+            out = torch.empty((B, H, W, self.in_ch), device=planes.data.device, dtype=torch.float32)
         if not preloaded:  # (a producer may already have written x as chunks 0..3, e.g. the CrossPath tail)
             planes.load_f32(x, 0)
         ch = self.in_ch
@@ -144,7 +152,7 @@ class DRDB(nn.Module):
             else:
                 w1 = self._pk.get(f"p1x1{sfx}", self.conv.weight, pack)
                 ops.conv3x3_planes(planes, ch, wt, dil=2, bias=conv.bias, act=ops.ACT_RELU,
-                                   tail=(w1, self.conv.bias, x, out, ops.ACT_RELU), tag="drdb_tail")
+                                   tail=(w1, self.conv.bias, x, out, ops.ACT_RELU, x is None), tag="drdb_tail")
             ch += self.growth
         return out
 
@@ -574,17 +582,27 @@ class Fusion_Network3_ac(nn.Module):
         PRELU = ops.ACT_PRELU
         guard = ops.active_guard() if ops.conv3x3_mode() == "planes16" else None  # half pairs iff a guarded scope is running
         xs, pls = [], []
+        # (r4) on f16x3 planes a DRDB takes its residual from its own input chunks (hi + 2^-11 lo), so neither conv1 nor the
+        # first interaction's CrossPath tails write an fp32 copy of the DRDB inputs: 20 GB of stores and as many of reads per
+        # 64-pair step.  SEGMIF_DRDB_RES=fp32 keeps round 3's fp32 residual tensors (A/B switch; bf16 planes always do).
+        lean = guard is not None and _DRDB_RES_PLANES
         for x, conv, name in ((ir, self.conv1_ir, "conv1_ir"), (vis, self.conv1_vis, "conv1_vis")):
             pls.append(ops.Planes(B, H, W, DRDB.PLANES_CHUNKS, dev, guard))
-            # conv1 writes its 64 channels as fp32 (the DRDB's residual input) and, split, as the DRDB's first four chunks
+            # conv1 writes its 64 channels split, as the DRDB's first four chunks (and as fp32 - the DRDB's residual input - unless lean)
             xs.append(ops.conv2d(self._first_channel_nhwc(x), self._w(name), 64, 3, pad=1, bias=conv.bias, act=PRELU,
-                                 prelu=slope, planes=pls[-1]))
+                                 prelu=slope, planes=pls[-1], planes_only=lean))
         y1 = self.DRDB1.forward_planes(xs[0], pls[0], preloaded=True)
         y2 = self.DRDB2.forward_planes(xs[1], pls[1], preloaded=True)
         seg = seg1_fn()
         pre = self.ffm.cross.gram_ok()  # the CrossPath tail then writes the DRDB inputs pre-split as well
-        x1, x2 = self.ffm.forward_nhwc(y1, y2, seg, out1=xs[0], out2=xs[1], planes1=pls[0] if pre else None,
-                                       planes2=pls[1] if pre else None)
+        if pre and lean:
+            self.ffm.forward_nhwc(y1, y2, seg, planes1=pls[0], planes2=pls[1], planes_only=True)
+            x1 = x2 = None
+        else:
+            if lean:  # (the GEMM-form CrossPath has no planes epilogue: it needs fp32 outputs)
+                xs = [torch.empty((B, H, W, 64), device=dev, dtype=torch.float32) for _ in range(2)]
+            x1, x2 = self.ffm.forward_nhwc(y1, y2, seg, out1=xs[0], out2=xs[1], planes1=pls[0] if pre else None,
+                                           planes2=pls[1] if pre else None)
         y1 = self.DRDB3.forward_planes(x1, pls[0], out=y1, preloaded=pre)
         y2 = self.DRDB4.forward_planes(x2, pls[1], out=y2, preloaded=pre)
         del pls, xs, x1, x2

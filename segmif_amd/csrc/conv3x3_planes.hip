@@ -133,6 +133,7 @@ struct PlanesConvK {
   const unsigned char* w1;    // fused 1x1: [nchunks + 2][64][96]
   const float* bias1;
   const float* res;
+  int res_planes;             // f16x3 fused tail: the residual is the conv's own input chunks 0..3 (hi + 2^-11 lo), not an fp32 tensor
   float* out1;
   int ldr, ldo1, act1;
   int tiles_x, tiles_y;
@@ -566,6 +567,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (p.res) {
               const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n0);
               o += rv;
+            } else if (F16 && p.res_planes) {
+              // (r4) residual = the DRDB's own input, read back from its planes: channel n0 + e is element 4 (g & 1) + e of this
+              // lane's piece of chunk 2 nt + (g >> 1) - the order the accumulators hand out; x = hi + 2^-11 lo (23 bits)
+              const unsigned char* src = p.pin + ((long long)pt.b * p.in_total + 2 * nt + (g >> 1)) * chunk_bytes +
+                                         ((long long)(oy + PB) * p.Wp + ox + PB) * PXA + h * 16 + (g & 1) * 8;
+              typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+              const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(src), lo = *reinterpret_cast<const u32x2_t*>(src + 32);
+#pragma unroll
+              for (int e2 = 0; e2 < 2; ++e2) {
+                const f32x2 fh = __builtin_convertvector(__builtin_bit_cast(f16x2, hi[e2]), f32x2);
+                const f32x2 fl = __builtin_convertvector(__builtin_bit_cast(f16x2, lo[e2]), f32x2);
+                o[2 * e2] += fmaf(fl[0], 1.f / LSCALE, fh[0]);
+                o[2 * e2 + 1] += fmaf(fl[1], 1.f / LSCALE, fh[1]);
+              }
             }
             *reinterpret_cast<f32x4*>(p.out1 + m * p.ldo1 + n0) = o;
           }
@@ -907,6 +922,7 @@ static int conv3x3_planes_impl(const SegmifConvPlanes* d, bool f16, uint32_t* am
   k.w1 = (const unsigned char*)d->w1;
   k.bias1 = d->bias1 ? d->bias1 : zero_bias;
   k.res = d->res;
+  k.res_planes = (f16 && fuse && !d->res) ? d->res_from_planes : 0;
   k.out1 = d->out1;
   k.ldr = d->ldr; k.ldo1 = d->ldo1; k.act1 = d->act1;
   if (fuse) {

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
               if (res) y[e] += rr[i][j][g][e];
               yy[4 * gg + e] = y[e];
             }
-            *reinterpret_cast<f32x4*>(out + m * p.ldo + n) = y;
+            if (p.out) *reinterpret_cast<f32x4*>(out + m * p.ldo + n) = y;
           }
           if (PLANES && p.planes && col_of(j, 2 * q) < p.N) {
             // this lane's 8 of the chunk's 16 channels are positions 8 h .. 8 h + 7 of the chunk (sigma order): one
@@ -660,7 +660,7 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
 }
 
 static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& tile_out, int& nz_out, bool& halo_out) {
-  if (!d || !d->in || !d->wt || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return SEGMIF_EINVAL;
+  if (!d || !d->in || !d->wt || (!d->out && !d->planes_out) || d->M <= 0 || d->N <= 0 || d->K <= 0) return SEGMIF_EINVAL;  // (out may be NULL when the planes copy is the only consumer)
   halo_out = false;
   k.in = d->in; k.in2 = d->in2; k.wt = d->wt; k.bias = d->bias; k.res = d->res; k.prelu = d->prelu; k.out = d->out;
   k.M = d->M; k.N = d->N; k.K = d->K; k.Kp = (d->K + 15) / 16 * 16;
@@ -687,6 +687,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   k.pl_amax = k.pl_f16 ? d->planes_amax : nullptr;
   k.pl_amax_images = d->planes_amax_images > 1 ? d->planes_amax_images : 1;
   if (k.pl_amax && k.pl_amax_images > 1 && (long long)k.pl_amax_images * d->OH * d->OW != d->M) return SEGMIF_EINVAL;
+  if (!d->out && (!k.planes || nz > 1 || d->res)) return SEGMIF_EINVAL;  // planes-only output: the planes epilogue is the one that may skip the fp32 store
   if (k.planes) {
     int hp, wp;
     if (!k.vec4 || (d->N & 15) || nz > 1 || k.ln_gamma || d->planes_chunk0 < 0 || d->planes_chunk0 + d->N / 16 > d->planes_chunks ||

@@ -407,8 +407,9 @@ def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None,
                    tag=None):
     """3x3 'same' conv (dilation 1 | 2, 32 outputs) over the first `cin` channels of a Planes buffer.
     out_chunk0: write the result as chunks [out_chunk0, out_chunk0 + 2) of the same buffer; out: optional fp32
-    (B, H, W, 32) rows view; tail = (w1 PlanesWeight(64, cin + 32, 1), bias1, res, out1, act1): the fused 1x1 conv
-    out1 = res + act1(W1 . [input | result] + bias1)."""
+    (B, H, W, 32) rows view; tail = (w1 PlanesWeight(64, cin + 32, 1), bias1, res, out1, act1[, res_from_planes]): the fused
+    1x1 conv out1 = res + act1(W1 . [input | result] + bias1); res_from_planes (f16x3, res None): the residual is the input's
+    own chunks 0..3 (hi + 2^-11 lo) - the fp32 tensor behind them then needs no writer and no reader."""
     if not isinstance(wt, PlanesWeight) or (wt.N, wt.cin, wt.taps, wt.f16) != (32, cin, 9, planes.f16):
         raise RuntimeError("conv3x3_planes: weight image does not fit")
     planes.need(max(cin // 16, (out_chunk0 + 2) if out_chunk0 is not None else 0), "conv3x3_planes")
@@ -427,7 +428,11 @@ def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None,
             raise RuntimeError("conv3x3_planes: out shape mismatch")
         d.out, d.ldo = out.data_ptr(), ldo
     if tail is not None:
-        w1, bias1, res, out1, act1 = tail
+        w1, bias1, res, out1, act1 = tail[:5]
+        if len(tail) > 5 and tail[5]:  # residual = the conv's own input chunks 0..3 (f16x3 planes only), no fp32 tensor
+            if res is not None or not planes.f16:
+                raise RuntimeError("conv3x3_planes: res_from_planes needs f16x3 planes and no fp32 residual")
+            d.res_from_planes = 1
         if not isinstance(w1, PlanesWeight) or (w1.N, w1.cin, w1.taps, w1.f16) != (64, cin + 32, 1, planes.f16):
             raise RuntimeError("conv3x3_planes: tail weight image does not fit")
         _, c1, ldo1 = rows_view(out1, "out1")
@@ -803,14 +808,22 @@ def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
 
 
 def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
-           tile=-1, tag=None, planes=None, planes_chunk0=0, ln=None):
+           tile=-1, tag=None, planes=None, planes_chunk0=0, ln=None, planes_only=False):
     """NHWC convolution.  x: (B, H, W, Cin) rows view (may be a channel slice of a wider buffer);
     wt packed (N, Kp); out: (B, OH, OW, N) rows view (may be a channel slice) or None.
     planes: optional ops.Planes of the output geometry that also receives the result, split, as chunks
     [planes_chunk0, planes_chunk0 + N / 16) (fp32-packed weights only).
-    ln = (gamma, beta, eps): LayerNorm over the N = 64 output channels in the conv's epilogue (conv_ln_fusable)."""
+    ln = (gamma, beta, eps): LayerNorm over the N = 64 output channels in the conv's epilogue (conv_ln_fusable).
+    planes_only: write the planes copy and nothing else (returns None): the fp32 tensor has no reader."""
     if x.dim() != 4:
         raise RuntimeError("conv2d expects (B, H, W, C)")
+    if planes_only:
+        if planes is None or out is not None or res is not None or ln is not None or isinstance(wt, SplitWeight):
+            raise RuntimeError("conv2d: planes_only needs a planes buffer, fp32-packed weights and no fp32 output / residual / LayerNorm")
+        B, H, W = x.shape[0], x.shape[1], x.shape[2]
+        OH = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        OW = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        return _conv2d_planes_only(x, wt, N, k, stride, pad, dil, bias, act, prelu, tile, tag, planes, planes_chunk0, (B, OH, OW))
     if ln is not None and not aligned16(out, res, bias, ln[0], ln[1]):
         y = conv2d(x, wt, N, k, stride=stride, pad=pad, dil=dil, bias=bias, act=act, prelu=prelu, res=res, out=out, tile=tile,
                    tag=tag, planes=planes, planes_chunk0=planes_chunk0)
@@ -864,6 +877,35 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
             d.planes_amax, d.planes_amax_images = planes.guard.slot(B)
     _igemm(d, tag, dev=x.device)
     return out
+
+
+def _conv2d_planes_only(x, wt, N, k, stride, pad, dil, bias, act, prelu, tile, tag, planes, planes_chunk0, oshape):
+    """conv2d's launch with a NULL fp32 output: the epilogue writes the planes copy only."""
+    _, cin, lda = rows_view(x, "x")
+    B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    _, OH, OW = oshape
+    K = k * k * cin
+    kp = (K + 15) // 16 * 16
+    if tuple(_req(wt, "wt").shape) != (N, kp) or not wt.is_contiguous():
+        raise RuntimeError(f"packed weight must be contiguous ({N}, {kp}), got {tuple(wt.shape)}")
+    if (planes.B, planes.H, planes.W) != (B, OH, OW):
+        raise RuntimeError("conv2d: planes output needs a planes buffer of the output geometry")
+    planes.need(planes_chunk0 + N // 16, "conv2d planes output")
+    d = _lib.SegmifIgemm()
+    d.in_, d.wt, d.out = x.data_ptr(), wt.data_ptr(), None
+    d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
+    d.prelu = _req(prelu, "prelu").data_ptr() if prelu is not None else None
+    d.M, d.N, d.K = B * OH * OW, N, K
+    d.lda, d.ldo = lda, N
+    d.H, d.W, d.Cin, d.KH, d.KW = H, W, cin, k, k
+    d.stride, d.pad, d.dil, d.OH, d.OW = stride, pad, dil, OH, OW
+    d.act, d.nz, d.tile = act, 1, tile
+    d.planes_out, d.planes_chunks, d.planes_chunk0 = planes.data.data_ptr(), planes.chunks, planes_chunk0
+    if planes.f16:
+        d.planes_f16 = 1
+        d.planes_amax, d.planes_amax_images = planes.guard.slot(B)
+    _igemm(d, tag, dev=x.device)
+    return None
 
 
 def conv3x3_c32to1(x, wt, *, bias=None, act=ACT_NONE, prelu=None):

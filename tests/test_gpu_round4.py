@@ -512,3 +512,35 @@ def test_crosspath_tail_on_f16x3_arithmetic(ops):
     ref_pl.data.zero_()
     ref_pl.load_f32(out16.view(B, H, W, 64), chunk0=0)
     assert torch.equal(pl.data, ref_pl.data)
+
+
+def test_drdb_residual_from_its_own_planes(ops):
+    """conv3x3_planes_kernel<2, true, f16x3> with res_from_planes: the DRDB's residual x (core/model_fusion.py:157) read back
+    from the input chunks 0..3 (hi + 2^-11 lo) instead of an fp32 tensor - the same output to within the half pair's 23 bits
+    of x - and conv2d(planes_only=True): conv1's planes-only epilogue writes exactly the planes the fp32 + planes one does."""
+    B, H, W = 2, 24, 40
+    x = rnd(B, H, W, 192, seed=41) * 10.0 ** rnd(B, H, W, 1, seed=42, lo=-2, hi=1)
+    w, b = rnd(32, 192, 3, 3, seed=43) * 0.05, rnd(32, seed=44)
+    w1, b1 = rnd(64, 224, seed=45) * 0.05, rnd(64, seed=46)
+    xc = x.cuda()
+    outs = []
+    for lean in (False, True):
+        guard = ops.Planes16Guard("cuda", B)
+        pl = ops.Planes(B, H, W, 12, "cuda", guard).load_f32(xc)
+        out = torch.empty(B, H, W, 64, device="cuda")
+        ops.conv3x3_planes(pl, 192, ops.pack_weight_planes16(w.cuda()), dil=2, bias=b.cuda(), act=1,
+                           tail=(ops.pack_weight_planes16(w1.cuda()), b1.cuda(), None if lean else xc[..., :64], out, 1, lean))
+        outs.append(out)
+    d = (outs[1] - outs[0]).abs()
+    bound = 2.0 ** -22 * x[..., :64].abs().cuda() + 1e-30
+    assert bool((d <= bound).all()), float((d / bound).max())
+    assert float(d.max()) > 0  # (the residual really took the other route)
+    # conv1-style planes-only epilogue
+    img = rnd(B, H, W, 1, seed=47, lo=0.0, hi=1.0).cuda()
+    wc, bc, slope = rnd(64, 1, 3, 3, seed=48).cuda(), rnd(64, seed=49).cuda(), torch.tensor([0.25], device="cuda")
+    g1, g2 = ops.Planes16Guard("cuda", B), ops.Planes16Guard("cuda", B)
+    p1, p2 = ops.Planes(B, H, W, 12, "cuda", g1), ops.Planes(B, H, W, 12, "cuda", g2)
+    p1.data.zero_(), p2.data.zero_()
+    y = ops.conv2d(img, ops.pack_weight(wc), 64, 3, pad=1, bias=bc, act=ops.ACT_PRELU, prelu=slope, planes=p1)
+    assert ops.conv2d(img, ops.pack_weight(wc), 64, 3, pad=1, bias=bc, act=ops.ACT_PRELU, prelu=slope, planes=p2, planes_only=True) is None
+    assert torch.equal(p1.data, p2.data) and torch.equal(g1.maxima(), g2.maxima()) and float(y.abs().max()) > 0
