@@ -572,14 +572,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               // lane's piece of chunk 2 nt + (g >> 1) - the order the accumulators hand out; x = hi + 2^-11 lo (23 bits)
               const unsigned char* src = p.pin + ((long long)pt.b * p.in_total + 2 * nt + (g >> 1)) * chunk_bytes +
                                          ((long long)(oy + PB) * p.Wp + ox + PB) * PXA + h * 16 + (g & 1) * 8;
-              typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-              const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(src), lo = *reinterpret_cast<const u32x2_t*>(src + 32);
+              const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+              const uint32_t hw[2] = {s32[0], s32[1]}, lw[2] = {s32[8], s32[9]};  // (plane 1 = + 32 bytes)
 #pragma unroll
               for (int e2 = 0; e2 < 2; ++e2) {
-                const f32x2 fh = __builtin_convertvector(__builtin_bit_cast(f16x2, hi[e2]), f32x2);
-                const f32x2 fl = __builtin_convertvector(__builtin_bit_cast(f16x2, lo[e2]), f32x2);
-                o[2 * e2] += fmaf(fl[0], 1.f / LSCALE, fh[0]);
-                o[2 * e2 + 1] += fmaf(fl[1], 1.f / LSCALE, fh[1]);
+                const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[e2] & 0xffffu));
+                const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[e2] >> 16));
+                const float l0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(lw[e2] & 0xffffu));
+                const float l1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(lw[e2] >> 16));
+                o[2 * e2] += fmaf(l0, 1.f / LSCALE, h0);
+                o[2 * e2 + 1] += fmaf(l1, 1.f / LSCALE, h1);
               }
             }
             *reinterpret_cast<f32x4*>(p.out1 + m * p.ldo1 + n0) = o;
