@@ -532,7 +532,7 @@ def test_drdb_residual_from_its_own_planes(ops):
                            tail=(ops.pack_weight_planes16(w1.cuda()), b1.cuda(), None if lean else xc[..., :64], out, 1, lean))
         outs.append(out)
     d = (outs[1] - outs[0]).abs()
-    bound = 2.0 ** -22 * x[..., :64].abs().cuda() + 1e-30
+    bound = 2.0 ** -22 * (x[..., :64].abs().cuda() + outs[0].abs()) + 1e-30  # 23 bits of x, and the sum's own rounding
     assert bool((d <= bound).all()), float((d / bound).max())
     assert float(d.max()) > 0  # (the residual really took the other route)
     # conv1-style planes-only epilogue
