@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SEGMIF_ABI_VERSION 2
+#define SEGMIF_ABI_VERSION 3
 #define SEGMIF_EINVAL (-22)
 #define SEGMIF_ENOSYS (-38)
 
@@ -103,6 +103,12 @@ typedef struct SegmifIgemm {
   int32_t planes_f16;
   uint32_t* planes_amax;   /* or NULL */
   int32_t planes_amax_images;
+  /* optional ReLU mask applied LAST (after the residual): out = relu_mask[m][n] > 0 ? act(A.W^T + bias) + res : 0.
+   * The DRDB backward in gather form (core/model_fusion.py:134-157 differentiated): the conv that completes a block's
+   * gradient writes it through that block's ReLU mask (relu_mask = the block's forward output) straight into the slot
+   * the next conv reads - no separate mask pass.  Split 3x3 tile (14) only; anything else is SEGMIF_EINVAL. */
+  const float* relu_mask;  /* [M][ld_mask] or NULL */
+  int32_t ld_mask;
 } SegmifIgemm;
 
 int segmif_igemm_f32(const SegmifIgemm* desc, void* stream);
@@ -268,6 +274,10 @@ int segmif_colsum_f32(const float* x, float* out, double* workspace, int64_t row
 /* dx = dy * act'(.): ref = activation OUTPUT for ReLU / PReLU (slope > 0), PRE-activation for GELU. */
 int segmif_act_bwd_f32(const float* dy, const float* ref, float* dx, int64_t rows, int C, int ldy, int ldr,
                        int ldx, int act, const float* slope, void* stream);
+/* the same with the activation output given as ref - ref2 (r4: a DRDB keeps x and x + relu(.) - the mask source is their
+ * difference, formed in registers instead of by a full-resolution subtraction pass; core/model_fusion.py:153-157) */
+int segmif_act_bwd2_f32(const float* dy, const float* ref, const float* ref2, float* dx, int64_t rows, int C, int ldy,
+                        int ldr, int ldr2, int ldx, int act, const float* slope, void* stream);
 
 /*
  * LayerNorm over the last dimension: y = (x - mean) / sqrt(var + eps) * gamma + beta,
@@ -277,6 +287,13 @@ int segmif_act_bwd_f32(const float* dy, const float* ref, float* dx, int64_t row
  */
 int segmif_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y,
                          int64_t rows, int C, int ldx, int ldy, float eps, void* stream);
+/* Residual form of the training path (r4; core/mix_transformer.py:171-177: x = x + drop_path(f(norm(x)))):
+ *   sum = x + scale[row / rows_per_image] * branch  (scale NULL = 1: the per-sample stochastic-depth factor mask / keep)
+ *   y   = LayerNorm(sum)
+ * in one pass - the residual add, the DropPath multiply and the next LayerNorm were three. */
+int segmif_add_layernorm_f32(const float* x, const float* branch, const float* scale, int64_t rows_per_image,
+                             const float* gamma, const float* beta, float* sum, float* y, int64_t rows, int C, int ldx,
+                             int ldb, int lds, int ldy, float eps, void* stream);
 
 /*
  * Mix-FFN middle: depthwise 3x3 (pad 1) + bias + exact-erf GELU on tokens viewed as an
@@ -445,6 +462,12 @@ int segmif_dequantize_u8(const uint8_t* in_nhwc, float* out_nchw, int B, int C, 
 int segmif_layernorm_bwd_blocks(int64_t rows, int C);
 int segmif_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx, float* partial,
                              int64_t rows, int C, int ldx, int ldy, int lddx, float eps, void* stream);
+/* backward of segmif_add_layernorm_f32: dx = LayerNorm-backward(dy at x = the saved sum) + dres (the gradient arriving at the
+ * sum itself; NULL = none), dbranch = scale[row / rows_per_image] * dx (NULL with scale NULL: the branch's gradient IS dx).
+ * dx may alias dres. */
+int segmif_layernorm_bwd_add_f32(const float* x, const float* dy, const float* gamma, const float* dres, int lddres,
+                                 const float* scale, int64_t rows_per_image, float* dx, float* dbranch, int lddbr,
+                                 float* partial, int64_t rows, int C, int ldx, int ldy, int lddx, float eps, void* stream);
 
 /* Mix-FFN middle backward.  Part 1: z = dwconv(h)+b is recomputed, dz = dy * gelu'(z) is stored and
  * per-block partials [9 taps | bias][C] are written (segmif_dwconv_bwd_partial_rows rows x 10C floats;
@@ -462,7 +485,8 @@ int segmif_dwconv3x3_bias_bwd_f32(const float* h, const float* w9, const float* 
 int segmif_bilinear_nhwc_bwd_f32(const float* dy, float* dx, int B, int IH, int IW, int OH, int OW, int C,
                                  int lddy, int lddx, void* stream);
 
-/* attention training path (scores materialised): p = softmax(s*scale) in place; ds = p*(dp - sum(p*dp))*scale in place */
+/* attention training path (scores materialised): p = softmax(s*scale) in place; ds = p*(dp - sum(p*dp))*scale in place.
+ * Columns [L, ld) of every row (ld <= 1024: pitch padding a later GEMM contracts over) are set to zero by both. */
 int segmif_row_softmax_f32(float* s, int64_t rows, int L, int ld, float scale, void* stream);
 int segmif_row_softmax_bwd_f32(const float* p, float* dp, int64_t rows, int L, int ld, float scale, void* stream);
 
@@ -540,6 +564,9 @@ int segmif_prelu_f32(const float* z, const float* slope, float* y, int64_t n, vo
 int segmif_prelu_bwd_blocks(int64_t n);
 int segmif_prelu_bwd_f32(const float* dy, const float* z, const float* slope, float* dz, double* partial, float* dslope,
                          int64_t n, void* stream);
+/* the same with dy a rows view (rows x C, pitch lddy floats): a channel slice of a wider gradient buffer, read in place */
+int segmif_prelu_bwd_rows_f32(const float* dy, int64_t lddy, const float* z, const float* slope, float* dz, double* partial,
+                              float* dslope, int64_t rows, int C, void* stream);
 
 /* multi-tensor AdamW (utils/optimizer.py:6 -> torch.optim.AdamW arithmetic). table: device array of
  * {float* p; const float* g; float* m; float* v; int64 n; float lr; float wd;} entries

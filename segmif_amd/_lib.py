@@ -30,6 +30,7 @@ class SegmifIgemm(ctypes.Structure):
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
         ("planes_out", c_void_p), ("planes_chunks", c_int32), ("planes_chunk0", c_int32),
         ("planes_f16", c_int32), ("planes_amax", c_void_p), ("planes_amax_images", c_int32),
+        ("relu_mask", c_void_p), ("ld_mask", c_int32),
     ]
 
 
@@ -129,6 +130,14 @@ SIGNATURES = {
     "segmif_colsum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "segmif_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p]),
+    "segmif_act_bwd2_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                    c_void_p]),
+    "segmif_add_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                         c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "segmif_layernorm_bwd_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p,
+                                             c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "segmif_prelu_bwd_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                          c_void_p]),
     "segmif_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     "segmif_dwconv3x3_gelu_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "segmif_dwconv3x3_bias_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -211,7 +220,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.restype = res
         fn.argtypes = args
-    if lib.segmif_abi_version() != 2:
+    if lib.segmif_abi_version() != 3:
         raise HipLibraryMissing("libsegmif_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

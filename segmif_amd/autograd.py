@@ -30,16 +30,41 @@ def colsum(x2d, out=None, accumulate=False):
     return out
 
 
-def act_bwd(dy, ref, act, slope=None, out=None):
+class Out:
+    """An output placement (a rows view of a wider buffer: a DRDB's concat buffer, the two halves of conv2's input) handed to a
+    Function as a NON-tensor argument: the kernel writes there and the Function returns it as its (fresh) output."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t.detach()
+
+
+def _rows(t):
+    """t itself when the kernels can address it in place (a rows view on 16-byte boundaries), else a contiguous copy."""
+    try:
+        _, C, ld = rows_view(t, "gradient")
+    except RuntimeError:
+        return t.contiguous()
+    # (an expanded gradient - the ones of loss.sum() - passes rows_view with pitch 0: rows must not overlap)
+    return t if ld >= C and ops.aligned16(t) else t.contiguous()
+
+
+def act_bwd(dy, ref, act, slope=None, out=None, ref2=None):
+    """dx = dy * act'(.) with the activation output `ref` (ref - ref2 when ref2 is given: the output sits under a residual)."""
     rows, C, ldy = rows_view(dy, "dy")
     _, _, ldr = rows_view(ref, "ref")
     dx = torch.empty(dy.shape, device=dy.device, dtype=torch.float32) if out is None else out
     orow, oc, ldx = rows_view(dx, "dx")
     if (orow, oc) != (rows, C):
         raise RuntimeError("act_bwd out shape mismatch")
-    _lib.check(_lib.load().segmif_act_bwd_f32(dy.data_ptr(), ref.data_ptr(), dx.data_ptr(), rows, C, ldy, ldr, ldx, act,
-                                              slope.data_ptr() if slope is not None else None, _stream()),
-               "segmif_act_bwd_f32")
+    sl = slope.data_ptr() if slope is not None else None
+    if ref2 is not None:
+        _, _, ldr2 = rows_view(ref2, "ref2")
+        _lib.check(_lib.load().segmif_act_bwd2_f32(dy.data_ptr(), ref.data_ptr(), ref2.data_ptr(), dx.data_ptr(), rows, C, ldy, ldr,
+                                                   ldr2, ldx, act, sl, _stream()), "segmif_act_bwd2_f32")
+    else:
+        _lib.check(_lib.load().segmif_act_bwd_f32(dy.data_ptr(), ref.data_ptr(), dx.data_ptr(), rows, C, ldy, ldr, ldx, act,
+                                                  sl, _stream()), "segmif_act_bwd_f32")
     return dx
 
 
@@ -94,16 +119,16 @@ def conv_wgrad(x, dy, w_shape, k, stride, pad, dil, want_bias=False):
 TRAIN_SPLIT_MIN_ROWS = 500000
 
 
-def _gemm(x, w_nk, N, bias=None, act=ACT_NONE):
+def _gemm(x, w_nk, N, bias=None, act=ACT_NONE, res=None, out=None):
     """x @ w_nk^T (+ bias, act) for a plain (N, K) weight matrix: the bf16x6 GEMM for tall problems (same size rule as
     inference, ops.linear_auto), the fp32 tiles otherwise.  Training re-packs per call: the weights change every step."""
     rows, K, _ = rows_view(x, "x")
     # (measured at 8 images per step: with the per-call weight packing the bf16x6 GEMM only pays for the full-resolution
     # problems of the fusion net; the encoder's Linears - at most 153 600 rows - are 2.5 ms per step faster on the fp32 tiles)
     if rows >= TRAIN_SPLIT_MIN_ROWS and ops.linear_wants_split(rows, N, K):
-        return ops.linear_auto(x, ops.pack_linear(w_nk, half=False), N, bias=bias, act=act)
+        return ops.linear_auto(x, ops.pack_linear(w_nk, half=False), N, bias=bias, act=act, res=res, out=out)
     wt = w_nk if (K % 16 == 0 and w_nk.is_contiguous()) else ops.pack_weight(w_nk)
-    return ops.linear(x, wt, N, bias=bias, act=act)
+    return ops.linear(x, wt, N, bias=bias, act=act, res=res, out=out)
 
 
 def _no_prelu(act):
@@ -118,11 +143,11 @@ class LinearFn(torch.autograd.Function):
     """y = act(x @ w^T + b); w is the raw (N, K) Linear weight or a (N, K, 1, 1) conv weight."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, slope):
+    def forward(ctx, x, w, b, act, slope, out=None):
         _no_prelu(act)
         N = w.shape[0]
         w2 = w.reshape(N, -1)
-        y = _gemm(x, w2.detach().contiguous(), N, bias=b, act=act)
+        y = _gemm(x, w2.detach().contiguous(), N, bias=b, act=act, out=out.t if out is not None else None)
         ctx.act = act
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.has_bias = b is not None
@@ -134,7 +159,7 @@ class LinearFn(torch.autograd.Function):
         N = w.shape[0]
         w2 = w.reshape(N, -1)
         K = w2.shape[1]
-        dy = dy.contiguous()
+        dy = _rows(dy)  # (a channel slice of a concatenated gradient is read in place)
         dz = act_bwd(dy, y, ACT_RELU) if ctx.act == ACT_RELU else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -146,7 +171,7 @@ class LinearFn(torch.autograd.Function):
             dw = dw.reshape(w.shape)
         elif want_b:
             db = colsum(dz)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def _pack_conv(w, k, stride, pad, dil):
@@ -193,12 +218,10 @@ class ConvFn(torch.autograd.Function):
                 wt = w.permute(2, 3, 1, 0).reshape(k * k * cin, N).contiguous()  # [(ky,kx,c)][n]
                 wt = wt if N % 16 == 0 else ops.pack_weight(wt)
                 cols = ops.linear(dz.view(B, OH * OW, N), wt, k * k * cin)
-                cols = cols.view(B, OH, OW, k, k, cin).permute(0, 1, 3, 2, 4, 5).reshape(B, OH * k, OW * k, cin)
-                if OH * k == H and OW * k == W:
-                    dx = cols.contiguous()
-                else:  # rows / columns the forward conv dropped receive no gradient
-                    dx = torch.zeros((B, H, W, cin), device=x.device, dtype=torch.float32)
-                    dx[:, :OH * k, :OW * k] = cols
+                # patch -> image gather (rows / columns the forward conv dropped receive zeros)
+                dx = torch.empty((B, H, W, cin), device=x.device, dtype=torch.float32)
+                _lib.check(_lib.load().segmif_col2im_f32(cols.data_ptr(), dx.data_ptr(), B, H, W, cin, k, k, 0, OH, OW, _stream()),
+                           "segmif_col2im_f32")
             elif dil == 1:
                 # overlapping strided conv (patch embeds): cols = dY W^T on the matrix pipe, then a gather (col2im)
                 OH, OW = dz.shape[1], dz.shape[2]
@@ -225,35 +248,54 @@ class ConvFn(torch.autograd.Function):
 class PReluFn(torch.autograd.Function):
     """y = z > 0 ? z : a z with the fusion net's shared scalar slope `a` (core/model_fusion.py:1038).  A node of its own on
     the training path: the backward branches on the saved PRE-activation, so it is exact for any slope (nn.PReLU trains
-    through a <= 0; AdamW's weight decay can take it there), and d loss / d a comes out of the same kernel."""
+    through a <= 0; AdamW's weight decay can take it there), and d loss / d a comes out of the same kernel.
+    out: optional Out placement (a DRDB buffer's first channels: the block then starts without a copy)."""
 
     @staticmethod
-    def forward(ctx, z, slope):
+    def forward(ctx, z, slope, out=None):
         z = z.contiguous()
-        y = torch.empty_like(z)
-        _lib.check(_lib.load().segmif_prelu_f32(z.data_ptr(), _req(slope, "slope").data_ptr(), y.data_ptr(), z.numel(), _stream()),
-                   "segmif_prelu_f32")
+        if out is None:
+            y = torch.empty_like(z)
+            _lib.check(_lib.load().segmif_prelu_f32(z.data_ptr(), _req(slope, "slope").data_ptr(), y.data_ptr(), z.numel(), _stream()),
+                       "segmif_prelu_f32")
+        else:  # rows-view form of the same map: z * (z >= 0 ? 1 : a)
+            y = act_bwd(z, z, ACT_PRELU, slope=_req(slope, "slope"), out=out.t)
         ctx.save_for_backward(z, slope)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         z, slope = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy = _rows(dy)
         lib = _lib.load()
         n = z.numel()
         dz = torch.empty_like(z)
         part = torch.empty((2 * (lib.segmif_prelu_bwd_blocks(n) + 1),), device=z.device, dtype=torch.float64)
         dslope = torch.empty((1,), device=z.device, dtype=torch.float32)
-        _lib.check(lib.segmif_prelu_bwd_f32(dy.data_ptr(), z.data_ptr(), slope.data_ptr(), dz.data_ptr(), part.data_ptr(),
-                                            dslope.data_ptr(), n, _stream()), "segmif_prelu_bwd_f32")
-        return dz, (dslope.reshape(slope.shape) if ctx.needs_input_grad[1] else None)
+        if dy.is_contiguous():
+            _lib.check(lib.segmif_prelu_bwd_f32(dy.data_ptr(), z.data_ptr(), slope.data_ptr(), dz.data_ptr(), part.data_ptr(),
+                                                dslope.data_ptr(), n, _stream()), "segmif_prelu_bwd_f32")
+        else:  # a channel slice of a wider gradient buffer (the DRDB's), read in place
+            rows, C, ldy = rows_view(dy, "dy")
+            _lib.check(lib.segmif_prelu_bwd_rows_f32(dy.data_ptr(), ldy, z.data_ptr(), slope.data_ptr(), dz.data_ptr(),
+                                                     part.data_ptr(), dslope.data_ptr(), rows, C, _stream()),
+                       "segmif_prelu_bwd_rows_f32")
+        return dz, (dslope.reshape(slope.shape) if ctx.needs_input_grad[1] else None), None
+
+
+def _ln_param_grads(partial, C, want):
+    if not want:
+        return None, None
+    gb = colsum(partial)
+    return gb[:C], gb[C:]
 
 
 class LayerNormFn(torch.autograd.Function):
+    """out: optional Out placement for the result (a rows view of a wider buffer)."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
-        y = ops.layernorm(x, gamma, beta, eps)
+    def forward(ctx, x, gamma, beta, eps, out=None):
+        y = ops.layernorm(x, gamma, beta, eps, out=out.t if out is not None else None)
         ctx.eps = eps
         ctx.save_for_backward(x, gamma)
         return y
@@ -261,19 +303,85 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy = _rows(dy)  # (a channel slice of a concatenated gradient is read in place)
         rows, C, ldx = rows_view(x, "x")
+        _, _, ldy = rows_view(dy, "dy")
         lib = _lib.load()
         nblk = lib.segmif_layernorm_bwd_blocks(rows, C)
         partial = torch.empty((nblk, 2 * C), device=x.device, dtype=torch.float32)
         dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
         _lib.check(lib.segmif_layernorm_bwd_f32(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
-                                                partial.data_ptr(), rows, C, ldx, C, C, float(ctx.eps), _stream()),
+                                                partial.data_ptr(), rows, C, ldx, ldy, C, float(ctx.eps), _stream()),
                    "segmif_layernorm_bwd_f32")
-        if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
-            return dx, None, None, None
-        gb = colsum(partial)
-        return dx, gb[:C], gb[C:], None
+        dg, db = _ln_param_grads(partial, C, ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, dg, db, None, None
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """(x, branch, scale) -> (s, n):  s = x + scale[b] * branch,  n = LayerNorm(s)      (core/mix_transformer.py:171-177)
+
+    The residual add, the per-sample DropPath factor (scale (B,) = mask / keep, or None) and the NEXT LayerNorm of a
+    transformer block as one node and one kernel each way.  With branch = None it is a LayerNorm that also hands its input
+    on (s is x).  Why a node with two outputs: s feeds the next residual and n feeds the next branch, so in the backward the
+    gradient of the sum (ds) and the LayerNorm's input gradient meet HERE - one kernel forms dx = ds + LN'(dn) (and
+    dbranch = scale * dx) where autograd would otherwise run an accumulation pass (and a multiply) per residual connection:
+    112 + 108 elementwise launches per mit_b3 segmentation step in round 3."""
+
+    @staticmethod
+    def forward(ctx, x, branch, scale, gamma, beta, eps):
+        ctx.set_materialize_grads(False)
+        ctx.eps = eps
+        ctx.has_branch = branch is not None
+        if branch is None:
+            n = ops.layernorm(x, gamma, beta, eps)
+            ctx.save_for_backward(x, gamma, None)
+            return x, n
+        if x.shape != branch.shape or x.dim() != 3:
+            raise RuntimeError(f"AddLayerNormFn: token tensors (B, N, C) of one shape expected, got {tuple(x.shape)} / {tuple(branch.shape)}")
+        x, branch = x.contiguous(), branch.contiguous()
+        B, N, C = x.shape
+        if scale is not None:
+            scale = _req(scale, "scale").contiguous()
+            if scale.numel() != B:
+                raise RuntimeError("AddLayerNormFn: one scale per image")
+        if not ops.aligned16(gamma, beta):
+            gamma, beta = gamma.detach().clone(), beta.detach().clone()
+        s = torch.empty_like(x)
+        n = torch.empty_like(x)
+        _lib.check(_lib.load().segmif_add_layernorm_f32(x.data_ptr(), branch.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                                        N, _req(gamma).data_ptr(), _req(beta).data_ptr(), s.data_ptr(), n.data_ptr(),
+                                                        B * N, C, C, C, C, C, float(eps), _stream()), "segmif_add_layernorm_f32")
+        ctx.save_for_backward(s, gamma, scale)
+        return s, n
+
+    @staticmethod
+    def backward(ctx, ds, dn):
+        s, gamma, scale = ctx.saved_tensors
+        if dn is None:  # the normalised output went nowhere: only the sum's gradient passes through
+            if ds is None:
+                return None, None, None, None, None, None
+            db = None
+            if ctx.has_branch:
+                db = ds if scale is None else ds * scale.view(-1, 1, 1)
+            return ds, db, None, None, None, None
+        dn = _rows(dn)
+        rows, C, lds = rows_view(s, "s")
+        _, _, ldn = rows_view(dn, "dn")
+        if ds is not None:
+            ds = _rows(ds)
+        lib = _lib.load()
+        nblk = lib.segmif_layernorm_bwd_blocks(rows, C)
+        partial = torch.empty((nblk, 2 * C), device=s.device, dtype=torch.float32)
+        dx = torch.empty(s.shape, device=s.device, dtype=torch.float32)
+        scaled = ctx.has_branch and scale is not None
+        dbr = torch.empty(s.shape, device=s.device, dtype=torch.float32) if scaled else None
+        _lib.check(lib.segmif_layernorm_bwd_add_f32(
+            s.data_ptr(), dn.data_ptr(), gamma.data_ptr(), ds.data_ptr() if ds is not None else None,
+            rows_view(ds, "ds")[2] if ds is not None else 0, scale.data_ptr() if scaled else None, s.shape[1] if scaled else 0,
+            dx.data_ptr(), dbr.data_ptr() if scaled else None, C, partial.data_ptr(), rows, C, lds, ldn, C, float(ctx.eps),
+            _stream()), "segmif_layernorm_bwd_add_f32")
+        dg, db = _ln_param_grads(partial, C, ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        return dx, ((dbr if scaled else dx) if ctx.has_branch else None), None, dg, db, None
 
 
 class DwconvGeluFn(torch.autograd.Function):
@@ -352,19 +460,19 @@ class DwconvFn(torch.autograd.Function):
 
 class BilinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, OH, OW):
+    def forward(ctx, x, OH, OW, out=None):
         ctx.in_hw = (x.shape[1], x.shape[2])
-        return ops.bilinear(x, OH, OW)
+        return ops.bilinear(x, OH, OW, out=out.t if out is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
-        dy = dy.contiguous()
+        dy = _rows(dy)  # (a channel slice of the decoder's concatenated gradient is read in place)
         B, OH, OW, C = dy.shape
         IH, IW = ctx.in_hw
         dx = torch.empty((B, IH, IW, C), device=dy.device, dtype=torch.float32)
-        _lib.check(_lib.load().segmif_bilinear_nhwc_bwd_f32(dy.data_ptr(), dx.data_ptr(), B, IH, IW, OH, OW, C, C, C,
-                                                            _stream()), "segmif_bilinear_nhwc_bwd_f32")
-        return dx, None, None
+        _lib.check(_lib.load().segmif_bilinear_nhwc_bwd_f32(dy.data_ptr(), dx.data_ptr(), B, IH, IW, OH, OW, C,
+                                                            rows_view(dy, "dy")[2], C, _stream()), "segmif_bilinear_nhwc_bwd_f32")
+        return dx, None, None, None
 
 
 def _batched_heads_gemm(a, a_ld, a_bs, a_hs, w, w_ld, w_bs, w_hs, out, o_ld, o_bs, o_hs, B, heads, M, N, K):
@@ -405,8 +513,9 @@ class SrAttentionFn(torch.autograd.Function):
         dev = q.device
         lib = _lib.load()
         Lp = (Nk + 15) // 16 * 16  # score row pitch (zero padded so it can be a GEMM K dimension)
-        P = torch.zeros((B, heads, N, Lp), device=dev, dtype=torch.float32)
-        dP = torch.zeros((B, heads, N, Lp), device=dev, dtype=torch.float32)
+        # (the padding columns [Nk, Lp) are zeroed by the row-softmax kernels: no fill pass over the two score tensors)
+        P = torch.empty((B, heads, N, Lp), device=dev, dtype=torch.float32)
+        dP = torch.empty((B, heads, N, Lp), device=dev, dtype=torch.float32)
         kptr, vptr = kv.data_ptr(), kv.data_ptr() + 4 * C
         # S = q k^T ; dP = do v^T    (weights = k / v slices of kv, pitch 2C)
         _batched_heads_gemm(q.data_ptr(), C, N * C, hd, kptr, 2 * C, Nk * 2 * C, hd, P.data_ptr(), Lp,
@@ -426,23 +535,26 @@ class SrAttentionFn(torch.autograd.Function):
                             dq.data_ptr(), C, N * C, hd, B, heads, N, hd, Lp)
         # dk^T[d][key] = sum_n q[n][d] dS[n][key] ; dv^T[d][key] = sum_n do[n][d] P[n][key]  (wgrad form).
         # Written with key stride 2C into a (B, Lp, 2C) buffer: rows >= Nk are padding and are sliced away.
-        dkv = torch.empty((B, Lp, 2 * C), device=dev, dtype=torch.float32)
+        # (key count a multiple of 4: the contraction runs over the Nk real keys only - the kernel pads its own tiles with
+        # zeros - and dkv is exactly (B, Nk, 2C); otherwise over the padded pitch, rows >= Nk sliced away afterwards)
+        Kk = Nk if Nk % 4 == 0 else Lp
+        dkv = torch.empty((B, Kk, 2 * C), device=dev, dtype=torch.float32)
         ws = torch.empty((lib.segmif_wgrad_workspace_size(N, hd, Lp) * B * heads,), device=dev, dtype=torch.float32)
         for src, probs, col0 in ((q, dS, 0), (do, P, C)):
             # every (image, head) in one launch: batch z = b * heads + h
             d = _lib.SegmifIgemm()
             d.in_ = probs.data_ptr()
-            d.M, d.N, d.K, d.lda = N, hd, Lp, Lp
+            d.M, d.N, d.K, d.lda = N, hd, Kk, Lp
             d.H = d.W = d.OH = d.OW = 1
-            d.Cin = Lp
+            d.Cin = Kk
             d.KH = d.KW = d.stride = d.dil = 1
             d.nz, d.nz2 = B, heads
             d.in_zstride, d.in_zstride2 = heads * N * Lp, N * Lp
-            d.out_zstride, d.out_zstride2 = Lp * 2 * C, hd
+            d.out_zstride, d.out_zstride2 = Kk * 2 * C, hd
             # element (n = d, k = key) of (b, h) -> dkv[b][key][col0 + h*hd + d]
             _lib.check(lib.segmif_wgrad_batched2_f32(ctypes.byref(d), src.data_ptr(), C, N * C, hd, dkv.data_ptr() + 4 * col0, 1,
                                                      2 * C, ws.data_ptr(), 0, _stream()), "segmif_wgrad_batched2_f32")
-        return dq, dkv[:, :Nk], None, None
+        return dq, (dkv if Kk == Nk else dkv[:, :Nk]), None, None
 
 
 class SoftmaxCEFn(torch.autograd.Function):
@@ -475,12 +587,18 @@ class DRDBFn(torch.autograd.Function):
     the reference is a channel prefix of it)."""
 
     @staticmethod
-    def forward(ctx, x, *params):  # params = (w1, b1, ..., w5, b5, w6, b6)
+    def forward(ctx, x, home, *params):  # params = (w1, b1, ..., w5, b5, w6, b6)
+        """home: Out holding the (B, H, W, total) buffer whose first C0 channels x already IS (its producer wrote there:
+        PReluFn / LayerNormFn with out=), or None (x is copied in)."""
         B, H, W, C0 = x.shape
         growth = params[0].shape[0]
         total = C0 + 5 * growth
-        buf = torch.empty((B, H, W, total), device=x.device, dtype=torch.float32)
-        buf[..., :C0].copy_(x)
+        if home is not None and tuple(home.t.shape) == (B, H, W, total) and home.t.is_contiguous() \
+                and x.data_ptr() == home.t.data_ptr() and x.stride() == home.t[..., :C0].stride():
+            buf = home.t
+        else:
+            buf = torch.empty((B, H, W, total), device=x.device, dtype=torch.float32)
+            buf[..., :C0].copy_(x)
         ch = C0
         for i in range(5):
             w, b = params[2 * i], params[2 * i + 1]
@@ -496,15 +614,13 @@ class DRDBFn(torch.autograd.Function):
     def backward(ctx, dout):
         buf, out = ctx.saved_tensors[:2]
         params = ctx.saved_tensors[2:]
-        dout = dout.contiguous()
+        dout = _rows(dout)
         B, H, W, total = buf.shape
         C0 = out.shape[-1]
         growth = params[0].shape[0]
         grads = [None] * 12
         w6 = params[10].reshape(C0, total)
-        y6 = out - buf[..., :C0]  # relu output of the 1x1 branch (mask source)
-        dz6 = act_bwd(dout, y6, ACT_RELU)
-        del y6
+        dz6 = act_bwd(dout, out, ACT_RELU, ref2=buf[..., :C0])  # mask source: the 1x1 branch's relu output = out - x
         dbuf = torch.empty_like(buf)
         w6t = w6.t().contiguous()  # (total, C0): input-gradient weights, rows = concat channels
         ops.linear(dz6, w6t[:C0].contiguous(), C0, res=dout, out=dbuf[..., :C0])  # + residual path
@@ -519,19 +635,31 @@ class DRDBFn(torch.autograd.Function):
         # for the x block) outputs: the shape of the forward convs, same total FLOPs.
         dz = torch.empty((B, H, W, 5 * growth), device=buf.device, dtype=torch.float32)  # [dy5 | dy4 | .. | dy1]
         ch = total - growth
+        # block 5's gradient is complete after the 1x1 conv's input gradient: through its ReLU into the first dz slot
+        act_bwd(dbuf[..., ch:ch + growth], buf[..., ch:ch + growth], ACT_RELU, out=dz[..., :growth])
         for i in range(4, -1, -1):
             k = 4 - i
-            dy = act_bwd(dbuf[..., ch:ch + growth], buf[..., ch:ch + growth], ACT_RELU,
-                         out=dz[..., k * growth:(k + 1) * growth])
+            dy = dz[..., k * growth:(k + 1) * growth]
             grads[2 * i], grads[2 * i + 1] = conv_wgrad(buf[..., :ch], dy, params[2 * i].shape, 3, 1, 2, 2, want_bias=True)
             lo = ch - growth if i > 0 else 0
             # rows = the channels of the receiving block, columns = (tap rotated by 180 deg, dz channel)
             wcat = torch.cat([params[2 * q][:, lo:ch].flip(2, 3).transpose(0, 1) for q in range(4, i - 1, -1)], dim=1)
-            ops.conv2d(dz[..., :(k + 1) * growth], ops.pack_conv3x3(wcat.contiguous()), ch - lo, 3, pad=2, dil=2,
-                       res=dbuf[..., lo:ch], out=dbuf[..., lo:ch])
+            packed = ops.pack_conv3x3(wcat.contiguous())
+            src = dz[..., :(k + 1) * growth]
+            if i == 0:  # the block's input x: no activation between it and the convs
+                ops.conv2d(src, packed, ch - lo, 3, pad=2, dil=2, res=dbuf[..., lo:ch], out=dbuf[..., lo:ch])
+            elif isinstance(packed, ops.SplitWeight):
+                # (r4) this conv completes the gradient of block i - 1: its epilogue adds the 1x1 conv's part (res) and writes
+                # the sum through that block's ReLU mask straight into the next dz slot - no mask pass of its own
+                ops.conv2d(src, packed, ch - lo, 3, pad=2, dil=2, res=dbuf[..., lo:ch], out=dz[..., (k + 1) * growth:(k + 2) * growth],
+                           mask=buf[..., lo:ch])
+            else:
+                ops.conv2d(src, packed, ch - lo, 3, pad=2, dil=2, res=dbuf[..., lo:ch], out=dbuf[..., lo:ch])
+                act_bwd(dbuf[..., lo:ch], buf[..., lo:ch], ACT_RELU, out=dz[..., (k + 1) * growth:(k + 2) * growth])
             ch -= growth
-        dx = dbuf[..., :C0].contiguous() if ctx.needs_input_grad[0] else None
-        return (dx, *grads)
+        # (a rows view of the gradient buffer: the consumers - PReluFn / LayerNormFn backward - read it in place)
+        dx = dbuf[..., :C0] if ctx.needs_input_grad[0] else None
+        return (dx, None, *grads)
 
 
 class BatchedLinearFn(torch.autograd.Function):
@@ -553,7 +681,10 @@ class BatchedLinearFn(torch.autograd.Function):
         N = w.shape[1]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(dy, w.transpose(1, 2).contiguous(), K, batched_weight=True)
+            wt = w.transpose(1, 2)  # (B, K, N): the input-gradient GEMM contracts over N
+            if N % 16:  # (its packed form pads the contraction to a multiple of 16: linear_pred's 9 classes)
+                wt = torch.nn.functional.pad(wt, (0, (N + 15) // 16 * 16 - N))
+            dx = ops.linear(dy, wt.contiguous(), K, batched_weight=True)
         if ctx.needs_input_grad[1]:
             d = _lib.SegmifIgemm()
             d.in_ = x.data_ptr()
@@ -617,6 +748,142 @@ class BatchedLinear2Fn(torch.autograd.Function):
         return dxa, dxb, dw, db, (dy if ctx.needs_input_grad[4] else None)
 
 
+def _batched_wgrad(src, dy, dw, k0, n, N, K, db=None):
+    """dw[b][:, k0:k0+kk] = dy[b]^T src[b] per image (src (B, n, kk) rows view, dy (B, n, N) contiguous, dw (B, N, K))."""
+    B, kk = src.shape[0], src.shape[2]
+    d = _lib.SegmifIgemm()
+    d.in_ = src.data_ptr()
+    d.M, d.N, d.K, d.lda = n, N, kk, src.stride(1)
+    d.H = d.W = d.OH = d.OW = 1
+    d.Cin = kk
+    d.KH = d.KW = d.stride = d.dil = 1
+    d.nz = B
+    d.in_zstride = src.stride(0)
+    d.out_zstride = N * K
+    _wgrad(d, dy, N, dw[:, :, k0:], dy_zstride=n * N, sn=K, sk=1, nz=B, db=db)
+
+
+class CrossProjFn(torch.autograd.Function):
+    """The three channel_proj + ReLU of CrossPath (core/model_fusion.py:351-353) as ONE node with every half its own output:
+        (x1, x2, x3) -> (y1, u1, y2, u2, y3, u3, x1, x2),   [y_i | u_i] = relu(x_i W_i^T + b_i)
+    y_i / u_i are the two 64-channel halves of one (B, n, 128) buffer (rows views, nothing copied), x1 / x2 are handed on for
+    the residual of the closing projection.  Every output then has exactly ONE consumer (context reduction or TailPairFn), and
+    the gradients of the halves arrive separately and are written - through the ReLU mask - into the two halves of one dz
+    buffer; the residual's gradient joins the input gradient in that GEMM's epilogue.  The round-3 graph (a Linear node,
+    slices, a separate residual edge) cost 34 GB of autograd accumulation passes and 20 GB of zero-filled slice gradients per
+    8-image step."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, x3, w1, b1, w2, b2, w3, b3):
+        ctx.set_materialize_grads(False)
+        outs, ps = [], []
+        for x, w, b in ((x1, w1, b1), (x2, w2, b2), (x3, w3, b3)):
+            N = w.shape[0]
+            p = _gemm(x, w.detach().contiguous(), N, bias=b, act=ACT_RELU)
+            ps.append(p)
+            outs += [p[..., :N // 2], p[..., N // 2:]]
+        ctx.save_for_backward(x1, x2, x3, w1, w2, w3, *ps)
+        ctx.has_bias = tuple(b is not None for b in (b1, b2, b3))
+        return (*outs, x1, x2)
+
+    @staticmethod
+    def backward(ctx, *g):
+        xs, ws, ps = ctx.saved_tensors[:3], ctx.saved_tensors[3:6], ctx.saved_tensors[6:9]
+        gres = (g[6], g[7], None)
+        grads = [None] * 9
+        for i in range(3):
+            x, w, p = xs[i], ws[i], ps[i]
+            N, K = w.shape
+            h = N // 2
+            dz = torch.empty(p.shape, device=p.device, dtype=torch.float32)
+            for half, gy in ((0, g[2 * i]), (1, g[2 * i + 1])):
+                sl = slice(half * h, half * h + h)
+                if gy is None:
+                    dz[..., sl].zero_()
+                else:
+                    act_bwd(_rows(gy), p[..., sl], ACT_RELU, out=dz[..., sl])
+            if ctx.needs_input_grad[i]:
+                r = _rows(gres[i]) if gres[i] is not None else None
+                grads[i] = _gemm(dz, w.detach().t().contiguous(), K, res=r)  # + the residual's gradient, in the epilogue
+            want_b = ctx.has_bias[i] and ctx.needs_input_grad[4 + 2 * i]
+            if ctx.needs_input_grad[3 + 2 * i]:
+                r = linear_wgrad(x, dz, N, want_bias=want_b)
+                grads[3 + 2 * i], grads[4 + 2 * i] = r if want_b else (r, None)
+            elif want_b:
+                grads[4 + 2 * i] = colsum(dz)
+        return tuple(grads)
+
+
+class TailPairFn(torch.autograd.Function):
+    """Both closing projections of CrossPath (core/model_fusion.py:357-360 with the contexts folded into per-image weights):
+        t_i = x_i + [y3 | u_i] @ weff_i^T + b_i        i = 1, 2
+    as one node (two-source GEMMs, residual in the epilogue).  One node for the pair because y3 feeds both: its two gradient
+    contributions are summed by the second GEMM's epilogue instead of an autograd accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, y3, u1, u2, weff1, weff2, b1, b2, x1, x2):
+        N = weff1.shape[1]
+        ctx.save_for_backward(y3, u1, u2, weff1, weff2)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        t1 = ops.linear(y3, weff1.contiguous(), N, bias=b1, res=x1, x2=u1, batched_weight=True)
+        t2 = ops.linear(y3, weff2.contiguous(), N, bias=b2, res=x2, x2=u2, batched_weight=True)
+        return t1, t2
+
+    @staticmethod
+    def backward(ctx, dt1, dt2):
+        y3, u1, u2, weff1, weff2 = ctx.saved_tensors
+        dt = (dt1.contiguous(), dt2.contiguous())
+        B, n, Ka = y3.shape
+        Kb = u1.shape[2]
+        K, N = Ka + Kb, weff1.shape[1]
+        need = ctx.needs_input_grad
+        dy3 = None
+        du = [None, None]
+        dw = [None, None]
+        db = [None, None]
+        for i, (u, weff) in enumerate(((u1, weff1), (u2, weff2))):
+            wt = weff.detach().transpose(1, 2)  # (B, K, N): rows = the channels of [y3 | u_i]
+            if need[0]:  # the second image of y3's gradient accumulates onto the first
+                dy3 = ops.linear(dt[i], wt[:, :Ka].contiguous(), Ka, res=dy3, out=dy3, batched_weight=True)
+            if need[1 + i]:
+                du[i] = ops.linear(dt[i], wt[:, Ka:].contiguous(), Kb, batched_weight=True)
+            want_b = ctx.has_bias[i] and need[5 + i]
+            if need[3 + i]:
+                dw[i] = torch.empty((B, N, K), device=y3.device, dtype=torch.float32)
+                db[i] = _bias_out(want_b, N, y3)
+                _batched_wgrad(y3, dt[i], dw[i], 0, n, N, K, db=db[i])
+                _batched_wgrad(u, dt[i], dw[i], Ka, n, N, K)
+            elif want_b:
+                db[i] = colsum(dt[i])
+        # (the residuals' gradients are dt_i themselves: CrossProjFn adds them to its input gradients)
+        return dy3, du[0], du[1], dw[0], dw[1], db[0], db[1], (dt[0] if need[7] else None), (dt[1] if need[8] else None)
+
+
+class JoinFn(torch.autograd.Function):
+    """Tensors that ARE consecutive channel slices of one buffer (their producers wrote there: out= placements) -> that buffer:
+    torch.cat(parts, -1) without the copy, and without the slice-gradient copies of its backward."""
+
+    @staticmethod
+    def forward(ctx, whole, *parts):
+        w = whole.t
+        c0 = 0
+        ctx.cuts = []
+        for t in parts:
+            c1 = c0 + t.shape[-1]
+            ref = w[..., c0:c1]
+            if t.data_ptr() != ref.data_ptr() or t.shape != ref.shape or t.stride() != ref.stride():
+                raise RuntimeError("JoinFn: an input is not the expected channel slice of the buffer")
+            ctx.cuts.append((c0, c1))
+            c0 = c1
+        if c0 != w.shape[-1]:
+            raise RuntimeError("JoinFn: the inputs do not cover the buffer")
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        return (None, *(dw[..., a:b] for a, b in ctx.cuts))
+
+
 class KvContextFn(torch.autograd.Function):
     """ctx_raw[b][h] = K^T V per head with [K | V] = y @ wkv^T (no bias): the N-reduction of the linear
     cross attention (core/model_fusion.py:281, 316-318).  Forward = fused projection + reduction kernel
@@ -636,12 +903,12 @@ class KvContextFn(torch.autograd.Function):
         kv = ops.linear(y, wkv.contiguous(), 2 * C)  # (B, n, 128)
         dctx = dctx.float().contiguous()
         # dk = v @ D1^T-form, dv = k @ D2^T-form with block-diagonal (B, 64, 64) weights [out][in]
-        wk = torch.zeros((B, C, C), device=y.device, dtype=torch.float32)
-        wv = torch.zeros((B, C, C), device=y.device, dtype=torch.float32)
-        for h in range(8):
-            sl = slice(8 * h, 8 * h + 8)
-            wk[:, sl, sl] = dctx[:, h]  # dk[.., h8+i] = sum_j dctx[h][i][j] v[.., h8+j]
-            wv[:, sl, sl] = dctx[:, h].transpose(1, 2)  # dv[.., h8+j] = sum_i dctx[h][i][j] k[.., h8+i]
+        # block-diagonal weights, one broadcast product each (not 8 slice assignments):
+        #   wk[b][h8+i][h8+j] = dctx[b][h][i][j]   dk[.., h8+i] = sum_j dctx[h][i][j] v[.., h8+j]
+        #   wv[b][h8+j][h8+i] = dctx[b][h][i][j]   dv[.., h8+j] = sum_i dctx[h][i][j] k[.., h8+i]
+        eye = torch.eye(8, device=y.device, dtype=torch.float32).view(1, 8, 1, 8, 1)
+        wk = (dctx.view(B, 8, 8, 1, 8) * eye).reshape(B, C, C)
+        wv = (dctx.transpose(2, 3).reshape(B, 8, 8, 1, 8) * eye).reshape(B, C, C)
         dkv = torch.empty_like(kv)
         ops.linear(kv[..., C:], wk, C, out=dkv[..., :C], batched_weight=True)
         ops.linear(kv[..., :C], wv, C, out=dkv[..., C:], batched_weight=True)
@@ -902,24 +1169,32 @@ def ycrcb2rgb(ycc, y=None):
     return YCrCb2RgbFn.apply(ycc, y)
 
 
-def linear(x, w, b=None, act=ACT_NONE, slope=None):
+def linear(x, w, b=None, act=ACT_NONE, slope=None, out=None):
     if act == ACT_PRELU:  # the shared PReLU is a node of its own: its backward reads the pre-activation (PReluFn)
-        return PReluFn.apply(LinearFn.apply(x, w, b, ACT_NONE, None), slope)
-    return LinearFn.apply(x, w, b, act, slope)
+        return PReluFn.apply(LinearFn.apply(x, w, b, ACT_NONE, None), slope, out)
+    return LinearFn.apply(x, w, b, act, slope, out)
 
 
-def conv2d(x, w, b=None, k=3, stride=1, pad=0, dil=1, act=ACT_NONE, slope=None):
+def conv2d(x, w, b=None, k=3, stride=1, pad=0, dil=1, act=ACT_NONE, slope=None, out=None):
+    """out (Out placement) is honoured for act == PReLU only (the activation node writes it)."""
     if act == ACT_PRELU:
-        return PReluFn.apply(ConvFn.apply(x, w, b, k, stride, pad, dil, ACT_NONE, None), slope)
+        return PReluFn.apply(ConvFn.apply(x, w, b, k, stride, pad, dil, ACT_NONE, None), slope, out)
+    if out is not None:
+        raise RuntimeError("ag.conv2d: out= needs act == ACT_PRELU")
     return ConvFn.apply(x, w, b, k, stride, pad, dil, act, slope)
 
 
-def prelu(z, slope):
-    return PReluFn.apply(z, slope)
+def prelu(z, slope, out=None):
+    return PReluFn.apply(z, slope, out)
 
 
-def layernorm(x, gamma, beta, eps):
-    return LayerNormFn.apply(x, gamma, beta, eps)
+def layernorm(x, gamma, beta, eps, out=None):
+    return LayerNormFn.apply(x, gamma, beta, eps, out)
+
+
+def add_layernorm(x, branch, scale, gamma, beta, eps):
+    """-> (s, n) = (x + scale[b] * branch, LayerNorm(s)); branch None: (x, LayerNorm(x))."""
+    return AddLayerNormFn.apply(x, branch, scale, gamma, beta, eps)
 
 
 def dwconv(h, w, b, H, W):
@@ -930,8 +1205,8 @@ def dwconv_gelu(h, w, b, H, W):
     return DwconvGeluFn.apply(h, w, b, H, W)
 
 
-def bilinear(x, OH, OW):
-    return BilinearFn.apply(x, OH, OW)
+def bilinear(x, OH, OW, out=None):
+    return BilinearFn.apply(x, OH, OW, out)
 
 
 def sr_attention(q, kv, heads, scale):
@@ -942,8 +1217,8 @@ def softmax_ce(logits_nhwc, labels, ignore_index=255):
     return SoftmaxCEFn.apply(logits_nhwc, labels, ignore_index)
 
 
-def drdb(x, params):
-    return DRDBFn.apply(x, *params)
+def drdb(x, params, home=None):
+    return DRDBFn.apply(x, home, *params)
 
 
 def batched_linear(x, w, bias=None):
@@ -956,6 +1231,19 @@ def batched_linear2(xa, xb, w, bias=None, res=None):
 
 def kv_context(y, wkv):
     return KvContextFn.apply(y, wkv)
+
+
+def cross_proj(x1, x2, x3, w1, b1, w2, b2, w3, b3):
+    return CrossProjFn.apply(x1, x2, x3, w1, b1, w2, b2, w3, b3)
+
+
+def tail_pair(y3, u1, u2, weff1, weff2, b1, b2, x1, x2):
+    return TailPairFn.apply(y3, u1, u2, weff1, weff2, b1, b2, x1, x2)
+
+
+def join(whole, *parts):
+    """whole: Out of the buffer; parts: tensors already living in its consecutive channel slices."""
+    return JoinFn.apply(whole, *parts)
 
 
 def gauss_blur11(x):

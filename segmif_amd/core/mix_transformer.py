@@ -310,17 +310,43 @@ class MixVisionTransformer(nn.Module):
         train = wants_grad(self, x)
         for s in range(stages):
             t, H, W = getattr(self, f"patch_embed{s + 1}")(x)
-            for blk in getattr(self, f"block{s + 1}"):
-                t = blk.forward_train(t, H, W) if train else blk.forward_(t, H, W)
             norm = getattr(self, f"norm{s + 1}")
             if train:
-                t = ag.layernorm(t, norm.weight, norm.bias, norm.eps)
+                t = self._stage_train(getattr(self, f"block{s + 1}"), norm, t, H, W)
             else:
+                for blk in getattr(self, f"block{s + 1}"):
+                    t = blk.forward_(t, H, W)
                 t = ops.layernorm(t, norm.weight, norm.bias, norm.eps, out=t)
             f = t.view(t.shape[0], H, W, t.shape[2])
             feats.append(f)
             x = ops.as_nchw(f)
         return feats
+
+    def _stage_train(self, blocks, norm, t, H, W):
+        """The blocks of one stage + the stage norm on the autograd path, as a chain of ag.add_layernorm nodes: every
+        `x = x + drop_path(branch)` (ref :171-177) is fused with the LayerNorm that reads its result next - the other norm of
+        the same block, norm1 of the next block, or the stage norm - so a residual connection is one kernel forward and one
+        backward (Block.forward_train keeps the plain formulation for a block used on its own)."""
+        stochastic = [blk.training and isinstance(blk.drop_path, _DropPath) and blk.drop_path.drop_prob > 0 for blk in blocks]
+        scales = None
+        if any(stochastic):
+            # timm DropPath, per sample and per branch: every Bernoulli(keep) / keep factor of the stage from ONE draw
+            probs = tuple(1.0 - (blk.drop_path.drop_prob if st else 0.0) for blk, st in zip(blocks, stochastic) for _ in (0, 1))
+            cache = self.__dict__.setdefault("_keep_cache", {})  # (device constants: no host copy inside a captured step)
+            keep = cache.get((probs, t.device))
+            if keep is None:
+                keep = cache[(probs, t.device)] = torch.tensor(probs, dtype=torch.float32, device=t.device).view(-1, 1)
+            scales = torch.bernoulli(keep.expand(-1, t.shape[0])) / keep  # (2 * blocks, B)
+        s, branch, sc = t, None, None
+        for i, blk in enumerate(blocks):
+            s, n = ag.add_layernorm(s, branch, sc, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+            a = blk.attn.forward_train(n, H, W)
+            s, n = ag.add_layernorm(s, a, scales[2 * i] if stochastic[i] else None, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            branch = blk.mlp.forward_train(n, H, W)
+            sc = scales[2 * i + 1] if stochastic[i] else None
+        if branch is None:  # (a stage without blocks)
+            return ag.layernorm(t, norm.weight, norm.bias, norm.eps)
+        return ag.add_layernorm(s, branch, sc, norm.weight, norm.bias, norm.eps)[1]
 
     def forward_features(self, x):
         return [ops.as_nchw(f) for f in self.forward_features_nhwc(x)]

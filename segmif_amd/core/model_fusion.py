@@ -169,8 +169,9 @@ class DRDB(nn.Module):
             ps += [conv.weight, conv.bias]
         return ps + [self.conv.weight, self.conv.bias]
 
-    def forward_train_nhwc(self, x):
-        return ag.drdb(x.contiguous(), self._params())
+    def forward_train_nhwc(self, x, home=None):
+        """home: ag.Out of a new_buffer() whose first in_ch channels x already is (its producer wrote there): no copy in."""
+        return ag.drdb(x if home is not None else x.contiguous(), self._params(), home)
 
     def forward(self, x):
         require_device(x, "DRDB input")
@@ -233,10 +234,8 @@ class _LinearCrossAttention(nn.Module):
 def _block_diag_batched(ctx):
     """(B, h, d, d) contexts [i][j] -> (B, h d, h d) with W[b][h d + j][h d + i] = ctx[b][h][i][j] (q @ ctx == q @ W^T)."""
     B, h, d, _ = ctx.shape
-    w = ctx.new_zeros((B, h * d, h * d))
-    for k in range(h):
-        w[:, k * d:(k + 1) * d, k * d:(k + 1) * d] = ctx[:, k].transpose(1, 2)
-    return w
+    eye = torch.eye(h, device=ctx.device, dtype=ctx.dtype).view(1, h, 1, h, 1)
+    return (ctx.transpose(2, 3).reshape(B, h, d, 1, d) * eye).reshape(B, h * d, h * d)  # one broadcast product, not h slice writes
 
 
 class CrossAttention(_LinearCrossAttention):
@@ -371,32 +370,32 @@ class CrossPath(nn.Module):
             and self.cross_attn2.kv2.bias is None \
             and ops.aligned16(*(p for p in self.parameters() if p.dim() == 1))  # 16-byte bias / LayerNorm loads in the tail
 
-    def forward_tokens_train(self, x1, x2, seg):
+    def forward_tokens_train(self, x1, x2, seg, out1=None, out2=None):
         """autograd path: heavy contractions in HIP Functions, the 8x8 context softmax and the fold into
-        end_proj (tensors of a few KB) in torch autograd."""
+        end_proj (tensors of a few KB) in torch autograd.  out_i: optional ag.Out placements of the two results.
+        (r4) Three nodes carry the full-resolution tensors - ag.cross_proj (the three channel_proj with every 64-channel half
+        its own output), ag.kv_context x 3, ag.tail_pair (both closing projections) - arranged so that each big tensor has one
+        consumer: no autograd accumulation passes, no zero-padded slice gradients."""
         C = self.dim
         heads, d = 8, 8
-        p = [ag.linear(x, getattr(self, f"channel_proj{i}").weight, getattr(self, f"channel_proj{i}").bias,
-                       act=ops.ACT_RELU) for i, x in ((1, x1), (2, x2), (3, seg))]
-        y = [t[..., :C] for t in p]
-        u = [t[..., C:] for t in p]
-        ctx3 = torch.softmax(ag.kv_context(u[2], self.cross_attn.kv3.weight) * self.cross_attn.scale, dim=-2)
-        ctx1 = torch.softmax(ag.kv_context(y[0], self.cross_attn2.kv1.weight) * self.cross_attn2.scale, dim=-2)
-        ctx2 = torch.softmax(ag.kv_context(y[1], self.cross_attn2.kv2.weight) * self.cross_attn2.scale, dim=-2)
-        outs = []
-        for i, (x, ui, ctx_i) in enumerate(((x1, u[0], ctx1), (x2, u[1], ctx2)), start=1):
-            end = getattr(self, f"end_proj{i}")
-            B = x.shape[0]
+        cp = [getattr(self, f"channel_proj{i}") for i in (1, 2, 3)]
+        y1, u1, y2, u2, y3, u3, x1r, x2r = ag.cross_proj(x1, x2, seg, cp[0].weight, cp[0].bias, cp[1].weight, cp[1].bias,
+                                                         cp[2].weight, cp[2].bias)
+        ctx3 = torch.softmax(ag.kv_context(u3, self.cross_attn.kv3.weight) * self.cross_attn.scale, dim=-2)
+        ctx1 = torch.softmax(ag.kv_context(y1, self.cross_attn2.kv1.weight) * self.cross_attn2.scale, dim=-2)
+        ctx2 = torch.softmax(ag.kv_context(y2, self.cross_attn2.kv2.weight) * self.cross_attn2.scale, dim=-2)
+        B = x1.shape[0]
+        weffs = []
+        for end, ctx_i in ((self.end_proj1, ctx1), (self.end_proj2, ctx2)):
             wz = end.weight[:, :C].reshape(C, heads, d).double()  # [n][h][j]; contexts are fp64
             wv = end.weight[:, C:].reshape(C, heads, d).double()
             # Weff[b][n][h*d+i] = sum_j ctx[b][h][i][j] * Wend[n][ofs + h*d + j]
-            weff = torch.cat((torch.einsum("bhij,nhj->bnhi", ctx_i, wz).reshape(B, C, C),
-                              torch.einsum("bhij,nhj->bnhi", ctx3, wv).reshape(B, C, C)), dim=-1).float()
-            # x + [y3 | u_i] @ Weff^T + b as one node (two-source GEMM, residual in the epilogue: no cat, no separate add)
-            t = ag.batched_linear2(y[2], ui, weff, end.bias, x)
-            norm = getattr(self, f"norm{i}")
-            outs.append(ag.layernorm(t, norm.weight, norm.bias, norm.eps))
-        return outs[0], outs[1]
+            weffs.append(torch.cat((torch.einsum("bhij,nhj->bnhi", ctx_i, wz).reshape(B, C, C),
+                                    torch.einsum("bhij,nhj->bnhi", ctx3, wv).reshape(B, C, C)), dim=-1).float())
+        # x_i + [y3 | u_i] @ Weff_i^T + b_i for both modalities as one node (two-source GEMMs, residual in the epilogue)
+        t1, t2 = ag.tail_pair(y3, u1, u2, weffs[0], weffs[1], self.end_proj1.bias, self.end_proj2.bias, x1r, x2r)
+        return (ag.layernorm(t1, self.norm1.weight, self.norm1.bias, self.norm1.eps, out=out1),
+                ag.layernorm(t2, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out2))
 
     def forward(self, x1, x2, segfeature):
         require_device(x1, "CrossPath input")
@@ -418,8 +417,9 @@ class FeatureFusionModule(nn.Module):
         output (returns None, None)."""
         B, H, W, C = x1.shape
         if wants_grad(self, x1, x2, seg):
+            # (out_i: ag.Out placements here - the next DRDB's buffer or the halves of conv2's input)
             r1, r2 = self.cross.forward_tokens_train(x1.reshape(B, H * W, C), x2.reshape(B, H * W, C),
-                                                     seg.reshape(B, H * W, C))
+                                                     seg.reshape(B, H * W, C), out1, out2)
             return r1.view(B, H, W, C), r2.view(B, H, W, C)
         tok = lambda t: None if t is None else t.view(B, H * W, t.shape[-1])
         if self.cross.gram_ok():
@@ -485,20 +485,32 @@ class Fusion_Network3_ac(nn.Module):
         def nhwc1(x):  # x[:, 0:1] as NHWC, autograd-aware
             return x[:, 0:1].permute(0, 2, 3, 1).contiguous()
 
-        def conv_prelu(x, conv):  # (ag.conv2d keeps the shared PReLU a node of its own: exact backward for any slope)
-            return ag.conv2d(x, conv.weight, conv.bias, k=3, pad=1, act=ops.ACT_PRELU, slope=slope)
+        def conv_prelu(x, conv, out=None):  # (ag.conv2d keeps the shared PReLU a node of its own: exact backward for any slope)
+            return ag.conv2d(x, conv.weight, conv.bias, k=3, pad=1, act=ops.ACT_PRELU, slope=slope, out=out)
 
-        x1 = conv_prelu(nhwc1(ir), self.conv1_ir)
-        x2 = conv_prelu(nhwc1(vis), self.conv1_vis)
-        x1 = self.DRDB1.forward_train_nhwc(x1)
-        x2 = self.DRDB2.forward_train_nhwc(x2)
+        def home(drdb):  # a DRDB's concat buffer; its producer writes the first 64 channels in place (no copy in)
+            buf = drdb.new_buffer(B, H, W, ir.device)
+            return ag.Out(buf), ag.Out(buf[..., :drdb.in_ch])
+
+        def tokens_out(o):  # the same placement as a (B, H * W, C) token view (what CrossPath's LayerNorm writes)
+            return ag.Out(o.t.view(B, H * W, o.t.shape[-1])) if o.t.is_contiguous() else \
+                ag.Out(o.t.as_strided((B, H * W, o.t.shape[-1]), (H * W * o.t.stride(2), o.t.stride(2), 1), o.t.storage_offset()))
+
+        h1, o1 = home(self.DRDB1)
+        h2, o2 = home(self.DRDB2)
+        x1 = self.DRDB1.forward_train_nhwc(conv_prelu(nhwc1(ir), self.conv1_ir, o1), h1)
+        x2 = self.DRDB2.forward_train_nhwc(conv_prelu(nhwc1(vis), self.conv1_vis, o2), h2)
         seg = ag.linear(out1.permute(0, 2, 3, 1).contiguous(), self.conv3.weight, self.conv3.bias)
-        x1, x2 = self.ffm.forward_nhwc(x1, x2, seg)
-        x1 = self.DRDB3.forward_train_nhwc(x1)
-        x2 = self.DRDB4.forward_train_nhwc(x2)
+        h1, o1 = home(self.DRDB3)
+        h2, o2 = home(self.DRDB4)
+        x1, x2 = self.ffm.forward_nhwc(x1, x2, seg, out1=tokens_out(o1), out2=tokens_out(o2))
+        x1 = self.DRDB3.forward_train_nhwc(x1, h1)
+        x2 = self.DRDB4.forward_train_nhwc(x2, h2)
         seg = ag.linear(out2.permute(0, 2, 3, 1).contiguous(), self.conv4.weight, self.conv4.bias)
-        x1, x2 = self.ffm.forward_nhwc(x1, x2, seg)
-        f = conv_prelu(torch.cat((x1, x2), dim=-1), self.conv2)
+        # the second interaction writes the two halves of conv2's input in place: no torch.cat, no slice-gradient copies
+        cat = torch.empty((B, H, W, 128), device=ir.device, dtype=torch.float32)
+        x1, x2 = self.ffm.forward_nhwc(x1, x2, seg, out1=tokens_out(ag.Out(cat[..., :64])), out2=tokens_out(ag.Out(cat[..., 64:])))
+        f = conv_prelu(ag.join(ag.Out(cat), x1, x2), self.conv2)
         f = conv_prelu(f, self.conv21)
         f = conv_prelu(f, self.conv22)
         return f.permute(0, 3, 1, 2)

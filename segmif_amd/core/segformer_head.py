@@ -127,11 +127,16 @@ class SegFormerHead(nn.Module):
         c1, c2, c3, c4 = feats
         B, H1, W1, _ = c1.shape
         fuse = self.linear_fuse
+        # every scale writes its slice of the concatenated tensor in place (ag.Out placements + ag.join): no torch.cat, and the
+        # backward reads the slices of the concatenated gradient in place as well
+        E = self.linear_c1.proj.out_features
+        whole = torch.empty((B, H1, W1, 4 * E), device=c1.device, dtype=torch.float32)
         parts = []
-        for mlp, c in ((self.linear_c4, c4), (self.linear_c3, c3), (self.linear_c2, c2)):
-            parts.append(ag.bilinear(ag.linear(c.contiguous(), mlp.proj.weight, mlp.proj.bias), H1, W1))
-        parts.append(ag.linear(c1.contiguous(), self.linear_c1.proj.weight, self.linear_c1.proj.bias))
-        cat = torch.cat(parts, dim=-1)
+        for slot, (mlp, c) in enumerate(((self.linear_c4, c4), (self.linear_c3, c3), (self.linear_c2, c2))):
+            parts.append(ag.bilinear(ag.linear(c.contiguous(), mlp.proj.weight, mlp.proj.bias), H1, W1,
+                                     out=ag.Out(whole[..., slot * E:(slot + 1) * E])))
+        parts.append(ag.linear(c1.contiguous(), self.linear_c1.proj.weight, self.linear_c1.proj.bias, out=ag.Out(whole[..., 3 * E:])))
+        cat = ag.join(ag.Out(whole), *parts)
         w = fuse.conv.weight.flatten(1)
         b = fuse.conv.bias
         if fuse.with_norm and self.training:
@@ -153,8 +158,15 @@ class SegFormerHead(nn.Module):
                 w = w * s[:, None]
                 b = fuse.bn.bias - fuse.bn.running_mean * s
             y = ag.linear(cat, w, b, act=ops.ACT_RELU)
-        if self.training:
-            y = self.dropout(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+        if self.training and self.dropout.p > 0:
+            # Dropout2d(0.1) zeroes whole channels per sample and scales the rest by 1 / keep (ref :1090-1097 via mmseg's head):
+            # (y * m_b) @ W^T == y @ (W * m_b)^T, so the mask goes onto per-image copies of linear_pred's (classes x E) weight - a
+            # few KB - instead of two full passes over the (B, H/4, W/4, E) tensor (forward multiply + its backward)
+            E = y.shape[-1]
+            keep = 1.0 - self.dropout.p
+            mask = torch.empty((B, 1, E), device=y.device, dtype=torch.float32).bernoulli_(keep) / keep
+            wb = self.linear_pred.weight.flatten(1).unsqueeze(0) * mask
+            return ag.batched_linear(y.reshape(B, H1 * W1, E), wb, self.linear_pred.bias).view(B, H1, W1, -1)
         return ag.linear(y, self.linear_pred.weight, self.linear_pred.bias)
 
     def forward_nhwc(self, feats):

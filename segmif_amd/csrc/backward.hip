@@ -20,7 +20,10 @@ template <int G, int IT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ partial, long long rows, int C, int ldx,
-                                                            int ldy, int lddx, float eps, int rows_per_block) {
+                                                            int ldy, int lddx, float eps, int rows_per_block,
+                                                            const float* __restrict__ dres, int lddres,
+                                                            const float* __restrict__ scale, long long rpi,
+                                                            float* __restrict__ dbr, int lddbr) {
   constexpr int SLOTS = 256 / G;
   __shared__ float red[256 * IT * 4];
   const int tid = threadIdx.x, sub = tid % G, slot = tid / G;
@@ -92,7 +95,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           const float xh = (xv[it][e] - mean) * rstd;
           o[e] = rstd * (gy[it][e] * gm[it][e] - m1 - xh * m2);
         }
+        if (dres) {  // residual form: the gradient arriving at the sum itself joins here (no separate accumulation pass)
+          const f32x4 rr4 = *reinterpret_cast<const f32x4*>(dres + row * lddres + 4 * u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += rr4[e];
+        }
         *reinterpret_cast<f32x4*>(dx + row * lddx + 4 * u) = o;
+        if (dbr) {  // ... and the branch's gradient is the same row times its per-sample stochastic-depth factor
+          const float sc = scale[row / rpi];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] *= sc;
+          *reinterpret_cast<f32x4*>(dbr + row * lddbr + 4 * u) = o;
+        }
       }
     }
   }
@@ -122,11 +136,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+struct LnBwdAdd {  // residual form (autograd.AddLayerNormFn): dx += dres; dbr = scale[row / rpi] * dx.  All zero: plain backward.
+  const float* dres = nullptr; int lddres = 0; const float* scale = nullptr; long long rpi = 1; float* dbr = nullptr; int lddbr = 0;
+};
+
 template <int G, int IT>
 int launch_ln_bwd(const float* x, const float* dy, const float* g, float* dx, float* partial, long long rows, int C,
-                  int ldx, int ldy, int lddx, float eps, int rpb, int nblk, hipStream_t s) {
+                  int ldx, int ldy, int lddx, float eps, int rpb, int nblk, hipStream_t s, const LnBwdAdd& a) {
   hipLaunchKernelGGL((layernorm_bwd_kernel<G, IT>), dim3((unsigned)nblk), dim3(256), 0, s, x, dy, g, dx, partial, rows,
-                     C, ldx, ldy, lddx, eps, rpb);
+                     C, ldx, ldy, lddx, eps, rpb, a.dres, a.lddres, a.scale, a.rpi, a.dbr, a.lddbr);
   return (int)hipGetLastError();
 }
 
@@ -357,6 +375,7 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ s,
   for (int i = 0; i < 16; ++i) {
     const int j = lane + 64 * i;
     if (j < L) p[j] = v[i] * inv;
+    else if (j < ld) p[j] = 0.f;  // pitch padding: a later GEMM contracts over the whole pitch
   }
 }
 
@@ -382,6 +401,7 @@ __global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const float* __res
   for (int i = 0; i < 16; ++i) {
     const int j = lane + 64 * i;
     if (j < L) dr[j] = pv[i] * (dv[i] - dot) * scale;
+    else if (j < ld) dr[j] = 0.f;
   }
 }
 
@@ -668,8 +688,8 @@ extern "C" int segmif_layernorm_bwd_blocks(int64_t rows, int C) {
   return (int)((rows + rpb - 1) / rpb);
 }
 
-extern "C" int segmif_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx, float* partial,
-                                        int64_t rows, int C, int ldx, int ldy, int lddx, float eps, void* stream) {
+static int ln_bwd_dispatch(const float* x, const float* dy, const float* gamma, float* dx, float* partial, int64_t rows, int C,
+                           int ldx, int ldy, int lddx, float eps, void* stream, const LnBwdAdd& a) {
   if (!x || !dy || !gamma || !dx || !partial || rows <= 0 || C <= 0 || (C & 3) || C > 1024 || (ldx & 3) || (ldy & 3) ||
       (lddx & 3))
     return SEGMIF_EINVAL;
@@ -685,12 +705,29 @@ extern "C" int segmif_layernorm_bwd_f32(const float* x, const float* dy, const f
   hipStream_t s = (hipStream_t)stream;
   // partial rows beyond nblk2 (if any) must not be read: zero them
   if (nblk2 < nblk) hipMemsetAsync(partial + (long long)nblk2 * 2 * C, 0, (size_t)(nblk - nblk2) * 2 * C * sizeof(float), s);
-  if (nvec <= 8) return launch_ln_bwd<8, 1>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s);
-  if (nvec <= 16) return launch_ln_bwd<16, 1>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s);
-  if (nvec <= 32) return launch_ln_bwd<32, 1>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s);
-  if (nvec <= 64) return launch_ln_bwd<64, 1>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s);
-  if (nvec <= 128) return launch_ln_bwd<64, 2>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s);
-  return launch_ln_bwd<64, 4>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s);
+  if (nvec <= 8) return launch_ln_bwd<8, 1>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s, a);
+  if (nvec <= 16) return launch_ln_bwd<16, 1>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s, a);
+  if (nvec <= 32) return launch_ln_bwd<32, 1>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s, a);
+  if (nvec <= 64) return launch_ln_bwd<64, 1>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s, a);
+  if (nvec <= 128) return launch_ln_bwd<64, 2>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s, a);
+  return launch_ln_bwd<64, 4>(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, rpb_al, nblk2, s, a);
+}
+
+extern "C" int segmif_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx, float* partial,
+                                        int64_t rows, int C, int ldx, int ldy, int lddx, float eps, void* stream) {
+  return ln_bwd_dispatch(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, stream, LnBwdAdd());
+}
+
+extern "C" int segmif_layernorm_bwd_add_f32(const float* x, const float* dy, const float* gamma, const float* dres, int lddres,
+                                            const float* scale, int64_t rows_per_image, float* dx, float* dbranch, int lddbr,
+                                            float* partial, int64_t rows, int C, int ldx, int ldy, int lddx, float eps,
+                                            void* stream) {
+  if ((dres && ((lddres & 3) || ((uintptr_t)dres & 15))) || (dbranch && (!scale || (lddbr & 3) || ((uintptr_t)dbranch & 15))))
+    return SEGMIF_EINVAL;
+  if (scale && (rows_per_image <= 0 || rows % rows_per_image)) return SEGMIF_EINVAL;
+  LnBwdAdd a;
+  a.dres = dres; a.lddres = lddres; a.scale = scale; a.rpi = scale ? rows_per_image : 1; a.dbr = dbranch; a.lddbr = lddbr;
+  return ln_bwd_dispatch(x, dy, gamma, dx, partial, rows, C, ldx, ldy, lddx, eps, stream, a);
 }
 
 extern "C" int64_t segmif_dwconv_bwd_partial_rows(int B, int H, int W) {
@@ -745,14 +782,14 @@ extern "C" int segmif_bilinear_nhwc_bwd_f32(const float* dy, float* dx, int B, i
 }
 
 extern "C" int segmif_row_softmax_f32(float* s, int64_t rows, int L, int ld, float scale, void* stream) {
-  if (!s || rows <= 0 || L <= 0 || L > 1024 || ld < L) return SEGMIF_EINVAL;
+  if (!s || rows <= 0 || L <= 0 || ld > 1024 || ld < L) return SEGMIF_EINVAL;
   hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s,
                      (long long)rows, L, ld, scale);
   return (int)hipGetLastError();
 }
 
 extern "C" int segmif_row_softmax_bwd_f32(const float* p, float* dp, int64_t rows, int L, int ld, float scale, void* stream) {
-  if (!p || !dp || rows <= 0 || L <= 0 || L > 1024 || ld < L) return SEGMIF_EINVAL;
+  if (!p || !dp || rows <= 0 || L <= 0 || ld > 1024 || ld < L) return SEGMIF_EINVAL;
   hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp,
                      (long long)rows, L, ld, scale);
   return (int)hipGetLastError();

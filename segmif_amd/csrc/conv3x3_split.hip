@@ -316,6 +316,7 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
         else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
         else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
         if (p.res) y += p.res[m * p.ldr + n];
+        if (p.mask && !(p.mask[m * p.ldm + n] > 0.f)) y = 0.f;  // DRDB backward: through the receiving block's ReLU
         p.out[m * p.ldo + n] = y;
       }
     }

@@ -639,6 +639,7 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
   const int rc = igemm_resolve(d, k, mode, tile, nz, halo);
   if (rc != 0) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (d->relu_mask && !(halo && tile == kSplitTile)) return SEGMIF_EINVAL;  // the mask epilogue exists in the split 3x3 kernel only
   if (halo) return tile == kSplitTile ? conv3x3_split_launch(k, s) : conv3x3_halo_launch(k, tile - kHaloTile0, s);
   if (k.splitk > 1) {
     if (!d->workspace || d->workspace_floats < (int64_t)k.splitk * k.M * k.N) k.splitk = 1;  // no room: plain launch
@@ -672,6 +673,8 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   k.nz2 = d->nz2 > 0 ? d->nz2 : 1;
   k.in_zs2 = d->in_zstride2; k.wt_zs2 = d->wt_zstride2; k.out_zs2 = d->out_zstride2; k.res_zs2 = d->res_zstride2;
   k.ln_gamma = d->ln_gamma; k.ln_beta = d->ln_beta; k.ln_eps = d->ln_eps;
+  k.mask = d->relu_mask; k.ldm = d->ld_mask;
+  if (k.mask && k.ldm < d->N) return SEGMIF_EINVAL;
   if (k.ln_gamma && (!k.ln_beta || d->N != 64 || d->act != SEGMIF_ACT_NONE)) return SEGMIF_EINVAL;
   k.ldw = d->ldw > 0 ? d->ldw : k.Kp;
   if (k.ldw % 4) return SEGMIF_EINVAL;

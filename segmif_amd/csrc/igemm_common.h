@@ -38,6 +38,8 @@ struct IgemmK {
   int pl_f16;             // planes are f16x3 half pairs (64 bytes per pixel) instead of bf16 triples (96)
   uint32_t* pl_amax;      // f16x3: range slots receiving max |output| (planes16.h) or null
   int pl_amax_images;     // > 1: one slot per image (M = images x OH x OW), else everything reports to pl_amax[0]
+  const float* mask;  // split 3x3 tile only: out = mask[m][n] > 0 ? y : 0, applied after the residual (DRDB backward)
+  int ldm;
   int vec4;  // epilogue may use 16-byte accesses: N, ldo, ldr, z strides multiples of 4 and out / res / bias / ws 16-byte aligned
 };
 

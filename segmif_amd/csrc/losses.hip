@@ -248,17 +248,19 @@ __global__ __launch_bounds__(256) void prelu_kernel(const float* __restrict__ z,
 template <int V>
 __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                         const float* __restrict__ slope, float* __restrict__ dz,
-                                                        double* __restrict__ partial, long long nv) {
+                                                        double* __restrict__ partial, long long nv, int upr, long long lddy) {
+  // upr > 0: dy is a rows view (upr V-element units per row, pitch lddy floats) - a channel slice of a wider gradient buffer
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   double s = 0.0;
   if (i < nv) {
     const float a = slope[0];
     float g[V], v[V], o[V];
+    const float* gp = upr ? dy + (i / upr) * lddy + (i % upr) * V : dy + i * V;
     if (V == 4) {
-      *reinterpret_cast<float4*>(g) = reinterpret_cast<const float4*>(dy)[i];
+      *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(gp);
       *reinterpret_cast<float4*>(v) = reinterpret_cast<const float4*>(z)[i];
     } else {
-      g[0] = dy[i];
+      g[0] = gp[0];
       v[0] = z[i];
     }
     float t = 0.f;
@@ -371,21 +373,32 @@ extern "C" int segmif_prelu_f32(const float* z, const float* slope, float* y, in
 
 extern "C" int segmif_prelu_bwd_blocks(int64_t n) { return (int)((n + 255) / 256); }  // upper bound for both paths
 
-extern "C" int segmif_prelu_bwd_f32(const float* dy, const float* z, const float* slope, float* dz, double* partial,
-                                    float* dslope, int64_t n, void* stream) {
+static int prelu_bwd_dispatch(const float* dy, const float* z, const float* slope, float* dz, double* partial, float* dslope,
+                              int64_t n, int C, int64_t lddy, void* stream) {
   if (!dy || !z || !slope || !dz || !partial || !dslope || n <= 0) return SEGMIF_EINVAL;
   int nblk;
-  if (prelu_vec(dy, z, dz, n)) {
+  if (prelu_vec(dy, z, dz, n) && !(C & 3) && !(lddy & 3)) {
     nblk = (int)((n / 4 + 255) / 256);
     hipLaunchKernelGGL(prelu_bwd_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, z, slope, dz, partial,
-                       (long long)(n / 4));
+                       (long long)(n / 4), C / 4, (long long)lddy);
   } else {
     nblk = (int)((n + 255) / 256);
     hipLaunchKernelGGL(prelu_bwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, z, slope, dz, partial,
-                       (long long)n);
+                       (long long)n, C, (long long)lddy);
   }
   // partial holds 2 * (segmif_prelu_bwd_blocks(n) + 1) doubles: the pair after the last block's receives the fixed-order sum
   hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk, partial + 2 * (long long)nblk);
   hipLaunchKernelGGL(f64_to_f32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, partial + 2 * (long long)nblk, dslope);
   return (int)hipGetLastError();
+}
+
+extern "C" int segmif_prelu_bwd_f32(const float* dy, const float* z, const float* slope, float* dz, double* partial,
+                                    float* dslope, int64_t n, void* stream) {
+  return prelu_bwd_dispatch(dy, z, slope, dz, partial, dslope, n, 0, 0, stream);
+}
+
+extern "C" int segmif_prelu_bwd_rows_f32(const float* dy, int64_t lddy, const float* z, const float* slope, float* dz, double* partial,
+                                         float* dslope, int64_t rows, int C, void* stream) {
+  if (rows <= 0 || C <= 0 || lddy < C) return SEGMIF_EINVAL;
+  return prelu_bwd_dispatch(dy, z, slope, dz, partial, dslope, rows * C, C, lddy, stream);
 }

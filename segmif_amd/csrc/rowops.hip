@@ -16,10 +16,15 @@ namespace {
 // LayerNorm: G lanes cooperate on one row (G = 8..64, power of two), values stay in registers,
 // two-pass mean / biased variance like aten's (core/mix_transformer.py:152-153 etc.).
 // ---------------------------------------------------------------------------------------------
+// Residual form (training path, autograd.AddLayerNormFn): br != NULL normalises s = x + scale[row / rpi] * br (scale NULL = 1:
+// rpi rows per image, the per-sample stochastic-depth factor) and also stores s - the residual add, the DropPath multiply and
+// the LayerNorm of a transformer block in one pass.
 template <int G, int IT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
-                                                        long long rows, int C, int ldx, int ldy, float eps) {
+                                                        long long rows, int C, int ldx, int ldy, float eps,
+                                                        const float* __restrict__ br, int ldb, const float* __restrict__ scale,
+                                                        long long rpi, float* __restrict__ sum_out, int lds) {
   constexpr int RPB = 256 / G;  // rows per block
   const int tid = threadIdx.x;
   const int sub = tid % G;
@@ -32,7 +37,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int it = 0; it < IT; ++it) {
     const int u = sub + it * G;
     v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row_ok && u < nvec) v[it] = *reinterpret_cast<const f32x4*>(x + row * ldx + 4 * u);
+    if (row_ok && u < nvec) {
+      v[it] = *reinterpret_cast<const f32x4*>(x + row * ldx + 4 * u);
+      if (br) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(br + row * ldb + 4 * u);
+        const float sc = scale ? scale[row / rpi] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[it][e] = fmaf(sc, b4[e], v[it][e]);
+        *reinterpret_cast<f32x4*>(sum_out + row * lds + 4 * u) = v[it];
+      }
+    }
     sum += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
   }
 #pragma unroll
@@ -67,12 +81,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+struct LnAdd {  // the residual form's extra operands (all zero: plain LayerNorm)
+  const float* br = nullptr; int ldb = 0; const float* scale = nullptr; long long rpi = 1; float* sum_out = nullptr; int lds = 0;
+};
+
 template <int G, int IT>
 int launch_ln(const float* x, const float* g, const float* b, float* y, long long rows, int C, int ldx, int ldy,
-              float eps, hipStream_t s) {
+              float eps, hipStream_t s, const LnAdd& a = LnAdd()) {
   constexpr int RPB = 256 / G;
   hipLaunchKernelGGL((layernorm_kernel<G, IT>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, x, g, b, y,
-                     rows, C, ldx, ldy, eps);
+                     rows, C, ldx, ldy, eps, a.br, a.ldb, a.scale, a.rpi, a.sum_out, a.lds);
   return (int)hipGetLastError();
 }
 
@@ -422,6 +440,25 @@ extern "C" int segmif_layernorm_f32(const float* x, const float* gamma, const fl
   if (nvec <= 64) return launch_ln<64, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s);
   if (nvec <= 128) return launch_ln<64, 2>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s);
   return launch_ln<64, 4>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s);
+}
+
+extern "C" int segmif_add_layernorm_f32(const float* x, const float* branch, const float* scale, int64_t rows_per_image,
+                                        const float* gamma, const float* beta, float* sum, float* y, int64_t rows, int C, int ldx,
+                                        int ldb, int lds, int ldy, float eps, void* stream) {
+  if (!x || !branch || !sum || !gamma || !beta || !y || rows <= 0 || C <= 0 || (C & 3) || C > 1024 || ((ldx | ldb | lds | ldy) & 3))
+    return SEGMIF_EINVAL;
+  if (scale && (rows_per_image <= 0 || rows % rows_per_image)) return SEGMIF_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)branch | (uintptr_t)sum | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return SEGMIF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  LnAdd a;
+  a.br = branch; a.ldb = ldb; a.scale = scale; a.rpi = scale ? rows_per_image : 1; a.sum_out = sum; a.lds = lds;
+  const int nvec = C >> 2;
+  if (nvec <= 8) return launch_ln<8, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s, a);
+  if (nvec <= 16) return launch_ln<16, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s, a);
+  if (nvec <= 32) return launch_ln<32, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s, a);
+  if (nvec <= 64) return launch_ln<64, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s, a);
+  if (nvec <= 128) return launch_ln<64, 2>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s, a);
+  return launch_ln<64, 4>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s, a);
 }
 
 // XT output columns per thread (x0 = XT xp ..) and a 3 x (XT + 2) register window: XT + 2 16-byte loads per row serve XT

@@ -992,12 +992,15 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restr
 // PReLU (sign test; PReLU needs slope > 0 for sign(out) == sign(pre)) and the PRE-activation for GELU.
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ref,
                                                       float* __restrict__ dx, long long rows, int C, int ldy, int ldr,
-                                                      int ldx, int act, const float* __restrict__ slope_p) {
+                                                      int ldx, int act, const float* __restrict__ slope_p,
+                                                      const float* __restrict__ ref2, int ldr2) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * C) return;
   const long long row = i / C;
   const int c = (int)(i - row * C);
-  const float g = dy[row * ldy + c], v = ref[row * ldr + c];
+  const float g = dy[row * ldy + c];
+  float v = ref[row * ldr + c];
+  if (ref2) v -= ref2[row * ldr2 + c];  // the activation output is ref - ref2 (a residual was added after it)
   float o;
   if (act == SEGMIF_ACT_RELU) o = v > 0.f ? g : 0.f;
   else if (act == SEGMIF_ACT_PRELU) o = v >= 0.f ? g : g * *slope_p;
@@ -1208,7 +1211,8 @@ extern "C" int segmif_colsum_f32(const float* x, float* out, double* workspace, 
 // 16-byte form of act_bwd_kernel: a block owns `rb` rows and walks their (row, channel quad) units, 32-bit index math only
 __global__ __launch_bounds__(256) void act_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ ref,
                                                           float* __restrict__ dx, long long rows, int c4n, int rb, int ldy, int ldr,
-                                                          int ldx, int act, const float* __restrict__ slope_p) {
+                                                          int ldx, int act, const float* __restrict__ slope_p,
+                                                          const float* __restrict__ ref2, int ldr2) {
   const long long row0 = (long long)blockIdx.x * rb;
   const int nrows = (int)(rows - row0 < rb ? rows - row0 : rb);
   const float a = act == SEGMIF_ACT_PRELU ? *slope_p : 0.f;
@@ -1216,7 +1220,12 @@ __global__ __launch_bounds__(256) void act_bwd_vec_kernel(const float* __restric
     const int r = u / c4n, cq = u - r * c4n;
     const long long row = row0 + r;
     const f32x4 g = *reinterpret_cast<const f32x4*>(dy + row * ldy + 4 * cq);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(ref + row * ldr + 4 * cq);
+    f32x4 v = *reinterpret_cast<const f32x4*>(ref + row * ldr + 4 * cq);
+    if (ref2) {
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(ref2 + row * ldr2 + 4 * cq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] -= v2[e];
+    }
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1232,19 +1241,31 @@ __global__ __launch_bounds__(256) void act_bwd_vec_kernel(const float* __restric
   }
 }
 
-extern "C" int segmif_act_bwd_f32(const float* dy, const float* ref, float* dx, int64_t rows, int C, int ldy, int ldr,
-                                  int ldx, int act, const float* slope, void* stream) {
+static int act_bwd_dispatch(const float* dy, const float* ref, const float* ref2, int ldr2, float* dx, int64_t rows, int C, int ldy,
+                            int ldr, int ldx, int act, const float* slope, void* stream) {
   if (!dy || !ref || !dx || rows <= 0 || C <= 0) return SEGMIF_EINVAL;
   if (act == SEGMIF_ACT_PRELU && !slope) return SEGMIF_EINVAL;
   const long long total = (long long)rows * C;
-  if (!((C | ldy | ldr | ldx) & 3) && !(((uintptr_t)dy | (uintptr_t)ref | (uintptr_t)dx) & 15) && rows < (1ll << 33)) {
+  if (!((C | ldy | ldr | ldx | (ref2 ? ldr2 : 0)) & 3) &&
+      !(((uintptr_t)dy | (uintptr_t)ref | (uintptr_t)dx | (uintptr_t)ref2) & 15) && rows < (1ll << 33)) {
     const int c4n = C >> 2;
     const int rb = c4n >= 1024 ? 1 : 1024 / c4n;  // ~four 16-byte units per thread
     hipLaunchKernelGGL(act_bwd_vec_kernel, dim3((unsigned)((rows + rb - 1) / rb)), dim3(256), 0, (hipStream_t)stream, dy, ref, dx,
-                       (long long)rows, c4n, rb, ldy, ldr, ldx, act, slope);
+                       (long long)rows, c4n, rb, ldy, ldr, ldx, act, slope, ref2, ldr2);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, ref,
-                     dx, (long long)rows, C, ldy, ldr, ldx, act, slope);
+                     dx, (long long)rows, C, ldy, ldr, ldx, act, slope, ref2, ldr2);
   return (int)hipGetLastError();
+}
+
+extern "C" int segmif_act_bwd_f32(const float* dy, const float* ref, float* dx, int64_t rows, int C, int ldy, int ldr,
+                                  int ldx, int act, const float* slope, void* stream) {
+  return act_bwd_dispatch(dy, ref, nullptr, 0, dx, rows, C, ldy, ldr, ldx, act, slope, stream);
+}
+
+extern "C" int segmif_act_bwd2_f32(const float* dy, const float* ref, const float* ref2, float* dx, int64_t rows, int C, int ldy,
+                                   int ldr, int ldr2, int ldx, int act, const float* slope, void* stream) {
+  if (!ref2) return SEGMIF_EINVAL;
+  return act_bwd_dispatch(dy, ref, ref2, ldr2, dx, rows, C, ldy, ldr, ldx, act, slope, stream);
 }

@@ -808,15 +808,18 @@ def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
 
 
 def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
-           tile=-1, tag=None, planes=None, planes_chunk0=0, ln=None, planes_only=False):
+           tile=-1, tag=None, planes=None, planes_chunk0=0, ln=None, planes_only=False, mask=None):
     """NHWC convolution.  x: (B, H, W, Cin) rows view (may be a channel slice of a wider buffer);
     wt packed (N, Kp); out: (B, OH, OW, N) rows view (may be a channel slice) or None.
     planes: optional ops.Planes of the output geometry that also receives the result, split, as chunks
     [planes_chunk0, planes_chunk0 + N / 16) (fp32-packed weights only).
     ln = (gamma, beta, eps): LayerNorm over the N = 64 output channels in the conv's epilogue (conv_ln_fusable).
-    planes_only: write the planes copy and nothing else (returns None): the fp32 tensor has no reader."""
+    planes_only: write the planes copy and nothing else (returns None): the fp32 tensor has no reader.
+    mask: (B, OH, OW, N) rows view; out = mask > 0 ? act(conv + bias) + res : 0 (split 3x3 weights only: the DRDB backward)."""
     if x.dim() != 4:
         raise RuntimeError("conv2d expects (B, H, W, C)")
+    if mask is not None and (planes is not None or ln is not None or not isinstance(wt, SplitWeight)):
+        raise RuntimeError("conv2d: mask= needs split 3x3 weights and no planes / LayerNorm epilogue")
     if planes_only:
         if planes is None or out is not None or res is not None or ln is not None or isinstance(wt, SplitWeight):
             raise RuntimeError("conv2d: planes_only needs a planes buffer, fp32-packed weights and no fp32 output / residual / LayerNorm")
@@ -863,6 +866,11 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
     d.H, d.W, d.Cin, d.KH, d.KW = H, W, cin, k, k
     d.stride, d.pad, d.dil, d.OH, d.OW = stride, pad, dil, OH, OW
     d.act, d.nz, d.tile = act, 1, tile
+    if mask is not None:
+        mrow, mc, ldm = rows_view(mask, "mask")
+        if (mrow, mc) != (orow, N):
+            raise RuntimeError("mask shape mismatch")
+        d.relu_mask, d.ld_mask = mask.data_ptr(), ldm
     if ln is not None:
         if isinstance(wt, SplitWeight) or N != 64 or act != ACT_NONE:
             raise RuntimeError("conv2d: the fused LayerNorm epilogue needs fp32-packed weights, N = 64 and no activation")

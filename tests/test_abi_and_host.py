@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, s), f"{s} declared in segmif_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.segmif_abi_version() == 2
+    assert lib.segmif_abi_version() == 3
     assert lib.segmif_igemm_num_tiles() == 15
     assert lib.segmif_linattn_num_blocks(307200) == 300
 

@@ -544,3 +544,126 @@ def test_drdb_residual_from_its_own_planes(ops):
     y = ops.conv2d(img, ops.pack_weight(wc), 64, 3, pad=1, bias=bc, act=ops.ACT_PRELU, prelu=slope, planes=p1)
     assert ops.conv2d(img, ops.pack_weight(wc), 64, 3, pad=1, bias=bc, act=ops.ACT_PRELU, prelu=slope, planes=p2, planes_only=True) is None
     assert torch.equal(p1.data, p2.data) and torch.equal(g1.maxima(), g2.maxima()) and float(y.abs().max()) > 0
+
+
+# ---- training path: the fused residual / placement nodes (torch's own elementwise kernels out of the steps) ----
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("C,with_branch,with_scale,with_ds", [(64, True, True, True), (320, True, False, True), (512, True, True, False),
+                                                              (128, False, False, True), (64, False, False, False)])
+def test_add_layernorm_node_vs_fp64_autograd(ops, C, with_branch, with_scale, with_ds):
+    """ag.add_layernorm: (s, n) = (x + scale[b] * branch, LayerNorm(s)) forward and backward in one kernel each, against torch
+    autograd in fp64 - with and without the branch, the per-sample factor (one sample dropped: factor 0), and a gradient
+    arriving at s."""
+    from segmif_amd import autograd as ag
+    import torch.nn.functional as F
+    B, N = 3, 70
+    x, br = rnd(B, N, C, seed=1), rnd(B, N, C, seed=2)
+    gamma, beta = rnd(C, seed=3, lo=0.5, hi=1.5), rnd(C, seed=4)
+    w_s, w_n = rnd(B, N, C, seed=5), rnd(B, N, C, seed=6)
+    scale = torch.tensor([0.0, 1 / 0.9, 1 / 0.9]) if with_scale else None
+    leaves = [t.cuda().requires_grad_() for t in (x, br, gamma, beta)]
+    xg, bg, gg, betag = leaves
+    # (the node's input is a non-leaf on the real path; x * 1 keeps the leaf's .grad readable when s is x itself)
+    s, n = ag.add_layernorm(xg * 1.0, bg if with_branch else None, scale.cuda() if with_scale else None, gg, betag, 1e-6)
+    loss = (n * w_n.cuda()).sum() + ((s * w_s.cuda()).sum() if with_ds else 0.0)
+    loss.backward()
+    ref = [t.double().requires_grad_() for t in (x, br, gamma, beta)]
+    s_ref = ref[0] + (ref[1] * (scale.double().view(B, 1, 1) if with_scale else 1.0) if with_branch else 0.0)
+    n_ref = F.layer_norm(s_ref, (C,), ref[2], ref[3], 1e-6)
+    ((n_ref * w_n.double()).sum() + ((s_ref * w_s.double()).sum() if with_ds else 0.0)).backward()
+    assert _rel(s, s_ref.detach()) < 1e-6 and _rel(n, n_ref.detach()) < 1e-5
+    for name, a, b in zip(("x", "branch", "gamma", "beta"), leaves, ref):
+        if name == "branch" and not with_branch:
+            assert a.grad is None
+            continue
+        assert _rel(a.grad, b.grad) < 2e-5, name
+
+
+def test_relu_mask_from_two_references_and_prelu_placement(ops):
+    """act_bwd with the activation output given as ref - ref2 (the DRDB's 1x1 branch: out - x), PReluFn writing into a channel
+    slice of a wider buffer, and its backward reading a channel slice of a wider gradient buffer in place."""
+    from segmif_amd import autograd as ag
+    B, H, W, C, T = 2, 9, 13, 64, 224
+    x, r = rnd(B, H, W, C, seed=1), rnd(B, H, W, C, seed=2).clamp_min(0)
+    dy = rnd(B, H, W, C, seed=3)
+    out = (x + r).cuda()
+    buf = torch.zeros(B, H, W, T).cuda()
+    buf[..., :C] = x.cuda()
+    got = ag.act_bwd(dy.cuda(), out, ops.ACT_RELU, ref2=buf[..., :C])
+    want = dy.cuda() * ((out - buf[..., :C]) > 0)
+    assert torch.equal(got, want)
+    # PReLU: negative slope too (the node branches on the pre-activation)
+    for slope in (0.25, -0.3):
+        z = rnd(B, H, W, C, seed=4).cuda().requires_grad_()
+        a = torch.tensor([slope]).cuda().requires_grad_()
+        home = torch.full((B, H, W, T), 7.0).cuda()
+        y = ag.prelu(z, a, ag.Out(home[..., :C]))
+        assert y.data_ptr() == home.data_ptr() and torch.equal(home[..., C:], torch.full((B, H, W, T - C), 7.0).cuda())
+        gbuf = rnd(B, H, W, T, seed=5).cuda()
+        y.backward(gbuf[..., :C])  # a rows view of a wider gradient buffer
+        zr = z.detach().double().requires_grad_()
+        ar = a.detach().double().requires_grad_()
+        yr = torch.where(zr > 0, zr, ar * zr)
+        yr.backward(gbuf[..., :C].double())
+        assert _rel(y, yr.detach()) < 1e-7 and _rel(z.grad, zr.grad) < 1e-7 and _rel(a.grad, ar.grad) < 1e-5
+
+
+def test_crosspath_training_nodes_vs_fp64_autograd(ops):
+    """CrossPath on the autograd path (ag.cross_proj / kv_context / tail_pair, results placed into wider buffers) against the
+    reference formulation (core/model_fusion.py:329-361) written in torch fp64: outputs and every gradient."""
+    from segmif_amd.core import model_fusion as mf
+    from segmif_amd import autograd as ag
+    torch.manual_seed(0)
+    m = mf.CrossPath(64).cuda()
+    with torch.no_grad():
+        for name, p in m.named_parameters():  # (kv weights small: the context logits stay O(1), the softmax well conditioned)
+            std = 0.1 if p.dim() == 1 else (0.05 if ".kv" in name else 0.2)
+            p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel() + len(name))) * std)
+        m.norm1.weight.add_(1.0)
+        m.norm2.weight.add_(1.0)
+    B, n, C = 2, 37 * 11, 64
+    xs = [rnd(B, n, C, seed=s) for s in (1, 2, 3)]
+    leaves = [t.cuda().requires_grad_() for t in xs]
+    wide = torch.zeros(B, n, 128).cuda()
+    o1, o2 = m.forward_tokens_train(leaves[0] * 1.0, leaves[1] * 1.0, leaves[2] * 1.0, ag.Out(wide[..., :64]), ag.Out(wide[..., 64:]))
+    g1, g2 = rnd(B, n, C, seed=4), rnd(B, n, C, seed=5)
+    ((o1 * g1.cuda()).sum() + (o2 * g2.cuda()).sum()).backward()
+    assert o1.data_ptr() == wide.data_ptr()
+
+    # reference formulation in fp64
+    import copy
+    import torch.nn.functional as F
+    r = copy.deepcopy(m).cpu().double()
+    ref = [t.double().requires_grad_() for t in xs]
+
+    def ctx_of(kv_lin, t):  # ref :303-318 / :263-281
+        kv = kv_lin(t).reshape(B, -1, 2, 8, 8).permute(2, 0, 3, 1, 4)
+        k, v = kv[0], kv[1]
+        return ((k.transpose(-2, -1) @ v) * (8 ** -0.5)).softmax(dim=-2)
+
+    p = [F.relu(getattr(r, f"channel_proj{i}")(t)) for i, t in ((1, ref[0]), (2, ref[1]), (3, ref[2]))]
+    y = [t[..., :C] for t in p]
+    u = [t[..., C:] for t in p]
+    ctx3 = ctx_of(r.cross_attn.kv3, u[2])
+    ctx1, ctx2 = ctx_of(r.cross_attn2.kv1, y[0]), ctx_of(r.cross_attn2.kv2, y[1])
+
+    def apply_ctx(q, ctx):  # ref :283-286
+        return (q.reshape(B, -1, 8, 8).permute(0, 2, 1, 3) @ ctx).permute(0, 2, 1, 3).reshape(B, -1, C)
+
+    v1, v2 = apply_ctx(u[0], ctx3), apply_ctx(u[1], ctx3)
+    z1, z2 = apply_ctx(y[2], ctx1), apply_ctx(y[2], ctx2)
+    r1 = r.norm1(ref[0] + r.end_proj1(torch.cat((z1, v1), dim=-1)))
+    r2 = r.norm2(ref[1] + r.end_proj2(torch.cat((z2, v2), dim=-1)))
+    ((r1 * g1.double()).sum() + (r2 * g2.double()).sum()).backward()
+    assert _rel(o1, r1.detach()) < 1e-4 and _rel(o2, r2.detach()) < 1e-4
+    worst = {}
+    for i, (a, b) in enumerate(zip(leaves, ref)):
+        worst[f"x{i + 1}"] = _rel(a.grad, b.grad)
+    for (name, pa), (_, pb) in zip(m.named_parameters(), r.named_parameters()):
+        worst[name] = _rel(pa.grad, pb.grad)
+    observed("crosspath_train_nodes_worst_grad_rel", max(worst.values()))
+    bad = {k: v for k, v in worst.items() if v > 5e-4}
+    assert not bad, bad

@@ -22,6 +22,7 @@ ap.add_argument("--height", type=int, default=480); ap.add_argument("--width", t
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--graph", action="store_true", help="seg step: forward + backward replayed from a hipGraph")
 ap.add_argument("--train-mode", action="store_true", help="module.train(): DropPath, Dropout2d, BatchNorm batch statistics")
+ap.add_argument("--native-sites", default="", help="write a table of the torch (aten) ops one step still issues, by call site, to this file")
 a = ap.parse_args()
 rank, local_rank, world = dist.env_world()
 torch.cuda.set_device(local_rank)
@@ -56,6 +57,43 @@ else:
     step = lambda: tr.step(ir, vis, mask, labels)
     gflop = {"mit_b3": 2304.0, "mit_b1": 2000.0}.get(a.backbone, 0)
 for _ in range(a.warmup): l = step()
+if a.native_sites and rank == 0:
+    # which Python lines still hand device work to torch's own kernels (at::native): every aten op of ONE step, grouped by
+    # (op, innermost segmif_amd frame), ranked by the bytes its tensors span.  Views and metadata ops move nothing and are skipped.
+    import collections, traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from torch.utils._pytree import tree_flatten
+    SKIP = ("view", "reshape", "expand", "permute", "transpose", "slice", "select", "unsqueeze", "squeeze", "detach", "alias",
+            "as_strided", "t.default", "size", "stride", "is_", "_unsafe_view", "unbind", "split", "narrow", "chunk", "sym_",
+            "empty", "_local_scalar_dense", "unfold", "lift_fresh", "record_stream", "numel", "dim", "storage_offset")
+    agg = collections.defaultdict(lambda: [0, 0])
+
+    class Sites(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            name = str(func)
+            if not any(k in name for k in SKIP):
+                nbytes = sum(t.numel() * t.element_size() for t in tree_flatten((args, kwargs, out))[0]
+                             if isinstance(t, torch.Tensor) and t.is_cuda)
+                site = "autograd engine (no Python frame)"
+                for fr in reversed(traceback.extract_stack(limit=40)):
+                    if "segmif_amd" in fr.filename and "train_bench" not in fr.filename:
+                        site = f"{os.path.relpath(fr.filename, ROOT)}:{fr.lineno} {fr.name}"
+                        break
+                e = agg[(name, site)]
+                e[0] += 1
+                e[1] += nbytes
+            return out
+
+    with Sites():
+        l = step()
+    torch.cuda.synchronize()
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    with open(a.native_sites, "w") as f:
+        f.write(f"# aten ops of one {a.step} step ({'train' if a.train_mode else 'eval-regime'} mode, batch {B}) by call site; MB = bytes spanned by the op's device tensors\n")
+        f.write(f"# total {sum(v[0] for _, v in rows)} ops, {sum(v[1] for _, v in rows) / 1e6:.0f} MB\n")
+        for (name, site), (n, nb) in rows:
+            f.write(f"{n:6d} {nb / 1e6:10.1f} MB  {name:44s} {site}\n")
 dist.fence(); t0 = time.perf_counter()
 for _ in range(a.steps): l = step()
 dist.fence(); dt = dist.max_over_ranks((time.perf_counter() - t0) / a.steps)
