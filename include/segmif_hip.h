@@ -109,6 +109,15 @@ typedef struct SegmifIgemm {
    * the next conv reads - no separate mask pass.  Split 3x3 tile (14) only; anything else is SEGMIF_EINVAL. */
   const float* relu_mask;  /* [M][ld_mask] or NULL */
   int32_t ld_mask;
+  /* split 3x3 tile (14) on f16x3 arithmetic (r4, the training path): wt = segmif_conv3x3_split16_pack image, activations split
+   * into half pairs in the kernel after scaling by the power of two that puts max |input| in [2^13, 2^14).  split_in_amax:
+   * split_in_amax_n (1..64) device words holding the IEEE bit pattern of max |x| per channel block of the input (written by
+   * split_out_amax of the producing launches or by segmif_amax_f32; the kernel takes their maximum; all zero = scale 1;
+   * inf / NaN = every output NaN).  split_out_amax (either arithmetic, or NULL): atomic max of |output| bit patterns. */
+  int32_t split_f16;
+  const uint32_t* split_in_amax;
+  int32_t split_in_amax_n;
+  uint32_t* split_out_amax;
 } SegmifIgemm;
 
 int segmif_igemm_f32(const SegmifIgemm* desc, void* stream);
@@ -137,6 +146,13 @@ int segmif_pack_conv_weight(const float* src_oihw, float* dst, int N, int Cin, i
  */
 int64_t segmif_conv3x3_split_weight_bytes(int N, int Cin);
 int segmif_conv3x3_split_pack(const float* packed, int N, int Cin, int ldw, void* out, void* stream);
+/* f16x3 form of the same image (r4): rows scaled by a power of two, planes W0 | Wl | 2^-11 W0 as halves, then one float per
+ * padded output channel (the scale's inverse).  Re-packed per call on the training path (weights change every step). */
+int64_t segmif_conv3x3_split16_weight_bytes(int N, int Cin);
+int segmif_conv3x3_split16_pack(const float* packed, int N, int Cin, int ldw, void* out, void* stream);
+/* max |x| of a rows view (rows x C floats, pitch ld; C, ld multiples of 4, 16-byte aligned) folded into *slot as an IEEE bit
+ * pattern by atomic integer max (a NaN stays on top); the caller zeroes the slot first */
+int segmif_amax_f32(const float* x, int64_t rows, int C, int ld, uint32_t* slot, void* stream);
 
 /*
  * Dense GEMM with bf16x6 arithmetic (csrc/gemm_split.hip): out = res + act(A W^T + bias), A (M, K) fp32 rows (pitch lda,

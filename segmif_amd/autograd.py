@@ -600,10 +600,20 @@ class DRDBFn(torch.autograd.Function):
             buf = torch.empty((B, H, W, total), device=x.device, dtype=torch.float32)
             buf[..., :C0].copy_(x)
         ch = C0
+        # f16x3 convs (ops.train_conv_f16): range slots [x | out1 .. out5] - x's from one reduction pass, the others from the
+        # producing conv's epilogue; conv i scales its staged input by the maximum over slots 0 .. i
+        f16 = ops.train_conv_f16() and C0 % 16 == 0 and growth % 16 == 0
+        slots = torch.zeros((8,), device=x.device, dtype=torch.int32) if f16 else None
+        if f16:
+            ops.amax_rows(buf[..., :C0], slots[0:1])
         for i in range(5):
             w, b = params[2 * i], params[2 * i + 1]
-            ops.conv2d(buf[..., :ch], ops.pack_conv3x3(w), growth, 3, pad=2, dil=2, bias=b, act=ACT_RELU,
-                       out=buf[..., ch:ch + growth])
+            if f16:
+                ops.conv2d(buf[..., :ch], ops.pack_weight_split16(w), growth, 3, pad=2, dil=2, bias=b, act=ACT_RELU,
+                           out=buf[..., ch:ch + growth], in_amax=slots[:i + 1], out_amax=slots[i + 1:i + 2])
+            else:
+                ops.conv2d(buf[..., :ch], ops.pack_conv3x3(w), growth, 3, pad=2, dil=2, bias=b, act=ACT_RELU,
+                           out=buf[..., ch:ch + growth])
             ch += growth
         w6, b6 = params[10], params[11]
         out = ops.linear(buf, ops.pack_weight(w6), C0, bias=b6, act=ACT_RELU, res=buf[..., :C0])
@@ -637,6 +647,11 @@ class DRDBFn(torch.autograd.Function):
         ch = total - growth
         # block 5's gradient is complete after the 1x1 conv's input gradient: through its ReLU into the first dz slot
         act_bwd(dbuf[..., ch:ch + growth], buf[..., ch:ch + growth], ACT_RELU, out=dz[..., :growth])
+        f16 = ops.train_conv_f16() and C0 % 16 == 0 and growth % 16 == 0
+        slots = None
+        if f16:  # range slots of the dz blocks, in the order they are produced (gradients: 1e-7 and below - scaled, not guarded)
+            slots = torch.zeros((8,), device=buf.device, dtype=torch.int32)
+            ops.amax_rows(dz[..., :growth], slots[0:1])
         for i in range(4, -1, -1):
             k = 4 - i
             dy = dz[..., k * growth:(k + 1) * growth]
@@ -644,15 +659,16 @@ class DRDBFn(torch.autograd.Function):
             lo = ch - growth if i > 0 else 0
             # rows = the channels of the receiving block, columns = (tap rotated by 180 deg, dz channel)
             wcat = torch.cat([params[2 * q][:, lo:ch].flip(2, 3).transpose(0, 1) for q in range(4, i - 1, -1)], dim=1)
-            packed = ops.pack_conv3x3(wcat.contiguous())
+            packed = ops.pack_weight_split16(wcat.contiguous()) if f16 else ops.pack_conv3x3(wcat.contiguous())
             src = dz[..., :(k + 1) * growth]
+            rng = dict(in_amax=slots[:k + 1], out_amax=slots[k + 1:k + 2]) if f16 else {}
             if i == 0:  # the block's input x: no activation between it and the convs
-                ops.conv2d(src, packed, ch - lo, 3, pad=2, dil=2, res=dbuf[..., lo:ch], out=dbuf[..., lo:ch])
+                ops.conv2d(src, packed, ch - lo, 3, pad=2, dil=2, res=dbuf[..., lo:ch], out=dbuf[..., lo:ch], **rng)
             elif isinstance(packed, ops.SplitWeight):
                 # (r4) this conv completes the gradient of block i - 1: its epilogue adds the 1x1 conv's part (res) and writes
                 # the sum through that block's ReLU mask straight into the next dz slot - no mask pass of its own
                 ops.conv2d(src, packed, ch - lo, 3, pad=2, dil=2, res=dbuf[..., lo:ch], out=dz[..., (k + 1) * growth:(k + 2) * growth],
-                           mask=buf[..., lo:ch])
+                           mask=buf[..., lo:ch], **rng)
             else:
                 ops.conv2d(src, packed, ch - lo, 3, pad=2, dil=2, res=dbuf[..., lo:ch], out=dbuf[..., lo:ch])
                 act_bwd(dbuf[..., lo:ch], buf[..., lo:ch], ACT_RELU, out=dz[..., (k + 1) * growth:(k + 2) * growth])

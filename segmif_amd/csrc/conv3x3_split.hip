@@ -38,11 +38,22 @@
 // better: 16-row patches at one workgroup per CU, a ping-pong workgroup (two halves held in anti-phase
 // by a barrier per phase), static wave priority by LDS slot, four accumulation chains, contiguous
 // instead of 64-byte halo reads.  Next (round 2): a persistent, LDS-double-buffered schedule.
+//
+// f16x3 form (round 4, the training path's default; F16 = true below).  Same kernel, half pairs instead of bf16 triples:
+// x = hi + 2^-11 lo (planes16.h), weights as W0 | Wl | 2^-11 W0 of the row scaled by a power of two (conv3x3_planes.hip's
+// format), THREE products (lo W0s, hi Wl, hi W0) instead of six - the matrix pipe was 56 % of a call.  A half has 5 exponent
+// bits, and this kernel also multiplies GRADIENTS (1e-7 and below), so the range is not guarded but MADE: the caller passes
+// the device slots holding max |x| of the input's channel blocks (their producers' epilogues, or segmif_amax_f32), the kernel
+// scales the staged values by the power of two that puts that maximum in [2^13, 2^14) and takes it out again in the
+// epilogue (exact both ways).  Every element then carries 22 significant bits down to 2^-27 of the tensor's maximum -
+// below fp32's own resolution of a sum that contains the maximum.  A NaN / inf maximum makes the scale NaN: the output is
+// all NaN instead of quietly wrong.
 #include <hip/hip_runtime.h>
 #include "device_once.h"
 #include <stdint.h>
 
 #include "igemm_common.h"
+#include "planes16.h"
 #include "segmif_hip.h"
 
 #ifndef SPLIT_INTERLEAVE
@@ -74,8 +85,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 constexpr int STW = 32;
-constexpr int ROWB = 112;  // LDS bytes per pixel / weight row
+constexpr int ROWB = 112;    // LDS bytes per weight row (3 planes) and per bf16x3 pixel
+constexpr int ROWB_H = 80;   // per f16x3 pixel: 2 planes x 32 B + 16 B pad (conflict-free ds_read_b128 over 16 pixels: 20-dword stride)
 
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: a -> low half
   f32x2 v = {a, b};
@@ -95,17 +109,20 @@ inline int split_nout(int N) { return N <= 32 ? 32 : 64; }
 
 // STH = patch height: 8 (4 waves, 79 KB LDS with NOUT = 32 -> two workgroups per CU, one loading while
 // the other multiplies) or 16 (8 waves, one workgroup per CU; needed when NOUT = 64 fills the LDS).
-template <int NOUT, int DIL, int STH>
+template <int NOUT, int DIL, int STH, bool F16>
 __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_kernel(const IgemmK p, int tiles_x, int tiles_y) {
   constexpr int NT = STH * 32;
+  constexpr int NPA = F16 ? 2 : 3;          // activation planes
+  constexpr int AROW = F16 ? ROWB_H : ROWB; // LDS bytes per staged pixel
+  constexpr int NPROD = F16 ? 3 : 6;
   constexpr int HH = STH + 2 * DIL, HW = STW + 2 * DIL, HP = HH * HW;
   constexpr int A_UNITS = HP * 4;         // float4 units: 16 channels = 4 per pixel
   constexpr int B_UNITS = 9 * NOUT * 6;   // 16-byte units of split weights per chunk
   constexpr int AJ = (A_UNITS + NT - 1) / NT, BJ = (B_UNITS + NT - 1) / NT;
   constexpr int TN = NOUT / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-  unsigned char* As = smem_b;              // [HP][ROWB]
-  unsigned char* Bs = smem_b + HP * ROWB;  // [9 * NOUT][ROWB]
+  unsigned char* As = smem_b;              // [HP][AROW]
+  unsigned char* Bs = smem_b + HP * AROW;  // [9 * NOUT][ROWB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int pp = u >> 2, q4 = u & 3;
     const int hy = pp / HW, hx = pp - hy * HW;
     const int gy = y0 - DIL + hy, gx = x0 - DIL + hx;
-    a_dst[j] = u < A_UNITS ? pp * ROWB + q4 * 8 : -1;
+    a_dst[j] = u < A_UNITS ? pp * AROW + q4 * 8 : -1;
     a_ok[j] = u < A_UNITS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     a_off[j] = (a_ok[j] ? ((long long)gy * p.W + gx) * p.lda : 0) + q4 * 4;
   }
@@ -150,26 +167,51 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
     b_src[j] = u < B_UNITS ? u : B_UNITS - 1;
   }
 
+  // f16x3: the power of two that puts the input's largest magnitude (the callers' range slots) into [2^13, 2^14)
+  float s_in = 1.f, s_out = 1.f;
+  if (F16) {
+    uint32_t mx = 0u;
+    for (int i = 0; i < p.in_amax_n; ++i) {
+      const uint32_t v = p.in_amax[i];
+      mx = v > mx ? v : mx;
+    }
+    if (mx >= 0x7f800000u) s_in = __uint_as_float(0x7fc00000u);  // inf / NaN somewhere in the input: fail loudly (all NaN)
+    else if (mx) {
+      int eb = 13 - ((int)(mx >> 23) - 127) + 127;
+      eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
+      s_in = __uint_as_float((uint32_t)eb << 23);
+    }
+    s_out = 1.f / s_in;  // exact (a power of two)
+  }
+
   f32x4 ra[AJ];
-  u32x2 pa[AJ][3];  // the same units after the split: [plane] = 4 bf16
+  u32x2 pa[AJ][NPA];  // the same units after the split: [plane] = 4 bf16 / halves
   u32x4 rb[BJ];
   auto gload_a = [&](int j, int c) { ra[j] = *reinterpret_cast<const f32x4*>(in + a_off[j] + c * 16); };
   auto gload_b = [&](int j, int c) { rb[j] = wsp[(long long)c * B_UNITS + b_src[j]]; };
   auto split_unit = [&](int j) {  // registers only: interleaved with the tail of the previous chunk's MFMAs
-    uint32_t p0a, p1a, p2a, p0b, p1b, p2b;
     const f32x4 x = a_ok[j] ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-    split3(x[0], x[1], p0a, p1a, p2a);
-    split3(x[2], x[3], p0b, p1b, p2b);
-    pa[j][0] = u32x2{p0a, p0b};
-    pa[j][1] = u32x2{p1a, p1b};
-    pa[j][2] = u32x2{p2a, p2b};
+    if constexpr (F16) {
+      uint32_t ha, la, hb, lb;
+      p16::split2(x[0] * s_in, x[1] * s_in, ha, la);
+      p16::split2(x[2] * s_in, x[3] * s_in, hb, lb);
+      pa[j][0] = u32x2{ha, hb};
+      pa[j][1] = u32x2{la, lb};
+    } else {
+      uint32_t p0a, p1a, p2a, p0b, p1b, p2b;
+      split3(x[0], x[1], p0a, p1a, p2a);
+      split3(x[2], x[3], p0b, p1b, p2b);
+      pa[j][0] = u32x2{p0a, p0b};
+      pa[j][1] = u32x2{p1a, p1b};
+      pa[j][NPA - 1] = u32x2{p2a, p2b};
+    }
   };
   auto sstore = [&]() {
 #pragma unroll
     for (int j = 0; j < AJ; ++j)
       if (a_dst[j] >= 0) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(As + a_dst[j] + pl * 32) = pa[j][pl];
+        for (int pl = 0; pl < NPA; ++pl) *reinterpret_cast<u32x2*>(As + a_dst[j] + pl * 32) = pa[j][pl];
       }
 #pragma unroll
     for (int j = 0; j < BJ; ++j)
@@ -191,19 +233,27 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
   // before the MFMAs of step s are issued (double-buffered A set, 3-deep weight ring), so the LDS
   // latency hides under 6-12 MFMAs instead of stalling the wave once per fragment.
   const int R0 = (DIL == 2) ? ((wave >> 1) * 4 + (wave & 1)) : 2 * wave;
-  const unsigned char* a_lane = As + (R0 * HW + r) * ROWB + h * 16;
+  const unsigned char* a_lane = As + (R0 * HW + r) * AROW + h * 16;
   const unsigned char* b_lane = Bs + r * ROWB + h * 16;
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first
-  constexpr int PW[6] = {0, 1, 2, 0, 1, 0};
+  // products (activation plane, weight plane), least significant first: six for bf16 triples,
+  // three for half pairs (lo x 2^-11 W0, hi x Wl, hi x W0)
+  constexpr int PA[6] = {F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0, 0};
+  constexpr int PW[6] = {F16 ? 2 : 0, 1, F16 ? 0 : 2, 0, 1, 0};
   constexpr int SPLIT_FROM = 12 - AJ;
 
   constexpr bool W_AHEAD = TN == 1;  // two output-channel tiles: the 3-deep weight ring would spill
-  bf16x8 F[2][3], Wr[W_AHEAD ? 3 : 2][TN][3];
+  bf16x8 F[2][NPA], Wr[W_AHEAD ? 3 : 2][TN][3];  // (16-byte register quads; reinterpreted as halves for the f16 MFMA)
   auto load_f = [&](int st) {
     const int kx = st >> 2, m = st & 3;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      F[st & 1][pl] = *reinterpret_cast<const bf16x8*>(a_lane + (m * DIL * HW + kx * DIL) * ROWB + pl * 32);
+    for (int pl = 0; pl < NPA; ++pl)
+      F[st & 1][pl] = *reinterpret_cast<const bf16x8*>(a_lane + (m * DIL * HW + kx * DIL) * AROW + pl * 32);
+  };
+  auto mma = [&](const bf16x8& a, const bf16x8& b, f32x16 c) {
+    if constexpr (F16)
+      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   };
   auto load_w = [&](int st) {
     const int kx = st >> 2, m = st & 3;
@@ -257,14 +307,12 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
       __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           if (SPLIT_DBG & 1) continue;
-          if (m < 3)
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[st & 1][PA[t]], Wr[wc][j][PW[t]], acc[0][j], 0, 0, 0);
-          if (m > 0)
-            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[st & 1][PA[t]], Wr[wp][j][PW[t]], acc[1][j], 0, 0, 0);
+          if (m < 3) acc[0][j] = mma(F[st & 1][PA[t]], Wr[wc][j][PW[t]], acc[0][j]);
+          if (m > 0) acc[1][j] = mma(F[st & 1][PA[t]], Wr[wp][j][PW[t]], acc[1][j]);
         }
       if (st >= SPLIT_FROM && !(SPLIT_DBG & 4)) split_unit(st - SPLIT_FROM);
 #if SPLIT_INTERLEAVE
@@ -272,7 +320,7 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
       // a staging load and a few of the split's VALU ops, so that a wave alone on its SIMD (its partner
       // storing to LDS or parked at a barrier) still feeds the matrix pipe back-to-back
 #pragma unroll
-      for (int t = 0; t < 12 * TN; ++t) {  // (6-MFMA steps leave the tail groups without an MFMA)
+      for (int t = 0; t < 2 * NPROD * TN; ++t) {  // (steps with one sub-tile leave the tail groups without an MFMA)
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
         if (t < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
@@ -297,6 +345,10 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
   // ---- epilogue (same contract as the fp32 halo kernel) ----------------------------------------
   const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
   const long long img = (long long)b * p.H * p.W;
+  // f16x3: the rows' own power-of-two scales sit behind the weight image (one float per padded output channel)
+  const float* wdesc = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.wt) +
+                                                      (long long)gridDim.y * nchunks * B_UNITS * 16);
+  uint32_t amx = 0u;  // largest |output| this lane wrote (bit pattern), for the consumer's scale
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int oy = y0 + R0 + i * DIL;
@@ -306,28 +358,31 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
       const int n = nbase + j * 32 + r;
       if (n >= p.N) continue;
       const float bv = p.bias ? p.bias[n] : 0.f;
+      const float desc = F16 ? s_out * wdesc[n] : 1.f;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int ox = x0 + (v & 3) + 8 * (v >> 2) + 4 * h;
         if (ox >= p.W) continue;
         const long long m = img + (long long)oy * p.W + ox;
-        float y = acc[i][j][v] + bv;
+        float y = (F16 ? acc[i][j][v] * desc : acc[i][j][v]) + bv;
         if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
         else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
         else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
         if (p.res) y += p.res[m * p.ldr + n];
         if (p.mask && !(p.mask[m * p.ldm + n] > 0.f)) y = 0.f;  // DRDB backward: through the receiving block's ReLU
         p.out[m * p.ldo + n] = y;
+        amx = p16::absmax_bits(amx, y, 0.f);
       }
     }
   }
+  if (p.out_amax) p16::fold_bits(p.out_amax, 0, 0, amx);
 }
 
-template <int NOUT, int DIL, int STH>
+template <int NOUT, int DIL, int STH, bool F16>
 int launch(const IgemmK& k, hipStream_t stream) {
   constexpr int HP = (STH + 2 * DIL) * (STW + 2 * DIL);
-  constexpr size_t smem = (size_t)(HP + 9 * NOUT) * ROWB + ((SPLIT_DBG & 64) && STH == 8 ? 40960 : 0);  // 64: one workgroup per CU
-  auto fn = conv3x3_split_kernel<NOUT, DIL, STH>;
+  constexpr size_t smem = (size_t)HP * (F16 ? ROWB_H : ROWB) + (size_t)9 * NOUT * ROWB + ((SPLIT_DBG & 64) && STH == 8 ? 40960 : 0);  // 64: one workgroup per CU
+  auto fn = conv3x3_split_kernel<NOUT, DIL, STH, F16>;
   static segmif::PerDeviceFlag raised_flag;  // idempotent attribute; benign race
   bool& raised = raised_flag.here();
   if (!raised) {
@@ -364,15 +419,75 @@ __global__ void split_pack_kernel(const float* __restrict__ w, int N, int Cin, i
   out[row * 48 + 32 + c16] = (uint16_t)(p2 & 0xffffu);
 }
 
+// f16x3 weights: [n-tile][chunk][tap][n][W0 | Wl | 2^-11 W0][16] halves of the row scaled by 2^e(n), then one float per
+// padded output channel: 2^-e(n)  (2^14 <= 2^e(n) max|w[n][.]| < 2^15; e = 0 for an all-zero row)
+__global__ void split16_scale_kernel(const float* __restrict__ w, int N, int K, int ldw, int Npad, float* __restrict__ inv_scale) {
+  const int n = blockIdx.x;
+  float mx = 0.f;
+  if (n < N)
+    for (int k = threadIdx.x; k < K; k += 64) mx = fmaxf(mx, fabsf(w[(long long)n * ldw + k]));
+  mx = p16::wave_max(mx);
+  if (threadIdx.x == 0 && n < Npad) {
+    int e = 0;
+    if (mx >= 1e-30f && mx <= 3e38f) e = 14 - (int)((__float_as_uint(mx) >> 23) - 127);
+    inv_scale[n] = ldexpf(1.f, -e);
+  }
+}
+
+__global__ void split16_pack_kernel(const float* __restrict__ w, int N, int Cin, int ldw, int NOUT, long long total,
+                                    const float* __restrict__ inv_scale, uint16_t* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int nchunks = Cin / 16;
+  const int c16 = (int)(idx & 15);
+  long long t = idx >> 4;
+  const int n = (int)(t % NOUT); t /= NOUT;
+  const int tap = (int)(t % 9); t /= 9;
+  const int chunk = (int)(t % nchunks);
+  const int nt = (int)(t / nchunks);
+  const int gn = nt * NOUT + n;
+  const float x = gn < N ? w[(long long)gn * ldw + tap * Cin + chunk * 16 + c16] * (1.f / inv_scale[gn]) : 0.f;  // exact: power of two
+  const _Float16 w0 = (_Float16)x;
+  const _Float16 wl = (_Float16)(x - (float)w0);
+  const _Float16 ws = (_Float16)((float)w0 * (1.f / p16::LSCALE));
+  const long long row = (((long long)nt * nchunks + chunk) * 9 + tap) * NOUT + n;
+  out[row * 48 + c16] = __builtin_bit_cast(uint16_t, w0);
+  out[row * 48 + 16 + c16] = __builtin_bit_cast(uint16_t, wl);
+  out[row * 48 + 32 + c16] = __builtin_bit_cast(uint16_t, ws);
+}
+
+// max |x| of a rows view (rows x C, pitch ld) folded into one range slot (IEEE bit pattern; a NaN stays on top)
+__global__ __launch_bounds__(256) void amax_rows_kernel(const float* __restrict__ x, long long rows, int c4n, int rb, int ld,
+                                                        uint32_t* __restrict__ slot) {
+  const long long row0 = (long long)blockIdx.x * rb;
+  const int nrows = (int)(rows - row0 < rb ? rows - row0 : rb);
+  uint32_t m = 0u;
+  for (int u = threadIdx.x; u < nrows * c4n; u += 256) {
+    const int r = u / c4n, cq = u - r * c4n;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (row0 + r) * ld + 4 * cq);
+    m = p16::absmax_bits(p16::absmax_bits(m, v[0], v[1]), v[2], v[3]);
+  }
+  p16::fold_bits(slot, 0, 0, m);
+}
+
 }  // namespace
 
-int conv3x3_split_launch(const IgemmK& k, hipStream_t s) {
+template <bool F16>
+static int split_launch(const IgemmK& k, hipStream_t s) {
   const bool wide = split_nout(k.N) == 64;
-  if (wide) return k.dil == 2 ? launch<64, 2, 16>(k, s) : launch<64, 1, 16>(k, s);
+  if (wide) return k.dil == 2 ? launch<64, 2, 16, F16>(k, s) : launch<64, 1, 16, F16>(k, s);
 #if SPLIT_DBG & 128  // 16-row patches for NOUT = 32 too (one workgroup per CU)
-  return k.dil == 2 ? launch<32, 2, 16>(k, s) : launch<32, 1, 16>(k, s);
+  return k.dil == 2 ? launch<32, 2, 16, F16>(k, s) : launch<32, 1, 16, F16>(k, s);
 #endif
-  return k.dil == 2 ? launch<32, 2, 8>(k, s) : launch<32, 1, 8>(k, s);
+  return k.dil == 2 ? launch<32, 2, 8, F16>(k, s) : launch<32, 1, 8, F16>(k, s);
+}
+
+int conv3x3_split_launch(const IgemmK& k, hipStream_t s) {
+  if (k.split_f16) {
+    if (!k.in_amax || k.in_amax_n <= 0 || k.in_amax_n > 64) return SEGMIF_EINVAL;  // the f16x3 form needs its input's range slots
+    return split_launch<true>(k, s);
+  }
+  return split_launch<false>(k, s);
 }
 
 }  // namespace segmif
@@ -397,3 +512,32 @@ extern "C" int segmif_debug_split_timeline(void* dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(split_timeline), bytes < sizeof(split_timeline) ? bytes : sizeof(split_timeline));
 }
 #endif
+
+extern "C" int64_t segmif_conv3x3_split16_weight_bytes(int N, int Cin) {
+  const int64_t image = segmif_conv3x3_split_weight_bytes(N, Cin);  // same 96-byte rows, then one float per padded output channel
+  if (!image) return 0;
+  const int nout = segmif::split_nout(N);
+  return image + (int64_t)((N + nout - 1) / nout) * nout * 4;
+}
+
+extern "C" int segmif_conv3x3_split16_pack(const float* packed, int N, int Cin, int ldw, void* out, void* stream) {
+  if (!packed || !out || N <= 0 || Cin <= 0 || Cin % 16 || ldw < 9 * Cin) return SEGMIF_EINVAL;
+  const int nout = segmif::split_nout(N);
+  const int npad = (N + nout - 1) / nout * nout;
+  const long long total = (long long)npad * 9 * Cin;
+  float* inv_scale = reinterpret_cast<float*>((unsigned char*)out + total * 6);
+  hipLaunchKernelGGL(segmif::split16_scale_kernel, dim3((unsigned)npad), dim3(64), 0, (hipStream_t)stream, packed, N, 9 * Cin, ldw, npad,
+                     inv_scale);
+  hipLaunchKernelGGL(segmif::split16_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     packed, N, Cin, ldw, nout, total, inv_scale, (uint16_t*)out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_amax_f32(const float* x, int64_t rows, int C, int ld, uint32_t* slot, void* stream) {
+  if (!x || !slot || rows <= 0 || C <= 0 || (C & 3) || (ld & 3) || ld < C || ((uintptr_t)x & 15)) return SEGMIF_EINVAL;
+  const int c4n = C >> 2;
+  const int rb = c4n >= 2048 ? 1 : 2048 / c4n;  // ~eight 16-byte units per thread
+  hipLaunchKernelGGL(segmif::amax_rows_kernel, dim3((unsigned)((rows + rb - 1) / rb)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)rows, c4n, rb, ld, slot);
+  return (int)hipGetLastError();
+}

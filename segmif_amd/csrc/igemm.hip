@@ -639,7 +639,7 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
   const int rc = igemm_resolve(d, k, mode, tile, nz, halo);
   if (rc != 0) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (d->relu_mask && !(halo && tile == kSplitTile)) return SEGMIF_EINVAL;  // the mask epilogue exists in the split 3x3 kernel only
+  if ((d->relu_mask || d->split_f16 || d->split_out_amax) && !(halo && tile == kSplitTile)) return SEGMIF_EINVAL;  // split 3x3 kernel only
   if (halo) return tile == kSplitTile ? conv3x3_split_launch(k, s) : conv3x3_halo_launch(k, tile - kHaloTile0, s);
   if (k.splitk > 1) {
     if (!d->workspace || d->workspace_floats < (int64_t)k.splitk * k.M * k.N) k.splitk = 1;  // no room: plain launch
@@ -674,6 +674,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   k.in_zs2 = d->in_zstride2; k.wt_zs2 = d->wt_zstride2; k.out_zs2 = d->out_zstride2; k.res_zs2 = d->res_zstride2;
   k.ln_gamma = d->ln_gamma; k.ln_beta = d->ln_beta; k.ln_eps = d->ln_eps;
   k.mask = d->relu_mask; k.ldm = d->ld_mask;
+  k.split_f16 = d->split_f16; k.in_amax = d->split_in_amax; k.in_amax_n = d->split_in_amax_n; k.out_amax = d->split_out_amax;
   if (k.mask && k.ldm < d->N) return SEGMIF_EINVAL;
   if (k.ln_gamma && (!k.ln_beta || d->N != 64 || d->act != SEGMIF_ACT_NONE)) return SEGMIF_EINVAL;
   k.ldw = d->ldw > 0 ? d->ldw : k.Kp;

@@ -40,6 +40,10 @@ struct IgemmK {
   int pl_amax_images;     // > 1: one slot per image (M = images x OH x OW), else everything reports to pl_amax[0]
   const float* mask;  // split 3x3 tile only: out = mask[m][n] > 0 ? y : 0, applied after the residual (DRDB backward)
   int ldm;
+  int split_f16;             // split 3x3 tile: wt is an f16x3 image (segmif_conv3x3_split16_pack), in_amax must be given
+  const uint32_t* in_amax;   // range slots (bit patterns of max |x|) of the input's channel blocks; the kernel takes their maximum
+  int in_amax_n;
+  uint32_t* out_amax;        // or null: receives max |output| (for the consumer's scale)
   int vec4;  // epilogue may use 16-byte accesses: N, ldo, ldr, z strides multiples of 4 and out / res / bias / ws 16-byte aligned
 };
 

@@ -78,10 +78,10 @@ def pack_weight(w):
 class SplitWeight:
     """bf16x6 image of a packed 3x3 conv weight (segmif_conv3x3_split_pack): three bf16 planes per fp32
     weight in the streaming order of tile 14 (csrc/conv3x3_split.hip)."""
-    __slots__ = ("data", "N", "cin")
+    __slots__ = ("data", "N", "cin", "f16")
 
-    def __init__(self, data, N, cin):
-        self.data, self.N, self.cin = data, N, cin
+    def __init__(self, data, N, cin, f16=False):
+        self.data, self.N, self.cin, self.f16 = data, N, cin, f16  # f16: the f16x3 image (segmif_conv3x3_split16_pack)
 
 
 _CONV3X3_MODES = ("planes", "planes16", "bf16x6", "fp32")
@@ -158,6 +158,46 @@ def pack_weight_split(w):
     _lib.check(lib.segmif_conv3x3_split_pack(packed.data_ptr(), N, cin, packed.shape[1], out.data_ptr(), _stream()),
                "segmif_conv3x3_split_pack")
     return SplitWeight(out, N, cin)
+
+
+def pack_weight_split16(w):
+    """OIHW 3x3 weight -> SplitWeight in the f16x3 form (rows scaled by powers of two, half planes W0 | Wl | 2^-11 W0): the
+    training path's convs; conv2d then needs in_amax= (the input's range slots)."""
+    N, cin = w.shape[0], w.shape[1]
+    packed = pack_weight(w)
+    lib = _lib.load()
+    nbytes = lib.segmif_conv3x3_split16_weight_bytes(N, cin)
+    if nbytes <= 0:
+        raise RuntimeError(f"split packing needs Cin % 16 == 0, got Cin={cin}")
+    out = torch.empty((nbytes,), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.segmif_conv3x3_split16_pack(packed.data_ptr(), N, cin, packed.shape[1], out.data_ptr(), _stream()),
+               "segmif_conv3x3_split16_pack")
+    return SplitWeight(out, N, cin, f16=True)
+
+
+# Arithmetic of the TRAINING path's 3x3 convs (forward + input gradients of the DRDBs): "f16x3" (default, r4) = half pairs x
+# three products with the input scaled into the half's range from device-side range slots; "bf16x6" = round 3's bf16 triples.
+_TRAIN_CONV = os.environ.get("SEGMIF_TRAIN_CONV", "f16x3")
+if _TRAIN_CONV not in ("f16x3", "bf16x6"):
+    raise RuntimeError(f"SEGMIF_TRAIN_CONV must be 'f16x3' or 'bf16x6', got {_TRAIN_CONV!r}")
+
+
+def train_conv_f16():
+    return _TRAIN_CONV == "f16x3" and _conv3x3_mode != "fp32"
+
+
+def set_train_conv(mode):
+    global _TRAIN_CONV
+    if mode not in ("f16x3", "bf16x6"):
+        raise ValueError("mode must be 'f16x3' or 'bf16x6'")
+    prev, _TRAIN_CONV = _TRAIN_CONV, mode
+    return prev
+
+
+def amax_rows(x, slot):
+    """Fold max |x| of a rows view into slot (a one-element int32 device tensor holding an IEEE bit pattern; zero it first)."""
+    rows, C, ld = rows_view(x, "x")
+    _lib.check(_lib.load().segmif_amax_f32(x.data_ptr(), rows, C, ld, slot.data_ptr(), _stream()), "segmif_amax_f32")
 
 
 def pack_conv3x3(w):
@@ -808,14 +848,16 @@ def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
 
 
 def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
-           tile=-1, tag=None, planes=None, planes_chunk0=0, ln=None, planes_only=False, mask=None):
+           tile=-1, tag=None, planes=None, planes_chunk0=0, ln=None, planes_only=False, mask=None, in_amax=None, out_amax=None):
     """NHWC convolution.  x: (B, H, W, Cin) rows view (may be a channel slice of a wider buffer);
     wt packed (N, Kp); out: (B, OH, OW, N) rows view (may be a channel slice) or None.
     planes: optional ops.Planes of the output geometry that also receives the result, split, as chunks
     [planes_chunk0, planes_chunk0 + N / 16) (fp32-packed weights only).
     ln = (gamma, beta, eps): LayerNorm over the N = 64 output channels in the conv's epilogue (conv_ln_fusable).
     planes_only: write the planes copy and nothing else (returns None): the fp32 tensor has no reader.
-    mask: (B, OH, OW, N) rows view; out = mask > 0 ? act(conv + bias) + res : 0 (split 3x3 weights only: the DRDB backward)."""
+    mask: (B, OH, OW, N) rows view; out = mask > 0 ? act(conv + bias) + res : 0 (split 3x3 weights only: the DRDB backward).
+    in_amax: int32 device tensor of range slots covering the input's channel blocks (required by f16x3 split weights);
+    out_amax: one-element int32 device tensor receiving max |out| (split weights only)."""
     if x.dim() != 4:
         raise RuntimeError("conv2d expects (B, H, W, C)")
     if mask is not None and (planes is not None or ln is not None or not isinstance(wt, SplitWeight)):
@@ -866,6 +908,16 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
     d.H, d.W, d.Cin, d.KH, d.KW = H, W, cin, k, k
     d.stride, d.pad, d.dil, d.OH, d.OW = stride, pad, dil, OH, OW
     d.act, d.nz, d.tile = act, 1, tile
+    if isinstance(wt, SplitWeight) and wt.f16:
+        if in_amax is None or in_amax.dtype != torch.int32 or not in_amax.is_cuda or not in_amax.is_contiguous() or not 1 <= in_amax.numel() <= 64:
+            raise RuntimeError("conv2d: f16x3 split weights need in_amax= (1..64 contiguous int32 range slots on the device)")
+        d.split_f16, d.split_in_amax, d.split_in_amax_n = 1, in_amax.data_ptr(), in_amax.numel()
+    elif in_amax is not None and not isinstance(wt, SplitWeight):
+        raise RuntimeError("conv2d: in_amax= is for split 3x3 weights")
+    if out_amax is not None:
+        if not isinstance(wt, SplitWeight) or out_amax.dtype != torch.int32 or not out_amax.is_cuda:
+            raise RuntimeError("conv2d: out_amax= needs split 3x3 weights and an int32 device slot")
+        d.split_out_amax = out_amax.data_ptr()
     if mask is not None:
         mrow, mc, ldm = rows_view(mask, "mask")
         if (mrow, mc) != (orow, N):

@@ -667,3 +667,52 @@ def test_crosspath_training_nodes_vs_fp64_autograd(ops):
     observed("crosspath_train_nodes_worst_grad_rel", max(worst.values()))
     bad = {k: v for k, v in worst.items() if v > 5e-4}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("cin,N,dil", [(64, 32, 2), (160, 64, 2), (128, 64, 1), (64, 32, 1)])
+@pytest.mark.parametrize("scale", [1.0, 3e-7, 2e4])
+def test_split_conv_on_f16x3_with_the_range_made_on_the_device(ops, cin, N, dil, scale):
+    """The training path's 3x3 conv on half pairs x three products (csrc/conv3x3_split.hip, F16): the input is scaled into the
+    half's range by the power of two derived from device-side range slots, so activations of order 1, gradients of order 1e-7
+    and large values all come out fp32-class - against torch's conv in fp64, next to the bf16x6 form of the same kernel."""
+    B, H, W = 2, 37, 45
+    x = (rnd(B, H, W, cin, seed=1) * scale).cuda()
+    w = rnd(N, cin, 3, 3, seed=2, lo=-0.05, hi=0.05) * torch.logspace(-3, 1, N).view(N, 1, 1, 1)  # per-row scales 1e-3 .. 10
+    b = (rnd(N, seed=3) * scale).cuda()
+    ref = torch.nn.functional.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double(), b.double().cpu(), padding=dil, dilation=dil)
+    ref = ref.permute(0, 2, 3, 1)
+    slots = torch.zeros(3, dtype=torch.int32).cuda()
+    half = cin // 32 * 16
+    ops.amax_rows(x[..., :half], slots[0:1])   # two channel blocks, two slots: the kernel takes their maximum
+    ops.amax_rows(x[..., half:], slots[1:2])
+    assert float(slots[:2].view(torch.float32).max()) == float(x.abs().max())
+    y16 = ops.conv2d(x, ops.pack_weight_split16(w.cuda()), N, 3, pad=dil, dil=dil, bias=b, in_amax=slots[:2], out_amax=slots[2:3])
+    y6 = ops.conv2d(x, ops.pack_weight_split(w.cuda()), N, 3, pad=dil, dil=dil, bias=b)
+    den = float(ref.abs().max())
+    e16 = float((y16.double().cpu() - ref).abs().max()) / den
+    e6 = float((y6.double().cpu() - ref).abs().max()) / den
+    observed(f"split_conv_f16x3_vs_fp64[{cin},{N},{dil},{scale}]", {"f16x3": e16, "bf16x6": e6})
+    assert e16 < 2e-6 and e6 < 2e-6, (e16, e6)
+    assert float(slots[2:3].view(torch.float32)) == float(y16.abs().max())  # the epilogue's report of max |out|
+
+
+def test_split_conv_f16x3_mask_epilogue_and_nan_input(ops):
+    """The DRDB-backward epilogue (residual, then the receiving block's ReLU mask) on the f16x3 form, and the loud failure:
+    a NaN anywhere in the input turns the whole output NaN (the range slot carries it)."""
+    B, H, W, cin, N = 1, 19, 40, 64, 32
+    x = (rnd(B, H, W, cin, seed=1) * 1e-6).cuda()
+    w = rnd(N, cin, 3, 3, seed=2, lo=-0.05, hi=0.05).cuda()
+    res = (rnd(B, H, W, N, seed=3) * 1e-6).cuda()
+    fwd = rnd(B, H, W, N, seed=4).clamp_min(0).cuda()  # a ReLU output: zeros where the unit was off
+    slots = torch.zeros(2, dtype=torch.int32).cuda()
+    ops.amax_rows(x, slots[0:1])
+    y = ops.conv2d(x, ops.pack_weight_split16(w), N, 3, pad=2, dil=2, res=res, mask=fwd, in_amax=slots[:1], out_amax=slots[1:2])
+    ref = torch.nn.functional.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu(), padding=2, dilation=2).permute(0, 2, 3, 1)
+    ref = (ref + res.double().cpu()) * (fwd.cpu() > 0)
+    assert float((y.double().cpu() - ref).abs().max()) / float(ref.abs().max()) < 2e-6
+    assert torch.equal(y == 0, (fwd <= 0) | (y == 0)) and bool((y[fwd <= 0] == 0).all())
+    x[0, 3, 5, 7] = float("nan")
+    slots.zero_()
+    ops.amax_rows(x, slots[0:1])
+    y = ops.conv2d(x, ops.pack_weight_split16(w), N, 3, pad=2, dil=2, in_amax=slots[:1])
+    assert bool(torch.isnan(y).all())

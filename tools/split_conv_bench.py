@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""The training path's 3x3 convs at 8 x 480 x 640, bf16x6 against f16x3 (csrc/conv3x3_split.hip): the DRDB shapes forward
+(64..192 -> 32, dilation 2), the gather-form input gradients (32..160 -> 32 / 64) and conv2 / conv21 (dilation 1)."""
+import os, sys, json
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from segmif_amd import ops
+B, H, W = 8, 480, 640
+out = {}
+for cin, N, dil in ((64, 32, 2), (128, 32, 2), (192, 32, 2), (160, 64, 2), (128, 64, 1), (64, 32, 1)):
+    x = torch.rand(B, H, W, cin, device="cuda") - 0.5
+    w = (torch.rand(N, cin, 3, 3, device="cuda") - 0.5) * 0.1
+    slots = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.amax_rows(x, slots[0:1])
+    y = torch.empty(B, H, W, N, device="cuda")
+    rec = {}
+    for name, pk, kw in (("bf16x6", ops.pack_weight_split(w), {}), ("f16x3", ops.pack_weight_split16(w), dict(in_amax=slots[:1], out_amax=slots[1:2]))):
+        for _ in range(3):
+            ops.conv2d(x, pk, N, 3, pad=dil, dil=dil, out=y, **kw)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            ops.conv2d(x, pk, N, 3, pad=dil, dil=dil, out=y, **kw)
+        b.record(); torch.cuda.synchronize()
+        rec[name] = a.elapsed_time(b) / 10
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(10):
+        ops.amax_rows(x, slots[0:1])
+    t1.record(); torch.cuda.synchronize()
+    rec["amax_pass_ms"] = t0.elapsed_time(t1) / 10
+    out[f"{cin}->{N} dil{dil}"] = rec
+    print(f"{cin:4d} -> {N:3d} dil {dil}:  bf16x6 {rec['bf16x6']:.3f} ms   f16x3 {rec['f16x3']:.3f} ms   (amax pass over the input {rec['amax_pass_ms']:.3f} ms)")
+print(json.dumps(out))
