@@ -118,6 +118,10 @@ typedef struct SegmifIgemm {
   const uint32_t* split_in_amax;
   int32_t split_in_amax_n;
   uint32_t* split_out_amax;
+  /* segmif_wgrad_f32 with split_f16 != 0 (3x3 stride-1 convs, the two-team kernel): the same f16x3 arithmetic for the weight
+   * gradient - split_in_amax covers the input's channel blocks, wgrad_dy_amax those of dY */
+  const uint32_t* wgrad_dy_amax;
+  int32_t wgrad_dy_amax_n;
 } SegmifIgemm;
 
 int segmif_igemm_f32(const SegmifIgemm* desc, void* stream);

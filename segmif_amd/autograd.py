@@ -99,8 +99,9 @@ def linear_wgrad(x, dy, N, want_bias=False):
     return (dw, db) if want_bias else dw
 
 
-def conv_wgrad(x, dy, w_shape, k, stride, pad, dil, want_bias=False):
-    """dW in OIHW (and db, fused). x: (B,H,W,Cin) rows view; dy: (B,OH,OW,N) rows view."""
+def conv_wgrad(x, dy, w_shape, k, stride, pad, dil, want_bias=False, amax=None):
+    """dW in OIHW (and db, fused). x: (B,H,W,Cin) rows view; dy: (B,OH,OW,N) rows view.
+    amax = (x's range slots, dy's range slots): the f16x3 form of the 3x3 stride-1 kernel (int32 device tensors)."""
     N, cin = w_shape[0], w_shape[1]
     B, H, W, _ = x.shape
     _, _, lda = rows_view(x, "x")
@@ -110,6 +111,11 @@ def conv_wgrad(x, dy, w_shape, k, stride, pad, dil, want_bias=False):
     d.M, d.N, d.K, d.lda = rows, N, k * k * cin, lda
     d.H, d.W, d.Cin, d.KH, d.KW = H, W, cin, k, k
     d.stride, d.pad, d.dil, d.OH, d.OW = stride, pad, dil, dy.shape[1], dy.shape[2]
+    if amax is not None:
+        xs, ys = amax
+        d.split_f16 = 1
+        d.split_in_amax, d.split_in_amax_n = xs.data_ptr(), xs.numel()
+        d.wgrad_dy_amax, d.wgrad_dy_amax_n = ys.data_ptr(), ys.numel()
     dw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
     db = _bias_out(want_bias, N, x)
     _wgrad(d, dy, ldy, dw, db=db)
@@ -186,31 +192,52 @@ class ConvFn(torch.autograd.Function):
     """NHWC convolution y = act(conv(x, w) + b), w in OIHW."""
 
     @staticmethod
+    def _f16(k, stride, pad, dil, cin, N):
+        """3x3 stride-1 'same' convs with both channel counts in the split kernel's range run on f16x3 (ops.train_conv_f16):
+        forward, input gradient (the roles of cin and N swapped) and weight gradient."""
+        return k == 3 and stride == 1 and pad == dil and dil in (1, 2) and ops.train_conv_f16() and cin % 16 == 0 and N % 16 == 0 \
+            and 16 <= N <= 256 and 16 <= cin <= 256
+
+    @staticmethod
     def forward(ctx, x, w, b, k, stride, pad, dil, act, slope):
         _no_prelu(act)
         N = w.shape[0]
-        y = ops.conv2d(x, _pack_conv(w, k, stride, pad, dil), N, k, stride=stride, pad=pad, dil=dil, bias=b, act=act,
-                       prelu=slope)
+        xslot = None
+        if ConvFn._f16(k, stride, pad, dil, x.shape[-1], N) and ops.aligned16(x):
+            xslot = torch.zeros((1,), device=x.device, dtype=torch.int32)  # max |x|: the kernel scales its staged input from it
+            ops.amax_rows(x, xslot)
+            y = ops.conv2d(x, ops.pack_weight_split16(w), N, k, stride=stride, pad=pad, dil=dil, bias=b, act=act, prelu=slope,
+                           in_amax=xslot)
+        else:
+            y = ops.conv2d(x, _pack_conv(w, k, stride, pad, dil), N, k, stride=stride, pad=pad, dil=dil, bias=b, act=act,
+                           prelu=slope)
         ctx.geom = (k, stride, pad, dil, act)
         ctx.has_bias = b is not None
-        ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
+        ctx.save_for_backward(x, w, y if act == ACT_RELU else None, xslot)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, xslot = ctx.saved_tensors
         k, stride, pad, dil, act = ctx.geom
         N, cin = w.shape[0], w.shape[1]
         dy = dy.contiguous()
         dz = act_bwd(dy, y, ACT_RELU) if act == ACT_RELU else dy
         dx = dw = db = None
+        zslot = None
+        if xslot is not None:  # the f16x3 kernels: dz's range slot serves the input gradient and the weight gradient
+            zslot = torch.zeros((1,), device=x.device, dtype=torch.int32)
+            ops.amax_rows(dz, zslot)
         if ctx.needs_input_grad[0]:
             B, H, W, _ = x.shape
             if stride == 1:
                 # full correlation with the 180-degree rotated, in/out-swapped kernel
                 wr = w.flip(2, 3).transpose(0, 1).contiguous()
-                dx = ops.conv2d(dz, _pack_conv(wr, k, 1, dil * (k - 1) - pad, dil), cin, k, stride=1,
-                                pad=dil * (k - 1) - pad, dil=dil)
+                if zslot is not None:
+                    dx = ops.conv2d(dz, ops.pack_weight_split16(wr), cin, k, stride=1, pad=dil * (k - 1) - pad, dil=dil, in_amax=zslot)
+                else:
+                    dx = ops.conv2d(dz, _pack_conv(wr, k, 1, dil * (k - 1) - pad, dil), cin, k, stride=1,
+                                    pad=dil * (k - 1) - pad, dil=dil)
             elif stride == k and pad == 0 and dil == 1:
                 # non-overlapping patches (sr conv): every input pixel belongs to exactly one patch, so
                 # dX is one dense GEMM dY (M', N) @ W (N, k*k*Cin) followed by a patch -> image permutation
@@ -238,7 +265,7 @@ class ConvFn(torch.autograd.Function):
                     dz.shape[2], N, cin, _stream()), "segmif_conv_dgrad_strided_f32")
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            r = conv_wgrad(x, dz, w.shape, k, stride, pad, dil, want_bias=want_b)
+            r = conv_wgrad(x, dz, w.shape, k, stride, pad, dil, want_bias=want_b, amax=(xslot, zslot) if zslot is not None else None)
             dw, db = (r if want_b else (r, None))
         elif want_b:
             db = colsum(dz)
@@ -617,13 +644,13 @@ class DRDBFn(torch.autograd.Function):
             ch += growth
         w6, b6 = params[10], params[11]
         out = ops.linear(buf, ops.pack_weight(w6), C0, bias=b6, act=ACT_RELU, res=buf[..., :C0])
-        ctx.save_for_backward(buf, out, *params)
+        ctx.save_for_backward(buf, out, slots, *params)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        buf, out = ctx.saved_tensors[:2]
-        params = ctx.saved_tensors[2:]
+        buf, out, fslots = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
         dout = _rows(dout)
         B, H, W, total = buf.shape
         C0 = out.shape[-1]
@@ -655,7 +682,9 @@ class DRDBFn(torch.autograd.Function):
         for i in range(4, -1, -1):
             k = 4 - i
             dy = dz[..., k * growth:(k + 1) * growth]
-            grads[2 * i], grads[2 * i + 1] = conv_wgrad(buf[..., :ch], dy, params[2 * i].shape, 3, 1, 2, 2, want_bias=True)
+            # (conv i's input = x and the outputs of convs 1 .. i: forward slots 0 .. i; dy = dz block k: slot k)
+            rng_w = (fslots[:i + 1], slots[k:k + 1]) if f16 and fslots is not None else None
+            grads[2 * i], grads[2 * i + 1] = conv_wgrad(buf[..., :ch], dy, params[2 * i].shape, 3, 1, 2, 2, want_bias=True, amax=rng_w)
             lo = ch - growth if i > 0 else 0
             # rows = the channels of the receiving block, columns = (tap rotated by 180 deg, dz channel)
             wcat = torch.cat([params[2 * q][:, lo:ch].flip(2, 3).transpose(0, 1) for q in range(4, i - 1, -1)], dim=1)

@@ -170,18 +170,8 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
   // f16x3: the power of two that puts the input's largest magnitude (the callers' range slots) into [2^13, 2^14)
   float s_in = 1.f, s_out = 1.f;
   if (F16) {
-    uint32_t mx = 0u;
-    for (int i = 0; i < p.in_amax_n; ++i) {
-      const uint32_t v = p.in_amax[i];
-      mx = v > mx ? v : mx;
-    }
-    if (mx >= 0x7f800000u) s_in = __uint_as_float(0x7fc00000u);  // inf / NaN somewhere in the input: fail loudly (all NaN)
-    else if (mx) {
-      int eb = 13 - ((int)(mx >> 23) - 127) + 127;
-      eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
-      s_in = __uint_as_float((uint32_t)eb << 23);
-    }
-    s_out = 1.f / s_in;  // exact (a power of two)
+    s_in = p16::range_scale(p.in_amax, p.in_amax_n);  // (NaN for an inf / NaN input: fail loudly, all NaN)
+    s_out = 1.f / s_in;                               // exact (a power of two)
   }
 
   f32x4 ra[AJ];

@@ -97,5 +97,21 @@ __device__ __forceinline__ void fold_bits(uint32_t* slots, int b_lo, int b_hi, u
   }
 }
 
+// The power of two that puts the largest magnitude recorded in n range slots (IEEE bit patterns) into [2^13, 2^14): what the
+// training kernels multiply their staged operands by before splitting them into halves (exact, taken out again afterwards).
+// All-zero slots: 1.  An inf / NaN maximum: NaN - the consumer's whole output turns NaN instead of quietly wrong.
+__device__ __forceinline__ float range_scale(const uint32_t* slots, int n) {
+  uint32_t mx = 0u;
+  for (int i = 0; i < n; ++i) {
+    const uint32_t v = slots[i];
+    mx = v > mx ? v : mx;
+  }
+  if (mx >= 0x7f800000u) return __uint_as_float(0x7fc00000u);
+  if (!mx) return 1.f;
+  int eb = 13 - ((int)(mx >> 23) - 127) + 127;
+  eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
+  return __uint_as_float((uint32_t)eb << 23);
+}
+
 }  // namespace p16
 }  // namespace segmif

@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include "igemm_common.h"
+#include "planes16.h"
 #include "segmif_hip.h"
 
 #ifndef WG3_DBG
@@ -243,6 +244,10 @@ struct Wg3K {
   int B, H, W, Cin, N, Kp, ldy, lda;
   int tiles_x, tiles_y, tiles_total, tiles_per_strip, nchunks, yvec;
   int dbg;  // diagnosis only, builds with -DWG3_DBG=1 (SEGMIF_WG3_DBG): 1 skip the MFMA loop, 2 skip the split + LDS stores, 4 skip the global loads
+  // f16x3 form of the two-team kernel: range slots (bit patterns of max |.|) of dY and of the input's channel blocks
+  const uint32_t* dy_amax;
+  const uint32_t* in_amax;
+  int dy_amax_n, in_amax_n;
 };
 
 template <int DIL, bool VEC>  // VEC: dY rows are 16-byte loadable and the block's 32 output channels all exist
@@ -418,6 +423,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3K p) {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t wg_pk_bf16(float a, float b) {
@@ -632,8 +638,14 @@ __global__ __launch_bounds__(256) void wgrad3x3_split_kernel(const Wg3K p) {
 // row, the halo is 8 x 36 pixels.  Everything else - pair-packed planes, dword windows for the three horizontal taps, strips,
 // partial slabs, reduce - is the one-team kernel's.
 // ---------------------------------------------------------------------------------------------------
-template <int DIL>  // 2: DRDB convs (tap shift = one dword); 1: conv2 / conv21 (tap shift = half a dword: the middle tap is a funnel shift)
+// F16 (round 4, default on the training path): both operands as half pairs x = hi + lo of the value scaled by the power of two
+// that puts the tensor's maximum (device range slots, planes16.h range_scale) in [2^13, 2^14) - lo is kept UNscaled here
+// (with the maximum pinned at 2^13 it stays a normal half down to 2^-3, i.e. 2^-16 of the maximum; below that its absolute
+// error is 2^-25, 2^-38 of the maximum) so that the three products hi.hi, hi.lo, lo.hi share one accumulator; the partial
+// slabs are written back unscaled (exact).  Half the matrix-pipe work and two thirds of the LDS traffic of the bf16x6 form.
+template <int DIL, bool F16>  // DIL 2: DRDB convs (tap shift = one dword); 1: conv2 / conv21 (tap shift = half a dword: the middle tap is a funnel shift)
 __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
+  constexpr int NPL = F16 ? 2 : 3, NPROD = F16 ? 3 : 6;
   constexpr int TH = 4, TW = 32, HH = TH + 2 * DIL, HWD = TW + 2 * DIL;
   constexpr int NB = DIL == 2 ? 6 : 5;   // dwords of a halo row a lane reads per (k-step, vertical tap)
   constexpr int YPAIRS = TH * TW / 2;    // 64
@@ -641,9 +653,15 @@ __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
   constexpr int XPAIRS = HH * XROWP;     // 144
   constexpr int YJ = YPAIRS * 8 / 256;   // 2 units per staging thread
   constexpr int XJ = (XPAIRS * 8 + 255) / 256;  // 5
-  constexpr int BUF = 3 * YPAIRS * 32 + 3 * XPAIRS * 32;  // dwords per tile buffer (79 872 bytes)
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+  constexpr int BUF = NPL * YPAIRS * 32 + NPL * XPAIRS * 32;  // dwords per tile buffer (bf16x6: 79 872 bytes)
+  // products (dY plane, input plane), least significant first: six for bf16 triples, lo.hi, hi.lo, hi.hi for half pairs
+  constexpr int PA[6] = {F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0, 0};
+  constexpr int PB[6] = {0, 1, F16 ? 0 : 2, 0, 1, 0};
+  float s_y = 1.f, s_x = 1.f;
+  if (F16) {
+    s_y = p16::range_scale(p.dy_amax, p.dy_amax_n);
+    s_x = p16::range_scale(p.in_amax, p.in_amax_n);
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint32_t* bufs = reinterpret_cast<uint32_t*>(smem);
   const int tid = threadIdx.x, team = tid >> 8, t256 = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
@@ -702,32 +720,47 @@ __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
         }
       }
     };
-    auto put = [&](uint32_t* base, int npairs, int unit, const f32x4 v0, const f32x4 v1) {
-      u32x4 w0, w1, w2;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        uint32_t a, b, d;
-        wg_split3(v0[c], v1[c], a, b, d);
-        w0[c] = a; w1[c] = b; w2[c] = d;
-      }
+    auto put = [&](uint32_t* base, int npairs, int unit, const f32x4 v0, const f32x4 v1, float sc) {
       uint32_t* dst = base + unit * 4;
-      *reinterpret_cast<u32x4*>(dst) = w0;
-      *reinterpret_cast<u32x4*>(dst + npairs * 32) = w1;
-      *reinterpret_cast<u32x4*>(dst + 2 * npairs * 32) = w2;
+      if constexpr (F16) {
+        u32x4 w0, w1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const p16::f2 v = {v0[c] * sc, v1[c] * sc};
+          const p16::h2 hi = __builtin_convertvector(v, p16::h2);  // round to nearest even
+          const p16::f2 back = __builtin_convertvector(hi, p16::f2);
+          const p16::f2 res = {v[0] - back[0], v[1] - back[1]};     // exact in fp32
+          w0[c] = __builtin_bit_cast(uint32_t, hi);
+          w1[c] = __builtin_bit_cast(uint32_t, __builtin_convertvector(res, p16::h2));
+        }
+        *reinterpret_cast<u32x4*>(dst) = w0;
+        *reinterpret_cast<u32x4*>(dst + npairs * 32) = w1;
+      } else {
+        u32x4 w0, w1, w2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          uint32_t a, b, d;
+          wg_split3(v0[c], v1[c], a, b, d);
+          w0[c] = a; w1[c] = b; w2[c] = d;
+        }
+        *reinterpret_cast<u32x4*>(dst) = w0;
+        *reinterpret_cast<u32x4*>(dst + npairs * 32) = w1;
+        *reinterpret_cast<u32x4*>(dst + (NPL - 1) * npairs * 32) = w2;
+      }
     };
     auto sstore = [&](uint32_t* Ys) {
-      uint32_t* Xs = Ys + 3 * YPAIRS * 32;
+      uint32_t* Xs = Ys + NPL * YPAIRS * 32;
 #pragma unroll
       for (int j = 0; j < YJ; ++j) {
         const f32x4 v0 = (okbits >> (2 * j)) & 1 ? ry[2 * j] : zero4, v1 = (okbits >> (2 * j + 1)) & 1 ? ry[2 * j + 1] : zero4;
-        put(Ys, YPAIRS, t256 + 256 * j, v0, v1);
+        put(Ys, YPAIRS, t256 + 256 * j, v0, v1, s_y);
         if (want_bias) bsum += v0 + v1;
       }
 #pragma unroll
       for (int j = 0; j < XJ; ++j) {
         const int u = t256 + 256 * j;
         const f32x4 v0 = (okbits >> (16 + 2 * j)) & 1 ? rx[2 * j] : zero4, v1 = (okbits >> (17 + 2 * j)) & 1 ? rx[2 * j + 1] : zero4;
-        if (u < XPAIRS * 8) put(Xs, XPAIRS, u, v0, v1);
+        if (u < XPAIRS * 8) put(Xs, XPAIRS, u, v0, v1, s_x);
       }
     };
     if (t_begin < t_end) gload(t_begin);
@@ -741,12 +774,12 @@ __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
     for (int tile = t_begin; tile < t_end; ++tile) {
       __syncthreads();
       const uint32_t* Ys = bufs + ((tile - t_begin) & 1) * BUF;
-      const uint32_t* Xs = Ys + 3 * YPAIRS * 32;
+      const uint32_t* Xs = Ys + NPL * YPAIRS * 32;
       auto read_a = [&](int it, u32x4* a) {  // it = 3 ks + ky
         const int ks = it / 3;
         const uint32_t* ya = Ys + (wave * 16 + 8 * ks + 4 * h) * 32 + r;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
           for (int i = 0; i < 4; ++i) a[pl][i] = ya[(pl * YPAIRS + i) * 32];
       };
@@ -754,12 +787,12 @@ __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
         const int ks = it / 3, ky = it % 3;
         const uint32_t* xa = Xs + ((wave + ky * DIL) * XROWP + 8 * ks + 4 * h) * 32 + r;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
           for (int i = 0; i < NB; ++i) b6[pl][i] = xa[(pl * XPAIRS + i) * 32];
       };
-      u32x4 a[2][3];
-      uint32_t b6[2][3][NB];
+      u32x4 a[2][NPL];
+      uint32_t b6[2][NPL][NB];
       read_a(0, a[0]);
       read_b(0, b6[0]);
 #pragma unroll
@@ -771,7 +804,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < NPROD; ++t)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             const int pl = PB[t];
@@ -784,8 +817,12 @@ __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) bw[i] = __builtin_amdgcn_alignbit(b6[cb][pl][i + 1], b6[cb][pl][i], 16);
             }
-            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ca][PA[t]]),
-                                                                       __builtin_bit_cast(bf16x8, bw), acc[ky * 3 + kx], 0, 0, 0);
+            if constexpr (F16)
+              acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, a[ca][PA[t]]),
+                                                                        __builtin_bit_cast(wg_f16x8, bw), acc[ky * 3 + kx], 0, 0, 0);
+            else
+              acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ca][PA[t]]),
+                                                                         __builtin_bit_cast(bf16x8, bw), acc[ky * 3 + kx], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -795,6 +832,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
   // combine the MFMA team's four waves tap by tap through LDS (all 512 threads take the barriers and share the summation)
   float* red = smem;  // [4][32][33]
   float* out = p.partial + (long long)strip * p.N * p.Kp;
+  const float desc = F16 ? (1.f / s_y) * (1.f / s_x) : 1.f;  // the two range scales taken out again (powers of two: exact)
   for (int t = 0; t < 9; ++t) {
     __syncthreads();
     if (team == 0) {
@@ -809,7 +847,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_split2_kernel(const Wg3K p) {
       const int n = i >> 5, c = i & 31;
       const float s4 = (red[(0 * 32 + n) * 33 + c] + red[(1 * 32 + n) * 33 + c]) +
                        (red[(2 * 32 + n) * 33 + c] + red[(3 * 32 + n) * 33 + c]);
-      if (n0 + n < p.N) out[(long long)(n0 + n) * p.Kp + t * p.Cin + c0 + c] = s4;
+      if (n0 + n < p.N) out[(long long)(n0 + n) * p.Kp + t * p.Cin + c0 + c] = F16 ? s4 * desc : s4;
     }
   }
   if (want_bias) {
@@ -1117,10 +1155,17 @@ static int wgrad_impl(const SegmifIgemm* d, const float* dy, int ldy, int64_t dy
         w.bias_partial = dbias ? workspace + strips * d->N * k.Kp : nullptr;
         grid = dim3((unsigned)(strips * w.nchunks), (unsigned)ntiles_n);
         const int xpairs = (4 + 2 * d->dil) * (32 + 2 * d->dil) / 2;
-        const size_t smem2 = (size_t)2 * (3 * 64 * 32 + 3 * xpairs * 32) * sizeof(uint32_t);
-        auto fn2 = d->dil == 2 ? wgrad3x3_split2_kernel<2> : wgrad3x3_split2_kernel<1>;
-        static segmif::PerDeviceFlag raised_flag4[2];
-        bool& raised4 = raised_flag4[d->dil == 2].here();
+        const bool f16 = d->split_f16 != 0;
+        if (f16 && (!d->split_in_amax || !d->wgrad_dy_amax || d->split_in_amax_n < 1 || d->split_in_amax_n > 64 ||
+                    d->wgrad_dy_amax_n < 1 || d->wgrad_dy_amax_n > 64))
+          return SEGMIF_EINVAL;
+        w.dy_amax = d->wgrad_dy_amax; w.dy_amax_n = d->wgrad_dy_amax_n; w.in_amax = d->split_in_amax; w.in_amax_n = d->split_in_amax_n;
+        const int npl = f16 ? 2 : 3;
+        const size_t smem2 = (size_t)2 * (npl * 64 * 32 + npl * xpairs * 32) * sizeof(uint32_t);
+        auto fn2 = d->dil == 2 ? (f16 ? wgrad3x3_split2_kernel<2, true> : wgrad3x3_split2_kernel<2, false>)
+                               : (f16 ? wgrad3x3_split2_kernel<1, true> : wgrad3x3_split2_kernel<1, false>);
+        static segmif::PerDeviceFlag raised_flag4[4];
+        bool& raised4 = raised_flag4[(d->dil == 2) * 2 + f16].here();
         if (!raised4) {
           hipError_t e4 = hipFuncSetAttribute((const void*)fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
           if (e4 != hipSuccess) return (int)e4;

@@ -716,3 +716,30 @@ def test_split_conv_f16x3_mask_epilogue_and_nan_input(ops):
     ops.amax_rows(x, slots[0:1])
     y = ops.conv2d(x, ops.pack_weight_split16(w), N, 3, pad=2, dil=2, in_amax=slots[:1])
     assert bool(torch.isnan(y).all())
+
+
+@pytest.mark.parametrize("cin,N,dil", [(64, 32, 2), (160, 32, 2), (128, 64, 1), (64, 32, 1)])
+@pytest.mark.parametrize("gscale", [1.0, 3e-7])
+def test_conv_wgrad_on_f16x3_with_device_ranges(ops, cin, N, dil, gscale):
+    """The 3x3 weight gradient's two-team kernel on half pairs (csrc/wgrad.hip, F16): both operands scaled from their range
+    slots - dY of gradient size (3e-7) included - against torch's conv2d_weight in fp64, next to the bf16x6 form."""
+    from segmif_amd import autograd as ag
+    B, H, W = 2, 37, 45
+    x = rnd(B, H, W, cin, seed=1).cuda()
+    dy = (rnd(B, H, W, N, seed=2) * gscale).cuda()
+    ref = torch.nn.grad.conv2d_weight(x.double().cpu().permute(0, 3, 1, 2), (N, cin, 3, 3), dy.double().cpu().permute(0, 3, 1, 2),
+                                      padding=dil, dilation=dil)
+    xs, ys = torch.zeros(2, dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
+    half = cin // 32 * 16
+    ops.amax_rows(x[..., :half], xs[0:1])
+    ops.amax_rows(x[..., half:], xs[1:2])
+    ops.amax_rows(dy, ys)
+    dw16, db16 = ag.conv_wgrad(x, dy, (N, cin, 3, 3), 3, 1, dil, dil, want_bias=True, amax=(xs, ys))
+    dw6, db6 = ag.conv_wgrad(x, dy, (N, cin, 3, 3), 3, 1, dil, dil, want_bias=True)
+    den = float(ref.abs().max())
+    e16 = float((dw16.double().cpu() - ref).abs().max()) / den
+    e6 = float((dw6.double().cpu() - ref).abs().max()) / den
+    observed(f"conv_wgrad_f16x3_vs_fp64[{cin},{N},{dil},{gscale}]", {"f16x3": e16, "bf16x6": e6})
+    assert e16 < 2e-6 and e6 < 2e-6, (e16, e6)
+    bref = dy.double().cpu().sum((0, 1, 2))
+    assert float((db16.double().cpu() - bref).abs().max()) / float(bref.abs().max()) < 1e-5

@@ -33,3 +33,22 @@ for cin, N, dil in ((64, 32, 2), (128, 32, 2), (192, 32, 2), (160, 64, 2), (128,
     out[f"{cin}->{N} dil{dil}"] = rec
     print(f"{cin:4d} -> {N:3d} dil {dil}:  bf16x6 {rec['bf16x6']:.3f} ms   f16x3 {rec['f16x3']:.3f} ms   (amax pass over the input {rec['amax_pass_ms']:.3f} ms)")
 print(json.dumps(out))
+
+# the matching weight gradients (two-team kernel), bf16x6 against f16x3
+from segmif_amd import autograd as ag
+for cin, N, dil in ((64, 32, 2), (128, 32, 2), (192, 32, 2), (128, 64, 1)):
+    x = torch.rand(B, H, W, cin, device="cuda") - 0.5
+    dy = (torch.rand(B, H, W, N, device="cuda") - 0.5) * 1e-6
+    xs, ys = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.amax_rows(x, xs); ops.amax_rows(dy, ys)
+    rec = {}
+    for name, am in (("bf16x6", None), ("f16x3", (xs, ys))):
+        for _ in range(3):
+            ag.conv_wgrad(x, dy, (N, cin, 3, 3), 3, 1, dil, dil, want_bias=True, amax=am)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            ag.conv_wgrad(x, dy, (N, cin, 3, 3), 3, 1, dil, dil, want_bias=True, amax=am)
+        b.record(); torch.cuda.synchronize()
+        rec[name] = a.elapsed_time(b) / 10
+    print(f"wgrad {cin:4d} -> {N:3d} dil {dil}:  bf16x6 {rec['bf16x6']:.3f} ms   f16x3 {rec['f16x3']:.3f} ms")
