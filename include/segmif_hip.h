@@ -113,11 +113,14 @@ typedef struct SegmifIgemm {
    * into half pairs in the kernel after scaling by the power of two that puts max |input| in [2^13, 2^14).  split_in_amax:
    * split_in_amax_n (1..64) device words holding the IEEE bit pattern of max |x| per channel block of the input (written by
    * split_out_amax of the producing launches or by segmif_amax_f32; the kernel takes their maximum; all zero = scale 1;
-   * inf / NaN = every output NaN).  split_out_amax (either arithmetic, or NULL): atomic max of |output| bit patterns. */
+   * inf / NaN = every output NaN).  split_out_amax (either arithmetic, or NULL): split_out_amax_n words (a power of two
+   * <= 64; 0 = 1) receiving the atomic max of |output| bit patterns, one atomic per workgroup spread over the words by
+   * workgroup index - the consumer passes all of them as (part of) its split_in_amax. */
   int32_t split_f16;
   const uint32_t* split_in_amax;
   int32_t split_in_amax_n;
   uint32_t* split_out_amax;
+  int32_t split_out_amax_n;
   /* segmif_wgrad_f32 with split_f16 != 0 (3x3 stride-1 convs, the two-team kernel): the same f16x3 arithmetic for the weight
    * gradient - split_in_amax covers the input's channel blocks, wgrad_dy_amax those of dY */
   const uint32_t* wgrad_dy_amax;
@@ -154,9 +157,10 @@ int segmif_conv3x3_split_pack(const float* packed, int N, int Cin, int ldw, void
  * padded output channel (the scale's inverse).  Re-packed per call on the training path (weights change every step). */
 int64_t segmif_conv3x3_split16_weight_bytes(int N, int Cin);
 int segmif_conv3x3_split16_pack(const float* packed, int N, int Cin, int ldw, void* out, void* stream);
-/* max |x| of a rows view (rows x C floats, pitch ld; C, ld multiples of 4, 16-byte aligned) folded into *slot as an IEEE bit
- * pattern by atomic integer max (a NaN stays on top); the caller zeroes the slot first */
-int segmif_amax_f32(const float* x, int64_t rows, int C, int ld, uint32_t* slot, void* stream);
+/* max |x| of a rows view (rows x C floats, pitch ld; C, ld multiples of 4, 16-byte aligned) folded into slots[0 .. nslots)
+ * (nslots a power of two <= 64: one atomic per block, spread over the words by block index; the maximum over the words
+ * is the tensor's) as IEEE bit patterns by atomic integer max (a NaN stays on top); the caller zeroes the words first */
+int segmif_amax_f32(const float* x, int64_t rows, int C, int ld, uint32_t* slots, int nslots, void* stream);
 
 /*
  * Dense GEMM with bf16x6 arithmetic (csrc/gemm_split.hip): out = res + act(A W^T + bias), A (M, K) fp32 rows (pitch lda,

@@ -31,7 +31,7 @@ class SegmifIgemm(ctypes.Structure):
         ("planes_out", c_void_p), ("planes_chunks", c_int32), ("planes_chunk0", c_int32),
         ("planes_f16", c_int32), ("planes_amax", c_void_p), ("planes_amax_images", c_int32),
         ("relu_mask", c_void_p), ("ld_mask", c_int32),
-        ("split_f16", c_int32), ("split_in_amax", c_void_p), ("split_in_amax_n", c_int32), ("split_out_amax", c_void_p),
+        ("split_f16", c_int32), ("split_in_amax", c_void_p), ("split_in_amax_n", c_int32), ("split_out_amax", c_void_p), ("split_out_amax_n", c_int32),
         ("wgrad_dy_amax", c_void_p), ("wgrad_dy_amax_n", c_int32),
     ]
 
@@ -86,7 +86,7 @@ SIGNATURES = {
     "segmif_conv3x3_split_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "segmif_conv3x3_split16_weight_bytes": (c_int64, [c_int, c_int]),
     "segmif_conv3x3_split16_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "segmif_amax_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "segmif_amax_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "segmif_gemm_split_weight_bytes": (c_int64, [c_int, c_int]),
     "segmif_gemm_split_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "segmif_gemm_split_f32": (c_int, [POINTER(SegmifGemmSplit), c_void_p]),

@@ -204,7 +204,7 @@ class ConvFn(torch.autograd.Function):
         N = w.shape[0]
         xslot = None
         if ConvFn._f16(k, stride, pad, dil, x.shape[-1], N) and ops.aligned16(x):
-            xslot = torch.zeros((1,), device=x.device, dtype=torch.int32)  # max |x|: the kernel scales its staged input from it
+            xslot = ops.range_slots(1, x.device).view(-1)  # max |x|: the kernel scales its staged input from it
             ops.amax_rows(x, xslot)
             y = ops.conv2d(x, ops.pack_weight_split16(w), N, k, stride=stride, pad=pad, dil=dil, bias=b, act=act, prelu=slope,
                            in_amax=xslot)
@@ -226,7 +226,7 @@ class ConvFn(torch.autograd.Function):
         dx = dw = db = None
         zslot = None
         if xslot is not None:  # the f16x3 kernels: dz's range slot serves the input gradient and the weight gradient
-            zslot = torch.zeros((1,), device=x.device, dtype=torch.int32)
+            zslot = ops.range_slots(1, x.device).view(-1)
             ops.amax_rows(dz, zslot)
         if ctx.needs_input_grad[0]:
             B, H, W, _ = x.shape
@@ -630,14 +630,14 @@ class DRDBFn(torch.autograd.Function):
         # f16x3 convs (ops.train_conv_f16): range slots [x | out1 .. out5] - x's from one reduction pass, the others from the
         # producing conv's epilogue; conv i scales its staged input by the maximum over slots 0 .. i
         f16 = ops.train_conv_f16() and C0 % 16 == 0 and growth % 16 == 0
-        slots = torch.zeros((8,), device=x.device, dtype=torch.int32) if f16 else None
+        slots = ops.range_slots(6, x.device) if f16 else None
         if f16:
-            ops.amax_rows(buf[..., :C0], slots[0:1])
+            ops.amax_rows(buf[..., :C0], slots[0])
         for i in range(5):
             w, b = params[2 * i], params[2 * i + 1]
             if f16:
                 ops.conv2d(buf[..., :ch], ops.pack_weight_split16(w), growth, 3, pad=2, dil=2, bias=b, act=ACT_RELU,
-                           out=buf[..., ch:ch + growth], in_amax=slots[:i + 1], out_amax=slots[i + 1:i + 2])
+                           out=buf[..., ch:ch + growth], in_amax=slots[:i + 1].view(-1), out_amax=slots[i + 1])
             else:
                 ops.conv2d(buf[..., :ch], ops.pack_conv3x3(w), growth, 3, pad=2, dil=2, bias=b, act=ACT_RELU,
                            out=buf[..., ch:ch + growth])
@@ -677,20 +677,21 @@ class DRDBFn(torch.autograd.Function):
         f16 = ops.train_conv_f16() and C0 % 16 == 0 and growth % 16 == 0
         slots = None
         if f16:  # range slots of the dz blocks, in the order they are produced (gradients: 1e-7 and below - scaled, not guarded)
-            slots = torch.zeros((8,), device=buf.device, dtype=torch.int32)
-            ops.amax_rows(dz[..., :growth], slots[0:1])
+            slots = ops.range_slots(5, buf.device)
+            ops.amax_rows(dz[..., :growth], slots[0])
         for i in range(4, -1, -1):
             k = 4 - i
             dy = dz[..., k * growth:(k + 1) * growth]
             # (conv i's input = x and the outputs of convs 1 .. i: forward slots 0 .. i; dy = dz block k: slot k)
-            rng_w = (fslots[:i + 1], slots[k:k + 1]) if f16 and fslots is not None else None
+            rng_w = (fslots[:i + 1].view(-1), slots[k]) if f16 and fslots is not None else None
             grads[2 * i], grads[2 * i + 1] = conv_wgrad(buf[..., :ch], dy, params[2 * i].shape, 3, 1, 2, 2, want_bias=True, amax=rng_w)
             lo = ch - growth if i > 0 else 0
             # rows = the channels of the receiving block, columns = (tap rotated by 180 deg, dz channel)
             wcat = torch.cat([params[2 * q][:, lo:ch].flip(2, 3).transpose(0, 1) for q in range(4, i - 1, -1)], dim=1)
             packed = ops.pack_weight_split16(wcat.contiguous()) if f16 else ops.pack_conv3x3(wcat.contiguous())
             src = dz[..., :(k + 1) * growth]
-            rng = dict(in_amax=slots[:k + 1], out_amax=slots[k + 1:k + 2]) if f16 else {}
+            # (the last conv's result - the gradient of the block's input - has no f16x3 consumer: no report)
+            rng = dict(in_amax=slots[:k + 1].view(-1), **(dict(out_amax=slots[k + 1]) if i > 0 else {})) if f16 else {}
             if i == 0:  # the block's input x: no activation between it and the convs
                 ops.conv2d(src, packed, ch - lo, 3, pad=2, dil=2, res=dbuf[..., lo:ch], out=dbuf[..., lo:ch], **rng)
             elif isinstance(packed, ops.SplitWeight):

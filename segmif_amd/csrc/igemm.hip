@@ -675,6 +675,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   k.ln_gamma = d->ln_gamma; k.ln_beta = d->ln_beta; k.ln_eps = d->ln_eps;
   k.mask = d->relu_mask; k.ldm = d->ld_mask;
   k.split_f16 = d->split_f16; k.in_amax = d->split_in_amax; k.in_amax_n = d->split_in_amax_n; k.out_amax = d->split_out_amax;
+  k.out_amax_n = d->split_out_amax_n > 0 ? d->split_out_amax_n : 1;
   if (k.mask && k.ldm < d->N) return SEGMIF_EINVAL;
   if (k.ln_gamma && (!k.ln_beta || d->N != 64 || d->act != SEGMIF_ACT_NONE)) return SEGMIF_EINVAL;
   k.ldw = d->ldw > 0 ? d->ldw : k.Kp;

@@ -43,7 +43,8 @@ struct IgemmK {
   int split_f16;             // split 3x3 tile: wt is an f16x3 image (segmif_conv3x3_split16_pack), in_amax must be given
   const uint32_t* in_amax;   // range slots (bit patterns of max |x|) of the input's channel blocks; the kernel takes their maximum
   int in_amax_n;
-  uint32_t* out_amax;        // or null: receives max |output| (for the consumer's scale)
+  uint32_t* out_amax;        // or null: out_amax_n words (a power of two) receiving max |output|, spread by workgroup index
+  int out_amax_n;
   int vec4;  // epilogue may use 16-byte accesses: N, ldo, ldr, z strides multiples of 4 and out / res / bias / ws 16-byte aligned
 };
 

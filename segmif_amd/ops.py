@@ -194,10 +194,19 @@ def set_train_conv(mode):
     return prev
 
 
+RANGE_WORDS = 8  # words per range slot: producers spread their one-atomic-per-workgroup over them, consumers take the maximum
+
+
+def range_slots(n, device):
+    """n zeroed range slots (n, RANGE_WORDS) int32: slot i receives max |.| of one tensor / channel block as IEEE bit patterns
+    (amax_rows, conv2d(out_amax=)); a consumer passes the slots covering its input, flattened, as in_amax."""
+    return torch.zeros((n, RANGE_WORDS), device=device, dtype=torch.int32)
+
+
 def amax_rows(x, slot):
-    """Fold max |x| of a rows view into slot (a one-element int32 device tensor holding an IEEE bit pattern; zero it first)."""
+    """Fold max |x| of a rows view into slot (a contiguous int32 device tensor of 1, 2, 4 .. 64 words; zero it first)."""
     rows, C, ld = rows_view(x, "x")
-    _lib.check(_lib.load().segmif_amax_f32(x.data_ptr(), rows, C, ld, slot.data_ptr(), _stream()), "segmif_amax_f32")
+    _lib.check(_lib.load().segmif_amax_f32(x.data_ptr(), rows, C, ld, slot.data_ptr(), slot.numel(), _stream()), "segmif_amax_f32")
 
 
 def pack_conv3x3(w):
@@ -856,8 +865,8 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
     ln = (gamma, beta, eps): LayerNorm over the N = 64 output channels in the conv's epilogue (conv_ln_fusable).
     planes_only: write the planes copy and nothing else (returns None): the fp32 tensor has no reader.
     mask: (B, OH, OW, N) rows view; out = mask > 0 ? act(conv + bias) + res : 0 (split 3x3 weights only: the DRDB backward).
-    in_amax: int32 device tensor of range slots covering the input's channel blocks (required by f16x3 split weights);
-    out_amax: one-element int32 device tensor receiving max |out| (split weights only)."""
+    in_amax: int32 device tensor of range words covering the input's channel blocks (required by f16x3 split weights);
+    out_amax: contiguous int32 device tensor of 1, 2, 4 .. 64 words receiving max |out| (split weights only)."""
     if x.dim() != 4:
         raise RuntimeError("conv2d expects (B, H, W, C)")
     if mask is not None and (planes is not None or ln is not None or not isinstance(wt, SplitWeight)):
@@ -915,9 +924,9 @@ def conv2d(x, wt, N, k, *, stride=1, pad=0, dil=1, bias=None, act=ACT_NONE, prel
     elif in_amax is not None and not isinstance(wt, SplitWeight):
         raise RuntimeError("conv2d: in_amax= is for split 3x3 weights")
     if out_amax is not None:
-        if not isinstance(wt, SplitWeight) or out_amax.dtype != torch.int32 or not out_amax.is_cuda:
-            raise RuntimeError("conv2d: out_amax= needs split 3x3 weights and an int32 device slot")
-        d.split_out_amax = out_amax.data_ptr()
+        if not isinstance(wt, SplitWeight) or out_amax.dtype != torch.int32 or not out_amax.is_cuda or not out_amax.is_contiguous():
+            raise RuntimeError("conv2d: out_amax= needs split 3x3 weights and a contiguous int32 device slot")
+        d.split_out_amax, d.split_out_amax_n = out_amax.data_ptr(), out_amax.numel()
     if mask is not None:
         mrow, mc, ldm = rows_view(mask, "mask")
         if (mrow, mc) != (orow, N):

@@ -681,19 +681,19 @@ def test_split_conv_on_f16x3_with_the_range_made_on_the_device(ops, cin, N, dil,
     b = (rnd(N, seed=3) * scale).cuda()
     ref = torch.nn.functional.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double(), b.double().cpu(), padding=dil, dilation=dil)
     ref = ref.permute(0, 2, 3, 1)
-    slots = torch.zeros(3, dtype=torch.int32).cuda()
+    slots = ops.range_slots(3, x.device)   # (3, 8) words: producers spread one atomic per workgroup over a slot's words
     half = cin // 32 * 16
-    ops.amax_rows(x[..., :half], slots[0:1])   # two channel blocks, two slots: the kernel takes their maximum
-    ops.amax_rows(x[..., half:], slots[1:2])
+    ops.amax_rows(x[..., :half], slots[0])   # two channel blocks, two slots: the kernel takes the maximum over all their words
+    ops.amax_rows(x[..., half:], slots[1])
     assert float(slots[:2].view(torch.float32).max()) == float(x.abs().max())
-    y16 = ops.conv2d(x, ops.pack_weight_split16(w.cuda()), N, 3, pad=dil, dil=dil, bias=b, in_amax=slots[:2], out_amax=slots[2:3])
+    y16 = ops.conv2d(x, ops.pack_weight_split16(w.cuda()), N, 3, pad=dil, dil=dil, bias=b, in_amax=slots[:2].view(-1), out_amax=slots[2])
     y6 = ops.conv2d(x, ops.pack_weight_split(w.cuda()), N, 3, pad=dil, dil=dil, bias=b)
     den = float(ref.abs().max())
     e16 = float((y16.double().cpu() - ref).abs().max()) / den
     e6 = float((y6.double().cpu() - ref).abs().max()) / den
     observed(f"split_conv_f16x3_vs_fp64[{cin},{N},{dil},{scale}]", {"f16x3": e16, "bf16x6": e6})
     assert e16 < 2e-6 and e6 < 2e-6, (e16, e6)
-    assert float(slots[2:3].view(torch.float32)) == float(y16.abs().max())  # the epilogue's report of max |out|
+    assert float(slots[2].view(torch.float32).max()) == float(y16.abs().max())  # the epilogue's report of max |out|
 
 
 def test_split_conv_f16x3_mask_epilogue_and_nan_input(ops):
