@@ -11,20 +11,20 @@ out = {}
 for cin, N, dil in ((64, 32, 2), (128, 32, 2), (192, 32, 2), (160, 64, 2), (128, 64, 1), (64, 32, 1)):
     x = torch.rand(B, H, W, cin, device="cuda") - 0.5
     w = (torch.rand(N, cin, 3, 3, device="cuda") - 0.5) * 0.1
-    slots = torch.zeros(2, dtype=torch.int32, device="cuda")
-    ops.amax_rows(x, slots[0:1])
+    slots = ops.range_slots(6, "cuda")  # as in a DRDB: up to six channel blocks x 8 words handed to one conv
+    ops.amax_rows(x, slots[0])
     y = torch.empty(B, H, W, N, device="cuda")
     rec = {}
     fresh = ops.range_slots(16, "cuda")  # a cold (zeroed) report slot per call, as inside a training step
     for name, pk, kw in (("bf16x6", ops.pack_weight_split(w), None), ("f16x3", ops.pack_weight_split16(w), True),
                          ("f16x3, 1-word report", ops.pack_weight_split16(w), 1)):
         for _ in range(3):
-            ops.conv2d(x, pk, N, 3, pad=dil, dil=dil, out=y, **({} if kw is None else dict(in_amax=slots[:1])))
+            ops.conv2d(x, pk, N, 3, pad=dil, dil=dil, out=y, **({} if kw is None else dict(in_amax=slots.view(-1))))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for it in range(10):
             ops.conv2d(x, pk, N, 3, pad=dil, dil=dil, out=y,
-                       **({} if kw is None else dict(in_amax=slots[:1], out_amax=fresh[it] if kw is True else fresh[it, :1])))
+                       **({} if kw is None else dict(in_amax=slots.view(-1), out_amax=fresh[it] if kw is True else fresh[it, :1])))
         b.record(); torch.cuda.synchronize()
         rec[name] = a.elapsed_time(b) / 10
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
