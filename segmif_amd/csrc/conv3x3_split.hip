@@ -349,27 +349,43 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
       if (n >= p.N) continue;
       const float bv = p.bias ? p.bias[n] : 0.f;
       const float desc = F16 ? s_out * wdesc[n] : 1.f;
+      // residual and mask values first, all sixteen of each in flight at once (unconditional loads from clamped columns):
+      // fetched one by one between the stores they were a chain of exposed latencies at the end of a 25 us workgroup
+      float rv[16], mv[16];
+      const long long row = img + (long long)oy * p.W;
+      if (p.res) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int ox = min(x0 + (v & 3) + 8 * (v >> 2) + 4 * h, p.W - 1);
+          rv[v] = p.res[(row + ox) * p.ldr + n];
+        }
+      }
+      if (p.mask) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int ox = min(x0 + (v & 3) + 8 * (v >> 2) + 4 * h, p.W - 1);
+          mv[v] = p.mask[(row + ox) * p.ldm + n];
+        }
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int ox = x0 + (v & 3) + 8 * (v >> 2) + 4 * h;
         if (ox >= p.W) continue;
-        const long long m = img + (long long)oy * p.W + ox;
         float y = (F16 ? acc[i][j][v] * desc : acc[i][j][v]) + bv;
         if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
         else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
         else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
-        if (p.res) y += p.res[m * p.ldr + n];
-        if (p.mask && !(p.mask[m * p.ldm + n] > 0.f)) y = 0.f;  // DRDB backward: through the receiving block's ReLU
-        p.out[m * p.ldo + n] = y;
+        if (p.res) y += rv[v];
+        if (p.mask && !(mv[v] > 0.f)) y = 0.f;  // DRDB backward: through the receiving block's ReLU
+        p.out[(row + ox) * p.ldo + n] = y;
         amx = p16::absmax_bits(amx, y, 0.f);
       }
     }
   }
   if (p.out_amax) {
     // One atomic per WORKGROUP, spread over out_amax_n words by workgroup index (the consumer takes the maximum over all of
-    // them): with one atomic per wave on a single word the first ~2000 resident waves - which all still read 0 - serialised
-    // in the memory system for ~0.2 ms per launch (r4: 0.80 ms per call inside the training step against 0.61 ms in a
-    // micro-benchmark that re-used a warm slot).
+    // them).  (Measured against one atomic per wave on a single cold word at 8 x 480 x 640: no difference either way -
+    // tools/split_conv_bench.py "1-word report"; kept because it cannot be worse and the slots are per-launch anyway.)
     amx = p16::wave_umax(amx);
     uint32_t* red = reinterpret_cast<uint32_t*>(smem_b);  // (every wave is past the chunk loop's closing barrier: the staging area is free)
     if (lane == 0) red[wave] = amx;

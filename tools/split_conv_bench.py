@@ -38,6 +38,30 @@ for cin, N, dil in ((64, 32, 2), (128, 32, 2), (192, 32, 2), (160, 64, 2), (128,
     print(f"{cin:4d} -> {N:3d} dil {dil}:  bf16x6 {rec['bf16x6']:.3f} ms   f16x3 {rec['f16x3']:.3f} ms   (1-word report {rec['f16x3, 1-word report']:.3f} ms; amax pass over the input {rec['amax_pass_ms']:.3f} ms)")
 print(json.dumps(out))
 
+# the DRDB backward's gather form as the step issues it: input and output channel slices of wide buffers, residual + ReLU mask in
+# the epilogue, range words of several blocks in, a cold report slot out
+for cin in (32, 64, 96, 128):
+    dzb = torch.rand(B, H, W, 160, device="cuda") * 1e-6
+    dbuf = torch.rand(B, H, W, 224, device="cuda") * 1e-6
+    buf = (torch.rand(B, H, W, 224, device="cuda") - 0.3).clamp_min(0)
+    w = (torch.rand(32, cin, 3, 3, device="cuda") - 0.5) * 0.1
+    slots = ops.range_slots(6, "cuda")
+    ops.amax_rows(dzb[..., :cin], slots[0])
+    fresh = ops.range_slots(16, "cuda")
+    rec = {}
+    for name, pk in (("bf16x6", ops.pack_weight_split(w)), ("f16x3", ops.pack_weight_split16(w))):
+        kw = dict(in_amax=slots.view(-1)) if pk.f16 else {}
+        for _ in range(3):
+            ops.conv2d(dzb[..., :cin], pk, 32, 3, pad=2, dil=2, res=dbuf[..., 64:96], out=dzb[..., cin:cin + 32], mask=buf[..., 64:96], **kw)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for it in range(10):
+            ops.conv2d(dzb[..., :cin], pk, 32, 3, pad=2, dil=2, res=dbuf[..., 64:96], out=dzb[..., cin:cin + 32], mask=buf[..., 64:96],
+                       **(dict(kw, out_amax=fresh[it]) if pk.f16 else {}))
+        b.record(); torch.cuda.synchronize()
+        rec[name] = a.elapsed_time(b) / 10
+    print(f"gather {cin:4d} -> 32 dil 2 (+res, mask, slices):  bf16x6 {rec['bf16x6']:.3f} ms   f16x3 {rec['f16x3']:.3f} ms")
+
 # the matching weight gradients (two-team kernel), bf16x6 against f16x3
 from segmif_amd import autograd as ag
 for cin, N, dil in ((64, 32, 2), (128, 32, 2), (192, 32, 2), (128, 64, 1)):
