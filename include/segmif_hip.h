@@ -106,7 +106,10 @@ typedef struct SegmifIgemm {
   /* optional ReLU mask applied LAST (after the residual): out = relu_mask[m][n] > 0 ? act(A.W^T + bias) + res : 0.
    * The DRDB backward in gather form (core/model_fusion.py:134-157 differentiated): the conv that completes a block's
    * gradient writes it through that block's ReLU mask (relu_mask = the block's forward output) straight into the slot
-   * the next conv reads - no separate mask pass.  Split 3x3 tile (14) only; anything else is SEGMIF_EINVAL. */
+   * the next conv reads - no separate mask pass.  Served by the split 3x3 tile (14) and by the 16-byte epilogue of the
+   * implicit-GEMM tiles (N, ldo, ld_mask multiples of 4, aligned pointers, no fused LayerNorm / planes copy / second batch
+   * level; a masked problem is never split along K): CrossPath's backward writes each gradient through the ReLU of the
+   * channel_proj half it belongs to (core/model_fusion.py:351-353).  Anything else is SEGMIF_EINVAL. */
   const float* relu_mask;  /* [M][ld_mask] or NULL */
   int32_t ld_mask;
   /* split 3x3 tile (14) on f16x3 arithmetic (r4, the training path): wt = segmif_conv3x3_split16_pack image, activations split
@@ -125,6 +128,7 @@ typedef struct SegmifIgemm {
    * gradient - split_in_amax covers the input's channel blocks, wgrad_dy_amax those of dY */
   const uint32_t* wgrad_dy_amax;
   int32_t wgrad_dy_amax_n;
+  int64_t mask_zstride;    /* relu_mask with nz > 1 (per-image weights): element stride between batch slices */
 } SegmifIgemm;
 
 int segmif_igemm_f32(const SegmifIgemm* desc, void* stream);

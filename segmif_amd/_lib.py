@@ -32,7 +32,7 @@ class SegmifIgemm(ctypes.Structure):
         ("planes_f16", c_int32), ("planes_amax", c_void_p), ("planes_amax_images", c_int32),
         ("relu_mask", c_void_p), ("ld_mask", c_int32),
         ("split_f16", c_int32), ("split_in_amax", c_void_p), ("split_in_amax_n", c_int32), ("split_out_amax", c_void_p), ("split_out_amax_n", c_int32),
-        ("wgrad_dy_amax", c_void_p), ("wgrad_dy_amax_n", c_int32),
+        ("wgrad_dy_amax", c_void_p), ("wgrad_dy_amax_n", c_int32), ("mask_zstride", c_int64),
     ]
 
 

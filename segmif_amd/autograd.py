@@ -809,6 +809,39 @@ def _batched_wgrad(src, dy, dw, k0, n, N, K, db=None):
     _wgrad(d, dy, N, dw[:, :, k0:], dy_zstride=n * N, sn=K, sk=1, nz=B, db=db)
 
 
+class ProjSink:
+    """Shared by CrossProjFn and the nodes that consume its halves (TailPairFn, KvContextFn).  In the backward a consumer's
+    last GEMM writes the gradient of a 64-channel half THROUGH that half's ReLU mask straight into CrossProjFn's dz buffer
+    (ops.linear(mask=): the mask lives in the GEMM's epilogue) and marks it; CrossProjFn recognises its own buffer and skips
+    the separate mask pass (twelve full-resolution read-read-write passes per fusion training step)."""
+
+    def __init__(self):
+        self.p = None          # the three relu(channel_proj) tensors (B, n, 2C), set by CrossProjFn.forward
+        self.dz = [None] * 3   # their gradient buffers, allocated on first use in the backward
+        self.done = set()
+
+    def slot(self, i, half):
+        """-> (where the masked gradient of half `half` of tensor i goes, that half's forward activation = its ReLU mask)."""
+        p = self.p[i]
+        if self.dz[i] is None:
+            self.dz[i] = torch.empty(p.shape, device=p.device, dtype=torch.float32)
+        h = p.shape[-1] // 2
+        sl = slice(half * h, half * h + h)
+        return self.dz[i][..., sl], p[..., sl]
+
+    def holds(self, i, half, g):
+        """True when g IS the marked slot (its consumer wrote it masked, in place)."""
+        if (i, half) not in self.done or self.dz[i] is None or g is None:
+            return False
+        h = self.p[i].shape[-1] // 2
+        ref = self.dz[i][..., half * h:half * h + h]
+        return g.data_ptr() == ref.data_ptr() and g.shape == ref.shape and g.stride() == ref.stride()
+
+    def reset(self):
+        self.dz = [None] * 3
+        self.done = set()
+
+
 class CrossProjFn(torch.autograd.Function):
     """The three channel_proj + ReLU of CrossPath (core/model_fusion.py:351-353) as ONE node with every half its own output:
         (x1, x2, x3) -> (y1, u1, y2, u2, y3, u3, x1, x2),   [y_i | u_i] = relu(x_i W_i^T + b_i)
@@ -820,8 +853,9 @@ class CrossProjFn(torch.autograd.Function):
     8-image step."""
 
     @staticmethod
-    def forward(ctx, x1, x2, x3, w1, b1, w2, b2, w3, b3):
+    def forward(ctx, x1, x2, x3, w1, b1, w2, b2, w3, b3, sink=None):
         ctx.set_materialize_grads(False)
+        ctx.sink = sink
         outs, ps = [], []
         for x, w, b in ((x1, w1, b1), (x2, w2, b2), (x3, w3, b3)):
             N = w.shape[0]
@@ -830,22 +864,28 @@ class CrossProjFn(torch.autograd.Function):
             outs += [p[..., :N // 2], p[..., N // 2:]]
         ctx.save_for_backward(x1, x2, x3, w1, w2, w3, *ps)
         ctx.has_bias = tuple(b is not None for b in (b1, b2, b3))
+        if sink is not None:
+            sink.p = ps
+            sink.reset()
         return (*outs, x1, x2)
 
     @staticmethod
     def backward(ctx, *g):
         xs, ws, ps = ctx.saved_tensors[:3], ctx.saved_tensors[3:6], ctx.saved_tensors[6:9]
         gres = (g[6], g[7], None)
-        grads = [None] * 9
+        grads = [None] * 10
+        sink = ctx.sink
         for i in range(3):
             x, w, p = xs[i], ws[i], ps[i]
             N, K = w.shape
             h = N // 2
-            dz = torch.empty(p.shape, device=p.device, dtype=torch.float32)
+            dz = sink.dz[i] if sink is not None and sink.dz[i] is not None else torch.empty(p.shape, device=p.device, dtype=torch.float32)
             for half, gy in ((0, g[2 * i]), (1, g[2 * i + 1])):
                 sl = slice(half * h, half * h + h)
                 if gy is None:
                     dz[..., sl].zero_()
+                elif sink is not None and sink.holds(i, half, gy):
+                    pass  # the consumer's GEMM epilogue already wrote this half, masked, where it belongs
                 else:
                     act_bwd(_rows(gy), p[..., sl], ACT_RELU, out=dz[..., sl])
             if ctx.needs_input_grad[i]:
@@ -857,6 +897,8 @@ class CrossProjFn(torch.autograd.Function):
                 grads[3 + 2 * i], grads[4 + 2 * i] = r if want_b else (r, None)
             elif want_b:
                 grads[4 + 2 * i] = colsum(dz)
+        if sink is not None:
+            sink.reset()
         return tuple(grads)
 
 
@@ -867,8 +909,10 @@ class TailPairFn(torch.autograd.Function):
     contributions are summed by the second GEMM's epilogue instead of an autograd accumulation pass."""
 
     @staticmethod
-    def forward(ctx, y3, u1, u2, weff1, weff2, b1, b2, x1, x2):
+    def forward(ctx, y3, u1, u2, weff1, weff2, b1, b2, x1, x2, sink=None):
+        """sink: the ProjSink of the CrossProjFn whose halves y3 = (2, 0), u1 = (0, 1), u2 = (1, 1) are (or None)."""
         N = weff1.shape[1]
+        ctx.sink = sink
         ctx.save_for_backward(y3, u1, u2, weff1, weff2)
         ctx.has_bias = (b1 is not None, b2 is not None)
         t1 = ops.linear(y3, weff1.contiguous(), N, bias=b1, res=x1, x2=u1, batched_weight=True)
@@ -887,12 +931,23 @@ class TailPairFn(torch.autograd.Function):
         du = [None, None]
         dw = [None, None]
         db = [None, None]
+        sink = ctx.sink if ctx.sink is not None and ctx.sink.p is not None else None
         for i, (u, weff) in enumerate(((u1, weff1), (u2, weff2))):
             wt = weff.detach().transpose(1, 2)  # (B, K, N): rows = the channels of [y3 | u_i]
             if need[0]:  # the second image of y3's gradient accumulates onto the first
-                dy3 = ops.linear(dt[i], wt[:, :Ka].contiguous(), Ka, res=dy3, out=dy3, batched_weight=True)
+                if i == 1 and sink is not None:  # ... and goes through y3's ReLU mask into CrossProjFn's buffer
+                    out, mk = sink.slot(2, 0)
+                    dy3 = ops.linear(dt[i], wt[:, :Ka].contiguous(), Ka, res=dy3, out=out, mask=mk, batched_weight=True)
+                    sink.done.add((2, 0))
+                else:
+                    dy3 = ops.linear(dt[i], wt[:, :Ka].contiguous(), Ka, res=dy3, out=dy3, batched_weight=True)
             if need[1 + i]:
-                du[i] = ops.linear(dt[i], wt[:, Ka:].contiguous(), Kb, batched_weight=True)
+                if sink is not None:
+                    out, mk = sink.slot(i, 1)
+                    du[i] = ops.linear(dt[i], wt[:, Ka:].contiguous(), Kb, out=out, mask=mk, batched_weight=True)
+                    sink.done.add((i, 1))
+                else:
+                    du[i] = ops.linear(dt[i], wt[:, Ka:].contiguous(), Kb, batched_weight=True)
             want_b = ctx.has_bias[i] and need[5 + i]
             if need[3 + i]:
                 dw[i] = torch.empty((B, N, K), device=y3.device, dtype=torch.float32)
@@ -902,7 +957,7 @@ class TailPairFn(torch.autograd.Function):
             elif want_b:
                 db[i] = colsum(dt[i])
         # (the residuals' gradients are dt_i themselves: CrossProjFn adds them to its input gradients)
-        return dy3, du[0], du[1], dw[0], dw[1], db[0], db[1], (dt[0] if need[7] else None), (dt[1] if need[8] else None)
+        return dy3, du[0], du[1], dw[0], dw[1], db[0], db[1], (dt[0] if need[7] else None), (dt[1] if need[8] else None), None
 
 
 class JoinFn(torch.autograd.Function):
@@ -936,7 +991,9 @@ class KvContextFn(torch.autograd.Function):
     (kv never hits HBM); backward recomputes kv with one GEMM."""
 
     @staticmethod
-    def forward(ctx, y, wkv):
+    def forward(ctx, y, wkv, sink=None, which=None):
+        """sink / which = (i, half): y is that half of a CrossProjFn output - its gradient is written through the ReLU mask."""
+        ctx.sink, ctx.which = sink, which
         ctx.save_for_backward(y, wkv)
         part = ops.linattn_kvpartial(y, wkv.contiguous())
         B = y.shape[0]
@@ -958,9 +1015,17 @@ class KvContextFn(torch.autograd.Function):
         dkv = torch.empty_like(kv)
         ops.linear(kv[..., C:], wk, C, out=dkv[..., :C], batched_weight=True)
         ops.linear(kv[..., :C], wv, C, out=dkv[..., C:], batched_weight=True)
-        dy = ops.linear(dkv, wkv.t().contiguous(), C) if ctx.needs_input_grad[0] else None
+        dy = None
+        if ctx.needs_input_grad[0]:
+            sink = ctx.sink if ctx.sink is not None and ctx.sink.p is not None else None
+            if sink is not None:
+                out, mk = sink.slot(*ctx.which)
+                dy = ops.linear(dkv, wkv.t().contiguous(), C, out=out, mask=mk)
+                sink.done.add(tuple(ctx.which))
+            else:
+                dy = ops.linear(dkv, wkv.t().contiguous(), C)
         dw = linear_wgrad(y, dkv, 2 * C) if ctx.needs_input_grad[1] else None
-        return dy, dw
+        return dy, dw, None, None
 
 
 class BatchNormReluFn(torch.autograd.Function):
@@ -1275,16 +1340,16 @@ def batched_linear2(xa, xb, w, bias=None, res=None):
     return BatchedLinear2Fn.apply(xa, xb, w, bias, res)
 
 
-def kv_context(y, wkv):
-    return KvContextFn.apply(y, wkv)
+def kv_context(y, wkv, sink=None, which=None):
+    return KvContextFn.apply(y, wkv, sink, which)
 
 
-def cross_proj(x1, x2, x3, w1, b1, w2, b2, w3, b3):
-    return CrossProjFn.apply(x1, x2, x3, w1, b1, w2, b2, w3, b3)
+def cross_proj(x1, x2, x3, w1, b1, w2, b2, w3, b3, sink=None):
+    return CrossProjFn.apply(x1, x2, x3, w1, b1, w2, b2, w3, b3, sink)
 
 
-def tail_pair(y3, u1, u2, weff1, weff2, b1, b2, x1, x2):
-    return TailPairFn.apply(y3, u1, u2, weff1, weff2, b1, b2, x1, x2)
+def tail_pair(y3, u1, u2, weff1, weff2, b1, b2, x1, x2, sink=None):
+    return TailPairFn.apply(y3, u1, u2, weff1, weff2, b1, b2, x1, x2, sink)
 
 
 def join(whole, *parts):

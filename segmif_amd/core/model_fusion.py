@@ -379,11 +379,13 @@ class CrossPath(nn.Module):
         C = self.dim
         heads, d = 8, 8
         cp = [getattr(self, f"channel_proj{i}") for i in (1, 2, 3)]
+        # (the sink lets the consumers' backward GEMMs write each half's gradient through its ReLU mask into cross_proj's buffer)
+        sink = ag.ProjSink()
         y1, u1, y2, u2, y3, u3, x1r, x2r = ag.cross_proj(x1, x2, seg, cp[0].weight, cp[0].bias, cp[1].weight, cp[1].bias,
-                                                         cp[2].weight, cp[2].bias)
-        ctx3 = torch.softmax(ag.kv_context(u3, self.cross_attn.kv3.weight) * self.cross_attn.scale, dim=-2)
-        ctx1 = torch.softmax(ag.kv_context(y1, self.cross_attn2.kv1.weight) * self.cross_attn2.scale, dim=-2)
-        ctx2 = torch.softmax(ag.kv_context(y2, self.cross_attn2.kv2.weight) * self.cross_attn2.scale, dim=-2)
+                                                         cp[2].weight, cp[2].bias, sink)
+        ctx3 = torch.softmax(ag.kv_context(u3, self.cross_attn.kv3.weight, sink, (2, 1)) * self.cross_attn.scale, dim=-2)
+        ctx1 = torch.softmax(ag.kv_context(y1, self.cross_attn2.kv1.weight, sink, (0, 0)) * self.cross_attn2.scale, dim=-2)
+        ctx2 = torch.softmax(ag.kv_context(y2, self.cross_attn2.kv2.weight, sink, (1, 0)) * self.cross_attn2.scale, dim=-2)
         B = x1.shape[0]
         weffs = []
         for end, ctx_i in ((self.end_proj1, ctx1), (self.end_proj2, ctx2)):
@@ -393,7 +395,7 @@ class CrossPath(nn.Module):
             weffs.append(torch.cat((torch.einsum("bhij,nhj->bnhi", ctx_i, wz).reshape(B, C, C),
                                     torch.einsum("bhij,nhj->bnhi", ctx3, wv).reshape(B, C, C)), dim=-1).float())
         # x_i + [y3 | u_i] @ Weff_i^T + b_i for both modalities as one node (two-source GEMMs, residual in the epilogue)
-        t1, t2 = ag.tail_pair(y3, u1, u2, weffs[0], weffs[1], self.end_proj1.bias, self.end_proj2.bias, x1r, x2r)
+        t1, t2 = ag.tail_pair(y3, u1, u2, weffs[0], weffs[1], self.end_proj1.bias, self.end_proj2.bias, x1r, x2r, sink)
         return (ag.layernorm(t1, self.norm1.weight, self.norm1.bias, self.norm1.eps, out=out1),
                 ag.layernorm(t2, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out2))
 

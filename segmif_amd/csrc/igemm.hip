@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
   }
   float* __restrict__ out = p.out + zb * p.out_zs + z2 * p.out_zs2;
   const float* __restrict__ res = p.res ? p.res + zb * p.res_zs + z2 * p.res_zs2 : nullptr;
+  const float* __restrict__ mask = p.mask ? p.mask + zb * p.mask_zs : nullptr;  // (16-byte epilogue only: checked at launch)
   // per-column constants of this block's BN columns -> LDS (the K loop's tiles are dead): bias, and for the fused
   // LayerNorm gamma and beta; read back as float4 (lgkmcnt, not in the way of the vector-memory queue)
   float* Cs = As;  // [3][BN]
@@ -435,6 +436,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
               y[e] = activate(acc[i][j][4 * g + e] + bb[e]);
               if (res) y[e] += rr[i][j][g][e];
               yy[4 * gg + e] = y[e];
+            }
+            if (mask) {  // through a ReLU whose OUTPUT the mask tensor is (the consumer's forward activation)
+              const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + m * p.ldm + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y[e] = mk[e] > 0.f ? y[e] : 0.f;
             }
             if (p.out) *reinterpret_cast<f32x4*>(out + m * p.ldo + n) = y;
           }
@@ -639,7 +645,13 @@ extern "C" int segmif_igemm_f32(const SegmifIgemm* d, void* stream) {
   const int rc = igemm_resolve(d, k, mode, tile, nz, halo);
   if (rc != 0) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if ((d->relu_mask || d->split_f16 || d->split_out_amax) && !(halo && tile == kSplitTile)) return SEGMIF_EINVAL;  // split 3x3 kernel only
+  if ((d->split_f16 || d->split_out_amax) && !(halo && tile == kSplitTile)) return SEGMIF_EINVAL;  // split 3x3 kernel only
+  if (d->relu_mask && !(halo && tile == kSplitTile)) {
+    // elsewhere the mask lives in the 16-byte epilogue of the implicit-GEMM tiles: no halo kernel, no fused LayerNorm, no planes
+    // copy, no split-K (igemm_resolve keeps a masked problem un-split)
+    if (halo || !k.vec4 || k.ln_gamma || k.planes || k.splitk > 1 || (k.ldm & 3) || ((uintptr_t)k.mask & 15) || (k.mask_zs & 3) || k.nz2 > 1)
+      return SEGMIF_EINVAL;
+  }
   if (halo) return tile == kSplitTile ? conv3x3_split_launch(k, s) : conv3x3_halo_launch(k, tile - kHaloTile0, s);
   if (k.splitk > 1) {
     if (!d->workspace || d->workspace_floats < (int64_t)k.splitk * k.M * k.N) k.splitk = 1;  // no room: plain launch
@@ -673,7 +685,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   k.nz2 = d->nz2 > 0 ? d->nz2 : 1;
   k.in_zs2 = d->in_zstride2; k.wt_zs2 = d->wt_zstride2; k.out_zs2 = d->out_zstride2; k.res_zs2 = d->res_zstride2;
   k.ln_gamma = d->ln_gamma; k.ln_beta = d->ln_beta; k.ln_eps = d->ln_eps;
-  k.mask = d->relu_mask; k.ldm = d->ld_mask;
+  k.mask = d->relu_mask; k.ldm = d->ld_mask; k.mask_zs = d->mask_zstride;
   k.split_f16 = d->split_f16; k.in_amax = d->split_in_amax; k.in_amax_n = d->split_in_amax_n; k.out_amax = d->split_out_amax;
   k.out_amax_n = d->split_out_amax_n > 0 ? d->split_out_amax_n : 1;
   if (k.mask && k.ldm < d->N) return SEGMIF_EINVAL;
@@ -746,7 +758,7 @@ static int igemm_resolve(const SegmifIgemm* d, IgemmK& k, int& mode_out, int& ti
   if (auto_tile && tile == 6 && d->K >= 128 && mode != MODE_GENERIC) tile = 12;  // prefetch distance 2: +3..9 % (profiles/r01_enc_gemm_tiles.txt)
   k.ntm = (int)((d->M + kTiles[tile].BM - 1) / kTiles[tile].BM);
   k.ntn = (d->N + kTiles[tile].BN - 1) / kTiles[tile].BN;
-  if (auto_tile && nz == 1 && (mode == MODE_DENSE || mode == MODE_CONV) && k.ldw == k.Kp && !k.ln_gamma && !k.planes) {
+  if (auto_tile && nz == 1 && (mode == MODE_DENSE || mode == MODE_CONV) && k.ldw == k.Kp && !k.ln_gamma && !k.planes && !k.mask) {
     k.splitk = plan_splitk(d->M, d->N, k.Kp, tile);
     if (k.splitk > 1) {
       const int nk = k.Kp / kTiles[tile].BK;

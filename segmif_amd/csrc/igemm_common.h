@@ -38,8 +38,9 @@ struct IgemmK {
   int pl_f16;             // planes are f16x3 half pairs (64 bytes per pixel) instead of bf16 triples (96)
   uint32_t* pl_amax;      // f16x3: range slots receiving max |output| (planes16.h) or null
   int pl_amax_images;     // > 1: one slot per image (M = images x OH x OW), else everything reports to pl_amax[0]
-  const float* mask;  // split 3x3 tile only: out = mask[m][n] > 0 ? y : 0, applied after the residual (DRDB backward)
-  int ldm;
+  const float* mask;  // out = mask[m][n] > 0 ? y : 0, applied after the residual: the split 3x3 tile (DRDB backward) and the
+  int ldm;            // dense tiles' 16-byte epilogue (CrossPath backward: a gradient written through the consumer's ReLU mask)
+  long long mask_zs;  // z stride of the mask (batched weights: one image per z)
   int split_f16;             // split 3x3 tile: wt is an f16x3 image (segmif_conv3x3_split16_pack), in_amax must be given
   const uint32_t* in_amax;   // range slots (bit patterns of max |x|) of the input's channel blocks; the kernel takes their maximum
   int in_amax_n;

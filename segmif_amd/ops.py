@@ -793,14 +793,17 @@ def _igemm(desc, tag=None, dev="cuda"):
 
 
 def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None, x2=None, tile=-1,
-           batched_weight=False, ln=None):
+           batched_weight=False, ln=None, mask=None):
     """out = res + act(x @ wt^T + bias).  x: rows view (..., K); wt: packed (N, Kp).
+    mask: rows view shaped like out; out = mask > 0 ? (that) : 0 - a gradient written through a ReLU whose output mask is.
     x2: optional second source (..., K2): A = [x | x2] along K (no concat materialised).
     batched_weight: wt is (B, N, Kp) with one weight per leading batch index of x (x.dim() == 3)."""
     if ln is not None and not aligned16(out, res, bias, ln[0], ln[1]):
         # the fused LayerNorm epilogue only exists in its 16-byte form: run the GEMM and the normalisation apart
         y = linear(x, wt, N, bias=bias, act=act, prelu=prelu, res=res, out=out, x2=x2, tile=tile, batched_weight=batched_weight)
         return layernorm(y, ln[0], ln[1], ln[2], out=y)
+    if mask is not None and ln is not None:
+        raise RuntimeError("linear: mask= and ln= exclude each other")
     rows, K1, lda = rows_view(x, "x")
     K = K1
     d = _lib.SegmifIgemm()
@@ -842,6 +845,13 @@ def linear(x, wt, N, *, bias=None, act=ACT_NONE, prelu=None, res=None, out=None,
         d.res, d.ldr = res.data_ptr(), ldr
         if batched_weight:
             d.res_zstride = res.stride(0)
+    if mask is not None:
+        mrow, mc, ldm = rows_view(mask, "mask")
+        if mc != N or mrow != orow:
+            raise RuntimeError("mask shape mismatch")
+        d.relu_mask, d.ld_mask = mask.data_ptr(), ldm
+        if batched_weight:
+            d.mask_zstride = mask.stride(0)
     d.M, d.N, d.K = rows, N, K
     d.lda, d.ldo = lda, ldo
     d.H = d.OH = 1

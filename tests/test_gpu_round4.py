@@ -745,3 +745,22 @@ def test_conv_wgrad_on_f16x3_with_device_ranges(ops, cin, N, dil, gscale):
     assert e16 < 2e-6 and e6 < 2e-6, (e16, e6)
     bref = dy.double().cpu().sum((0, 1, 2))
     assert float((db16.double().cpu() - bref).abs().max()) / float(bref.abs().max()) < 1e-5
+
+
+def test_gemm_epilogue_relu_mask(ops):
+    """ops.linear(mask=): out = mask > 0 ? x W^T (+ res) : 0 in the implicit-GEMM tiles' 16-byte epilogue - plain and with
+    per-image weights, output and mask as channel slices of wider buffers (how CrossPath's backward uses it)."""
+    B, n, K, N = 2, 407, 128, 64
+    x = rnd(B, n, K, seed=1).cuda()
+    w = rnd(N, K, seed=2).cuda()
+    wide_out = torch.full((B, n, 128), 7.0).cuda()
+    fwd = rnd(B, n, 128, seed=3).clamp_min(0).cuda()  # forward activations (ReLU outputs): the mask source
+    res = rnd(B, n, N, seed=4).cuda()
+    y = ops.linear(x, w, N, res=res, out=wide_out[..., 64:], mask=fwd[..., 64:])
+    ref = (x.double() @ w.double().t() + res.double()) * (fwd[..., 64:] > 0)
+    assert y.data_ptr() == wide_out[..., 64:].data_ptr() and bool((wide_out[..., :64] == 7.0).all())
+    assert float((y.double() - ref).abs().max()) < 1e-4 and bool((y[fwd[..., 64:] <= 0] == 0).all())
+    wb = rnd(B, N, K, seed=5).cuda()
+    yb = ops.linear(x, wb, N, out=wide_out[..., :64], mask=fwd[..., :64], batched_weight=True)
+    refb = torch.einsum("bnk,bmk->bnm", x.double(), wb.double()) * (fwd[..., :64] > 0)
+    assert float((yb.double() - refb).abs().max()) < 1e-4 and bool((yb[fwd[..., :64] <= 0] == 0).all())

@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/traincheck; mkdir -p $out
 timeout 700 python -m pytest tests/test_gpu_round4.py tests/test_gpu_backward.py tests/test_train_golden.py tests/test_gpu_round3.py -m gpu -x -q \
-  -k "add_layernorm or relu_mask or crosspath_training or split_conv or conv_wgrad or backward or train or prelu or graphed or gradients or adamw or ssim or softmax_ce or batchnorm" > $out/pytest.txt 2>&1
+  -k "add_layernorm or relu_mask or gemm_epilogue or crosspath_training or split_conv or conv_wgrad or backward or train or prelu or graphed or gradients or adamw or ssim or softmax_ce or batchnorm" > $out/pytest.txt 2>&1
 tail -15 $out/pytest.txt
 timeout 200 python tools/split_conv_bench.py > $out/split_conv_bench.txt 2>&1; grep -- "->" $out/split_conv_bench.txt | grep -v "{"
 for st in seg fusion; do
