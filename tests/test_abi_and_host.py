@@ -8,6 +8,7 @@ import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -351,3 +352,89 @@ def test_compute_results_host_port_matches_reference(golden_dir):
         metrics.confusion_matrix(torch.zeros(4, dtype=torch.int32), torch.zeros(4, dtype=torch.int64))
     with pytest.raises(RuntimeError):
         metrics.quantize_fused(torch.zeros(1, 3, 4, 4))
+
+
+def test_struct_layout_of_the_round4_igemm_fields_matches_c(lib, tmp_path):
+    """SegmifIgemm's round-4 tail (relu_mask .. mask_zstride: the DRDB / CrossPath backward epilogues and the f16x3 training convs'
+    range slots): size and every new field's offset against gcc."""
+    from segmif_amd._lib import SegmifIgemm
+    names = ["relu_mask", "ld_mask", "split_f16", "split_in_amax", "split_in_amax_n", "split_out_amax", "split_out_amax_n",
+             "wgrad_dy_amax", "wgrad_dy_amax_n", "mask_zstride"]
+    src = tmp_path / "layout_r4.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "segmif_hip.h"\nint main(){printf("%zu' + " %zu" * len(names) + '\\n",sizeof(SegmifIgemm)'
+                   + "".join(f",offsetof(SegmifIgemm,{n})" for n in names) + ");return 0;}")
+    exe = tmp_path / "layout_r4"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [ctypes.sizeof(SegmifIgemm)] + [getattr(SegmifIgemm, n).offset for n in names]
+
+
+def test_round4_training_entry_points_size_rules_and_rejections_without_a_gpu(lib):
+    """segmif_conv3x3_split16_* / segmif_amax_f32 / the residual LayerNorm pair / act_bwd2 / prelu_bwd_rows: buffer sizes and
+    EINVAL on null / malformed arguments - no kernel is launched."""
+    # f16x3 image = the bf16x6 image's 96-byte rows + one float per PADDED output channel (32- or 64-wide column tiles)
+    assert lib.segmif_conv3x3_split16_weight_bytes(32, 64) == lib.segmif_conv3x3_split_weight_bytes(32, 64) + 4 * 32
+    assert lib.segmif_conv3x3_split16_weight_bytes(48, 64) == lib.segmif_conv3x3_split_weight_bytes(48, 64) + 4 * 64
+    assert lib.segmif_conv3x3_split16_weight_bytes(32, 24) == 0
+    assert lib.segmif_conv3x3_split16_pack(None, 32, 64, 576, None, None) == -22
+    assert lib.segmif_amax_f32(None, 10, 64, 64, None, 8, None) == -22
+    assert lib.segmif_add_layernorm_f32(None, None, None, 0, None, None, None, None, 4, 64, 64, 64, 64, 64, 1e-5, None) == -22
+    assert lib.segmif_layernorm_bwd_add_f32(None, None, None, None, 0, None, 0, None, None, 0, None, 4, 64, 64, 64, 64, 1e-5, None) == -22
+    assert lib.segmif_act_bwd2_f32(None, None, None, None, 4, 64, 64, 64, 64, 64, 1, None, None) == -22
+    assert lib.segmif_prelu_bwd_rows_f32(None, 64, None, None, None, None, None, 4, 64, None) == -22
+
+
+def test_device_made_range_arithmetic_emulated_in_numpy():
+    """The training convs' f16x3 arithmetic (csrc/conv3x3_split.hip F16, csrc/wgrad.hip F16; planes16.h range_scale) restated in
+    numpy: the operand is scaled by the power of two that puts its maximum in [2^13, 2^14), split into half pairs, multiplied
+    in three products with fp32 accumulation and descaled - for activations of order 1, gradients of order 1e-7 and values of
+    order 1e4 the result is as close to fp64 as plain fp32 arithmetic is, where unscaled halves of the small tensor are ~100x off."""
+    rng = np.random.default_rng(0)
+
+    def range_scale(x):  # planes16.h: exponent E of max |x| -> 2^(13 - E); all zero -> 1
+        mx = np.abs(x).max()
+        return np.float32(1.0) if mx == 0 else np.float32(2.0 ** (13 - int(np.floor(np.log2(mx)))))
+
+    def mm32(a, b):
+        return a.astype(np.float32) @ b.astype(np.float32)
+
+    def conv_form(x, w, scaled=True):  # activations: hi + 2^-11 lo'; weights: rows scaled to 2^14, planes W0 | Wl | 2^-11 W0
+        s = range_scale(x) if scaled else np.float32(1.0)
+        xs = (x * s).astype(np.float32)
+        hi = xs.astype(np.float16)
+        lo = ((xs - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        e = 14 - np.floor(np.log2(np.abs(w).max(axis=0, keepdims=True)))
+        ws = (w * np.exp2(e)).astype(np.float32)
+        w0 = ws.astype(np.float16)
+        wl = (ws - w0.astype(np.float32)).astype(np.float16)
+        w0s = (w0.astype(np.float32) * np.float32(2.0 ** -11)).astype(np.float16)
+        acc = mm32(lo, w0s) + mm32(hi, wl) + mm32(hi, w0)
+        return acc * np.exp2(-e).astype(np.float32) / s
+
+    def wgrad_form(dy, x):  # both operands scaled, low halves UNscaled, products hi.hi + hi.lo + lo.hi in one accumulator
+        sy, sx = range_scale(dy), range_scale(x)
+        a, b = (dy * sy).astype(np.float32), (x * sx).astype(np.float32)
+        ah, bh = a.astype(np.float16), b.astype(np.float16)
+        al, bl = (a - ah.astype(np.float32)).astype(np.float16), (b - bh.astype(np.float32)).astype(np.float16)
+        acc = mm32(al.T, bh) + mm32(ah.T, bl) + mm32(ah.T, bh)
+        return acc / sy / sx
+
+    M, K, N = 4096, 288, 32
+    w = (0.05 * rng.standard_normal((K, N)) * np.logspace(-3, 1, N)[None, :]).astype(np.float32)
+    for scale in (1.0, 3e-7, 2e4):
+        x = (scale * rng.standard_normal((M, K))).astype(np.float32)
+        ref = x.astype(np.float64) @ w.astype(np.float64)
+        yard = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64)  # each output's conditioning
+        e16 = (np.abs(conv_form(x, w) - ref) / yard).max()
+        e32 = (np.abs(mm32(x, w) - ref) / yard).max()
+        assert e16 < 4 * e32 + 1e-7, (scale, e16, e32)
+        if scale < 1e-3:  # what the scale is for: the high halves of a 1e-7 tensor without it are subnormal (two or three bits)
+            assert (np.abs(conv_form(x, w, scaled=False) - ref) / yard).max() > max(20 * e16, 1e-6)
+    dy = (3e-7 * rng.standard_normal((M, N))).astype(np.float32)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    ref = dy.astype(np.float64).T @ x.astype(np.float64)
+    yard = np.abs(dy).astype(np.float64).T @ np.abs(x).astype(np.float64)
+    e16 = (np.abs(wgrad_form(dy, x) - ref) / yard).max()
+    e32 = (np.abs(mm32(dy.T, x) - ref) / yard).max()
+    assert e16 < 4 * e32 + 1e-7, (e16, e32)
+    assert range_scale(np.zeros(4, np.float32)) == 1.0 and 2 ** 13 <= 0.3 * range_scale(np.float32([0.3])) < 2 ** 14
