@@ -183,12 +183,28 @@ def train_leg(args, rank, world, seg, fus):
 
     out = {"batch_per_gpu": B, "global_batch": B * world, "steps": steps, "warmup": warm, "world_size": world,
            "backbone": args.backbone, "height": H, "width": W}
+    # One GPU: the segmentation step's forward + loss + backward is replayed from a hipGraph (segmif_amd.train.GraphedSegTrainStep:
+    # the same kernels on the same data, bitwise the eager step - tests/test_gpu_round3.py; ~3 000 launches of ~15 us leave the host
+    # out of the loop), the optimizer update stays outside it; the eager time is reported beside it.  Data parallel runs stay eager:
+    # their gradient buckets are launched from autograd hooks DURING backward, which a replay has none of.
+    graph_seg = world == 1 and os.environ.get("SEGMIF_BENCH_SEG_GRAPH", "1") != "0"
     for mode in ("train", "eval_regime"):
         seg.train(mode == "train")
         fus.train(mode == "train")
         for name, step, red in (("seg", lambda: seg_train_step(seg, opt_seg, x, labels, crit, red_seg), red_seg),
                                 ("fusion", lambda: trainer.step(ir3, vis3, mask3, labels), red_fus)):
             dt, loss, exposed_ms = timed(step, red)
+            eager_ms = graph_note = None
+            if name == "seg" and graph_seg:
+                try:
+                    from segmif_amd.train import GraphedSegTrainStep
+                    gstep = GraphedSegTrainStep(seg, opt_seg, crit, x, labels)
+                    dt_g, loss_g, _ = timed(lambda: gstep(), None)
+                    eager_ms, dt, loss = 1e3 * dt, dt_g, loss_g
+                    del gstep
+                except Exception as e:  # (capture refused: keep the eager figure and say so)
+                    graph_note = f"hipGraph capture failed, eager step reported: {type(e).__name__}: {e}"[:300]
+                opt_seg.zero_grad(set_to_none=True)
             gf = GFLOP_TRAIN.get((args.backbone, name))
             gfx = GFLOP_TRAIN_EXECUTED.get((args.backbone, name, False), gf)  # (the default fusion step skips the seg net's weight gradients)
             rec = {"ms_per_step": 1e3 * dt, "samples_per_s": world * B / dt, "loss": loss,
@@ -199,6 +215,10 @@ def train_leg(args, rank, world, seg, fus):
                            if p.grad is not None)}
             if name == "fusion" and trainer.last_lap is not None:
                 rec["lap_loss2_reported"] = float(trainer.last_lap)
+            if eager_ms is not None:
+                rec["hipgraph_replay"], rec["eager_ms_per_step"] = True, eager_ms
+            if graph_note is not None:
+                rec["hipgraph_replay"], rec["note"] = False, graph_note
             out[f"{name}_{mode}"] = rec
     # the reference's side effect reproduced: the fusion step also forming the segmentation net's weight gradients (3 x forward
     # of everything differentiated: the full 2 304 GFLOP per sample), train mode
