@@ -224,6 +224,11 @@ def train_leg(args, rank, world, seg, fus):
     # of everything differentiated: the full 2 304 GFLOP per sample), train mode
     seg.train(True)
     fus.train(True)
+    if red_seg is not None:
+        # this leg's backward also reaches the segmentation net's parameters, whose gradients nothing reads and no rank
+        # exchanges: the segmentation step's reducer (its hooks sit on those parameters) has done its work - detach it, or its
+        # hooks would see a second backward without a finish() in between
+        red_seg.close()
     dt, loss, _ = timed(lambda: trainer_full.step(ir3, vis3, mask3, labels), red_fus)
     gf = GFLOP_TRAIN.get((args.backbone, "fusion"))
     out["fusion_train_with_seg_weight_grads"] = {
