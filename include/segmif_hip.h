@@ -183,6 +183,11 @@ typedef struct SegmifGemmSplit {
    * (ky, kx, c) order, taps outside the image read as zeros; K = k * k * C, M = B * OH * OW with OH = (H + 2 pad - k) / st + 1;
    * `w` is the image of the conv weight in the same order (segmif_pack_conv_weight's [N][Kp] rows).  0 = plain rows. */
   int32_t patch_k, patch_st, patch_pad, patch_H, patch_W;
+  /* segmif_gemm_split16_f32 only (r4, experimental: SEGMIF_TRAIN_GEMM=f16x3): every workgroup scans its own 128-row tile of A
+   * for max |a| and scales the staged values by the power of two that puts it in [2^13, 2^14), removed again in the
+   * epilogue - fp32-class results for inputs of any magnitude (gradients), no range slots (amax must be NULL), plain rows
+   * (no patch mode) */
+  int32_t self_scale;
 } SegmifGemmSplit;
 int64_t segmif_gemm_split_weight_bytes(int N, int K);
 int segmif_gemm_split_pack(const float* w, int N, int K, int ldw, void* out, void* stream);

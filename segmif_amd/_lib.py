@@ -51,7 +51,7 @@ class SegmifGemmSplit(ctypes.Structure):
     _fields_ = [("a", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("prelu", c_void_p), ("out", c_void_p),
                 ("M", c_int64), ("N", c_int32), ("K", c_int32), ("lda", c_int32), ("ldo", c_int32), ("ldr", c_int32),
                 ("act", c_int32), ("patch_k", c_int32), ("patch_st", c_int32), ("patch_pad", c_int32), ("patch_H", c_int32),
-                ("patch_W", c_int32)]
+                ("patch_W", c_int32), ("self_scale", c_int32)]
 
 
 class SegmifCrossTail(ctypes.Structure):

@@ -133,6 +133,10 @@ def _gemm(x, w_nk, N, bias=None, act=ACT_NONE, res=None, out=None):
     # problems of the fusion net; the encoder's Linears - at most 153 600 rows - are 2.5 ms per step faster on the fp32 tiles)
     if rows >= TRAIN_SPLIT_MIN_ROWS and ops.linear_wants_split(rows, N, K):
         return ops.linear_auto(x, ops.pack_linear(w_nk, half=False), N, bias=bias, act=act, res=res, out=out)
+    if ops.train_gemm_f16(rows, N, K) and act != ACT_PRELU and x.data_ptr() % 16 == 0 and rows_view(x, "x")[2] % 4 == 0 \
+            and ops._vec4(out) and ops._vec4(res) and ops._vec4(bias):
+        # (experimental switch SEGMIF_TRAIN_GEMM=f16x3: half pairs x three products, the A tile scaled by its own maximum)
+        return ops.linear_selfscaled(x, w_nk, N, bias=bias, act=act, res=res, out=out)
     wt = w_nk if (K % 16 == 0 and w_nk.is_contiguous()) else ops.pack_weight(w_nk)
     return ops.linear(x, wt, N, bias=bias, act=act, res=res, out=out)
 

@@ -102,14 +102,16 @@ __device__ __forceinline__ void fold_bits(uint32_t* slots, int b_lo, int b_hi, u
 // All-zero slots: 1.  An inf / NaN maximum: NaN - the consumer's whole output turns NaN instead of quietly wrong.
 // (n <= 64 words, read one per lane and reduced across the wave: a scalar loop over 48 words was a chain of 48 dependent
 // loads at the head of every workgroup - a third of a 30 us workgroup in the training step's convs.)
-__device__ __forceinline__ float range_scale(const uint32_t* slots, int n) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t mx = wave_umax(lane < n ? slots[lane] : 0u);
+__device__ __forceinline__ float scale_of(uint32_t mx) {  // mx: IEEE bit pattern of a maximum of magnitudes
   if (mx >= 0x7f800000u) return __uint_as_float(0x7fc00000u);
   if (!mx) return 1.f;
   int eb = 13 - ((int)(mx >> 23) - 127) + 127;
   eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
   return __uint_as_float((uint32_t)eb << 23);
+}
+__device__ __forceinline__ float range_scale(const uint32_t* slots, int n) {
+  const int lane = threadIdx.x & 63;
+  return scale_of(wave_umax(lane < n ? slots[lane] : 0u));
 }
 
 }  // namespace p16

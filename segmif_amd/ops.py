@@ -559,6 +559,58 @@ def pack_linear(w, half=None):
     return packed, GemmSplitWeight(out, N, K, img16)
 
 
+# EXPERIMENTAL (r4, off by default): the training path's tall GEMMs - forward and input gradient - on f16x3
+# with every workgroup scaling its own A tile into the half's range (segmif_gemm_split16_f32, self_scale), instead of the
+# exact-fp32 tiles.  Unit-tested against fp64 (tests/test_gpu_round4.py); NOT yet run through the training goldens, so not the
+# default: "fp32" = what the goldens were validated with.
+_TRAIN_GEMM = os.environ.get("SEGMIF_TRAIN_GEMM", "fp32")
+if _TRAIN_GEMM not in ("fp32", "f16x3"):
+    raise RuntimeError(f"SEGMIF_TRAIN_GEMM must be 'fp32' or 'f16x3', got {_TRAIN_GEMM!r}")
+
+
+def train_gemm_f16(rows, N, K):
+    return _TRAIN_GEMM == "f16x3" and rows >= GEMM_SPLIT_MIN_ROWS and N >= 128 and N % 4 == 0 and K % 32 == 0
+
+
+def set_train_gemm(mode):
+    global _TRAIN_GEMM
+    if mode not in ("fp32", "f16x3"):
+        raise ValueError("mode must be 'fp32' or 'f16x3'")
+    prev, _TRAIN_GEMM = _TRAIN_GEMM, mode
+    return prev
+
+
+def linear_selfscaled(x, w, N, *, bias=None, act=ACT_NONE, res=None, out=None):
+    """out = res + act(x @ w^T + bias) for a plain (N, K) fp32 weight on the f16x3 split GEMM with self-scaled A tiles (inputs
+    of any magnitude: gradients).  The weight image is packed per call (training: the weights change every step)."""
+    rows, K, lda = rows_view(x, "x")
+    wc = _req(w, "w").detach().contiguous()
+    if tuple(wc.shape) != (N, K) or K % 32 or N % 4 or lda % 4 or x.data_ptr() % 16:
+        raise RuntimeError(f"linear_selfscaled: needs a contiguous ({N}, K) weight with K % 32 == 0, N % 4 == 0 and 16-byte aligned rows")
+    if not (_vec4(out) and _vec4(res) and _vec4(bias)):
+        raise RuntimeError("linear_selfscaled: out / res / bias must allow 16-byte accesses")
+    lib = _lib.load()
+    img = torch.empty((lib.segmif_gemm_split16_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.segmif_gemm_split16_pack(wc.data_ptr(), N, K, K, img.data_ptr(), _stream()), "segmif_gemm_split16_pack")
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+    orow, oc, ldo = rows_view(out, "out")
+    if orow != rows or oc != N:
+        raise RuntimeError(f"out shape {tuple(out.shape)} does not match rows={rows}, N={N}")
+    d = _lib.SegmifGemmSplit()
+    d.a, d.w, d.out = x.data_ptr(), img.data_ptr(), out.data_ptr()
+    d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
+    d.M, d.N, d.K, d.lda, d.ldo, d.act = rows, N, K, lda, ldo, act
+    d.self_scale = 1
+    if res is not None:
+        rrow, rc, ldr = rows_view(res, "res")
+        if rc != N or rrow != rows:
+            raise RuntimeError("residual shape mismatch")
+        d.res, d.ldr = res.data_ptr(), ldr
+    _lib.check(lib.segmif_gemm_split16_f32(ctypes.byref(d), None, 1, _stream()), "segmif_gemm_split16_f32")
+    return out
+
+
 def linear_wants_split(rows, N, K):
     """The size rule of linear_auto, for callers that would rather not build a split weight image they will not use."""
     return _linear_mode != "fp32" and rows >= GEMM_SPLIT_MIN_ROWS and N >= 128 and N % 4 == 0 and K % 32 == 0

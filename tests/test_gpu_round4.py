@@ -764,3 +764,22 @@ def test_gemm_epilogue_relu_mask(ops):
     yb = ops.linear(x, wb, N, out=wide_out[..., :64], mask=fwd[..., :64], batched_weight=True)
     refb = torch.einsum("bnk,bmk->bnm", x.double(), wb.double()) * (fwd[..., :64] > 0)
     assert float((yb.double() - refb).abs().max()) < 1e-4 and bool((yb[fwd[..., :64] <= 0] == 0).all())
+
+
+@pytest.mark.parametrize("scale", [1.0, 3e-7, 2e4])
+def test_gemm_split_f16x3_with_self_scaled_tiles(ops, scale):
+    """segmif_gemm_split16_f32 with self_scale (experimental training switch SEGMIF_TRAIN_GEMM=f16x3): every workgroup scales
+    its own 128-row A tile into the half's range, so row blocks of very different magnitude - and gradients of 1e-7 - come
+    out fp32-class; bias, activation-free, residual, ragged M and a partial last column tile."""
+    M, K, N = 4096 + 37, 320, 320
+    x = rnd(M, K, seed=1) * scale
+    x[1000:2000] *= 1e-4   # row blocks three to four orders of magnitude apart: each tile has its own scale
+    x[3000:] *= 1e3
+    w = rnd(N, K, seed=2, lo=-0.05, hi=0.05) * torch.logspace(-2, 1, N).view(N, 1)
+    b, res = rnd(N, seed=3) * scale, rnd(M, N, seed=4) * scale
+    y = ops.linear_selfscaled(x.cuda(), w.cuda(), N, bias=b.cuda(), res=res.cuda())
+    ref = x.double() @ w.double().t() + b.double() + res.double()
+    yard = x.double().abs() @ w.double().abs().t() + b.double().abs() + res.double().abs()  # each output's conditioning
+    err = float(((y.double().cpu() - ref).abs() / yard).max())
+    observed(f"gemm_selfscaled_f16x3_vs_fp64[{scale}]", err)
+    assert err < 2e-6, err
