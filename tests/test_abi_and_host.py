@@ -438,3 +438,48 @@ def test_device_made_range_arithmetic_emulated_in_numpy():
     e32 = (np.abs(mm32(dy.T, x) - ref) / yard).max()
     assert e16 < 4 * e32 + 1e-7, (e16, e32)
     assert range_scale(np.zeros(4, np.float32)) == 1.0 and 2 ** 13 <= 0.3 * range_scale(np.float32([0.3])) < 2 ** 14
+
+
+def test_join_node_and_gradient_sink_host_logic():
+    """Host-side pieces of the training path that involve no kernel: JoinFn (producers wrote channel slices of one buffer; the node
+    hands on the buffer and splits its gradient into views - nothing is copied) and ProjSink (which gradient buffer a consumer's
+    GEMM epilogue writes a masked half into, and how CrossProjFn recognises it)."""
+    from segmif_amd import autograd as ag
+    whole = torch.zeros(2, 3, 5, 12)
+    a = (whole[..., :4].detach() + 0).requires_grad_()   # stand-ins for producers' outputs ...
+    b = (whole[..., 4:].detach() + 0).requires_grad_()
+    with pytest.raises(RuntimeError, match="not the expected channel slice"):
+        ag.join(ag.Out(whole), a, b)                      # ... that do NOT live in the buffer: refused
+
+    class Place(torch.autograd.Function):                 # a producer that writes into its placement, like LayerNormFn(out=)
+        @staticmethod
+        def forward(ctx, x, out):
+            out.t.copy_(x)
+            return out.t
+
+        @staticmethod
+        def backward(ctx, g):
+            Place.seen.append((g.data_ptr(), tuple(g.stride())))
+            return g, None
+    Place.seen = []
+    xa, xb = torch.randn(2, 3, 5, 4, requires_grad=True), torch.randn(2, 3, 5, 8, requires_grad=True)
+    pa, pb = Place.apply(xa, ag.Out(whole[..., :4])), Place.apply(xb, ag.Out(whole[..., 4:]))
+    j = ag.join(ag.Out(whole), pa, pb)
+    assert j.data_ptr() == whole.data_ptr() and torch.equal(j[..., :4], xa.detach()) and torch.equal(j[..., 4:], xb.detach())
+    g = torch.randn(2, 3, 5, 12)
+    j.backward(g)
+    assert torch.equal(xa.grad, g[..., :4]) and torch.equal(xb.grad, g[..., 4:])
+    assert sorted(p for p, _ in Place.seen) == sorted([g.data_ptr(), g[..., 4:].data_ptr()])  # views of the gradient, no copies
+    with pytest.raises(RuntimeError, match="do not cover"):
+        ag.join(ag.Out(whole), Place.apply(xa.detach(), ag.Out(whole[..., :4])))
+
+    sink = ag.ProjSink()
+    sink.p = [torch.rand(2, 7, 128) for _ in range(3)]
+    out, mask = sink.slot(1, 1)
+    assert out.shape == (2, 7, 64) and out.data_ptr() == sink.dz[1][..., 64:].data_ptr() and mask.data_ptr() == sink.p[1][..., 64:].data_ptr()
+    assert not sink.holds(1, 1, out)            # not marked yet
+    sink.done.add((1, 1))
+    assert sink.holds(1, 1, out) and not sink.holds(1, 0, out) and not sink.holds(1, 1, out.clone()) and not sink.holds(1, 1, None)
+    assert sink.slot(1, 0)[0].data_ptr() == sink.dz[1].data_ptr()  # the other half lives in the same buffer
+    sink.reset()
+    assert sink.dz == [None] * 3 and not sink.done
