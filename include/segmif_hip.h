@@ -601,6 +601,14 @@ int segmif_prelu_bwd_f32(const float* dy, const float* z, const float* slope, fl
 int segmif_prelu_bwd_rows_f32(const float* dy, int64_t lddy, const float* z, const float* slope, float* dz, double* partial,
                               float* dslope, int64_t rows, int C, void* stream);
 
+/* Batched strided copies (r4, experimental: SEGMIF_WEIGHT_PREP=1): table = nentries x { const float* src; float* dst; int64 n;
+ * int32 shape[4]; int64 stride[4] } (segmif_gather_entry_bytes() each, on the device); dst (contiguous) element j, unravelled
+ * row-major over shape, copies src[sum idx_d * stride_d] (strides in elements, may be negative); chunk i covers elements
+ * [chunk_off[i], chunk_off[i] + chunk_elems) of entry chunk_entry[i].  The training path's weight-derived tensors per step. */
+int segmif_gather_entry_bytes(void);
+int segmif_gather_copy_f32(const void* table, const int32_t* chunk_entry, const int64_t* chunk_off, int nchunks, int chunk_elems,
+                           void* stream);
+
 /* multi-tensor AdamW (utils/optimizer.py:6 -> torch.optim.AdamW arithmetic). table: device array of
  * {float* p; const float* g; float* m; float* v; int64 n; float lr; float wd;} entries
  * (segmif_adamw_entry_bytes() each); chunk_entry / chunk_off map each block to (entry, offset).

@@ -193,6 +193,8 @@ SIGNATURES = {
     "segmif_ssim_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p]),
     "segmif_sobel_l1_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "segmif_sobel_l1_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "segmif_gather_entry_bytes": (c_int, []),
+    "segmif_gather_copy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "segmif_adamw_entry_bytes": (c_int, []),
     "segmif_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
                                c_void_p]),

@@ -14,6 +14,30 @@ import torch
 
 from . import _lib, ops
 from .ops import ACT_GELU, ACT_NONE, ACT_PRELU, ACT_RELU, _req, _stream, rows_view
+from .weightprep import PREP, spec_of_view
+
+
+# weight-derived tensors: served from the step's one batched gather when SEGMIF_WEIGHT_PREP=1 (weightprep.py), else built here
+def _w_transposed(w, N, K):
+    """(K, N) contiguous transpose of a Linear / 1x1-conv weight stored as (N, K[, 1, 1])."""
+    t = PREP.lookup(w, "T", lambda p: ((K, N), (1, K), 0)) if w.is_contiguous() else None
+    return t if t is not None else w.detach().reshape(N, K).t().contiguous()
+
+
+def _w_taps(w, N, cin, k):
+    """[(ky, kx, c)][n] form of an OIHW conv weight: the "weights" of the cols = dY W^T GEMM of a strided conv's input gradient."""
+    t = PREP.lookup(w, "taps", lambda p: spec_of_view(p.detach().permute(2, 3, 1, 0))) if w.is_contiguous() else None
+    return t.view(k * k * cin, N) if t is not None else w.detach().permute(2, 3, 1, 0).reshape(k * k * cin, N).contiguous()
+
+
+def _dw9(w, flipped=False):
+    """[9][C] tap-major form of a (C, 1, 3, 3) depthwise weight (flipped: taps reversed - the input gradient's kernel)."""
+    C = w.shape[0]
+    if flipped:
+        t = PREP.lookup(w, "dw9f", lambda p: ((9, C), (-1, 9), 8)) if w.is_contiguous() else None
+        return t if t is not None else ops.pack_dw_weight(w).flip(0).contiguous()
+    t = PREP.lookup(w, "dw9", lambda p: ((9, C), (1, 9), 0)) if w.is_contiguous() else None
+    return t if t is not None else ops.pack_dw_weight(w)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -173,7 +197,7 @@ class LinearFn(torch.autograd.Function):
         dz = act_bwd(dy, y, ACT_RELU) if ctx.act == ACT_RELU else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _gemm(dz, w2.detach().t().contiguous(), K)  # (K, N): "weights" of the input-gradient GEMM
+            dx = _gemm(dz, _w_transposed(w, N, K), K)  # (K, N): "weights" of the input-gradient GEMM
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             r = linear_wgrad(x, dz, N, want_bias=want_b)
@@ -246,7 +270,7 @@ class ConvFn(torch.autograd.Function):
                 # non-overlapping patches (sr conv): every input pixel belongs to exactly one patch, so
                 # dX is one dense GEMM dY (M', N) @ W (N, k*k*Cin) followed by a patch -> image permutation
                 OH, OW = dz.shape[1], dz.shape[2]
-                wt = w.permute(2, 3, 1, 0).reshape(k * k * cin, N).contiguous()  # [(ky,kx,c)][n]
+                wt = _w_taps(w, N, cin, k)  # [(ky,kx,c)][n]
                 wt = wt if N % 16 == 0 else ops.pack_weight(wt)
                 cols = ops.linear(dz.view(B, OH * OW, N), wt, k * k * cin)
                 # patch -> image gather (rows / columns the forward conv dropped receive zeros)
@@ -256,7 +280,7 @@ class ConvFn(torch.autograd.Function):
             elif dil == 1:
                 # overlapping strided conv (patch embeds): cols = dY W^T on the matrix pipe, then a gather (col2im)
                 OH, OW = dz.shape[1], dz.shape[2]
-                wt = w.detach().permute(2, 3, 1, 0).reshape(k * k * cin, N).contiguous()  # [(ky, kx, c)][n]
+                wt = _w_taps(w, N, cin, k)  # [(ky, kx, c)][n]
                 cols = _gemm(dz.view(B, OH * OW, N), wt, k * k * cin)
                 dx = torch.empty((B, H, W, cin), device=x.device, dtype=torch.float32)
                 _lib.check(_lib.load().segmif_col2im_f32(cols.data_ptr(), dx.data_ptr(), B, H, W, cin, k, stride, pad, OH, OW,
@@ -420,7 +444,7 @@ class DwconvGeluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, w, b, H, W):
-        y = ops.dwconv3x3_gelu(h, ops.pack_dw_weight(w), b, H, W)
+        y = ops.dwconv3x3_gelu(h, _dw9(w), b, H, W)
         ctx.hw = (H, W)
         ctx.save_for_backward(h, w, b)
         return y
@@ -432,7 +456,7 @@ class DwconvGeluFn(torch.autograd.Function):
         B, _, C = h.shape
         dy = dy.contiguous()
         lib = _lib.load()
-        w9 = ops.pack_dw_weight(w)
+        w9 = _dw9(w)
         prow = lib.segmif_dwconv_bwd_partial_rows(B, H, W)
         partial = torch.empty((prow, 10 * C), device=h.device, dtype=torch.float32)
         dz = torch.empty_like(h)
@@ -447,7 +471,7 @@ class DwconvGeluFn(torch.autograd.Function):
         dh = None
         if ctx.needs_input_grad[0]:
             dh = torch.empty_like(h)
-            w9f = w9.flip(0).contiguous()
+            w9f = _dw9(w, flipped=True)
             _lib.check(lib.segmif_dwconv3x3_plain_f32(dz.data_ptr(), w9f.data_ptr(), dh.data_ptr(), B, H, W, C,
                                                       _stream()), "segmif_dwconv3x3_plain_f32")
         return dh, dw, db, None, None
@@ -464,7 +488,7 @@ class DwconvFn(torch.autograd.Function):
                                f"128 (every MiT hidden width is), got {h.shape[2]}")
         ctx.hw = (H, W)
         ctx.save_for_backward(h, w)
-        return ops.dwconv3x3_bias(h, ops.pack_dw_weight(w), b, H, W)
+        return ops.dwconv3x3_bias(h, _dw9(w), b, H, W)
 
     @staticmethod
     def backward(ctx, dy):
@@ -473,7 +497,7 @@ class DwconvFn(torch.autograd.Function):
         B, _, C = h.shape
         dy = dy.contiguous()
         lib = _lib.load()
-        w9 = ops.pack_dw_weight(w)
+        w9 = _dw9(w)
         dw = db = dh = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             partial = torch.empty((lib.segmif_dwconv_bwd_partial_rows(B, H, W), 10 * C), device=h.device, dtype=torch.float32)
@@ -484,7 +508,7 @@ class DwconvFn(torch.autograd.Function):
             db = sums[9]
         if ctx.needs_input_grad[0]:
             dh = torch.empty_like(h)
-            _lib.check(lib.segmif_dwconv3x3_plain_f32(dy.data_ptr(), w9.flip(0).contiguous().data_ptr(), dh.data_ptr(), B, H, W,
+            _lib.check(lib.segmif_dwconv3x3_plain_f32(dy.data_ptr(), _dw9(w, flipped=True).data_ptr(), dh.data_ptr(), B, H, W,
                                                       C, _stream()), "segmif_dwconv3x3_plain_f32")
         return dh, dw, db, None, None
 

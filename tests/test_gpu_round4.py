@@ -783,3 +783,38 @@ def test_gemm_split_f16x3_with_self_scaled_tiles(ops, scale):
     err = float(((y.double().cpu() - ref).abs() / yard).max())
     observed(f"gemm_selfscaled_f16x3_vs_fp64[{scale}]", err)
     assert err < 2e-6, err
+
+
+def test_weight_prep_batched_gather_equals_the_one_by_one_path(ops):
+    """segmif_amd/weightprep.py with the real gather kernel (segmif_gather_copy_f32): after one step has registered its
+    requests, the next step's weight-derived tensors come from ONE launch and the step's loss and gradients are bitwise those
+    of the one-by-one path (the same values reach the same kernels)."""
+    from segmif_amd import autograd as ag, weightprep
+    from segmif_amd.core import Network3
+    net = Network3("mit_b0", 9, pretrained=None)
+    dw.load_det_weights(net, seed=0)
+    net = net.cuda().eval()
+    x = dw.det_input("wp_x", (2, 3, 64, 96)).cuda()
+    y = dw.det_labels("wp_y", (2, 64, 96), 9).cuda()
+    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        loss = net._loss(x, y, crit)
+        loss.backward()
+        return float(loss), [p.grad.clone() for p in net.parameters() if p.grad is not None]
+
+    base_loss, base = step()
+    prep = weightprep.WeightPrep(enabled=True)
+    old, ag.PREP = ag.PREP, prep
+    try:
+        step()                      # registers the requests (all misses)
+        assert prep.misses > 20 and prep.hits == 0
+        prep.begin_step()
+        assert prep.batches == 1
+        loss, grads = step()        # served from the batch
+        assert prep.hits >= prep.misses // 2
+    finally:
+        ag.PREP = old
+    assert loss == base_loss and len(grads) == len(base) and all(torch.equal(a, b) for a, b in zip(grads, base))
