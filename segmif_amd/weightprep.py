@@ -1,5 +1,7 @@
 """Weight-derived tensors of the training path, built as ONE launch per step (EXPERIMENTAL, off by default:
-SEGMIF_WEIGHT_PREP=1; written in round 4, not yet run on a GPU - DESIGN.md section 7).
+SEGMIF_WEIGHT_PREP=1; round 4: bitwise equal to the one-by-one path on the GPU and NO faster - the segmentation step is bound by its
+kernels, not by launches, and the naive gather gives back what the launches saved: profiles/r04_weight_prep_ab.txt, DESIGN.md
+section 7).
 
 Every training step re-derives small tensors from the parameters it is about to differentiate: W^T for the input-gradient
 GEMM of each Linear (core/mix_transformer.py's q / kv / proj / fc1 / fc2 ...), the tap-major [9][C] form of each depthwise
