@@ -183,11 +183,6 @@ typedef struct SegmifGemmSplit {
    * (ky, kx, c) order, taps outside the image read as zeros; K = k * k * C, M = B * OH * OW with OH = (H + 2 pad - k) / st + 1;
    * `w` is the image of the conv weight in the same order (segmif_pack_conv_weight's [N][Kp] rows).  0 = plain rows. */
   int32_t patch_k, patch_st, patch_pad, patch_H, patch_W;
-  /* segmif_gemm_split16_f32 only (r4, experimental: SEGMIF_TRAIN_GEMM=f16x3): every workgroup scans its own 128-row tile of A
-   * for max |a| and scales the staged values by the power of two that puts it in [2^13, 2^14), removed again in the
-   * epilogue - fp32-class results for inputs of any magnitude (gradients), no range slots (amax must be NULL), plain rows
-   * (no patch mode) */
-  int32_t self_scale;
 } SegmifGemmSplit;
 int64_t segmif_gemm_split_weight_bytes(int N, int K);
 int segmif_gemm_split_pack(const float* w, int N, int K, int ldw, void* out, void* stream);
@@ -421,6 +416,10 @@ int segmif_linattn_fold_f32(const double* partial, const float* wend, float* wef
  *    symmetric 64 x 64 matrix, 32 x 32 row-major); fp32 inside a 32-pixel run, fp64 across runs.
  *  - segmif_crosspath_fold_f32: K^T V = Wk G Wv^T per head from the Gram partials ([Wk; Wv] = the raw (128, 64) kv
  *    weight), softmax over the k index of (K^T V) * scale, folded into end_proj exactly like segmif_linattn_fold_f32.
+ *    cond (or NULL): B words, one per image; the launch raises cond[b] (integer atomic max over fp32 bit patterns) to
+ *    kappa = max over its 64 softmax columns of max_i |logit_i| * (1 - p_max) - the factor by which this softmax amplifies a
+ *    RELATIVE error of its logits.  The host's f16x3 guard reads it beside the range slots: an image whose kappa passes a
+ *    calibrated bound is computed again with the 3x3 convs in exact fp32 (round 5; core/model_fusion.py:281-286, :316-326).
  *  - segmif_crosspath_tail_f32: out = LayerNorm_64(x_i + Weff_b . [ReLU(W3 x_3 + b3) | ReLU(Wi x_i + bi)] + bend):
  *    channel_proj halves, the context-folded end_proj (Weff: (B, 64, 128)), residual and norm in one pass over the
  *    tokens; optionally also emits out as planes chunks 0..3 (conv3x3_planes format, H * W == N) for the next DRDB.
@@ -440,16 +439,13 @@ typedef struct SegmifCrossTail {
   int32_t planes_f16;                               /* != 0: an f16x3 buffer (segmif_planes16_*) */
   uint32_t* planes_amax;                            /* f16x3: range slot(s) for max |out|, or NULL */
   int32_t planes_amax_images;                       /* == B: planes_amax[image]; <= 1: planes_amax[0] */
-  /* arith_f16 != 0: the kernel's own contractions on f16x3 operands (half pairs x three products; default: bf16 triples x six);
-   * arith_amax (or NULL) then receives max |x_3|, |x_i| of the pixels it split, indexed like planes_amax */
-  int32_t arith_f16; uint32_t* arith_amax; int32_t arith_amax_images;
 } SegmifCrossTail;
 
 int segmif_crosspath_gram_blocks(int64_t N);
 int segmif_crosspath_gram_f32(const float* x, int ldx, const float* w, const float* bias, double* partial, int B, int64_t N,
                               void* stream);
 int segmif_crosspath_fold_f32(const double* partial, int nblk, const float* wkv, const float* wend, float* weff, int B,
-                              int Nout, int ldw, int wofs, int ldweff, int kofs, float scale, void* stream);
+                              int Nout, int ldw, int wofs, int ldweff, int kofs, float scale, uint32_t* cond, void* stream);
 int segmif_crosspath_tail_f32(const SegmifCrossTail* desc, void* stream);
 
 /*
@@ -600,14 +596,6 @@ int segmif_prelu_bwd_f32(const float* dy, const float* z, const float* slope, fl
 /* the same with dy a rows view (rows x C, pitch lddy floats): a channel slice of a wider gradient buffer, read in place */
 int segmif_prelu_bwd_rows_f32(const float* dy, int64_t lddy, const float* z, const float* slope, float* dz, double* partial,
                               float* dslope, int64_t rows, int C, void* stream);
-
-/* Batched strided copies (r4, experimental: SEGMIF_WEIGHT_PREP=1): table = nentries x { const float* src; float* dst; int64 n;
- * int32 shape[4]; int64 stride[4] } (segmif_gather_entry_bytes() each, on the device); dst (contiguous) element j, unravelled
- * row-major over shape, copies src[sum idx_d * stride_d] (strides in elements, may be negative); chunk i covers elements
- * [chunk_off[i], chunk_off[i] + chunk_elems) of entry chunk_entry[i].  The training path's weight-derived tensors per step. */
-int segmif_gather_entry_bytes(void);
-int segmif_gather_copy_f32(const void* table, const int32_t* chunk_entry, const int64_t* chunk_off, int nchunks, int chunk_elems,
-                           void* stream);
 
 /* multi-tensor AdamW (utils/optimizer.py:6 -> torch.optim.AdamW arithmetic). table: device array of
  * {float* p; const float* g; float* m; float* v; int64 n; float lr; float wd;} entries

@@ -51,7 +51,7 @@ class SegmifGemmSplit(ctypes.Structure):
     _fields_ = [("a", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("prelu", c_void_p), ("out", c_void_p),
                 ("M", c_int64), ("N", c_int32), ("K", c_int32), ("lda", c_int32), ("ldo", c_int32), ("ldr", c_int32),
                 ("act", c_int32), ("patch_k", c_int32), ("patch_st", c_int32), ("patch_pad", c_int32), ("patch_H", c_int32),
-                ("patch_W", c_int32), ("self_scale", c_int32)]
+                ("patch_W", c_int32)]
 
 
 class SegmifCrossTail(ctypes.Structure):
@@ -62,7 +62,6 @@ class SegmifCrossTail(ctypes.Structure):
         ("B", c_int32), ("N", c_int64),
         ("planes_out", c_void_p), ("H", c_int32), ("W", c_int32), ("planes_chunks", c_int32),
         ("planes_f16", c_int32), ("planes_amax", c_void_p), ("planes_amax_images", c_int32),
-        ("arith_f16", c_int32), ("arith_amax", c_void_p), ("arith_amax_images", c_int32),
     ]
 
 
@@ -109,7 +108,7 @@ SIGNATURES = {
     "segmif_crosspath_gram_blocks": (c_int, [c_int64]),
     "segmif_crosspath_gram_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "segmif_crosspath_fold_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                        c_int, c_float, c_void_p]),
+                                        c_int, c_float, c_void_p, c_void_p]),
     "segmif_crosspath_tail_f32": (c_int, [POINTER(SegmifCrossTail), c_void_p]),
     "segmif_color3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "segmif_mixffn_weight_bytes": (c_int64, [c_int]),
@@ -193,8 +192,6 @@ SIGNATURES = {
     "segmif_ssim_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p]),
     "segmif_sobel_l1_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "segmif_sobel_l1_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "segmif_gather_entry_bytes": (c_int, []),
-    "segmif_gather_copy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "segmif_adamw_entry_bytes": (c_int, []),
     "segmif_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
                                c_void_p]),

@@ -14,30 +14,24 @@ import torch
 
 from . import _lib, ops
 from .ops import ACT_GELU, ACT_NONE, ACT_PRELU, ACT_RELU, _req, _stream, rows_view
-from .weightprep import PREP, spec_of_view
 
 
-# weight-derived tensors: served from the step's one batched gather when SEGMIF_WEIGHT_PREP=1 (weightprep.py), else built here
+# weight-derived tensors of the backward pass (built per call: the weights change every step)
 def _w_transposed(w, N, K):
     """(K, N) contiguous transpose of a Linear / 1x1-conv weight stored as (N, K[, 1, 1])."""
-    t = PREP.lookup(w, "T", lambda p: ((K, N), (1, K), 0)) if w.is_contiguous() else None
-    return t if t is not None else w.detach().reshape(N, K).t().contiguous()
+    return w.detach().reshape(N, K).t().contiguous()
 
 
 def _w_taps(w, N, cin, k):
     """[(ky, kx, c)][n] form of an OIHW conv weight: the "weights" of the cols = dY W^T GEMM of a strided conv's input gradient."""
-    t = PREP.lookup(w, "taps", lambda p: spec_of_view(p.detach().permute(2, 3, 1, 0))) if w.is_contiguous() else None
-    return t.view(k * k * cin, N) if t is not None else w.detach().permute(2, 3, 1, 0).reshape(k * k * cin, N).contiguous()
+    return w.detach().permute(2, 3, 1, 0).reshape(k * k * cin, N).contiguous()
 
 
 def _dw9(w, flipped=False):
     """[9][C] tap-major form of a (C, 1, 3, 3) depthwise weight (flipped: taps reversed - the input gradient's kernel)."""
-    C = w.shape[0]
     if flipped:
-        t = PREP.lookup(w, "dw9f", lambda p: ((9, C), (-1, 9), 8)) if w.is_contiguous() else None
-        return t if t is not None else ops.pack_dw_weight(w).flip(0).contiguous()
-    t = PREP.lookup(w, "dw9", lambda p: ((9, C), (1, 9), 0)) if w.is_contiguous() else None
-    return t if t is not None else ops.pack_dw_weight(w)
+        return ops.pack_dw_weight(w).flip(0).contiguous()
+    return ops.pack_dw_weight(w)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -157,10 +151,6 @@ def _gemm(x, w_nk, N, bias=None, act=ACT_NONE, res=None, out=None):
     # problems of the fusion net; the encoder's Linears - at most 153 600 rows - are 2.5 ms per step faster on the fp32 tiles)
     if rows >= TRAIN_SPLIT_MIN_ROWS and ops.linear_wants_split(rows, N, K):
         return ops.linear_auto(x, ops.pack_linear(w_nk, half=False), N, bias=bias, act=act, res=res, out=out)
-    if ops.train_gemm_f16(rows, N, K) and act != ACT_PRELU and x.data_ptr() % 16 == 0 and rows_view(x, "x")[2] % 4 == 0 \
-            and ops._vec4(out) and ops._vec4(res) and ops._vec4(bias):
-        # (experimental switch SEGMIF_TRAIN_GEMM=f16x3: half pairs x three products, the A tile scaled by its own maximum)
-        return ops.linear_selfscaled(x, w_nk, N, bias=bias, act=act, res=res, out=out)
     wt = w_nk if (K % 16 == 0 and w_nk.is_contiguous()) else ops.pack_weight(w_nk)
     return ops.linear(x, wt, N, bias=bias, act=act, res=res, out=out)
 

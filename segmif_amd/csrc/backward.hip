@@ -620,36 +620,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamEntry* __restrict_
   }
 }
 
-// Many small strided copies in ONE launch: dst_e (contiguous, n_e elements) = src_e viewed with a 4-d shape and arbitrary -
-// also negative - element strides.  The training path's weight-derived tensors (W^T for the input-gradient GEMMs, tap-major
-// depthwise / conv weights, flipped taps: ~300 launches of a few microseconds per segmentation step when built one by one)
-// go through it as one batch per step (segmif_amd/weightprep.py).  Same chunk table as adamw_kernel.
-struct GatherEntry {
-  const float* src;   // element the all-zero index maps to
-  float* dst;
-  long long n;        // shape[0] * shape[1] * shape[2] * shape[3]
-  int shape[4];
-  long long stride[4];
-};
-
-__global__ __launch_bounds__(256) void gather_copy_kernel(const GatherEntry* __restrict__ table, const int* __restrict__ chunk_entry,
-                                                          const long long* __restrict__ chunk_off, int chunk_elems) {
-  const GatherEntry e = table[chunk_entry[blockIdx.x]];
-  const long long base = chunk_off[blockIdx.x];
-  for (int i = threadIdx.x; i < chunk_elems; i += 256) {
-    const long long j = base + i;
-    if (j >= e.n) break;
-    long long r = j, off = 0;
-#pragma unroll
-    for (int d = 3; d >= 0; --d) {
-      const long long q = r / e.shape[d];
-      off += (r - q * e.shape[d]) * e.stride[d];
-      r = q;
-    }
-    e.dst[j] = e.src[off];
-  }
-}
-
 // Input gradient of a strided convolution, second half.  First half: cols = dY (rows = output pixels) x W^T as ONE dense GEMM
 // on the matrix pipe, cols[b][oy][ox][(ky, kx, c)]; this kernel gathers them back: input pixel (y, x) receives the taps
 // with ky = (y + pad) mod s (+ s, + 2 s ..) from output pixel ((y + pad - ky) / s, ..).  The scalar gather kernel it replaces
@@ -852,16 +822,6 @@ extern "C" int segmif_adamw_f32(const void* table, const int32_t* chunk_entry, c
   if (!table || !chunk_entry || !chunk_off || nchunks <= 0 || chunk_elems <= 0 || !(bc1 > 0.f) || !(bc2s > 0.f)) return SEGMIF_EINVAL;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)table,
                      (const int*)chunk_entry, (const long long*)chunk_off, beta1, beta2, eps, bc1, bc2s, chunk_elems);
-  return (int)hipGetLastError();
-}
-
-extern "C" int segmif_gather_entry_bytes(void) { return (int)sizeof(GatherEntry); }
-
-extern "C" int segmif_gather_copy_f32(const void* table, const int32_t* chunk_entry, const int64_t* chunk_off, int nchunks,
-                                      int chunk_elems, void* stream) {
-  if (!table || !chunk_entry || !chunk_off || nchunks <= 0 || chunk_elems <= 0) return SEGMIF_EINVAL;
-  hipLaunchKernelGGL(gather_copy_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const GatherEntry*)table,
-                     (const int*)chunk_entry, (const long long*)chunk_off, chunk_elems);
   return (int)hipGetLastError();
 }
 

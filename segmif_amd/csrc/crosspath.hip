@@ -130,70 +130,6 @@ __device__ __forceinline__ void wfrag(const unsigned char* base, int row, int pi
   for (int k = 0; k < 3; ++k) out[k] = *reinterpret_cast<const u32x4*>(a + k * plane_bytes);
 }
 
-// ---- f16x3 arithmetic (planes16.h): weights as three half planes W0 | W - W0 | 2^-11 W0 of the row scaled by a power of two,
-// activations as half pairs split in registers; three products per MAC, least significant first: lo W0s, hi Wl, hi W0
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-struct Op2 {
-  u32x4 hi, lo;
-};
-__device__ __forceinline__ Op2 split8h(const f32x4 a, const f32x4 b) {
-  const float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  Op2 o;
-  p16::split8(y, o.hi, o.lo);
-  return o;
-}
-__device__ __forceinline__ Op2 split8h(const f32x16 t, int s) {  // accumulator registers 8s .. 8s+7
-  return split8h(f32x4{t[8 * s], t[8 * s + 1], t[8 * s + 2], t[8 * s + 3]},
-                 f32x4{t[8 * s + 4], t[8 * s + 5], t[8 * s + 6], t[8 * s + 7]});
-}
-__device__ __forceinline__ f16x8 oph(const u32x4 v) { return __builtin_bit_cast(f16x8, v); }
-// acc += W X with the weight planes `w` as the MFMA's first operand (rows) and the half pair `x` as its second
-__device__ __forceinline__ f32x16 mma3(const u32x4* w, const Op2& x, f32x16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oph(w[2]), oph(x.lo), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oph(w[1]), oph(x.hi), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oph(w[0]), oph(x.hi), acc, 0, 0, 0);
-  return acc;
-}
-__device__ __forceinline__ void split3h(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const h2 w0 = {(_Float16)x0, (_Float16)x1};
-  const h2 wl = {(_Float16)(x0 - (float)w0[0]), (_Float16)(x1 - (float)w0[1])};
-  const h2 ws = {(_Float16)((float)w0[0] * (1.f / p16::LSCALE)), (_Float16)((float)w0[1] * (1.f / p16::LSCALE))};
-  p0 = __builtin_bit_cast(uint32_t, w0);
-  p1 = __builtin_bit_cast(uint32_t, wl);
-  p2 = __builtin_bit_cast(uint32_t, ws);
-}
-__device__ __forceinline__ float pow2_scale(float mx) {  // brings mx into [2^14, 2^15); 1 for zero / non-finite
-  int e = 0;
-  if (mx >= 1e-30f && mx <= 3e38f) e = 14 - (int)((__float_as_uint(mx) >> 23) - 127);
-  return ldexpf(1.f, e);
-}
-// f16x3 LDS image of 64 rows x NCOL columns (64 | 128) of a row-major fp32 matrix, same positions as stage_split64; the row
-// scale 2^-e(n) goes to inv[n].  One row per LPR lanes (a half-wave for 64 columns, a wave for 128): its maximum is a
-// shuffle reduction.  Must be called by all `nthreads` threads (a multiple of 64).
-template <int NCOL>
-__device__ __forceinline__ void stage_split_h(const float* __restrict__ w, int ldw, unsigned char* dst, int pitch, float* inv,
-                                              int tid, int nthreads) {
-  constexpr int LPR = NCOL / 2;  // lanes (pairs of columns) per row
-  for (int u = tid; u < 64 * LPR; u += nthreads) {
-    const int row = u / LPR, pp = 2 * (u % LPR);
-    const int s = pp >> 4, hh = (pp >> 3) & 1, j = pp & 7;
-    const int col = 16 * s + 4 * hh + (j & 3) + 8 * (j >> 2);
-    const f32x2 v = *reinterpret_cast<const f32x2*>(w + (long long)row * ldw + col);
-    float mx = fmaxf(fabsf(v[0]), fabsf(v[1]));
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    const float sc = pow2_scale(mx);
-    uint32_t a, b, c;
-    split3h(v[0] * sc, v[1] * sc, a, b, c);
-    unsigned char* d = dst + row * pitch + pp * 2;
-    *reinterpret_cast<uint32_t*>(d) = a;
-    *reinterpret_cast<uint32_t*>(d + NCOL * 2) = b;
-    *reinterpret_cast<uint32_t*>(d + NCOL * 4) = c;
-    if (u % LPR == 0) inv[row] = 1.f / sc;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                              const float* __restrict__ bias, double* __restrict__ partial,
@@ -300,7 +236,7 @@ __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __rest
 __global__ __launch_bounds__(1024) void crosspath_fold_kernel(const double* __restrict__ partial, int nblk,
                                                               const float* __restrict__ wkv, const float* __restrict__ wend,
                                                               float* __restrict__ weff, int Nout, int ldw, int wofs, int ldweff,
-                                                              int kofs, float scale) {
+                                                              int kofs, float scale, uint32_t* __restrict__ cond) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* G = dsm;            // [64][64]
   double* T1 = dsm + 4096;    // [64][64]  Wk G
@@ -333,14 +269,33 @@ __global__ __launch_bounds__(1024) void crosspath_fold_kernel(const double* __re
   __syncthreads();
   if (tid < 64) {  // one (h, j) column per thread: softmax over i (dim = -2)
     const int hh = tid >> 3, j = tid & 7;
-    double mx = -1e300;
-    for (int i = 0; i < 8; ++i) mx = fmax(mx, ctx[hh * 64 + i * 8 + j]);
+    double mx = -1e300, amx = 0.0;
+    for (int i = 0; i < 8; ++i) {
+      mx = fmax(mx, ctx[hh * 64 + i * 8 + j]);
+      amx = fmax(amx, fabs(ctx[hh * 64 + i * 8 + j]));
+    }
     double ev[8], sum = 0.0;
     for (int i = 0; i < 8; ++i) {
       ev[i] = exp(ctx[hh * 64 + i * 8 + j] - mx);
       sum += ev[i];
     }
     for (int i = 0; i < 8; ++i) ctx[hh * 64 + i * 8 + j] = ev[i] / sum;
+    if (cond) {
+      // Conditioning of this softmax column with respect to RELATIVE errors of its logits (which is what the arithmetic of
+      // the producers leaves: the logits are sums over all pixels of products of features): d p_i = p_i (dL_i - sum_k p_k dL_k)
+      // with |dL_i| <= eps |L_i|, so |dp| <= eps * max|L| * 2 (1 - p_max) to first order - large logits only hurt while the
+      // column is still undecided.  kappa = max |L| (1 - p_max); a one-hot column (p_max = 1 / sum = 1) reports 0, NaN logits
+      // report NaN (top of the integer order).  Non-negative floats order like their bit patterns: integer atomic max.
+      const float kappa = (float)(amx * (1.0 - 1.0 / sum));
+      uint32_t bits = __float_as_uint(kappa);
+      if (kappa != kappa) bits = 0x7fc00000u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)bits, o);
+        bits = other > bits ? other : bits;
+      }
+      if (tid == 0 && bits > cond[b]) atomicMax(cond + b, bits);
+    }
   }
   __syncthreads();
   for (int o = tid; o < Nout * 64; o += 1024) {
@@ -364,8 +319,6 @@ struct TailK {
   int pl_f16;                         // the copy is an f16x3 one (half pairs, 64 bytes per pixel; planes16.h)
   uint32_t* pl_amax;                  // f16x3: range slot(s) for max |out| or null
   int pl_amax_images;                 // > 1: slot index = image (blockIdx.y)
-  uint32_t* ar_amax;                  // f16x3 ARITHMETIC: range slot(s) for max |x_3|, |x_i| or null
-  int ar_amax_images;
   long long N;
   int ld3, ldi, ldo;
   int W, Hp, Wp, chunks;              // planes geometry (image width, padded dims, chunk images per batch element)
@@ -373,33 +326,22 @@ struct TailK {
 };
 
 // F16: the planes copy is an f16x3 one (its own instantiation: the bf16 kernel sits at the register limit).
-// A16: the ARITHMETIC is f16x3 too (r4): the three weight matrices are staged as scaled half planes (row scales in LDS), the
-// pixels and the intermediate relu(channel_proj) are split into half pairs in registers, three MFMA products per MAC instead
-// of six - the kernel then runs at its HBM traffic instead of at the matrix pipe + vector ALU.
-template <bool F16, bool A16>
+template <bool F16>
 __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* W3s = smem_raw;             // [64][WPB]
   unsigned char* Wis = W3s + 64 * WPB;       // [64][WPB]
   unsigned char* Wes = Wis + 64 * WPB;       // [64][WPB2]
-  float* Cst = reinterpret_cast<float*>(Wes + 64 * WPB2);  // b3[64] bi[64] bend[64] gamma[64] beta[64] | A16: 2^-e of W3, Wi, Weff rows
+  float* Cst = reinterpret_cast<float*>(Wes + 64 * WPB2);  // b3[64] bi[64] bend[64] gamma[64] beta[64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
-  if constexpr (A16) {
-    stage_split_h<64>(p.w3, 64, W3s, WPB, Cst + 320, tid, 512);
-    stage_split_h<64>(p.wi, 64, Wis, WPB, Cst + 384, tid, 512);
-    stage_split_h<128>(p.weff + (long long)b * 64 * 128, 128, Wes, WPB2, Cst + 448, tid, 512);
-  } else {
-    stage_split64(p.w3, 64, 0, W3s, WPB, 0, 128, tid, 512);
-    stage_split64(p.wi, 64, 0, Wis, WPB, 0, 128, tid, 512);
-  }
+  stage_split64(p.w3, 64, 0, W3s, WPB, 0, 128, tid, 512);
+  stage_split64(p.wi, 64, 0, Wis, WPB, 0, 128, tid, 512);
   {
     const float* we = p.weff + (long long)b * 64 * 128;
-    if constexpr (!A16) {
-      stage_split64(we, 128, 0, Wes, WPB2, 0, 256, tid, 512);
-      stage_split64(we, 128, 64, Wes, WPB2, 64, 256, tid, 512);
-    }
+    stage_split64(we, 128, 0, Wes, WPB2, 0, 256, tid, 512);
+    stage_split64(we, 128, 64, Wes, WPB2, 64, 256, tid, 512);
     if (tid < 320) {
       const int a = tid >> 6, c = tid & 63;
       const float* src = a == 0 ? p.b3 : a == 1 ? p.bi : a == 2 ? p.bend : a == 3 ? p.gamma : p.beta;
@@ -414,7 +356,6 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
   const long long ntiles = (p.N + 31) / 32;
   const long long stride = (long long)gridDim.x * CP_WAVES;
   uint32_t pl_amx = 0u;  // f16x3 planes copy: largest |out| this lane wrote (p16::absmax_pk patterns)
-  uint32_t ar_amx = 0u;  // f16x3 arithmetic: largest |operand| this lane split, as an fp32 bit pattern
   auto load = [&](long long tt, const float* __restrict__ base, int ld, f32x4* dst) {  // a pixel's channels 8q + 4h .. +3
     const long long px = tt * 32 + r;
     const bool ok = tt < ntiles && px < p.N;
@@ -442,24 +383,9 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
     const bool ok = px < p.N;
     int zo = 0;  // opaque zero in every LDS address below (see the Gram kernel): keeps ~200 registers of loop-invariant
     asm volatile("" : "+v"(zo));  // weight fragments from being hoisted out of the tile loop
-    // range of the two pixel rows about to be split (fp32 bit patterns).  The intermediate relu(channel_proj) is NOT tracked: any
-    // extra vector use of those accumulators makes hipcc spill ~300 registers here; it is bounded by |W| |x| + |b|, an overflow of it
-    // turns the output into inf / NaN, which the planes copy's own slot reports.
-    if constexpr (A16) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        ar_amx = p16::absmax_bits(p16::absmax_bits(ar_amx, c3[q][0], c3[q][1]), c3[q][2], c3[q][3]);
-        ar_amx = p16::absmax_bits(p16::absmax_bits(ar_amx, ci[q][0], ci[q][1]), ci[q][2], ci[q][3]);
-      }
-    }
-    f32x16 z[2];  // end_proj accumulators, bias as the initial value (A16: applied after the row scale instead)
-    if constexpr (A16) {
-      z[0] = zero16();
-      z[1] = zero16();
-    } else {
-      z[0] = rows16(Cst + zo + 128);
-      z[1] = rows16(Cst + zo + 160);
-    }
+    f32x16 z[2];  // end_proj accumulators, bias as the initial value
+    z[0] = rows16(Cst + zo + 128);
+    z[1] = rows16(Cst + zo + 160);
     // two passes: source 0 = x_3 -> y_3 half (W3, columns 0..63 of Weff), source 1 = x_i -> u_i half (Wi, columns 64..127)
 #pragma unroll
     for (int src = 0; src < 2; ++src) {
@@ -469,77 +395,37 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
       // (v&3) + 8 (v>>2) + 4h of the 32-row tile
       const unsigned char* Wsrc = (src == 0 ? W3s : Wis) + zo;
       f32x16 tt[2];
-      if constexpr (A16) {
-        tt[0] = zero16();
-        tt[1] = zero16();
-      } else {
-        tt[0] = rows16(Cst + zo + src * 64);
-        tt[1] = rows16(Cst + zo + src * 64 + 32);
-      }
+      tt[0] = rows16(Cst + zo + src * 64);
+      tt[1] = rows16(Cst + zo + src * 64 + 32);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        Op3 xs;
-        Op2 xh;
-        if constexpr (A16) {
-          xh = split8h(xc[2 * s], xc[2 * s + 1]);
-        } else {
-          xs = split8(xc[2 * s], xc[2 * s + 1]);
-        }
+        const Op3 xs = split8(xc[2 * s], xc[2 * s + 1]);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           u32x4 wf[3];
           wfrag(Wsrc, nt * 32 + r, WPB, 128, s, h, wf);
-          if constexpr (A16) tt[nt] = mma3(wf, xh, tt[nt]);
-          else tt[nt] = mma6(wf, xs.p, tt[nt]);
+          tt[nt] = mma6(wf, xs.p, tt[nt]);
         }
       }
       if (src == 0) load(t + stride, x3b, p.ld3, c3);  // (its rows have been split: the registers take the next tile's)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        if constexpr (A16) {  // row scale 2^-e(c), bias, ReLU
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(Cst + zo + 320 + src * 64 + nt * 32 + 8 * g + 4 * h);
-            const f32x4 bs = *reinterpret_cast<const f32x4*>(Cst + zo + src * 64 + nt * 32 + 8 * g + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tt[nt][4 * g + e] = fmaxf(fmaf(tt[nt][4 * g + e], sc[e], bs[e]), 0.f);
-          }
-        } else {
-#pragma unroll
-          for (int v = 0; v < 16; ++v) tt[nt][v] = fmaxf(tt[nt][v], 0.f);
-        }
+        for (int v = 0; v < 16; ++v) tt[nt][v] = fmaxf(tt[nt][v], 0.f);
       }
       // stage 2: Z[m][px] += sum_c Weff[m][c] T[c][px]: registers 8s' .. 8s'+7 of tile nt are the K-slots of step 2nt + s'
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
-          Op3 tk;
-          Op2 th;
-          if constexpr (A16) {
-            th = split8h(tt[nt], sp);
-          } else {
-            tk = split8(tt[nt], sp);
-          }
+          const Op3 tk = split8(tt[nt], sp);
           const int ks = src * 4 + nt * 2 + sp;
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
             u32x4 wf[3];
             wfrag(Wes + zo, mt * 32 + r, WPB2, 256, ks, h, wf);
-            if constexpr (A16) z[mt] = mma3(wf, th, z[mt]);
-            else z[mt] = mma6(wf, tk.p, z[mt]);
+            z[mt] = mma6(wf, tk.p, z[mt]);
           }
-        }
-    }
-    if constexpr (A16) {  // end_proj: row scale 2^-e(m), then the bias
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(Cst + zo + 448 + mt * 32 + 8 * g + 4 * h);
-          const f32x4 bs = *reinterpret_cast<const f32x4*>(Cst + zo + 128 + mt * 32 + 8 * g + 4 * h);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) z[mt][4 * g + e] = fmaf(z[mt][4 * g + e], sc[e], bs[e]);
         }
     }
     // epilogue: + residual x_i (same channel layout: channel 32 mt + 8 g + 4 h + e = ci[4 mt + g][e]), LayerNorm over the
@@ -619,9 +505,6 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
   if constexpr (F16) {
     if (p.pl_amax) p16::fold_pat(p.pl_amax, p.pl_amax_images > 1 ? b : 0, p.pl_amax_images > 1 ? b : 0, pl_amx);
   }
-  if constexpr (A16) {
-    if (p.ar_amax) p16::fold_bits(p.ar_amax, p.ar_amax_images > 1 ? b : 0, p.ar_amax_images > 1 ? b : 0, ar_amx);
-  }
 }
 
 }  // namespace
@@ -646,7 +529,8 @@ extern "C" int segmif_crosspath_gram_f32(const float* x, int ldx, const float* w
 }
 
 extern "C" int segmif_crosspath_fold_f32(const double* partial, int nblk, const float* wkv, const float* wend, float* weff, int B,
-                                         int Nout, int ldw, int wofs, int ldweff, int kofs, float scale, void* stream) {
+                                         int Nout, int ldw, int wofs, int ldweff, int kofs, float scale, uint32_t* cond,
+                                         void* stream) {
   if (!partial || !wkv || !wend || !weff || B <= 0 || nblk <= 0 || Nout <= 0) return SEGMIF_EINVAL;
   constexpr size_t smem = (size_t)(2 * 4096 + 512) * sizeof(double);
   static segmif::PerDeviceFlag raised_flag;
@@ -657,7 +541,7 @@ extern "C" int segmif_crosspath_fold_f32(const double* partial, int nblk, const 
     raised = true;
   }
   hipLaunchKernelGGL(crosspath_fold_kernel, dim3((unsigned)B), dim3(1024), smem, (hipStream_t)stream, partial, nblk, wkv, wend,
-                     weff, Nout, ldw, wofs, ldweff, kofs, scale);
+                     weff, Nout, ldw, wofs, ldweff, kofs, scale, cond);
   return (int)hipGetLastError();
 }
 
@@ -674,10 +558,6 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
   k.pl_amax = k.pl_f16 ? d->planes_amax : nullptr;
   k.pl_amax_images = d->planes_amax_images;
   if (k.pl_amax && k.pl_amax_images > 1 && k.pl_amax_images != d->B) return SEGMIF_EINVAL;
-  const bool a16 = d->arith_f16 != 0;
-  k.ar_amax = a16 ? d->arith_amax : nullptr;
-  k.ar_amax_images = d->arith_amax_images;
-  if (k.ar_amax && k.ar_amax_images > 1 && k.ar_amax_images != d->B) return SEGMIF_EINVAL;
   k.N = d->N; k.ld3 = d->ld3; k.ldi = d->ldi; k.ldo = d->ldo;
   k.W = 0; k.Hp = 0; k.Wp = 0; k.chunks = 0;
   if (k.planes) {
@@ -695,21 +575,14 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
   static segmif::PerDeviceFlag raised_flag;
   bool& raised = raised_flag.here();
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)crosspath_tail_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)crosspath_tail_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)crosspath_tail_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)crosspath_tail_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)crosspath_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)crosspath_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
   const dim3 grid((unsigned)wgs, (unsigned)d->B);
   hipStream_t st = (hipStream_t)stream;
-  if (k.pl_f16) {
-    if (a16) hipLaunchKernelGGL((crosspath_tail_kernel<true, true>), grid, dim3(512), smem, st, k);
-    else hipLaunchKernelGGL((crosspath_tail_kernel<true, false>), grid, dim3(512), smem, st, k);
-  } else {
-    if (a16) hipLaunchKernelGGL((crosspath_tail_kernel<false, true>), grid, dim3(512), smem, st, k);
-    else hipLaunchKernelGGL((crosspath_tail_kernel<false, false>), grid, dim3(512), smem, st, k);
-  }
+  if (k.pl_f16) hipLaunchKernelGGL(crosspath_tail_kernel<true>, grid, dim3(512), smem, st, k);
+  else hipLaunchKernelGGL(crosspath_tail_kernel<false>, grid, dim3(512), smem, st, k);
   return (int)hipGetLastError();
 }

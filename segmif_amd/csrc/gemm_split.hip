@@ -86,7 +86,6 @@ struct GemmSplitK {
   // (pixel pitch lda = C, C % GBK == 0): A row (b, oy, ox) is the patch at (st oy - pad, st ox - pad), k = (ky, kx, c); a K step
   // of GBK floats lies inside one tap (ky, kx), whose pixel is either inside the image or contributes zeros
   int patch_k, patch_st, patch_pad, patch_H, patch_W, patch_OH, patch_OW;
-  int self_scale;  // f16x3, SELF instantiation: the workgroup scales its own A tile into the half's range (training path)
 };
 
 template <bool F16>
@@ -95,14 +94,8 @@ __device__ __forceinline__ f32x16 gemm_mfma(const u32x4& a, const u32x4& b, cons
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// SELF (f16x3 only; the training path's GEMMs, whose inputs include gradients of 1e-7 and have no guarded scope to fall back
-// from): before the K loop the workgroup scans its own 128-row A tile for max |a| (L2-resident for the column tiles that follow
-// the first), scales the staged values by the power of two that puts it in [2^13, 2^14) (planes16.h scale_of) and takes it
-// out again in the epilogue.  A per-tile scale is exact - it is removed per tile - and needs no cooperation from whoever
-// produced A.  The plain instantiations are untouched (same ISA as before).
-template <bool F16, bool SELF = false>
+template <bool F16>
 __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
-  static_assert(F16 || !SELF, "self-scaling is an f16x3 feature");
   constexpr int APITCH = F16 ? GPITCH_H : GPITCH;   // LDS row of A
   constexpr int AHALF = F16 ? 64 : 96;              // bytes per K half of an A row
   constexpr int NPA = F16 ? 2 : 3, NPROD = F16 ? 3 : 6;
@@ -151,30 +144,6 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
     }
     a_dst[j] = row * APITCH + (kq >> 2) * AHALF + (kq & 3) * 8;
   }
-  float s_in = 1.f, s_out = 1.f;
-  if constexpr (SELF) {
-    uint32_t mx = 0u;
-    const int kq4 = p.K >> 2;
-    for (int row = tid >> 3; row < GBM; row += 32) {  // 8 lanes walk a row 128 bytes at a time
-      if (m0 + row < p.M) {
-        const float* src = p.a + (m0 + row) * (long long)p.lda;
-        for (int q = tid & 7; q < kq4; q += 8) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q);
-          mx = p16::absmax_bits(p16::absmax_bits(mx, v[0], v[1]), v[2], v[3]);
-        }
-      }
-    }
-    mx = p16::wave_umax(mx);
-    uint32_t* red = reinterpret_cast<uint32_t*>(smem_g);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = red[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
-    __syncthreads();  // the staging area is about to be written
-    s_in = p16::scale_of(mx);
-    s_out = 1.f / s_in;  // exact: a power of two (NaN for an inf / NaN tile: its outputs turn NaN)
-  }
   f32x4 ra[4];
   uint32_t amx = 0u;  // f16x3: largest |A| this lane has split (p16::absmax_pk patterns)
   auto gload = [&](int ks) {
@@ -202,13 +171,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
       const f32x4 x = (a_ok[j] && ra_ok[j]) ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (F16) {
         uint32_t ha, la, hb, lb;
-        if constexpr (SELF) {
-          p16::split2(x[0] * s_in, x[1] * s_in, ha, la);
-          p16::split2(x[2] * s_in, x[3] * s_in, hb, lb);
-        } else {
-          p16::split2(x[0], x[1], ha, la);
-          p16::split2(x[2], x[3], hb, lb);
-        }
+        p16::split2(x[0], x[1], ha, la);
+        p16::split2(x[2], x[3], hb, lb);
         *reinterpret_cast<u32x2*>(As + a_dst[j]) = u32x2{ha, hb};
         *reinterpret_cast<u32x2*>(As + a_dst[j] + 32) = u32x2{la, lb};
         amx = p16::absmax_pk(p16::absmax_pk(amx, ha), hb);
@@ -319,7 +283,6 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
           const int n = n0 + wn * 64 + cl;
           f32x4 y = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
           if constexpr (F16) y *= *reinterpret_cast<const f32x4*>(p.wscale + n);  // (the scale array covers the padded columns)
-          if constexpr (SELF) y *= s_out;
           if (p.bias && n < p.N) y += *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -357,7 +320,6 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
         if (n >= p.N) continue;  // N % 4 == 0: a group of four is inside or outside as a whole
         f32x4 y = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         if constexpr (F16) y *= *reinterpret_cast<const f32x4*>(p.wscale + n);
-        if constexpr (SELF) y *= s_out;
         if (p.bias) y += *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -504,8 +466,6 @@ static int gemm_split_impl(const SegmifGemmSplit* d, bool f16, uint32_t* amax, i
   k.ntn = (d->N + GBN - 1) / GBN;
   k.patch_k = patch ? d->patch_k : 0; k.patch_st = d->patch_st; k.patch_pad = d->patch_pad;
   k.patch_H = d->patch_H; k.patch_W = d->patch_W; k.patch_OH = poh; k.patch_OW = pow_;
-  k.self_scale = d->self_scale;
-  if (d->self_scale && (!f16 || patch || amax)) return SEGMIF_EINVAL;  // f16x3 plain-row problems; no guard slots beside it
   k.amax = f16 ? amax : nullptr;
   k.amax_rows = d->M / (amax && amax_images > 1 ? amax_images : 1);
   k.wscale = reinterpret_cast<const float*>(k.w + segmif_gemm_split_weight_bytes(d->N, d->K));  // (f16x3 images only)
@@ -516,13 +476,11 @@ static int gemm_split_impl(const SegmifGemmSplit* d, bool f16, uint32_t* amax, i
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_split_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
   const dim3 grid((unsigned)((long long)k.ntm * k.ntn));
-  if (f16 && k.self_scale) hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(256), smem16, (hipStream_t)stream, k);
-  else if (f16) hipLaunchKernelGGL(gemm_split_kernel<true>, grid, dim3(256), smem16, (hipStream_t)stream, k);
+  if (f16) hipLaunchKernelGGL(gemm_split_kernel<true>, grid, dim3(256), smem16, (hipStream_t)stream, k);
   else hipLaunchKernelGGL(gemm_split_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, k);
   return (int)hipGetLastError();
 }

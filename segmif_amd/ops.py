@@ -100,24 +100,6 @@ def crosspath_mode():
     return _crosspath_mode
 
 
-# The CrossPath tail's own contractions: "bf16x6" (default) or "f16x3" inside a guarded scope.  Measured equal-to-slower
-# (profiles/r04_crosspath_tail_arith_ab.txt): the kernel moves 896 B per pixel at 4.2 TB/s of mixed read / write traffic - it is bound
-# by HBM, not by its matrix work -, and the f16x3 instantiation spills ~30 registers.  Kept as a tested option.
-_CROSSPATH_ARITH = os.environ.get("SEGMIF_CROSSPATH_ARITH", "bf16x6")
-if _CROSSPATH_ARITH not in ("f16x3", "bf16x6"):
-    raise RuntimeError(f"SEGMIF_CROSSPATH_ARITH must be 'f16x3' or 'bf16x6', got {_CROSSPATH_ARITH!r}")
-
-
-def set_crosspath_arith(mode):
-    """'bf16x6' (default): bf16 triples x six products everywhere; 'f16x3': inside a guarded scope crosspath_tail runs its
-    contractions on half pairs x three products (no faster: the kernel is HBM-bound)."""
-    global _CROSSPATH_ARITH
-    if mode not in ("f16x3", "bf16x6"):
-        raise ValueError("mode must be 'f16x3' or 'bf16x6'")
-    prev, _CROSSPATH_ARITH = _CROSSPATH_ARITH, mode
-    return prev
-
-
 def set_crosspath_mode(mode):
     """'gram' (default): CrossPath in inference on the Gram-matrix kernels of csrc/crosspath.hip; 'gemm': round 1's
     channel_proj GEMMs + fused kv reductions + two-source end_proj GEMM."""
@@ -226,14 +208,21 @@ class Planes16Guard:
     tensors pass; inf and NaN read as overflow (the slots hold integer maxima of bit patterns: a NaN cannot be dropped)."""
     SLOTS = 1024
     LO, HI = 2.0 ** -13, 65504.0
+    # (r5) conditioning bound: an image whose CrossPath context softmax reports kappa = max |logit| (1 - p_max) above this is
+    # repeated with the 3x3 convs in exact fp32 (saturated()).  Calibrated in profiles/r05_cond_calibration.txt: the pair
+    # forward's f16x3 error against the float64 evaluation of the reference function stays below 1e-3 up to kappa ~ KAPPA and passes it beyond.
+    KAPPA = float(os.environ.get("SEGMIF_GUARD_KAPPA", "64"))
 
     def __init__(self, device, images=1):
         if os.environ.get("SEGMIF_GUARD_PER_IMAGE") == "0":  # A/B switch: one slot per launch, whole-batch repeats (round 3)
             images = 1
         self.images = max(1, int(images))
-        self.amax = torch.zeros((self.SLOTS, self.images), device=device, dtype=torch.int32)
+        # rows 0 .. SLOTS-1: range slots; row SLOTS: the conditioning words (one per image; crosspath_fold raises them);
+        # row SLOTS + 1: one pooled conditioning word for launches whose batch is not the guard's
+        self.amax = torch.zeros((self.SLOTS + 2, self.images), device=device, dtype=torch.int32)
         self.used = 0
         self.whole = set()  # rows written by a launch that did not index by image
+        self.cond_pooled = False
 
     def slot(self, images=None):
         """-> (device address of the next launch's row of range slots, amax_images for the kernel).  images: the batch the
@@ -248,27 +237,56 @@ class Planes16Guard:
             self.whole.add(row)
         return self.amax.data_ptr() + 4 * self.images * row, (self.images if per_image else 1)
 
+    def cond_slot(self, images):
+        """-> device address of the conditioning words for a launch over `images` images (segmif_crosspath_fold_f32's `cond`):
+        the guard's own row when the launch indexes the guard's batch, else None (pooled reporting needs one word per launch
+        image: such callers - a module run on its own with a batch the scope does not know - get no conditioning check)."""
+        if images == self.images:
+            return self.amax.data_ptr() + 4 * self.images * self.SLOTS
+        return None
+
     def reset(self):
         """Forget every launch (a recorded hipGraph re-fills the same rows on each replay)."""
         self.used = 0
         self.whole.clear()
         self.amax.zero_()
 
-    def maxima(self):
-        return self.amax[:self.used].cpu().view(torch.float32)
+    def _read(self):
+        """ONE device read-back: (range maxima of the used rows, conditioning words) as float32."""
+        host = self.amax.cpu().view(torch.float32)
+        return host[:self.used], host[self.SLOTS]
 
-    def tripped(self):
-        """-> bool tensor (images,): True where some tensor of that image left the half's range (or held inf / NaN)."""
-        m = self.maxima()
+    def maxima(self):
+        return self._read()[0]
+
+    def kappa(self):
+        """-> float tensor (images,): the largest softmax conditioning figure each image's CrossPath contexts reported."""
+        return self._read()[1]
+
+    def verdict(self):
+        """-> (tripped, saturated): bool tensors (images,).  tripped: some tensor of that image left the half's range (or held
+        inf / NaN) - repeat on bf16x6.  saturated: in range, but a CrossPath context softmax is ill-conditioned beyond KAPPA (or
+        its logits are NaN): the f16x3 convs' operand rounding would be amplified past the 1e-3 tolerance - repeat with the
+        3x3 convs in exact fp32.  One read-back for both."""
+        m, k = self._read()
         bad = ~((m == 0) | ((m >= self.LO) & (m < self.HI)))  # NaN fails every comparison: bad
-        out = bad.any(0)
+        out = bad.any(0) if bad.shape[0] else torch.zeros(self.images, dtype=torch.bool)
         for row in self.whole:
             if row < bad.shape[0] and bool(bad[row, 0]):
                 out[:] = True
-        return out
+        sat = ~(k <= self.KAPPA)  # NaN: saturated
+        return out, sat & ~out
+
+    def tripped(self):
+        """-> bool tensor (images,): True where some tensor of that image left the half's range (or held inf / NaN)."""
+        return self.verdict()[0]
+
+    def saturated(self):
+        return self.verdict()[1]
 
     def ok(self):
-        return not bool(self.tripped().any())
+        t, s = self.verdict()
+        return not bool(t.any() or s.any())
 
 
 class _Scope(threading.local):
@@ -279,14 +297,17 @@ class _Scope(threading.local):
 
 _scope = _Scope()
 _stats_lock = threading.Lock()
-_stats = {"scopes": 0, "fallbacks": 0, "images": 0, "images_repeated": 0, "streak": 0, "warned": False}
+_stats = {"scopes": 0, "fallbacks": 0, "images": 0, "images_repeated": 0, "images_repeated_fp32conv": 0, "streak": 0,
+          "warned": False}
 
 
-def _count(images, repeated):
+def _count(images, repeated, exact=0):
+    """repeated: images computed again on bf16x6 (range); exact: images computed again with the 3x3 convs in fp32 (conditioning)."""
     with _stats_lock:
         _stats["scopes"] += 1
         _stats["images"] += images
         _stats["images_repeated"] += repeated
+        _stats["images_repeated_fp32conv"] += exact
         if repeated:
             _stats["fallbacks"] += 1
             _stats["streak"] += 1
@@ -311,13 +332,14 @@ def range_fallbacks():
 def range_stats():
     """-> dict: guarded scopes, scopes with a repeat, images seen, images repeated (f16x3_trip_rate = repeated / seen)."""
     with _stats_lock:
-        d = {k: _stats[k] for k in ("scopes", "fallbacks", "images", "images_repeated")}
+        d = {k: _stats[k] for k in ("scopes", "fallbacks", "images", "images_repeated", "images_repeated_fp32conv")}
     d["trip_rate"] = d["images_repeated"] / d["images"] if d["images"] else 0.0
+    d["cond_repeat_rate"] = d["images_repeated_fp32conv"] / d["images"] if d["images"] else 0.0
     return d
 
 
 def f16x3_enabled():
-    return _conv3x3_mode == "planes16" or _linear_mode == "f16x3" or _attention_mode == "f16x3" or _CROSSPATH_ARITH == "f16x3"
+    return _conv3x3_mode == "planes16" or _linear_mode == "f16x3" or _attention_mode == "f16x3"
 
 
 def run_guarded(fn, device, enabled=None, images=1, redo=None):
@@ -333,19 +355,41 @@ def run_guarded(fn, device, enabled=None, images=1, redo=None):
     _scope.guard = guard = Planes16Guard(device, images)
     try:
         out = fn()
-        bad = guard.tripped()
+        bad, sat = guard.verdict()
     finally:
         _scope.guard = None
-    nbad = int(bad.sum())
-    _count(guard.images, nbad)
-    if nbad == 0:
+    return finish_guarded(out, bad, sat, fn, device, redo)
+
+
+def finish_guarded(out, bad, sat, fn, device, redo=None):
+    """The repeat half of a guarded scope, given its verdict (Planes16Guard.verdict()): images in `bad` left the half's range
+    and are computed again on the bf16x6 kernels; images in `sat` (r5) stayed in range but reported an ill-conditioned CrossPath
+    softmax and are computed again with the 3x3 convs in exact fp32 (tools/stats_bisect.py: that alone brings such an input
+    back to the exact-fp32 error class).  With `redo(out, idx)` only those images run again, else fn() as a whole."""
+    nbad, nsat, n = int(bad.sum()), int(sat.sum()), int(bad.numel())
+    _count(n, nbad, nsat)
+    if nbad == 0 and nsat == 0:
         return out
     _scope.suppress += 1
     try:
-        if redo is not None and nbad < guard.images:
-            return redo(out, bad.nonzero().flatten().to(device))
-        del out
-        return fn()
+        if redo is None or nbad == n or nsat == n:
+            del out
+            if nsat:  # (a whole-batch repeat serves both kinds: exact convs, everything else on bf16x6)
+                prev = set_conv3x3_mode("fp32")
+                try:
+                    return fn()
+                finally:
+                    set_conv3x3_mode(prev)
+            return fn()
+        if nbad:
+            out = redo(out, bad.nonzero().flatten().to(device))
+        if nsat:
+            prev = set_conv3x3_mode("fp32")
+            try:
+                out = redo(out, sat.nonzero().flatten().to(device))
+            finally:
+                set_conv3x3_mode(prev)
+        return out
     finally:
         _scope.suppress -= 1
 
@@ -358,8 +402,8 @@ def install_guard(guard):
 
 
 def run_unguarded(fn, images=1, repeated=None):
-    """fn() on the bf16x6 kernels, counted as a range fallback of `repeated` of `images` images (the repeat half of
-    run_guarded for such a caller)."""
+    """fn() on the bf16x6 kernels, counted as a range fallback of `repeated` of `images` images (for a caller that does its
+    own guard handling, and for measurements of the bf16x6 path)."""
     _count(images, images if repeated is None else repeated)
     _scope.suppress += 1
     try:
@@ -557,58 +601,6 @@ def pack_linear(w, half=None):
         img16 = torch.empty((lib.segmif_gemm_split16_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
         _lib.check(lib.segmif_gemm_split16_pack(wc.data_ptr(), N, K, K, img16.data_ptr(), _stream()), "segmif_gemm_split16_pack")
     return packed, GemmSplitWeight(out, N, K, img16)
-
-
-# EXPERIMENTAL (r4, off by default): the training path's tall GEMMs - forward and input gradient - on f16x3
-# with every workgroup scaling its own A tile into the half's range (segmif_gemm_split16_f32, self_scale), instead of the
-# exact-fp32 tiles.  Unit-tested against fp64 (tests/test_gpu_round4.py); NOT yet run through the training goldens, so not the
-# default: "fp32" = what the goldens were validated with.
-_TRAIN_GEMM = os.environ.get("SEGMIF_TRAIN_GEMM", "fp32")
-if _TRAIN_GEMM not in ("fp32", "f16x3"):
-    raise RuntimeError(f"SEGMIF_TRAIN_GEMM must be 'fp32' or 'f16x3', got {_TRAIN_GEMM!r}")
-
-
-def train_gemm_f16(rows, N, K):
-    return _TRAIN_GEMM == "f16x3" and rows >= GEMM_SPLIT_MIN_ROWS and N >= 128 and N % 4 == 0 and K % 32 == 0
-
-
-def set_train_gemm(mode):
-    global _TRAIN_GEMM
-    if mode not in ("fp32", "f16x3"):
-        raise ValueError("mode must be 'fp32' or 'f16x3'")
-    prev, _TRAIN_GEMM = _TRAIN_GEMM, mode
-    return prev
-
-
-def linear_selfscaled(x, w, N, *, bias=None, act=ACT_NONE, res=None, out=None):
-    """out = res + act(x @ w^T + bias) for a plain (N, K) fp32 weight on the f16x3 split GEMM with self-scaled A tiles (inputs
-    of any magnitude: gradients).  The weight image is packed per call (training: the weights change every step)."""
-    rows, K, lda = rows_view(x, "x")
-    wc = _req(w, "w").detach().contiguous()
-    if tuple(wc.shape) != (N, K) or K % 32 or N % 4 or lda % 4 or x.data_ptr() % 16:
-        raise RuntimeError(f"linear_selfscaled: needs a contiguous ({N}, K) weight with K % 32 == 0, N % 4 == 0 and 16-byte aligned rows")
-    if not (_vec4(out) and _vec4(res) and _vec4(bias)):
-        raise RuntimeError("linear_selfscaled: out / res / bias must allow 16-byte accesses")
-    lib = _lib.load()
-    img = torch.empty((lib.segmif_gemm_split16_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
-    _lib.check(lib.segmif_gemm_split16_pack(wc.data_ptr(), N, K, K, img.data_ptr(), _stream()), "segmif_gemm_split16_pack")
-    if out is None:
-        out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
-    orow, oc, ldo = rows_view(out, "out")
-    if orow != rows or oc != N:
-        raise RuntimeError(f"out shape {tuple(out.shape)} does not match rows={rows}, N={N}")
-    d = _lib.SegmifGemmSplit()
-    d.a, d.w, d.out = x.data_ptr(), img.data_ptr(), out.data_ptr()
-    d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
-    d.M, d.N, d.K, d.lda, d.ldo, d.act = rows, N, K, lda, ldo, act
-    d.self_scale = 1
-    if res is not None:
-        rrow, rc, ldr = rows_view(res, "res")
-        if rc != N or rrow != rows:
-            raise RuntimeError("residual shape mismatch")
-        d.res, d.ldr = res.data_ptr(), ldr
-    _lib.check(lib.segmif_gemm_split16_f32(ctypes.byref(d), None, 1, _stream()), "segmif_gemm_split16_f32")
-    return out
 
 
 def linear_wants_split(rows, N, K):
@@ -1271,9 +1263,11 @@ def crosspath_fold(part, wkv, wend, weff, wofs, kofs, scale):
     if tuple(_req(wkv, "wkv").shape) != (128, 64) or not wkv.is_contiguous():
         raise RuntimeError("crosspath_fold expects the raw contiguous (128, 64) kv weight")
     Nout = wend.shape[0]
+    guard = _scope.guard
+    cond = guard.cond_slot(B) if guard is not None else None  # (r5) the softmax's conditioning figure, per image
     _lib.check(_lib.load().segmif_crosspath_fold_f32(part.data_ptr(), nblk, wkv.data_ptr(), _req(wend).data_ptr(),
                                                      _req(weff).data_ptr(), B, Nout, wend.stride(0), wofs, weff.stride(1), kofs,
-                                                     float(scale), _stream()), "segmif_crosspath_fold_f32")
+                                                     float(scale), cond, _stream()), "segmif_crosspath_fold_f32")
     return weff
 
 
@@ -1316,9 +1310,6 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
         if planes.f16:
             d.planes_f16 = 1
             d.planes_amax, d.planes_amax_images = planes.guard.slot(B)
-    if _CROSSPATH_ARITH == "f16x3" and _scope.guard is not None:  # the kernel's own contractions on f16x3 operands
-        d.arith_f16 = 1
-        d.arith_amax, d.arith_amax_images = _scope.guard.slot(B)
     _side("cp_tail", lambda: _lib.check(_lib.load().segmif_crosspath_tail_f32(ctypes.byref(d), _stream()),
                                         "segmif_crosspath_tail_f32"),
           ((512.0 if planes_only else 768.0) + (0.0 if planes is None else 256.0 if planes.f16 else 384.0)) * B * N)  # + the planes copy: 4 | 6 B per element

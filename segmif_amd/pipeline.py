@@ -27,7 +27,8 @@ class PairForward:
         """-> (fused RGB (B,3,H,W), labels int32 (B,H,W)).  One guarded scope around the whole pair forward: the encoder's
         tall GEMMs and the fusion net's 3x3 convs run on f16x3 operands, their range slots - one per pair - are read back once
         at the end and exactly the pairs whose activations left the half's exponent range are computed again on the bf16x6
-        kernels (a pair's result does not depend on what else is in the batch)."""
+        kernels (a pair's result does not depend on what else is in the batch); (r5) pairs whose CrossPath context softmax
+        reports an ill-conditioned column (Planes16Guard.KAPPA) are computed again with the 3x3 convs in exact fp32."""
         return ops.run_guarded(lambda: self._eager_body(ir, vis, mask3), ir.device, images=ir.shape[0],
                                redo=lambda out, idx: self._redo(out, idx, ir, vis, mask3))
 
@@ -91,16 +92,13 @@ class PairForward:
                 dst.copy_(src)
         self._graph.replay()
         if self._graph_guard is not None:  # (one small read-back per replay)
-            bad = self._graph_guard.tripped()
-            nbad, n = int(bad.sum()), self._graph_guard.images
-            if nbad:
+            bad, sat = self._graph_guard.verdict()
+            if bool(bad.any() or sat.any()):
                 with torch.no_grad():
-                    if nbad == n:
-                        return ops.run_unguarded(lambda: self._eager_body(*self._static), images=n)
-                    idx = bad.nonzero().flatten().to(self._static[0].device)
-                    return ops.run_unguarded(lambda: self._redo(self._out, idx, *self._static), images=n, repeated=nbad)
-            else:
-                ops.run_unguarded(lambda: None, images=n, repeated=0)  # (statistics only)
+                    dev = self._static[0].device
+                    return ops.finish_guarded(self._out, bad, sat, lambda: self._eager_body(*self._static), dev,
+                                              redo=lambda out, idx: self._redo(out, idx, *self._static))
+            ops.finish_guarded(None, bad, sat, None, None)  # (statistics only)
         return self._out
 
     def __call__(self, ir, vis, mask3):

@@ -13,11 +13,9 @@ import torch
 from . import losses, ops
 from .core.model_fusion import RGB2YCrCb, YCrCb2RGB
 from .parallel import allreduce_scalar_mean
-from .weightprep import PREP
 
 
 def seg_train_step(seg_net, optimizer, images, labels, criterion, reducer=None):
-    PREP.begin_step()  # (SEGMIF_WEIGHT_PREP=1: this step's weight-derived tensors in one launch; a no-op otherwise)
     optimizer.zero_grad(set_to_none=True)
     loss = seg_net._loss(images, labels, criterion)
     loss.backward()
@@ -103,7 +101,6 @@ class FusionTrainer:
         self.history = []  # (loss1, loss2) per step, rank-averaged
 
     def step(self, ir3, vis3, mask3, labels, sync_loss_history=True):
-        PREP.begin_step()
         ir = ir3[:, 0:1]
         vis = RGB2YCrCb(vis3)
         with torch.no_grad():

@@ -178,6 +178,57 @@ def test_guarded_scope_repeats_only_the_images_that_tripped():
     assert 0.0 < s1["trip_rate"] <= 1.0
 
 
+def test_guarded_scope_repeats_ill_conditioned_images_with_exact_convs():
+    """(r5) The conditioning half of the guard on the host: crosspath_fold raises one word per image to the softmax's
+    kappa; an image above Planes16Guard.KAPPA (or NaN) that stayed in range is handed to `redo` with the 3x3 convs switched to
+    exact fp32 and the f16x3 kernels off; a range trip of the same image wins (bf16x6 repeat only); images below the bound keep
+    their first result; the statistics count the two kinds separately."""
+    from segmif_amd import ops
+    B = 4
+
+    def bits(v):
+        return int(torch.tensor([v], dtype=torch.float32).view(torch.int32))
+
+    def producer(ranges, kappas):
+        g = ops.active_guard()
+        if g is None:
+            return [ops.conv3x3_mode()] * B
+        ptr, _ = g.slot(B)
+        row = (ptr - g.amax.data_ptr()) // (4 * g.images)
+        cond = g.cond_slot(B)
+        assert cond == g.amax.data_ptr() + 4 * g.images * g.SLOTS and g.cond_slot(B + 1) is None
+        for b in range(B):
+            g.amax[row, b] = bits(ranges[b])
+            g.amax[g.SLOTS, b] = bits(kappas[b])
+        return ["f16x3"] * B
+
+    seen = []
+
+    def redo(out, idx):
+        assert ops.active_guard() is None
+        seen.append((ops.conv3x3_mode(), idx.tolist()))
+        for i in idx.tolist():
+            out[i] = ops.conv3x3_mode()
+        return out
+
+    K = ops.Planes16Guard.KAPPA
+    mode0 = ops.conv3x3_mode()
+    s0 = ops.range_stats()
+    out = ops.run_guarded(lambda: producer([1.0, 1.0, 7.0e4, 1.0], [0.5 * K, 2.0 * K, 3.0 * K, float("nan")]), "cpu",
+                          enabled=True, images=B, redo=redo)
+    assert out == ["f16x3", "fp32", mode0, "fp32"] and seen == [(mode0, [2]), ("fp32", [1, 3])]
+    assert ops.conv3x3_mode() == mode0
+    out = ops.run_guarded(lambda: producer([1.0] * B, [0.0, K, 0.25 * K, 0.0]), "cpu", enabled=True, images=B, redo=redo)
+    assert out == ["f16x3"] * B and len(seen) == 2                      # kappa == KAPPA still passes
+    out = ops.run_guarded(lambda: producer([1.0] * B, [9.0 * K] * B), "cpu", enabled=True, images=B, redo=redo)
+    assert out == ["fp32"] * B and len(seen) == 2                       # every image: one whole repeat, exact convs
+    out = ops.run_guarded(lambda: producer([1.0] * B, [9.0 * K] * B), "cpu", enabled=True, images=B)
+    assert out == ["fp32"] * B and ops.conv3x3_mode() == mode0          # no redo given: the same
+    s1 = ops.range_stats()
+    assert s1["images_repeated"] - s0["images_repeated"] == 1 and s1["images_repeated_fp32conv"] - s0["images_repeated_fp32conv"] == 2 + B + B
+    assert s1["cond_repeat_rate"] > 0.0
+
+
 def test_guard_state_is_per_thread():
     """Two threads in guarded scopes at once each see their own guard (the state used to be module globals)."""
     import threading
@@ -485,54 +536,3 @@ def test_join_node_and_gradient_sink_host_logic():
     assert sink.dz == [None] * 3 and not sink.done
 
 
-def test_weight_prep_cache_rules_and_specs():
-    """segmif_amd/weightprep.py (experimental, SEGMIF_WEIGHT_PREP=1): the derived-tensor specs the autograd Functions register
-    (transpose, tap-major conv weight, depthwise [9][C] and its flipped twin) describe exactly the tensors the one-by-one path
-    builds, and an entry is served only for the same parameter object at the same version - with the gather emulated in numpy."""
-    from segmif_amd import autograd as ag, ops, weightprep
-
-    def numpy_gather(entries, chunk_entry, chunk_off, device, items):
-        assert len(entries) == len(items) and all(e[2] == d.numel() for e, (_, d, *_) in zip(entries, items))
-        covered = {}
-        for ce, co in zip(chunk_entry, chunk_off):
-            covered[ce] = covered.get(ce, 0) + min(weightprep._CHUNK, entries[ce][2] - co)
-        assert all(covered[i] == e[2] for i, e in enumerate(entries))  # the chunks tile every entry exactly
-        for p, dst, shape, strides, offset in items:
-            idx = np.indices(shape).reshape(len(shape), -1)
-            src = offset + sum(idx[d] * strides[d] for d in range(len(shape)))
-            dst.copy_(torch.from_numpy(p.detach().numpy().ravel()[src].reshape(shape)))
-        return None
-
-    prep = weightprep.WeightPrep(enabled=True, launcher=numpy_gather)
-    old_prep, old_req = ag.PREP, ops._req
-    ag.PREP, ops._req = prep, (lambda t, *a: t)   # (ops.pack_dw_weight checks for a device tensor: not what is under test)
-    try:
-        lin = torch.nn.Parameter(torch.randn(6, 10))
-        c11 = torch.nn.Parameter(torch.randn(6, 10, 1, 1))
-        conv = torch.nn.Parameter(torch.randn(5, 4, 2, 2))
-        dw = torch.nn.Parameter(torch.randn(8, 1, 3, 3))
-        want = lambda: [lin.detach().t().contiguous(), c11.detach().reshape(6, 10).t().contiguous(),
-                        conv.detach().permute(2, 3, 1, 0).reshape(16, 5).contiguous(),
-                        dw.detach().reshape(8, 9).t().contiguous(), dw.detach().reshape(8, 9).t().flip(0).contiguous()]
-        got = lambda: [ag._w_transposed(lin, 6, 10), ag._w_transposed(c11, 6, 10), ag._w_taps(conv, 5, 4, 2), ag._dw9(dw),
-                       ag._dw9(dw, flipped=True)]
-        first = got()                                  # step 1: every request misses, is built the old way and remembered
-        assert all(torch.equal(a, b) for a, b in zip(first, want())) and prep.hits == 0 and prep.misses == 5
-        prep.begin_step()                              # step 2: one batch ...
-        assert prep.batches == 1
-        second = got()                                 # ... serves all five
-        assert prep.hits == 5 and all(torch.equal(a, b) for a, b in zip(second, want()))
-        assert second[0].data_ptr() != first[0].data_ptr()
-        with torch.no_grad():
-            lin.mul_(2.0)                              # the optimizer's update (bumps the version counter)
-        stale = got()
-        assert prep.hits == 9 and prep.misses == 6 and all(torch.equal(a, b) for a, b in zip(stale, want()))  # lin rebuilt the old way
-        prep.begin_step()                              # only the changed parameter is re-gathered
-        assert all(torch.equal(a, b) for a, b in zip(got(), want())) and prep.hits == 14
-        other = torch.nn.Parameter(lin.detach().clone())
-        assert prep.lookup(other, "T", lambda p: ((10, 6), (1, 10), 0)) is None          # another object: a miss
-        assert prep.lookup(lin.detach(), "T", lambda p: ((10, 6), (1, 10), 0)) is None   # not a Parameter: never cached
-        off = weightprep.WeightPrep(enabled=False, launcher=numpy_gather)
-        assert off.lookup(lin, "T", None) is None and not off._specs
-    finally:
-        ag.PREP, ops._req = old_prep, old_req

@@ -460,60 +460,6 @@ def test_mixffn_fused_inside_the_encoder(ops, nets):
     assert int((l1 != l0).sum()) <= 0.001 * l0.numel()
 
 
-def test_crosspath_tail_on_f16x3_arithmetic(ops):
-    """crosspath_tail_kernel<., A16> (an option: SEGMIF_CROSSPATH_ARITH=f16x3; measured no faster than the bf16x6 default - the
-    kernel is HBM-bound): inside a guarded scope the tail's own contractions (two channel_proj halves, the folded
-    end_proj) run on half pairs x three f16 products, the three weight matrices staged as power-of-two-scaled half planes -
-    against fp64, beside the bf16x6 arithmetic of the same kernel (yardstick), operands spanning 1e-3 .. 1e1 and weight rows
-    of very different magnitude, a ragged token count, per-image range slots for the pixels it split."""
-    import torch.nn.functional as F
-    B, H, W = 3, 13, 37
-    N = H * W
-    x3 = (rnd(B, N, 64, seed=71) * 10.0 ** rnd(B, N, 1, seed=1, lo=-3, hi=1)).cuda()
-    xi = (rnd(B, N, 224, seed=72) * 10.0 ** rnd(B, N, 1, seed=2, lo=-3, hi=1)).cuda()[..., :64]
-    w3, b3 = rnd(64, 64, seed=73) * 0.3 * 10.0 ** rnd(64, 1, seed=3, lo=-2, hi=0.5), rnd(64, seed=74) * 0.1
-    wi, bi = rnd(64, 64, seed=75) * 0.3 * 10.0 ** rnd(64, 1, seed=4, lo=-2, hi=0.5), rnd(64, seed=76) * 0.1
-    weff, bend = rnd(B, 64, 128, seed=77) * 0.2 * 10.0 ** rnd(B, 64, 1, seed=5, lo=-2, hi=0.5), rnd(64, seed=78) * 0.1
-    gm, bt = rnd(64, seed=79, lo=0.5, hi=1.5), rnd(64, seed=80)
-    t = torch.cat((F.relu(x3.cpu().double() @ w3.double().t() + b3.double()),
-                   F.relu(xi.cpu().double() @ wi.double().t() + bi.double())), dim=-1)
-    pre = xi.cpu().double() + torch.einsum("bnk,bok->bno", t, weff.double()) + bend.double()
-    ref = F.layer_norm(pre, (64,), gm.double(), bt.double(), 1e-5)
-    args = (x3, xi, w3.cuda(), b3.cuda(), wi.cuda(), bi.cuda(), weff.cuda(), bend.cuda(), (gm.cuda(), bt.cuda(), 1e-5))
-
-    def err(t_):
-        return float((t_.double().cpu() - ref).abs().max() / ref.abs().max())
-
-    out6 = ops.crosspath_tail(*args)                     # no guard: bf16 triples
-    guard = ops.Planes16Guard("cuda", B)
-    prev = ops.install_guard(guard)
-    old = ops.set_crosspath_arith("f16x3")
-    try:
-        pl = ops.Planes(B, H, W, 6, "cuda", guard)
-        pl.data.zero_()
-        out16 = ops.crosspath_tail(*args, planes=pl, hw=(H, W))
-        ops.set_crosspath_arith("bf16x6")
-        pl6 = ops.Planes(B, H, W, 6, "cuda", guard)
-        pl6.data.zero_()
-        out6g = ops.crosspath_tail(*args, planes=pl6, hw=(H, W))
-    finally:
-        ops.set_crosspath_arith(old)
-        ops.install_guard(prev)
-    assert torch.equal(out6g, out6) and not torch.equal(out16, out6)
-    e16, e6 = err(out16), err(out6)
-    observed("r4_crosspath_tail_arith", {"f16x3": e16, "bf16x6": e6})
-    assert e16 < TOL and e16 <= 3.0 * e6 + 2e-7, (e16, e6)
-    m = guard.maxima()  # rows: planes copy (f16x3 run), its arithmetic, planes copy (bf16x6-arithmetic run)
-    assert m.shape == (3, B) and guard.ok()
-    want = torch.maximum(x3.abs().amax(dim=(1, 2)), xi.abs().amax(dim=(1, 2))).cpu()
-    assert all(float(m[1, i]) == float(want[i]) for i in range(B))
-    # the planes copy of the f16x3 run is the split of ITS fp32 output
-    ref_pl = ops.Planes(B, H, W, 6, "cuda", ops.Planes16Guard("cuda"))
-    ref_pl.data.zero_()
-    ref_pl.load_f32(out16.view(B, H, W, 64), chunk0=0)
-    assert torch.equal(pl.data, ref_pl.data)
-
-
 def test_drdb_residual_from_its_own_planes(ops):
     """conv3x3_planes_kernel<2, true, f16x3> with res_from_planes: the DRDB's residual x (core/model_fusion.py:157) read back
     from the input chunks 0..3 (hi + 2^-11 lo) instead of an fp32 tensor - the same output to within the half pair's 23 bits
@@ -766,55 +712,3 @@ def test_gemm_epilogue_relu_mask(ops):
     assert float((yb.double() - refb).abs().max()) < 1e-4 and bool((yb[fwd[..., :64] <= 0] == 0).all())
 
 
-@pytest.mark.parametrize("scale", [1.0, 3e-7, 2e4])
-def test_gemm_split_f16x3_with_self_scaled_tiles(ops, scale):
-    """segmif_gemm_split16_f32 with self_scale (experimental training switch SEGMIF_TRAIN_GEMM=f16x3): every workgroup scales
-    its own 128-row A tile into the half's range, so row blocks of very different magnitude - and gradients of 1e-7 - come
-    out fp32-class; bias, activation-free, residual, ragged M and a partial last column tile."""
-    M, K, N = 4096 + 37, 320, 320
-    x = rnd(M, K, seed=1) * scale
-    x[1000:2000] *= 1e-4   # row blocks three to four orders of magnitude apart: each tile has its own scale
-    x[3000:] *= 1e3
-    w = rnd(N, K, seed=2, lo=-0.05, hi=0.05) * torch.logspace(-2, 1, N).view(N, 1)
-    b, res = rnd(N, seed=3) * scale, rnd(M, N, seed=4) * scale
-    y = ops.linear_selfscaled(x.cuda(), w.cuda(), N, bias=b.cuda(), res=res.cuda())
-    ref = x.double() @ w.double().t() + b.double() + res.double()
-    yard = x.double().abs() @ w.double().abs().t() + b.double().abs() + res.double().abs()  # each output's conditioning
-    err = float(((y.double().cpu() - ref).abs() / yard).max())
-    observed(f"gemm_selfscaled_f16x3_vs_fp64[{scale}]", err)
-    assert err < 2e-6, err
-
-
-def test_weight_prep_batched_gather_equals_the_one_by_one_path(ops):
-    """segmif_amd/weightprep.py with the real gather kernel (segmif_gather_copy_f32): after one step has registered its
-    requests, the next step's weight-derived tensors come from ONE launch and the step's loss and gradients are bitwise those
-    of the one-by-one path (the same values reach the same kernels)."""
-    from segmif_amd import autograd as ag, weightprep
-    from segmif_amd.core import Network3
-    net = Network3("mit_b0", 9, pretrained=None)
-    dw.load_det_weights(net, seed=0)
-    net = net.cuda().eval()
-    x = dw.det_input("wp_x", (2, 3, 64, 96)).cuda()
-    y = dw.det_labels("wp_y", (2, 64, 96), 9).cuda()
-    crit = torch.nn.CrossEntropyLoss(ignore_index=255)
-
-    def step():
-        for p in net.parameters():
-            p.grad = None
-        loss = net._loss(x, y, crit)
-        loss.backward()
-        return float(loss), [p.grad.clone() for p in net.parameters() if p.grad is not None]
-
-    base_loss, base = step()
-    prep = weightprep.WeightPrep(enabled=True)
-    old, ag.PREP = ag.PREP, prep
-    try:
-        step()                      # registers the requests (all misses)
-        assert prep.misses > 20 and prep.hits == 0
-        prep.begin_step()
-        assert prep.batches == 1
-        loss, grads = step()        # served from the batch
-        assert prep.hits >= prep.misses // 2
-    finally:
-        ag.PREP = old
-    assert loss == base_loss and len(grads) == len(base) and all(torch.equal(a, b) for a, b in zip(grads, base))
