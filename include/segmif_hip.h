@@ -187,6 +187,46 @@ typedef struct SegmifGemmSplit {
 int64_t segmif_gemm_split_weight_bytes(int N, int K);
 int segmif_gemm_split_pack(const float* w, int N, int K, int ldw, void* out, void* stream);
 int segmif_gemm_split_f32(const SegmifGemmSplit* desc, void* stream);
+/*
+ * (r5) The f16x3 GEMM with BOTH operands pre-split (csrc/gemm_pairs.hip): out = res + act(A W^T + bias) where A arrives in
+ * PAIRS format - a row of K values is K / 16 groups of 64 bytes, [16 hi halves | 16 lo halves], x = hi + 2^-11 lo - written
+ * once by its producer (segmif_layernorm_pairs_f32, segmif_dwconv3x3_gelu_pairs_f32, the attention kernel's pairs output,
+ * segmif_pairs_from_f32) with the same byte count as fp32, and W is the two-plane image of segmif_gemm_pairs_pack.  Both go
+ * HBM -> LDS by LDS-DMA; the kernel does no vector arithmetic on its operands.  Replaces the aten addmm of nn.Linear in
+ * core/mix_transformer.py:46-53 (fc1 / fc2), :94-115 (q / kv / proj) and, in patch mode, Attention's spatial-reduction conv
+ * (:73-75, :98-101) for the tall problems of stages 2-4.  Range: the PRODUCER of A folds max |x| into the guard slots.
+ *   lda_bytes: row pitch of A in bytes (>= 4 K, a multiple of 16); patch mode (patch_k > 0): A is a dense NHWC pairs image
+ *   (B, patch_H, patch_W, patch_C), patch_C % 16 == 0, row m = (b, oy, ox) the k x k patch at (st oy - pad, st ox - pad) in
+ *   (ky, kx, c) order, taps outside the image read as zeros, K = k k C;  tile_rows: 0 = chosen by size, 128 | 256 forces one.
+ */
+typedef struct SegmifGemmPairs {
+  const void* a; const void* w; const float* bias; const float* res; const float* prelu; float* out;
+  int64_t M; int64_t lda_bytes;
+  int32_t N, K, ldo, ldr, act;
+  int32_t patch_k, patch_st, patch_pad, patch_H, patch_W, patch_C;
+  int32_t tile_rows;
+} SegmifGemmPairs;
+int64_t segmif_gemm_pairs_weight_bytes(int N, int K);
+int segmif_gemm_pairs_pack(const float* w, int N, int K, int ldw, void* out, void* stream);
+int segmif_gemm_pairs_f32(const SegmifGemmPairs* desc, void* stream);
+/* fp32 rows (rows x C, pitch ldx floats) <-> pairs rows (pitch in bytes); C % 16 == 0.  amax (or NULL): range slots receiving
+ * max |x| (planes16 patterns), amax_images whole images of rows / amax_images rows each. */
+int segmif_pairs_from_f32(const float* x, int64_t ldx, void* y, int64_t ldy_bytes, int64_t rows, int C, uint32_t* amax,
+                          int amax_images, void* stream);
+int segmif_pairs_to_f32(const void* x, int64_t ldx_bytes, float* y, int64_t ldy, int64_t rows, int C, void* stream);
+/* Producers of PAIRS rows (r5): LayerNorm (core/mix_transformer.py:152-155 norm1 / norm2, :113 the norm after the sr conv),
+ * depthwise 3x3 + bias + GELU (:46-53, :376-387) and the fused attention kernel (:107-111) with their result written as half
+ * pairs - 16-channel groups of [16 hi | 16 lo], the fp32 row's byte count - and max |y| folded into the f16x3 range slot of the
+ * row's image (amax: amax_images words, rows / amax_images rows per image; NULL = no report).  Same arithmetic as
+ * segmif_layernorm_f32 / segmif_dwconv3x3_gelu_f32 / segmif_sr_attention_split16_f32; C % 16 == 0. */
+int segmif_layernorm_pairs_f32(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int C, int ldx,
+                               int ldy, float eps, uint32_t* amax, int amax_images, void* stream);
+int segmif_dwconv3x3_gelu_pairs_f32(const float* x, const float* w9, const float* bias, void* y, int B, int H, int W, int C,
+                                    uint32_t* amax, int amax_images, void* stream);
+int segmif_sr_attention_split16_pairs_f32(const float* q, const float* k, const float* v, void* out, void* workspace, int B,
+                                          int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo, float scale,
+                                          uint32_t* amax, uint32_t* out_amax, int amax_images, void* stream);
+
 /* The same GEMM with f16x3 arithmetic (half pairs x three products, see segmif_planes16_* below): A is split in the kernel,
  * max |A| of the staged rows is folded into the range slots amax[0 .. amax_images) (NULL = off): the M rows are
  * amax_images whole images of M / amax_images rows, image i reports to amax[i] (amax_images = 1: one slot) - the caller
@@ -417,9 +457,10 @@ int segmif_linattn_fold_f32(const double* partial, const float* wend, float* wef
  *  - segmif_crosspath_fold_f32: K^T V = Wk G Wv^T per head from the Gram partials ([Wk; Wv] = the raw (128, 64) kv
  *    weight), softmax over the k index of (K^T V) * scale, folded into end_proj exactly like segmif_linattn_fold_f32.
  *    cond (or NULL): B words, one per image; the launch raises cond[b] (integer atomic max over fp32 bit patterns) to
- *    kappa = max over its 64 softmax columns of max_i |logit_i| * (1 - p_max) - the factor by which this softmax amplifies a
- *    RELATIVE error of its logits.  The host's f16x3 guard reads it beside the range slots: an image whose kappa passes a
- *    calibrated bound is computed again with the 3x3 convs in exact fp32 (round 5; core/model_fusion.py:281-286, :316-326).
+ *    kappa = max over its 64 softmax columns of sum_i p_i (1 - p_i) A_i, A_i = |scale| sum_ab |Wk[i][a]| G[a][b] |Wv[j][b]|
+ *    (the logit without its cancellation) - the factor by which this softmax amplifies a RELATIVE error of the Gram
+ *    entries.  The host's f16x3 guard reads it beside the range slots: an image whose kappa passes a calibrated bound is
+ *    computed again with the 3x3 convs in exact fp32 (round 5; core/model_fusion.py:281-286, :316-326).
  *  - segmif_crosspath_tail_f32: out = LayerNorm_64(x_i + Weff_b . [ReLU(W3 x_3 + b3) | ReLU(Wi x_i + bi)] + bend):
  *    channel_proj halves, the context-folded end_proj (Weff: (B, 64, 128)), residual and norm in one pass over the
  *    tokens; optionally also emits out as planes chunks 0..3 (conv3x3_planes format, H * W == N) for the next DRDB.

@@ -54,6 +54,14 @@ class SegmifGemmSplit(ctypes.Structure):
                 ("patch_W", c_int32)]
 
 
+class SegmifGemmPairs(ctypes.Structure):
+    _fields_ = [("a", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("prelu", c_void_p), ("out", c_void_p),
+                ("M", c_int64), ("lda_bytes", c_int64),
+                ("N", c_int32), ("K", c_int32), ("ldo", c_int32), ("ldr", c_int32), ("act", c_int32),
+                ("patch_k", c_int32), ("patch_st", c_int32), ("patch_pad", c_int32), ("patch_H", c_int32), ("patch_W", c_int32),
+                ("patch_C", c_int32), ("tile_rows", c_int32)]
+
+
 class SegmifCrossTail(ctypes.Structure):
     _fields_ = [
         ("x3", c_void_p), ("xi", c_void_p), ("w3", c_void_p), ("b3", c_void_p), ("wi", c_void_p), ("bi", c_void_p),
@@ -105,6 +113,17 @@ SIGNATURES = {
     "segmif_planes16_weight_bytes": (c_int64, [c_int, c_int, c_int]),
     "segmif_planes16_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "segmif_conv3x3_planes_f16x3": (c_int, [POINTER(SegmifConvPlanes), c_void_p, c_int, c_void_p]),
+    "segmif_gemm_pairs_weight_bytes": (c_int64, [c_int, c_int]),
+    "segmif_gemm_pairs_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "segmif_gemm_pairs_f32": (c_int, [POINTER(SegmifGemmPairs), c_void_p]),
+    "segmif_pairs_from_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p]),
+    "segmif_pairs_to_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "segmif_layernorm_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
+                                         c_int, c_void_p]),
+    "segmif_dwconv3x3_gelu_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                              c_void_p]),
+    "segmif_sr_attention_split16_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                    c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "segmif_crosspath_gram_blocks": (c_int, [c_int64]),
     "segmif_crosspath_gram_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "segmif_crosspath_fold_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

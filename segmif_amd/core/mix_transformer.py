@@ -86,6 +86,8 @@ class Mlp(nn.Module):
 
     def forward(self, x, H, W, residual=None):
         """x: (B, N, C) tokens.  Returns fc2(gelu(dwconv(fc1(x)))) (+ residual, written in place)."""
+        if isinstance(x, ops.Pairs):
+            return self._forward_pairs(x, H, W, residual)
         if wants_grad(self, x):
             y = self.forward_train(x.contiguous(), H, W)
             return y if residual is None else residual + y
@@ -102,6 +104,28 @@ class Mlp(nn.Module):
         if self.drop.p > 0 and self.training:
             y = self.drop(y)
         return y
+
+
+    def pairs_ready(self):
+        packs = self._pk.get("fc1:" + ops.linear_mode(), self.fc1.weight, ops.pack_linear)
+        return packs[1] is not None and packs[1].pairs is not None and self.fc1.bias is not None \
+            and not (self.drop.p > 0 and self.training) and ops.aligned16(self.fc1.bias, self.fc2.bias, self.dwconv.dwconv.bias)
+
+    def _forward_pairs(self, xp, H, W, residual):
+        """(r5) x arrives as ops.Pairs (norm2 wrote half pairs): fc1 and fc2 on gemm_pairs - both operands by LDS-DMA, no
+        split inside the GEMM -, the depthwise conv + GELU writes fc2's operand as pairs.  Inference inside a guarded scope."""
+        pk = self._pk
+        lm = ops.linear_mode()
+        packs1 = pk.get("fc1:" + lm, self.fc1.weight, ops.pack_linear)
+        packs2 = pk.get("fc2:" + lm, self.fc2.weight, ops.pack_linear)
+        dw = self.dwconv.dwconv
+        h = ops.linear_pairs(xp, packs1, self.fc1.out_features, bias=self.fc1.bias)
+        w9 = pk.get("dw", dw.weight, ops.pack_dw_weight)
+        if packs2[1] is not None and packs2[1].pairs is not None and h.shape[2] % 16 == 0:
+            hp = ops.dwconv3x3_gelu_pairs(h, w9, dw.bias, H, W)
+            return ops.linear_pairs(hp, packs2, self.fc2.out_features, bias=self.fc2.bias, res=residual, out=residual)
+        h = ops.dwconv3x3_gelu(h, w9, dw.bias, H, W)
+        return ops.linear_auto(h, packs2, self.fc2.out_features, bias=self.fc2.bias, res=residual, out=residual)
 
 
 class Attention(nn.Module):
@@ -137,7 +161,38 @@ class Attention(nn.Module):
         a = ag.sr_attention(q, kv, self.num_heads, self.scale)
         return ag.linear(a, self.proj.weight, self.proj.bias)
 
+    def _forward_pairs(self, xp, H, W, residual):
+        """(r5) x arrives as ops.Pairs (norm1 wrote half pairs): q, the spatial-reduction conv (patch mode), kv and proj on
+        gemm_pairs; the LayerNorm after the sr conv and the attention kernel write their results as pairs for the next GEMM."""
+        B, N, C = xp.shape
+        pk = self._pk
+        lm = ops.linear_mode()
+        q = ops.linear_pairs(xp, pk.get("q:" + lm, self.q.weight, ops.pack_linear), C, bias=self.q.bias)
+        if self.sr_ratio > 1:
+            sr = self.sr_ratio
+            red = ops.linear_pairs(ops.Pairs(xp.t.view(B, H, W, C)), pk.get("sr:" + lm, self.sr.weight, ops.pack_sr_conv), C,
+                                   bias=self.sr.bias, patch=(sr, sr, 0))
+            redp = ops.layernorm_pairs(red.view(B, -1, C), self.norm.weight, self.norm.bias, self.norm.eps)
+        else:
+            redp = xp
+        kv = ops.linear_pairs(redp, pk.get("kv:" + lm, self.kv.weight, ops.pack_linear), 2 * C, bias=self.kv.bias)
+        a = ops.sr_attention(q, kv, self.num_heads, self.scale, pairs=True)
+        packs = pk.get("proj:" + lm, self.proj.weight, ops.pack_linear)
+        if isinstance(a, ops.Pairs):
+            return ops.linear_pairs(a, packs, C, bias=self.proj.bias, res=residual, out=residual)
+        return ops.linear_auto(a, packs, C, bias=self.proj.bias, res=residual, out=residual)
+
+    def pairs_ready(self):
+        """Every weight of this module has a gemm_pairs image (decided once per block by Block.forward_)."""
+        pk, lm = self._pk, ops.linear_mode()
+        names = [("q", self.q.weight, ops.pack_linear), ("kv", self.kv.weight, ops.pack_linear)]
+        if self.sr_ratio > 1:
+            names.append(("sr", self.sr.weight, ops.pack_sr_conv))
+        return all(p[1] is not None and p[1].pairs is not None for p in (pk.get(n + ":" + lm, w, f) for n, w, f in names))
+
     def forward(self, x, H, W, residual=None):
+        if isinstance(x, ops.Pairs):
+            return self._forward_pairs(x, H, W, residual)
         if wants_grad(self, x):
             y = self.forward_train(x.contiguous(), H, W)
             return y if residual is None else residual + y
@@ -189,14 +244,22 @@ class Block(nn.Module):
         """x <- x + dp(attn(LN(x))); x <- x + dp(mlp(LN(x))).  `x` is updated IN PLACE and returned
         (the encoder owns its token buffer; the public forward() works on a copy)."""
         stochastic = self.training and isinstance(self.drop_path, _DropPath) and self.drop_path.drop_prob > 0
-        xn = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        # (r5) stages 2-4 inside a guarded scope: both norms write HALF PAIRS (no fp32 copy) and every Linear of the block runs on
+        # gemm_pairs - the GEMMs do no operand split of their own (csrc/gemm_pairs.hip)
+        pairs = not stochastic and ops.pairs_block_ok(x) and self.attn.pairs_ready()
+        if pairs:
+            xn = ops.layernorm_pairs(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        else:
+            xn = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         if not stochastic:
             x = self.attn(xn, H, W, residual=x)
             if self.mlp.fusable(x):
                 # stages 1-2 inside a guarded scope: norm2 + fc1 + dwconv + GELU + fc2 + residual in ONE kernel, the hidden
                 # tensor never reaches HBM (csrc/mixffn.hip); returns a new token buffer (halo reads forbid in place)
                 return self.mlp.forward_fused(x, self.norm2, H, W)
-            xn = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=xn)
+            if pairs and self.mlp.pairs_ready():
+                return self.mlp(ops.layernorm_pairs(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), H, W, residual=x)
+            xn = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=xn.t if pairs else xn)
             return self.mlp(xn, H, W, residual=x)
         # train-mode stochastic depth (timm DropPath): per-sample Bernoulli scaling of each branch
         x = x + drop_path_scale(self.attn(xn, H, W), self.drop_path.drop_prob)

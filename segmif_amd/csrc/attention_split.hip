@@ -41,6 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(256) void sr_attention_pack_kernel(const float* __r
 template <bool F16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sr_attention_split_kernel(const float* __restrict__ q, const unsigned char* __restrict__ img,
                                                                  float* __restrict__ out, int N, int Nk, int ldq, int ldo,
-                                                                 float scale, int ntiles, uint32_t* amax, int amax_images) {
+                                                                 float scale, int ntiles, uint32_t* amax, int amax_images,
+                                                                 int out_pairs, uint32_t* out_amax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][IMG]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = vunit / l_tot;
+  uint32_t oamx = 0u;
   if (q_ok) {
     float* orow = out + ((long long)b * N + qi) * ldo + head * 64;
 #pragma unroll
@@ -352,11 +355,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 w{o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
-        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) = w;
+        if (F16 && out_pairs) {
+          // (r5) PAIRS output (gemm_pairs.hip: the proj Linear's A operand): channel c = 64 head + 32 dt + 8 g + 4 h .. + 3 lies in
+          // 16-group c >> 4 at half position c & 15; same byte count as the fp32 row
+          const int c = 32 * dt + 8 * g + 4 * h;
+          uint32_t ha, la, hb, lb;
+          p16::split2(w[0], w[1], ha, la);
+          p16::split2(w[2], w[3], hb, lb);
+          unsigned char* d8 = reinterpret_cast<unsigned char*>(orow) + (c >> 4) * 64 + (c & 15) * 2;
+          *reinterpret_cast<u32x2*>(d8) = u32x2{ha, hb};
+          *reinterpret_cast<u32x2*>(d8 + 32) = u32x2{la, lb};
+          oamx = p16::absmax_pk(p16::absmax_pk(oamx, ha), hb);
+        } else {
+          *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) = w;
+        }
       }
   }
   if constexpr (F16) {
     if (amax) p16::fold_pat(amax, amax_images > 1 ? b : 0, amax_images > 1 ? b : 0, q_ok ? amx : 0u);
+    if (out_pairs && out_amax) p16::fold_pat(out_amax, amax_images > 1 ? b : 0, amax_images > 1 ? b : 0, oamx);
   }
 }
 
@@ -369,7 +386,7 @@ extern "C" int64_t segmif_sr_attention_split_workspace(int B, int heads, int Nk)
 
 static int sr_attention_split_impl(bool f16, const float* q, const float* k, const float* v, float* out, void* workspace, int B,
                                    int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo, float scale, uint32_t* amax,
-                                   int amax_images, void* stream) {
+                                   int amax_images, void* stream, int out_pairs = 0, uint32_t* out_amax = nullptr) {
   if (!q || !k || !v || !out || !workspace || B <= 0 || heads <= 0 || N <= 0 || Nk <= 0 || hd != 64) return SEGMIF_EINVAL;
   if ((ldq | ldo) & 3 || (ldkv & 1)) return SEGMIF_EINVAL;
   if (((uintptr_t)q | (uintptr_t)out | (uintptr_t)workspace) & 15) return SEGMIF_EINVAL;
@@ -389,11 +406,11 @@ static int sr_attention_split_impl(bool f16, const float* q, const float* k, con
   if (f16) {
     hipLaunchKernelGGL(sr_attention_pack_kernel<true>, pgrid, dim3(256), 0, s, k, v, (unsigned char*)workspace, Nk, ldkv, ntiles);
     hipLaunchKernelGGL(sr_attention_split_kernel<true>, grid, dim3(256), 2 * IMG, s, q, (const unsigned char*)workspace, out, N, Nk,
-                       ldq, ldo, scale, ntiles, amax, amax_images);
+                       ldq, ldo, scale, ntiles, amax, amax_images, out_pairs, out_amax);
   } else {
     hipLaunchKernelGGL(sr_attention_pack_kernel<false>, pgrid, dim3(256), 0, s, k, v, (unsigned char*)workspace, Nk, ldkv, ntiles);
     hipLaunchKernelGGL(sr_attention_split_kernel<false>, grid, dim3(256), 2 * IMG, s, q, (const unsigned char*)workspace, out, N, Nk,
-                       ldq, ldo, scale, ntiles, (uint32_t*)nullptr, 1);
+                       ldq, ldo, scale, ntiles, (uint32_t*)nullptr, 1, 0, (uint32_t*)nullptr);
   }
   return (int)hipGetLastError();
 }
@@ -408,4 +425,13 @@ extern "C" int segmif_sr_attention_split16_f32(const float* q, const float* k, c
                                                int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo, float scale,
                                                uint32_t* amax, int amax_images, void* stream) {
   return sr_attention_split_impl(true, q, k, v, out, workspace, B, heads, N, Nk, hd, ldq, ldkv, ldo, scale, amax, amax_images, stream);
+}
+
+// (r5) the same with the output written in PAIRS format (gemm_pairs.hip; `out` is then a pairs buffer of ldo * 4 bytes per row)
+// and max |out| reported to out_amax (indexed like amax; or NULL): the proj Linear reads it by LDS-DMA with no split of its own
+extern "C" int segmif_sr_attention_split16_pairs_f32(const float* q, const float* k, const float* v, void* out, void* workspace, int B,
+                                                     int heads, int N, int Nk, int hd, int ldq, int ldkv, int ldo, float scale,
+                                                     uint32_t* amax, uint32_t* out_amax, int amax_images, void* stream) {
+  return sr_attention_split_impl(true, q, k, v, reinterpret_cast<float*>(out), workspace, B, heads, N, Nk, hd, ldq, ldkv, ldo, scale, amax,
+                                 amax_images, stream, 1, out_amax);
 }

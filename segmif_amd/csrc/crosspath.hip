@@ -253,40 +253,56 @@ __global__ __launch_bounds__(1024) void crosspath_fold_kernel(const double* __re
     G[u] = s;
   }
   __syncthreads();
+  double* T1a = ctx + 512;    // [64][64]  |Wk| G   (cond only)
+  double* actx = T1a + 4096;  // [8][8][8]  absolute-value logits (cond only)
   for (int u = tid; u < 4096; u += 1024) {  // T1[c][bq] = sum_a Wk[c][a] G[a][bq]
     const int c = u >> 6, bq = u & 63;
-    double s = 0.0;
-    for (int a = 0; a < 64; ++a) s += (double)wkv[c * 64 + a] * G[a * 64 + bq];
+    double s = 0.0, sa = 0.0;
+    for (int a = 0; a < 64; ++a) {
+      const double w = (double)wkv[c * 64 + a], g = G[a * 64 + bq];
+      s += w * g;
+      sa += fabs(w) * fabs(g);
+    }
     T1[u] = s;
+    if (cond) T1a[u] = sa;
   }
   __syncthreads();
   if (tid < 512) {  // (K^T V)[h][i][j] = sum_b T1[h*8+i][b] Wv[h*8+j][b]
     const int hh = tid >> 6, i = (tid >> 3) & 7, j = tid & 7;
-    double s = 0.0;
-    for (int q = 0; q < 64; ++q) s += T1[(hh * 8 + i) * 64 + q] * (double)wkv[(64 + hh * 8 + j) * 64 + q];
+    double s = 0.0, sa = 0.0;
+    for (int q = 0; q < 64; ++q) {
+      const double w = (double)wkv[(64 + hh * 8 + j) * 64 + q];
+      s += T1[(hh * 8 + i) * 64 + q] * w;
+      if (cond) sa += T1a[(hh * 8 + i) * 64 + q] * fabs(w);
+    }
     ctx[tid] = s * (double)scale;
+    if (cond) actx[tid] = sa * fabs((double)scale);
   }
   __syncthreads();
   if (tid < 64) {  // one (h, j) column per thread: softmax over i (dim = -2)
     const int hh = tid >> 3, j = tid & 7;
-    double mx = -1e300, amx = 0.0;
-    for (int i = 0; i < 8; ++i) {
-      mx = fmax(mx, ctx[hh * 64 + i * 8 + j]);
-      amx = fmax(amx, fabs(ctx[hh * 64 + i * 8 + j]));
-    }
+    double mx = -1e300;
+    for (int i = 0; i < 8; ++i) mx = fmax(mx, ctx[hh * 64 + i * 8 + j]);
     double ev[8], sum = 0.0;
     for (int i = 0; i < 8; ++i) {
       ev[i] = exp(ctx[hh * 64 + i * 8 + j] - mx);
       sum += ev[i];
     }
-    for (int i = 0; i < 8; ++i) ctx[hh * 64 + i * 8 + j] = ev[i] / sum;
+    double kap = 0.0;
+    for (int i = 0; i < 8; ++i) {
+      const double pi = ev[i] / sum;
+      ctx[hh * 64 + i * 8 + j] = pi;
+      if (cond) kap += pi * (1.0 - pi) * actx[hh * 64 + i * 8 + j];
+    }
     if (cond) {
-      // Conditioning of this softmax column with respect to RELATIVE errors of its logits (which is what the arithmetic of
-      // the producers leaves: the logits are sums over all pixels of products of features): d p_i = p_i (dL_i - sum_k p_k dL_k)
-      // with |dL_i| <= eps |L_i|, so |dp| <= eps * max|L| * 2 (1 - p_max) to first order - large logits only hurt while the
-      // column is still undecided.  kappa = max |L| (1 - p_max); a one-hot column (p_max = 1 / sum = 1) reports 0, NaN logits
-      // report NaN (top of the integer order).  Non-negative floats order like their bit patterns: integer atomic max.
-      const float kappa = (float)(amx * (1.0 - 1.0 / sum));
+      // Conditioning of this softmax column.  A logit is L_i = scale * sum_ab Wk[i][a] G[a][b] Wv[j][b] with G >= 0 (a Gram
+      // matrix of ReLU outputs): what the producers' arithmetic leaves on it is a RELATIVE error eps of the Gram entries, i.e.
+      // |dL_i| <= eps A_i with A_i = |scale| sum_ab |Wk[i][a]| G[a][b] |Wv[j][b]| - the logit without its cancellation, which
+      // can be orders of magnitude above |L_i|.  The softmax turns it into d p_i = p_i (dL_i - sum_k p_k dL_k), so a column's
+      // probabilities move by at most ~2 eps kappa, kappa = sum_i p_i (1 - p_i) A_i: large only while the column is undecided AND
+      // its logits are small differences of large sums.  A decided (one-hot) column reports ~0 whatever its magnitude; NaN
+      // logits report NaN (top of the integer order).  Non-negative floats order like their bit patterns: integer atomic max.
+      const float kappa = (float)kap;
       uint32_t bits = __float_as_uint(kappa);
       if (kappa != kappa) bits = 0x7fc00000u;
 #pragma unroll
@@ -532,7 +548,7 @@ extern "C" int segmif_crosspath_fold_f32(const double* partial, int nblk, const 
                                          int Nout, int ldw, int wofs, int ldweff, int kofs, float scale, uint32_t* cond,
                                          void* stream) {
   if (!partial || !wkv || !wend || !weff || B <= 0 || nblk <= 0 || Nout <= 0) return SEGMIF_EINVAL;
-  constexpr size_t smem = (size_t)(2 * 4096 + 512) * sizeof(double);
+  constexpr size_t smem = (size_t)(3 * 4096 + 2 * 512) * sizeof(double);
   static segmif::PerDeviceFlag raised_flag;
   bool& raised = raised_flag.here();
   if (!raised) {

@@ -6,9 +6,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "planes16.h"
 #include "segmif_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -24,7 +26,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         long long rows, int C, int ldx, int ldy, float eps,
                                                         const float* __restrict__ br, int ldb, const float* __restrict__ scale,
-                                                        long long rpi, float* __restrict__ sum_out, int lds) {
+                                                        long long rpi, float* __restrict__ sum_out, int lds, int pairs,
+                                                        uint32_t* __restrict__ amax, long long amax_rows) {
+  // pairs != 0 (r5): y receives the row in PAIRS format (gemm_pairs.hip: 16-channel groups of [16 hi | 16 lo] halves, ldy still in
+  // floats - the byte count is fp32's) and max |y| goes to the range slot of the row's image (amax, amax_rows rows per image)
   constexpr int RPB = 256 / G;  // rows per block
   const int tid = threadIdx.x;
   const int sub = tid % G;
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
   const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  uint32_t amx = 0u;
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int u = sub + it * G;
@@ -76,13 +82,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd * g[e] + bb[e];
-      *reinterpret_cast<f32x4*>(y + row * ldy + 4 * u) = o;
+      if (pairs) {
+        uint32_t ha, la, hb, lb;
+        segmif::p16::split2(o[0], o[1], ha, la);
+        segmif::p16::split2(o[2], o[3], hb, lb);
+        unsigned char* dst = reinterpret_cast<unsigned char*>(y + row * ldy) + (u >> 2) * 64 + (u & 3) * 8;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{ha, hb};
+        *reinterpret_cast<u32x2*>(dst + 32) = u32x2{la, lb};
+        amx = segmif::p16::absmax_pk(segmif::p16::absmax_pk(amx, ha), hb);
+      } else {
+        *reinterpret_cast<f32x4*>(y + row * ldy + 4 * u) = o;
+      }
     }
+  }
+  if (pairs && amax) {  // a wave holds 64 / G consecutive rows: they report to the image(s) they belong to
+    const long long r0 = (long long)blockIdx.x * RPB + (tid & ~63) / G;
+    long long r1 = r0 + 64 / G - 1;
+    if (r1 >= rows) r1 = rows - 1;
+    if (r0 < rows) segmif::p16::fold_pat(amax, (int)(r0 / amax_rows), (int)(r1 / amax_rows), amx);
   }
 }
 
-struct LnAdd {  // the residual form's extra operands (all zero: plain LayerNorm)
+struct LnAdd {  // the residual form's extra operands (all zero: plain LayerNorm); (r5) the pairs output's
   const float* br = nullptr; int ldb = 0; const float* scale = nullptr; long long rpi = 1; float* sum_out = nullptr; int lds = 0;
+  int pairs = 0; uint32_t* amax = nullptr; long long amax_rows = 1;
 };
 
 template <int G, int IT>
@@ -90,7 +113,7 @@ int launch_ln(const float* x, const float* g, const float* b, float* y, long lon
               float eps, hipStream_t s, const LnAdd& a = LnAdd()) {
   constexpr int RPB = 256 / G;
   hipLaunchKernelGGL((layernorm_kernel<G, IT>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, x, g, b, y,
-                     rows, C, ldx, ldy, eps, a.br, a.ldb, a.scale, a.rpi, a.sum_out, a.lds);
+                     rows, C, ldx, ldy, eps, a.br, a.ldb, a.scale, a.rpi, a.sum_out, a.lds, a.pairs, a.amax, a.amax_rows);
   return (int)hipGetLastError();
 }
 
@@ -442,6 +465,25 @@ extern "C" int segmif_layernorm_f32(const float* x, const float* gamma, const fl
   return launch_ln<64, 4>(x, gamma, beta, y, rows, C, ldx, ldy, eps, s);
 }
 
+extern "C" int segmif_layernorm_pairs_f32(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int C, int ldx,
+                                          int ldy, float eps, uint32_t* amax, int amax_images, void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0 || (C & 15) || C > 1024 || (ldx & 3) || (ldy & 3) || ldy < C)
+    return SEGMIF_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return SEGMIF_EINVAL;
+  if (amax && (amax_images < 1 || rows % amax_images)) return SEGMIF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  LnAdd a;
+  a.pairs = 1; a.amax = amax; a.amax_rows = rows / (amax ? amax_images : 1);
+  float* yf = reinterpret_cast<float*>(y);
+  const int nvec = C >> 2;
+  if (nvec <= 8) return launch_ln<8, 1>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
+  if (nvec <= 16) return launch_ln<16, 1>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
+  if (nvec <= 32) return launch_ln<32, 1>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
+  if (nvec <= 64) return launch_ln<64, 1>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
+  if (nvec <= 128) return launch_ln<64, 2>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
+  return launch_ln<64, 4>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
+}
+
 extern "C" int segmif_add_layernorm_f32(const float* x, const float* branch, const float* scale, int64_t rows_per_image,
                                         const float* gamma, const float* beta, float* sum, float* y, int64_t rows, int C, int ldx,
                                         int ldb, int lds, int ldy, float eps, void* stream) {
@@ -466,14 +508,16 @@ extern "C" int segmif_add_layernorm_f32(const float* x, const float* branch, con
 // rows (halo rows 1.125x instead of 1.25x).  Loads are unconditional from clamped addresses; out-of-image taps are zeroed
 // by select.  Round 3: 3.67 -> 4.4 TB/s of algorithmic traffic at XT = 2 over the encoder's shapes.
 constexpr int DW2_TY = 16;
-template <bool GELU, int XT>
+template <bool GELU, int XT, bool PAIRS = false>
 __global__ __launch_bounds__(256) void dwconv3x3_xt_kernel(const float* __restrict__ x, const float* __restrict__ w9,
                                                            const float* __restrict__ bias, float* __restrict__ y,
-                                                           int H, int W, int C) {
+                                                           int H, int W, int C, uint32_t* __restrict__ amax, int amax_images) {
+  // PAIRS (r5): y receives the tokens in PAIRS format (gemm_pairs.hip; same byte count), max |y| goes to the image's range slot
   const int c4n = C >> 2;
   const int wp = (W + XT - 1) / XT;
   const unsigned idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (unsigned)(wp * c4n)) return;
+  uint32_t amx = 0u;
+  if (idx >= (unsigned)(wp * c4n)) return;  // (a tail wave's remaining lanes form a prefix: the range report's butterfly still reaches lane 0)
   const int xp = (int)(idx / (unsigned)c4n), c = (int)(idx - (unsigned)xp * c4n) * 4;
   const int x0 = XT * xp;
   const int y0 = blockIdx.y * DW2_TY;
@@ -513,7 +557,19 @@ __global__ __launch_bounds__(256) void dwconv3x3_xt_kernel(const float* __restri
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = GELU ? gelu_exact(a[e]) : a[e];
-      if (x0 + j < W) *reinterpret_cast<f32x4*>(dst + (long long)j * C) = o;
+      if constexpr (PAIRS) {
+        if (x0 + j < W) {
+          uint32_t ha, la, hb, lb;
+          segmif::p16::split2(o[0], o[1], ha, la);
+          segmif::p16::split2(o[2], o[3], hb, lb);
+          unsigned char* d8 = reinterpret_cast<unsigned char*>(dst + (long long)j * C - c) + (c >> 4) * 64 + (c & 15) * 2;
+          *reinterpret_cast<u32x2*>(d8) = u32x2{ha, hb};
+          *reinterpret_cast<u32x2*>(d8 + 32) = u32x2{la, lb};
+          amx = segmif::p16::absmax_pk(segmif::p16::absmax_pk(amx, ha), hb);
+        }
+      } else {
+        if (x0 + j < W) *reinterpret_cast<f32x4*>(dst + (long long)j * C) = o;
+      }
     }
 #pragma unroll
     for (int k = 0; k < XT + 2; ++k) {
@@ -521,6 +577,19 @@ __global__ __launch_bounds__(256) void dwconv3x3_xt_kernel(const float* __restri
       win[1][k] = win[2][k];
     }
   }
+  if constexpr (PAIRS) {
+    if (amax) segmif::p16::fold_pat(amax, amax_images > 1 ? blockIdx.z : 0, amax_images > 1 ? blockIdx.z : 0, amx);
+  }
+}
+
+// dwconv + bias + GELU with the result in PAIRS format (the A operand of fc2 on gemm_pairs): the two-column kernel only
+static int launch_dwconv_pairs(const float* x, const float* w9, const float* bias, void* y, int B, int H, int W, int C, uint32_t* amax,
+                               int amax_images, hipStream_t s) {
+  const long long per_row = (long long)((W + 1) / 2) * (C >> 2);
+  dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)((H + DW2_TY - 1) / DW2_TY), (unsigned)B);
+  hipLaunchKernelGGL((dwconv3x3_xt_kernel<true, 2, true>), grid, dim3(256), 0, s, x, w9, bias, reinterpret_cast<float*>(y), H, W, C, amax,
+                     amax_images);
+  return (int)hipGetLastError();
 }
 
 template <bool GELU>
@@ -531,8 +600,8 @@ static int launch_dwconv(const float* x, const float* w9, const float* bias, flo
     const int XT = xt >= 4 ? 4 : 2;
     const long long per_row = (long long)((W + XT - 1) / XT) * (C >> 2);
     dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)((H + DW2_TY - 1) / DW2_TY), (unsigned)B);
-    if (XT == 4) hipLaunchKernelGGL((dwconv3x3_xt_kernel<GELU, 4>), grid, dim3(256), 0, s, x, w9, bias, y, H, W, C);
-    else hipLaunchKernelGGL((dwconv3x3_xt_kernel<GELU, 2>), grid, dim3(256), 0, s, x, w9, bias, y, H, W, C);
+    if (XT == 4) hipLaunchKernelGGL((dwconv3x3_xt_kernel<GELU, 4>), grid, dim3(256), 0, s, x, w9, bias, y, H, W, C, (uint32_t*)nullptr, 1);
+    else hipLaunchKernelGGL((dwconv3x3_xt_kernel<GELU, 2>), grid, dim3(256), 0, s, x, w9, bias, y, H, W, C, (uint32_t*)nullptr, 1);
   } else {
     const long long per_row = (long long)W * (C >> 2);
     dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)((H + DW_TY - 1) / DW_TY), (unsigned)B);
@@ -621,6 +690,15 @@ extern "C" int segmif_dwconv3x3_gelu_f32(const float* x, const float* w9, const 
   if (!x || !w9 || !bias || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return SEGMIF_EINVAL;
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w9 | (uintptr_t)bias) & 15) return SEGMIF_EINVAL;
   return launch_dwconv<true>(x, w9, bias, y, B, H, W, C, (hipStream_t)stream);
+}
+
+// (r5) the same with the result in PAIRS format (gemm_pairs.hip) and max |y| reported per image: C % 16 == 0
+extern "C" int segmif_dwconv3x3_gelu_pairs_f32(const float* x, const float* w9, const float* bias, void* y, int B, int H, int W, int C,
+                                               uint32_t* amax, int amax_images, void* stream) {
+  if (!x || !w9 || !bias || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 15)) return SEGMIF_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w9 | (uintptr_t)bias) & 15) return SEGMIF_EINVAL;
+  if (amax && amax_images != 1 && amax_images != B) return SEGMIF_EINVAL;
+  return launch_dwconv_pairs(x, w9, bias, y, B, H, W, C, amax, amax_images, (hipStream_t)stream);
 }
 
 // DWConv.forward on its own (core/mix_transformer.py:381-387): depthwise 3x3 + bias, no activation

@@ -555,11 +555,12 @@ def conv3x3_planes(planes, cin, wt, *, dil, bias=None, act=ACT_NONE, prelu=None,
 
 class GemmSplitWeight:
     """segmif_gemm_split_pack image of an (N, K) Linear weight (bf16x6 dense GEMM, csrc/gemm_split.hip); half: the
-    segmif_gemm_split16_pack image of the same weight (f16x3) or None."""
-    __slots__ = ("data", "N", "K", "half")
+    segmif_gemm_split16_pack image of the same weight (f16x3) or None; pairs: (r5) the two-plane segmif_gemm_pairs_pack image
+    (f16x3 with the A operand pre-split by its producer, csrc/gemm_pairs.hip) or None."""
+    __slots__ = ("data", "N", "K", "half", "pairs")
 
-    def __init__(self, data, N, K, half=None):
-        self.data, self.N, self.K, self.half = data, N, K, half
+    def __init__(self, data, N, K, half=None, pairs=None):
+        self.data, self.N, self.K, self.half, self.pairs = data, N, K, half, pairs
 
 
 _LINEAR_MODES = ("f16x3", "bf16x6", "fp32")
@@ -584,6 +585,152 @@ def set_linear_mode(mode):
     return prev
 
 
+# ---- (r5) PAIRS: activations pre-split by their producer, both GEMM operands by LDS-DMA (csrc/gemm_pairs.hip) ----------------
+_PAIRS = os.environ.get("SEGMIF_GEMM_PAIRS", "on")  # "off": round 4's gemm_split<f16x3> everywhere (A/B switch)
+if _PAIRS not in ("on", "off"):
+    raise RuntimeError(f"SEGMIF_GEMM_PAIRS must be 'on' or 'off', got {_PAIRS!r}")
+PAIRS_MIN_ROWS = 8192  # below this a transformer block's GEMMs stay on round 4's kernels (fp32 tiles with split-K for the short ones)
+
+
+def pairs_mode():
+    return _PAIRS
+
+
+def set_pairs_mode(mode):
+    global _PAIRS
+    if mode not in ("on", "off"):
+        raise ValueError("mode must be 'on' or 'off'")
+    prev, _PAIRS = _PAIRS, mode
+    return prev
+
+
+class Pairs:
+    """Tokens (B, N, C) in PAIRS format: every row is C / 16 groups of 64 bytes, [16 hi halves | 16 lo halves], x = hi + 2^-11 lo
+    (include/segmif_hip.h, segmif_gemm_pairs_f32).  `.t` is a float32 tensor of the LOGICAL shape whose storage holds those
+    bytes (the byte count is fp32's): only the pairs kernels may read it.  Produced inside a guarded scope only - its producer
+    has folded max |x| into the range slots."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+def pairs_block_ok(x):
+    """True when a transformer block over tokens x (B, N, C) should run its Linears on gemm_pairs: inside a guarded f16x3 scope,
+    C a multiple of 16 and at least 128 (a 128-column tile), enough rows to fill the chip."""
+    return (_PAIRS == "on" and _scope.guard is not None and _linear_mode == "f16x3" and x.dim() == 3 and x.is_contiguous()
+            and x.shape[2] >= 128 and x.shape[2] % 16 == 0 and x.shape[0] * x.shape[1] >= PAIRS_MIN_ROWS and x.data_ptr() % 16 == 0)
+
+
+def _pack_pairs(wc, N, K):
+    """The two-plane weight image of gemm_pairs for a contiguous fp32 (N, K) matrix, or None when the kernel cannot take it."""
+    if _PAIRS != "on" or K % 16 or N % 4 or N < 128:
+        return None
+    lib = _lib.load()
+    img = torch.empty((lib.segmif_gemm_pairs_weight_bytes(N, K),), device=wc.device, dtype=torch.uint8)
+    _lib.check(lib.segmif_gemm_pairs_pack(wc.data_ptr(), N, K, K, img.data_ptr(), _stream()), "segmif_gemm_pairs_pack")
+    return img
+
+
+def _guard_slot(images):
+    guard = _scope.guard
+    if guard is None:
+        raise RuntimeError("PAIRS tensors exist inside a guarded f16x3 scope only (ops.run_guarded / install_guard)")
+    return guard.slot(images)
+
+
+def pairs_from_f32(x):
+    """fp32 tokens (B, N, C) -> Pairs (a producer for tensors whose own kernel has no pairs epilogue; tests)."""
+    rows, C, ldx = rows_view(x, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    images = x.shape[0] if x.dim() == 3 else None
+    amax, nimg = _guard_slot(images)
+    _lib.check(_lib.load().segmif_pairs_from_f32(x.data_ptr(), ldx, out.data_ptr(), 4 * C, rows, C, amax, nimg, _stream()),
+               "segmif_pairs_from_f32")
+    return Pairs(out)
+
+
+def pairs_to_f32(xp):
+    rows, C, ld = rows_view(xp.t, "pairs")
+    out = torch.empty_like(xp.t)
+    _lib.check(_lib.load().segmif_pairs_to_f32(xp.t.data_ptr(), 4 * ld, out.data_ptr(), C, rows, C, _stream()), "segmif_pairs_to_f32")
+    return out
+
+
+def layernorm_pairs(x, gamma, beta, eps):
+    """LayerNorm over the last dim of contiguous tokens (B, N, C), C % 16 == 0, written as Pairs (no fp32 copy)."""
+    rows, C, ldx = rows_view(x, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    if not aligned16(gamma, beta):
+        gamma, beta = gamma.detach().clone(), beta.detach().clone()
+    amax, nimg = _guard_slot(x.shape[0] if x.dim() == 3 else None)
+    _lib.check(_lib.load().segmif_layernorm_pairs_f32(x.data_ptr(), _req(gamma).data_ptr(), _req(beta).data_ptr(), out.data_ptr(),
+                                                      rows, C, ldx, C, float(eps), amax, nimg, _stream()), "segmif_layernorm_pairs_f32")
+    return Pairs(out)
+
+
+def dwconv3x3_gelu_pairs(x, w9, bias, H, W):
+    """dwconv3x3_gelu with the result as Pairs (the A operand of fc2)."""
+    _req(x, "x")
+    if not x.is_contiguous() or x.dim() != 3 or x.shape[1] != H * W or x.shape[2] % 16:
+        raise RuntimeError("dwconv3x3_gelu_pairs expects contiguous (B, H*W, C) with C % 16 == 0")
+    B, _, C = x.shape
+    out = torch.empty_like(x)
+    amax, nimg = _guard_slot(B)
+    _side("dwconv", lambda: _lib.check(_lib.load().segmif_dwconv3x3_gelu_pairs_f32(
+        x.data_ptr(), _req(w9).data_ptr(), _req(bias).data_ptr(), out.data_ptr(), B, H, W, C, amax, nimg, _stream()),
+        "segmif_dwconv3x3_gelu_pairs_f32"), 8.0 * x.numel())
+    return Pairs(out)
+
+
+def linear_pairs(xp, packs, N, *, bias=None, act=ACT_NONE, res=None, out=None, patch=None, tile_rows=0):
+    """out = res + act(x @ W^T + bias) for x in PAIRS format and packs = pack_linear(W) / pack_sr_conv(W) (whose GemmSplitWeight
+    carries the pairs image).  patch = (k, stride, pad): x is a contiguous (B, H, W, C) pairs image and the rows are its k x k
+    patches (Attention's spatial-reduction conv) -> (B, OH, OW, N)."""
+    split = packs[1]
+    if split is None or split.pairs is None:
+        raise RuntimeError("linear_pairs: the weight carries no pairs image (N >= 128, N % 4 == 0, K % 16 == 0, SEGMIF_GEMM_PAIRS=on)")
+    x = xp.t
+    d = _lib.SegmifGemmPairs()
+    if patch is not None:
+        k, st, pad = patch
+        B, H, W, C = x.shape
+        if not x.is_contiguous():
+            raise RuntimeError("linear_pairs: patch mode needs a contiguous (B, H, W, C) image")
+        OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+        rows, K = B * OH * OW, k * k * C
+        d.patch_k, d.patch_st, d.patch_pad, d.patch_H, d.patch_W, d.patch_C = k, st, pad, H, W, C
+        d.lda_bytes = 4 * C
+        oshape = (B, OH, OW, N)
+    else:
+        rows, K, lda = rows_view(x, "x")
+        d.lda_bytes = 4 * lda
+        oshape = x.shape[:-1] + (N,)
+    if (split.N, split.K) != (N, K):
+        raise RuntimeError(f"linear_pairs: weight {split.N}x{split.K} does not fit N {N}, K {K}")
+    if not (_vec4(out) and _vec4(res) and _vec4(bias)):
+        raise RuntimeError("linear_pairs: out / res / bias must allow 16-byte accesses")
+    if out is None:
+        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+    orow, oc, ldo = rows_view(out, "out")
+    if orow != rows or oc != N:
+        raise RuntimeError(f"linear_pairs: out shape {tuple(out.shape)} does not match rows={rows}, N={N}")
+    d.a, d.w, d.out = x.data_ptr(), split.pairs.data_ptr(), out.data_ptr()
+    d.bias = _req(bias, "bias").data_ptr() if bias is not None else None
+    d.M, d.N, d.K, d.ldo, d.act, d.tile_rows = rows, N, K, ldo, act, tile_rows
+    if res is not None:
+        rrow, rc, ldr = rows_view(res, "res")
+        if rc != N or rrow != rows:
+            raise RuntimeError("residual shape mismatch")
+        d.res, d.ldr = res.data_ptr(), ldr
+    _lib.check(_lib.load().segmif_gemm_pairs_f32(ctypes.byref(d), _stream()), "segmif_gemm_pairs_f32")
+    return out
+
+
 def pack_linear(w, half=None):
     """(N, K) Linear weight -> (fp32 packing, GemmSplitWeight or None).  Cache entries must be keyed on linear_mode().
     half: also build the f16x3 image (default: when linear_mode() is 'f16x3'; training passes False - it re-packs per step
@@ -596,11 +743,12 @@ def pack_linear(w, half=None):
     wc = w.detach().contiguous()
     out = torch.empty((lib.segmif_gemm_split_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
     _lib.check(lib.segmif_gemm_split_pack(wc.data_ptr(), N, K, K, out.data_ptr(), _stream()), "segmif_gemm_split_pack")
-    img16 = None
+    img16 = pimg = None
     if _linear_mode == "f16x3" if half is None else half:
         img16 = torch.empty((lib.segmif_gemm_split16_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
         _lib.check(lib.segmif_gemm_split16_pack(wc.data_ptr(), N, K, K, img16.data_ptr(), _stream()), "segmif_gemm_split16_pack")
-    return packed, GemmSplitWeight(out, N, K, img16)
+        pimg = _pack_pairs(wc, N, K)
+    return packed, GemmSplitWeight(out, N, K, img16, pimg)
 
 
 def linear_wants_split(rows, N, K):
@@ -671,11 +819,12 @@ def pack_sr_conv(w):
     lib = _lib.load()
     out = torch.empty((lib.segmif_gemm_split_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
     _lib.check(lib.segmif_gemm_split_pack(packed.data_ptr(), N, K, K, out.data_ptr(), _stream()), "segmif_gemm_split_pack")
-    img16 = None
+    img16 = pimg = None
     if _linear_mode == "f16x3":
         img16 = torch.empty((lib.segmif_gemm_split16_weight_bytes(N, K),), device=w.device, dtype=torch.uint8)
         _lib.check(lib.segmif_gemm_split16_pack(packed.data_ptr(), N, K, K, img16.data_ptr(), _stream()), "segmif_gemm_split16_pack")
-    return packed, GemmSplitWeight(out, N, K, img16)
+        pimg = _pack_pairs(packed, N, K)
+    return packed, GemmSplitWeight(out, N, K, img16, pimg)
 
 
 def patch_conv_auto(x, packs, N, k, stride, pad, *, bias=None):
@@ -1170,8 +1319,9 @@ def set_attention_mode(mode):
     return prev
 
 
-def sr_attention(q, kv, heads, scale):
-    """q: (B, N, C) contiguous; kv: (B, Nk, 2C) contiguous (k | v) -> (B, N, C)."""
+def sr_attention(q, kv, heads, scale, pairs=False):
+    """q: (B, N, C) contiguous; kv: (B, Nk, 2C) contiguous (k | v) -> (B, N, C).  pairs=True: return the result as ops.Pairs
+    when the f16x3 kernel runs (inside a guarded scope, head_dim 64, N >= 1024), the fp32 tensor otherwise."""
     _req(q, "q"), _req(kv, "kv")
     B, N, C = q.shape
     Nk = kv.shape[1]
@@ -1184,6 +1334,13 @@ def sr_attention(q, kv, heads, scale):
     if hd == 64 and _attention_mode != "fp32" and N >= 1024:  # below that the K/V pack launch outweighs the matrix-pipe gain
         ws = torch.empty((lib.segmif_sr_attention_split_workspace(B, heads, Nk),), device=q.device, dtype=torch.uint8)
         guard = _scope.guard
+        if _attention_mode == "f16x3" and guard is not None and pairs:
+            amax, nimg = guard.slot(B)
+            oamax, _ = guard.slot(B)
+            _lib.check(lib.segmif_sr_attention_split16_pairs_f32(q.data_ptr(), kptr, kptr + 4 * C, out.data_ptr(), ws.data_ptr(), B,
+                                                                 heads, N, Nk, hd, C, 2 * C, C, float(scale), amax, oamax, nimg,
+                                                                 _stream()), "segmif_sr_attention_split16_pairs_f32")
+            return Pairs(out)
         if _attention_mode == "f16x3" and guard is not None:
             amax, nimg = guard.slot(B)
             _lib.check(lib.segmif_sr_attention_split16_f32(q.data_ptr(), kptr, kptr + 4 * C, out.data_ptr(), ws.data_ptr(), B, heads,

@@ -5,7 +5,7 @@
     backward against records of the reference's modules and autograd;
   * LapLoss2 forward / backward (lap_loss.py:100-118) against the reference's value and gradient;
   * the shared PReLU's own autograd node (any slope) against torch.
-Observed errors are appended to gpurun_out/parity_observed.json (DESIGN.md quotes them)."""
+Observed errors are appended to gpurun_out/parity_observed/*.json (DESIGN.md quotes them)."""
 import json
 import os
 
@@ -23,17 +23,7 @@ TIGHT = 1e-4
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def observed(name, value):
-    """Best-effort log of an observed error (never fails a test)."""
-    try:
-        d = os.path.join(ROOT, "gpurun_out")
-        os.makedirs(d, exist_ok=True)
-        p = os.path.join(d, "parity_observed.json")
-        rec = json.load(open(p)) if os.path.exists(p) else {}
-        rec[name] = value
-        json.dump(rec, open(p, "w"), indent=1, sort_keys=True)
-    except OSError:
-        pass
+from _observed import observed  # noqa: E402  (per-test files under gpurun_out/parity_observed/)
 
 
 @pytest.fixture(scope="module")

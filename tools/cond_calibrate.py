@@ -2,7 +2,7 @@
 """(r5) Calibration of the f16x3 guard's conditioning bound (ops.Planes16Guard.KAPPA).
 
 For several input families (mit_b1, 64x96 - the size at which the CPU oracle in float64 takes seconds) prints, PER PAIR: the
-conditioning figure kappa = max |logit| (1 - p_max) its CrossPath context softmaxes reported (csrc/crosspath.hip,
+conditioning figure kappa = max over columns of sum_i p_i (1 - p_i) A_i (A: the logits without their cancellation) its CrossPath context softmaxes reported (csrc/crosspath.hip,
 crosspath_fold_kernel), and the error of the fused image against the oracle evaluated in float64 (the truth) for
   f16x3 (default, no repeat) | bf16x6 | f16x3 but 3x3 convs in exact fp32 (what a saturated pair is repeated with) |
   everything on exact-fp32 MFMA | the oracle in float32 (= the reference's own arithmetic).
@@ -41,8 +41,9 @@ def main():
     sd64 = [{k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()} for sd in (sd_seg, sd_fus)]
     img = _image_like(3, 64, 96, 11)
     fams = [("U[0,1) det", _inputs(3, 64, 96, 1), 1.0)]
-    fams += [(f"image-like x{s:g}", img, s) for s in (0.25, 1.0, 1.5, 2.0, 2.5, 3.0, 4.0, 6.0)]
-    fams += [("U[0,1) det x3", _inputs(3, 64, 96, 2), 3.0), ("U[0,1) det x6", _inputs(3, 64, 96, 2), 6.0)]
+    fams += [(f"image-like x{s:g}", img, s) for s in (1.0, 1.5, 2.0, 3.0, 4.0, 6.0)]
+    fams += [("U[0,1) det x3", _inputs(3, 64, 96, 2), 3.0)]
+    fams += [(f"image-like(seed 12) x{s:g}", _image_like(3, 64, 96, 12), s) for s in (2.0, 4.0)]
     print("# family | pair | kappa | err f16x3 | err bf16x6 | err f16x3+fp32 convs | err all-fp32-MFMA | err oracle fp32 (reference arithmetic)")
     for name, (ir, vis, mask), s in fams:
         ir, vis, mask = ir * s, vis * s, mask * s
@@ -70,7 +71,7 @@ def main():
                 ops.set_conv3x3_mode(prev[0]), ops.set_linear_mode(prev[1]), ops.set_attention_mode(prev[2])
         cols = [per_pair_err(t, truth) for t in (f16, b6, c32, a32, ref["fused"])]
         for b in range(ir.shape[0]):
-            print(f"{name:18s} | {b} | {kappa[b]:9.3g} | " + " | ".join(f"{c[b]:.2e}" for c in cols) + (" | RANGE-TRIPPED" if tripped[b] else ""),
+            print(f"{name:24s} | {b} | {kappa[b]:9.3g} | " + " | ".join(f"{c[b]:.2e}" for c in cols) + (" | RANGE-TRIPPED" if tripped[b] else ""),
                   flush=True)
     # the bench workload: mit_b3, 480x640, U[0,1) inputs (bench.py's generator) - kappa only
     del seg, fus, pipe
