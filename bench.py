@@ -168,17 +168,23 @@ def train_leg(args, rank, world, seg, fus):
             loss = step()
         if reducer is not None:
             reducer.time_exposed_wait = True
-        exposed = []
+        exposed, per_bucket = [], None
         dist.fence()
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
             if reducer is not None:
                 exposed.append(reducer.exposed_wait_s)
+                pb = reducer.exposed_wait_per_bucket_s
+                per_bucket = pb if per_bucket is None or len(pb) != len(per_bucket) else [a + b for a, b in zip(per_bucket, pb)]
         dist.fence()
-        dt = dist.max_over_ranks((time.perf_counter() - t0) / steps)
+        mine = (time.perf_counter() - t0) / steps
+        dt = dist.max_over_ranks(mine)
+        spread = dist.gather_over_ranks(1e3 * mine)
         if reducer is not None:
             reducer.time_exposed_wait = False
+        timed.last = {"ms_per_step_per_rank": {"min": min(spread), "max": max(spread), "all": spread},
+                      "allreduce_exposed_ms_per_bucket": [1e3 * v / steps for v in per_bucket] if per_bucket else None}
         return dt, float(loss), (1e3 * sum(exposed) / len(exposed) if exposed else None)
 
     out = {"batch_per_gpu": B, "global_batch": B * world, "steps": steps, "warmup": warm, "world_size": world,
@@ -213,6 +219,8 @@ def train_leg(args, rank, world, seg, fus):
                    "grad_bytes": red.gradient_bytes() if red is not None else
                    4 * sum(p.numel() for p in (fus.parameters() if name == "fusion" else [q for grp in g for q in grp])
                            if p.grad is not None)}
+            if world > 1:  # (r5) so that the first real multi-GPU run is diagnosable from this one line
+                rec.update(timed.last)
             if name == "fusion" and trainer.last_lap is not None:
                 rec["lap_loss2_reported"] = float(trainer.last_lap)
             if eager_ms is not None:
@@ -376,9 +384,13 @@ def main():
         ops.set_launch_timer(None)
     assert labels.shape == (B, H, W)
 
+    rank_ms = dist.gather_over_ranks(1000.0 * elapsed / args.steps)  # per-rank spread: a slow GPU / link shows here
     elapsed = dist.max_over_ranks(elapsed)
     trip = ops.range_stats()  # (warm-up + timed steps of the headline configuration)
-    trip["granularity"] = "one pair: range slots per image, only the pairs that tripped are repeated on bf16x6"
+    trip["granularity"] = ("one pair: range slots and a CrossPath-softmax conditioning word per image; pairs that left the half's range are "
+                           "repeated on bf16x6 (trip_rate), pairs whose softmax is ill-conditioned beyond Planes16Guard.KAPPA with "
+                           "exact-fp32 3x3 convs (cond_repeat_rate)")
+    trip["kappa_bound"] = ops.Planes16Guard.KAPPA
 
     # for continuity with rounds 1-2: the same step on bf16 triples throughout (6 products per MAC, no range guard)
     elapsed_bf16 = None
@@ -447,10 +459,12 @@ def main():
                 if ops.conv3x3_mode() == "planes16" else
                 "f32 (large contractions: fp32-equivalent 3-way bf16 split, 6 MFMA products; see arithmetic_modes)"),
             "f16x3_range_fallbacks": ops.range_fallbacks(),
-            "f16x3_trip_rate": trip["trip_rate"], "f16x3_guard": trip,
+            "f16x3_trip_rate": trip["trip_rate"], "f16x3_cond_repeat_rate": trip["cond_repeat_rate"], "f16x3_guard": trip,
+            "ms_per_step_per_rank": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
             "conv3x3_mode": ops.conv3x3_mode(),
             "arithmetic_modes": {"conv3x3": ops.conv3x3_mode(), "linear": ops.linear_mode(), "crosspath": ops.crosspath_mode(),
-                                 "attention": ops.attention_mode(), "mixffn": ops.mixffn_mode()},
+                                 "attention": ops.attention_mode(), "mixffn": ops.mixffn_mode(),
+                                 "encoder_gemms": "gemm_pairs (A pre-split by its producer)" if ops.pairs_mode() == "on" else "gemm_split"},
             "data": "synthetic",
             "config": {"workload": f"{args.backbone} pair forward (forward_fusion + Fusion_Network3_ac + Network3 "
                                    f"+ x4 bilinear + argmax), {H}x{W}, {B} pairs per GPU per step, eval mode, "
@@ -528,7 +542,17 @@ def main():
             hb = {}
             for tag, t in side.items():
                 n, ms, nbytes = t.summary()
-                if n:
+                if n and tag == "mixffn":
+                    # NOT an HBM-bound kernel: its hidden tensor never reaches HBM; it is bound by its vector-ALU /
+                    # matrix phases.  Work per token element of x: 2 GEMMs of 2 * 4C flops each + 9 * 2 * 4 depthwise flops.
+                    # The timer carries x in + out bytes (8 per element); C is 64 | 128 per launch: both bounds are given.
+                    elems = nbytes / 8.0
+                    lo, hi = elems * (16 * 64 + 72) / (ms * 1e-3) / 1e12, elems * (16 * 128 + 72) / (ms * 1e-3) / 1e12
+                    out["compute_kernels"] = {"mixffn": {"kernel": names[tag], "launches_timed": n, "avg_launch_ms": ms, "bound": "vector ALU / mfma",
+                                                         "tflops_if_all_C64": lo, "tflops_if_all_C128": hi, "peak_tflops": PEAK_BF16X6_TFLOPS * 2.0,
+                                                         "frac_of_peak_range": [lo / (PEAK_BF16X6_TFLOPS * 2.0), hi / (PEAK_BF16X6_TFLOPS * 2.0)],
+                                                         "hbm_GBps": nbytes / (ms * 1e-3) / 1e9}}
+                elif n:
                     hb[tag] = {"kernel": names[tag], "launches_timed": n, "avg_launch_ms": ms,
                                "algorithmic_GB_per_launch": nbytes / 1e9, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
                                "frac_of_8TBps": nbytes / (ms * 1e-3) / 8e12}

@@ -218,9 +218,11 @@ int segmif_pairs_to_f32(const void* x, int64_t ldx_bytes, float* y, int64_t ldy,
  * depthwise 3x3 + bias + GELU (:46-53, :376-387) and the fused attention kernel (:107-111) with their result written as half
  * pairs - 16-channel groups of [16 hi | 16 lo], the fp32 row's byte count - and max |y| folded into the f16x3 range slot of the
  * row's image (amax: amax_images words, rows / amax_images rows per image; NULL = no report).  Same arithmetic as
- * segmif_layernorm_f32 / segmif_dwconv3x3_gelu_f32 / segmif_sr_attention_split16_f32; C % 16 == 0. */
+ * segmif_layernorm_f32 / segmif_dwconv3x3_gelu_f32 / segmif_sr_attention_split16_f32; C % 16 == 0.  The LayerNorm's waves are
+ * short and numerous: it takes amax_sub (a power of two) consecutive ROWS of slots, amax_images words apart, and spreads its
+ * reports over them (a slot access serialises on its memory channel). */
 int segmif_layernorm_pairs_f32(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int C, int ldx,
-                               int ldy, float eps, uint32_t* amax, int amax_images, void* stream);
+                               int ldy, float eps, uint32_t* amax, int amax_images, int amax_sub, void* stream);
 int segmif_dwconv3x3_gelu_pairs_f32(const float* x, const float* w9, const float* bias, void* y, int B, int H, int W, int C,
                                     uint32_t* amax, int amax_images, void* stream);
 int segmif_sr_attention_split16_pairs_f32(const float* q, const float* k, const float* v, void* out, void* workspace, int B,

@@ -119,7 +119,7 @@ SIGNATURES = {
     "segmif_pairs_from_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "segmif_pairs_to_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "segmif_layernorm_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
-                                         c_int, c_void_p]),
+                                         c_int, c_int, c_void_p]),
     "segmif_dwconv3x3_gelu_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                               c_void_p]),
     "segmif_sr_attention_split16_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

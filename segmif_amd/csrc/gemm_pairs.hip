@@ -45,6 +45,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef PAIRS_DBG
+#define PAIRS_DBG 0  // tuning aid: 1 = s_memtime timeline probe (tools/pairs_timeline.py)
+#endif
+#if PAIRS_DBG
+__device__ unsigned long long pairs_timeline[1024][32][4];
+#define PAIRS_TL(step, slot)                                                                                         \
+  do {                                                                                                               \
+    if (tid == 0 && blockIdx.x < 1024 && (step) < 32) pairs_timeline[blockIdx.x][step][slot] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define PAIRS_TL(step, slot)
+#endif
+
 constexpr int PBK = 16;              // K step
 constexpr int PNT = 128;             // column tile
 constexpr int PROW = 64;             // bytes per LDS row (a 16-group of pairs: 2 planes x 16 halves)
@@ -186,17 +199,22 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM == 
   const int a_lane = (wm * 64 + r) * PROW, w_lane = MT * PROW + (wn * 64 + r) * PROW;
   const bool active = n0 + wn * 64 < p.N;  // (uniform) a wave whose 64 columns are all padding multiplies nothing
 
+  PAIRS_TL(29, 0);
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
     if (s < nks) issue(s, s);
+  PAIRS_TL(29, 1);
   int buf = 0;
   for (int ks = 0; ks < nks; ++ks) {
     // the stage about to be read has landed: everything this wave issued except the (at most S - 2) later stages
     const int later = nks - 1 - ks;
+    PAIRS_TL(ks, 0);
     if (later >= S - 2) wait_vm_barrier<P * (S - 2)>();
     else if (S == 4 && later == 1) wait_vm_barrier<P>();
     else wait_vm_barrier<0>();  // ... and everybody's; all waves are done reading the stage of step ks - 1
+    PAIRS_TL(ks, 1);
     if (ks + S - 1 < nks) issue(ks + S - 1, buf == 0 ? S - 1 : buf - 1);
+    PAIRS_TL(ks, 2);
     if (active) {
       const unsigned char* sb = smem_p + buf * STAGE;
       u32x4 ah[2], al[2], w0[2], wl[2], ws[2];
@@ -222,9 +240,12 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM == 
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(w0[j], ah[i], acc[i][j]);
     }
+    PAIRS_TL(ks, 3);
     buf = buf + 1 == S ? 0 : buf + 1;
   }
+  PAIRS_TL(30, 0);
   __syncthreads();  // the ring is free: the epilogue stages its rows there
+  PAIRS_TL(30, 1);
 
   // ---- epilogue (gemm_split's): row scale, bias, activation into a wave-private [32][68] tile, then 4 rows x 256 contiguous
   // bytes per instruction with the residual read the same way
@@ -263,6 +284,10 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM == 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites the tile
   }
+#if PAIRS_DBG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PAIRS_TL(31, 0);
+#endif
 }
 
 // f16x3 row scale 2^-e(n): 2^14 <= 2^e max |w[n][.]| < 2^15 (1 for vanishing rows and for the padding rows)
@@ -335,14 +360,14 @@ __global__ __launch_bounds__(256) void pairs_to_f32_kernel(const unsigned char* 
   const int c = (int)(idx - row * c4n) * 4;
   if (row >= rows) return;
   const unsigned char* src = x + row * ldx + (c >> 4) * 64 + (c & 15) * 2;
-  const u32x2 hi = *reinterpret_cast<const u32x2*>(src), lo = *reinterpret_cast<const u32x2*>(src + 32);
-  f32x4 o;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const p16::h2 a = __builtin_bit_cast(p16::h2, hi[e]), b = __builtin_bit_cast(p16::h2, lo[e]);
-    o[2 * e] = (float)a[0] + (float)b[0] * (1.f / p16::LSCALE);
-    o[2 * e + 1] = (float)a[1] + (float)b[1] * (1.f / p16::LSCALE);
-  }
+  const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+  const p16::h2 a0 = __builtin_bit_cast(p16::h2, s32[0]), a1 = __builtin_bit_cast(p16::h2, s32[1]);
+  const p16::h2 b0 = __builtin_bit_cast(p16::h2, s32[8]), b1 = __builtin_bit_cast(p16::h2, s32[9]);
+  constexpr float inv = 1.f / p16::LSCALE;
+  // (written out: the two-iteration loop over hi[e] / lo[e] this replaces was compiled to ONE dword load per plane and left
+  // values 2, 3 of every quad undefined - found by the round trip of tools/pairs_debug.py)
+  const f32x4 o = {fmaf((float)b0[0], inv, (float)a0[0]), fmaf((float)b0[1], inv, (float)a0[1]),
+                   fmaf((float)b1[0], inv, (float)a1[0]), fmaf((float)b1[1], inv, (float)a1[1])};
   *reinterpret_cast<f32x4*>(y + row * ldy + c) = o;
 }
 
@@ -350,6 +375,12 @@ __global__ __launch_bounds__(256) void pairs_to_f32_kernel(const unsigned char* 
 }  // namespace segmif
 
 using namespace segmif;
+
+#if PAIRS_DBG
+extern "C" int segmif_debug_pairs_timeline(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pairs_timeline), bytes < sizeof(pairs_timeline) ? bytes : sizeof(pairs_timeline));
+}
+#endif
 
 extern "C" int64_t segmif_gemm_pairs_weight_bytes(int N, int K) {
   if (N <= 0 || K <= 0 || K % PBK) return 0;

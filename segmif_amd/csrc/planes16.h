@@ -36,6 +36,25 @@ __device__ __forceinline__ void split8(const float* y, u4& hi, u4& lo) {
   }
 }
 
+// PAIRS rows (gemm_pairs.hip): a 16-channel group is 64 bytes, [16 hi | 16 lo].  Four consecutive lanes that hold 4 consecutive
+// channels each (split into ha, hb / la, lb by split2) own one group; storing 8 bytes per lane and plane would be 32-byte
+// partial writes with 32-byte holes - measured 10x slower than the fp32 store on the LayerNorm (profiles/r05_block_kernel_stats*).
+// Instead the quad trades dwords (DPP quad_perm, no LDS) so that lane q stores the 16-byte piece q of the group: one fully
+// coalesced dwordx4 store per lane.  -> the piece of lane (threadIdx.x & 3); all four lanes of the quad must be active.
+__device__ __forceinline__ u4 quad_piece(uint32_t ha, uint32_t hb, uint32_t la, uint32_t lb) {
+  // source lanes 2 (q & 1) and 2 (q & 1) + 1 of the quad: quad_perm [0, 2, 0, 2] = 0x88 and [1, 3, 1, 3] = 0xdd
+  const uint32_t h0a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ha, 0x88, 0xf, 0xf, false);
+  const uint32_t h0b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hb, 0x88, 0xf, 0xf, false);
+  const uint32_t h1a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ha, 0xdd, 0xf, 0xf, false);
+  const uint32_t h1b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hb, 0xdd, 0xf, 0xf, false);
+  const uint32_t l0a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)la, 0x88, 0xf, 0xf, false);
+  const uint32_t l0b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lb, 0x88, 0xf, 0xf, false);
+  const uint32_t l1a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)la, 0xdd, 0xf, 0xf, false);
+  const uint32_t l1b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lb, 0xdd, 0xf, 0xf, false);
+  const bool low = (threadIdx.x & 2) != 0;  // lanes 2, 3 of the quad store the lo plane's pieces
+  return u4{low ? l0a : h0a, low ? l0b : h0b, low ? l1a : h1a, low ? l1b : h1b};
+}
+
 // ---- range bookkeeping -----------------------------------------------------------------------------------------------
 // A producer tracks the largest magnitude it wrote on the HIGH halves' bit patterns (|half| as a 15-bit unsigned integer is
 // monotone in magnitude; +inf = 0x7c00, every NaN lies above it), two halves per operation (v_and_b32 + v_pk_max_u16 - the
@@ -67,6 +86,16 @@ __device__ __forceinline__ float wave_max(float v) {  // (weights' row scales: f
   return v;
 }
 
+// The look before the atomic: an atomic load (hipcc emits it with the cache-bypassing sc0 sc1 bits, so it sees other CUs'
+// atomics; a plain load would keep hitting a stale line in the CU's L1 and every wave would go on to the atomic).  Either way a
+// slot access costs ~5 ns of a memory channel's time and they serialise: a kernel must make FEW of them relative to its run
+// time.  (r5: the first LayerNorm that wrote half pairs folded once per wave - 76 800 accesses in a 20 us kernel - and took
+// 330 us, profiles/r05_block_kernel_stats_first.txt; it now walks a contiguous range of rows per workgroup and folds when the
+// image changes.  One access per wave is fine for kernels that run >= 10 ns per wave: the convs, attention.)
+__device__ __forceinline__ uint32_t slot_peek(const uint32_t* slot) {
+  return __atomic_load_n(slot, __ATOMIC_RELAXED);
+}
+
 // Fold this wave's running maximum (absmax_pk patterns) into the range slots of images b_lo .. b_hi (a wave whose rows
 // straddle an image boundary reports to both: conservative).  A slot holds the IEEE bit pattern of a non-negative float
 // (or NaN: it compares above inf).  The plain load first: a tensor has a few hundred thousand waves and all but a handful
@@ -78,7 +107,42 @@ __device__ __forceinline__ void fold_pat(uint32_t* slots, int b_lo, int b_hi, ui
   if ((threadIdx.x & 63) == 0 && v) {
     const uint32_t bits = __float_as_uint((float)__builtin_bit_cast(_Float16, (unsigned short)v));  // exact; NaN stays NaN
     for (int b = b_lo; b <= b_hi; ++b)
-      if (bits > __atomic_load_n(slots + b, __ATOMIC_RELAXED)) atomicMax(slots + b, bits);
+      if (bits > slot_peek(slots + b)) atomicMax(slots + b, bits);
+  }
+}
+
+// fold_pat without the look: the atomic is issued unconditionally and its result is not used, so the wave does not wait for it
+// (a no-return global_atomic_umax leaves like a store).  For kernels whose waves live for a microsecond - the LayerNorm that
+// writes half pairs - the look's LATENCY (a cache-bypassing load: several microseconds under load) is what costs: every wave
+// ends on it and holds its slot meanwhile (measured: 20 us -> 190 us).  Such a kernel spreads its reports over several rows of
+// slots instead, so that the atomics do not queue on one address.
+__device__ __forceinline__ void fold_pat_async(uint32_t* slots, int b_lo, int b_hi, uint32_t pat) {
+  uint32_t v = (pat & 0xffffu) > (pat >> 16) ? (pat & 0xffffu) : (pat >> 16);
+  v = wave_umax(v);
+  if ((threadIdx.x & 63) == 0 && v) {
+    const uint32_t bits = __float_as_uint((float)__builtin_bit_cast(_Float16, (unsigned short)v));
+    for (int b = b_lo; b <= b_hi; ++b) (void)__hip_atomic_fetch_max(slots + b, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// The same for a whole workgroup of up to 16 waves reporting to ONE image: the waves' maxima meet in LDS and one lane makes the
+// slot access (row kernels whose waves are short: see slot_peek).  Must be reached by every wave of the workgroup that is
+// still alive, partial waves included (lanes that left a wave early count as zero).
+__device__ __forceinline__ void fold_pat_block(uint32_t* slots, int b, uint32_t pat) {
+  __shared__ uint32_t red_pat[16];
+  uint32_t v = (pat & 0xffffu) > (pat >> 16) ? (pat & 0xffffu) : (pat >> 16);
+  v = wave_umax(v);
+  const int nw = (int)((blockDim.x * blockDim.y * blockDim.z + 63) >> 6);
+  if (threadIdx.x < 16) red_pat[threadIdx.x] = 0u;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red_pat[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw && w < 16; ++w) v = red_pat[w] > v ? red_pat[w] : v;
+    if (v) {  // (no look: the workgroup would sit on the load's latency; one fire-and-forget atomic per workgroup)
+      const uint32_t bits = __float_as_uint((float)__builtin_bit_cast(_Float16, (unsigned short)v));
+      (void)__hip_atomic_fetch_max(slots + b, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -93,7 +157,7 @@ __device__ __forceinline__ void fold_bits(uint32_t* slots, int b_lo, int b_hi, u
   bits = wave_umax(bits);
   if ((threadIdx.x & 63) == 0 && bits) {
     for (int b = b_lo; b <= b_hi; ++b)
-      if (bits > __atomic_load_n(slots + b, __ATOMIC_RELAXED)) atomicMax(slots + b, bits);
+      if (bits > slot_peek(slots + b)) atomicMax(slots + b, bits);
   }
 }
 

@@ -26,10 +26,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         long long rows, int C, int ldx, int ldy, float eps,
                                                         const float* __restrict__ br, int ldb, const float* __restrict__ scale,
-                                                        long long rpi, float* __restrict__ sum_out, int lds, int pairs,
-                                                        uint32_t* __restrict__ amax, long long amax_rows) {
-  // pairs != 0 (r5): y receives the row in PAIRS format (gemm_pairs.hip: 16-channel groups of [16 hi | 16 lo] halves, ldy still in
-  // floats - the byte count is fp32's) and max |y| goes to the range slot of the row's image (amax, amax_rows rows per image)
+                                                        long long rpi, float* __restrict__ sum_out, int lds) {
   constexpr int RPB = 256 / G;  // rows per block
   const int tid = threadIdx.x;
   const int sub = tid % G;
@@ -72,6 +69,63 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
   const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int u = sub + it * G;
+    if (row_ok && u < nvec) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * u);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + 4 * u);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd * g[e] + bb[e];
+      *reinterpret_cast<f32x4*>(y + row * ldy + 4 * u) = o;
+    }
+  }
+}
+
+// (r5) LayerNorm writing PAIRS rows (gemm_pairs.hip: 16-channel groups of [16 hi | 16 lo] halves; the byte count is fp32's) with
+// max |y| folded into the range slot of each row's image.  Same arithmetic and launch shape as layernorm_kernel.  Its waves live
+// for a row or two, so (planes16.h, fold_pat_async) they report with a fire-and-forget atomic - no look first, whose latency
+// every wave would end on - and the launch is given `nsub` ROWS of slots (a power of two, `sub_stride` words apart), workgroup i
+// reporting to row i % nsub: the 76 800 atomics of a stage-3 launch meet on nsub x images addresses instead of `images`.
+template <int G, int IT>
+__global__ __launch_bounds__(1024) void layernorm_pairs_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, unsigned char* __restrict__ y,
+                                                              long long rows, int C, int ldx, long long ldy_bytes, float eps,
+                                                              uint32_t* __restrict__ amax, long long amax_rows, int nsub,
+                                                              long long sub_stride) {
+  constexpr int RPB = 1024 / G;  // 16 waves per workgroup: ONE range report per workgroup (below)
+  const int tid = threadIdx.x;
+  const int sub = tid % G;
+  const long long row = (long long)blockIdx.x * RPB + tid / G;
+  const bool row_ok = row < rows;
+  const int nvec = C >> 2;
+  f32x4 v[IT];
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int u = sub + it * G;
+    v[it] = (row_ok && u < nvec) ? *reinterpret_cast<const f32x4*>(x + row * ldx + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+    sum += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+  }
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int u = sub + it * G;
+    if (u < nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[it][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+  const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
   uint32_t amx = 0u;
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
@@ -82,30 +136,46 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd * g[e] + bb[e];
-      if (pairs) {
-        uint32_t ha, la, hb, lb;
-        segmif::p16::split2(o[0], o[1], ha, la);
-        segmif::p16::split2(o[2], o[3], hb, lb);
-        unsigned char* dst = reinterpret_cast<unsigned char*>(y + row * ldy) + (u >> 2) * 64 + (u & 3) * 8;
-        *reinterpret_cast<u32x2*>(dst) = u32x2{ha, hb};
-        *reinterpret_cast<u32x2*>(dst + 32) = u32x2{la, lb};
-        amx = segmif::p16::absmax_pk(segmif::p16::absmax_pk(amx, ha), hb);
-      } else {
-        *reinterpret_cast<f32x4*>(y + row * ldy + 4 * u) = o;
-      }
+      uint32_t ha, la, hb, lb;
+      segmif::p16::split2(o[0], o[1], ha, la);
+      segmif::p16::split2(o[2], o[3], hb, lb);
+      // (the quad u & ~3 .. u | 3 = one 16-channel group is active as a whole: C % 16 == 0)
+      *reinterpret_cast<segmif::p16::u4*>(y + row * ldy_bytes + (u >> 2) * 64 + (u & 3) * 16) = segmif::p16::quad_piece(ha, hb, la, lb);
+      amx = segmif::p16::absmax_pk(segmif::p16::absmax_pk(amx, ha), hb);
     }
   }
-  if (pairs && amax) {  // a wave holds 64 / G consecutive rows: they report to the image(s) they belong to
-    const long long r0 = (long long)blockIdx.x * RPB + (tid & ~63) / G;
-    long long r1 = r0 + 64 / G - 1;
-    if (r1 >= rows) r1 = rows - 1;
-    if (r0 < rows) segmif::p16::fold_pat(amax, (int)(r0 / amax_rows), (int)(r1 / amax_rows), amx);
+  if (amax) {
+    // The workgroup's RPB consecutive rows normally belong to one image: its 16 waves meet in LDS and one lane reports with a
+    // fire-and-forget atomic (planes16.h, fold_pat_block).  Slot words of neighbouring images share a cache line and atomics on one
+    // line queue up (~10 ns each): with one report per WAVE a stage-2 launch queued 9 600 of them per line and took 118 us
+    // instead of 31.  A workgroup that straddles two images reports per wave.
+    uint32_t* slots = amax + (long long)(blockIdx.x & (unsigned)(nsub - 1)) * sub_stride;
+    const long long first = (long long)blockIdx.x * RPB;
+    long long last = first + RPB - 1;
+    if (last >= rows) last = rows - 1;
+    const int b0 = (int)(first / amax_rows), b1 = (int)(last / amax_rows);
+    if (b0 == b1) {
+      segmif::p16::fold_pat_block(slots, b0, amx);
+    } else {
+      const long long r0 = first + (tid & ~63) / G;
+      long long r1 = r0 + 64 / G - 1;
+      if (r1 >= rows) r1 = rows - 1;
+      if (r0 < rows) segmif::p16::fold_pat_async(slots, (int)(r0 / amax_rows), (int)(r1 / amax_rows), amx);
+    }
   }
 }
 
-struct LnAdd {  // the residual form's extra operands (all zero: plain LayerNorm); (r5) the pairs output's
+template <int G, int IT>
+int launch_ln_pairs(const float* x, const float* g, const float* b, void* y, long long rows, int C, int ldx, int ldy, float eps,
+                    uint32_t* amax, long long amax_rows, int nsub, long long sub_stride, hipStream_t s) {
+  constexpr int RPB = 1024 / G;
+  hipLaunchKernelGGL((layernorm_pairs_kernel<G, IT>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(1024), 0, s, x, g, b,
+                     reinterpret_cast<unsigned char*>(y), rows, C, ldx, (long long)ldy * 4, eps, amax, amax_rows, nsub, sub_stride);
+  return (int)hipGetLastError();
+}
+
+struct LnAdd {  // the residual form's extra operands (all zero: plain LayerNorm)
   const float* br = nullptr; int ldb = 0; const float* scale = nullptr; long long rpi = 1; float* sum_out = nullptr; int lds = 0;
-  int pairs = 0; uint32_t* amax = nullptr; long long amax_rows = 1;
 };
 
 template <int G, int IT>
@@ -113,7 +183,7 @@ int launch_ln(const float* x, const float* g, const float* b, float* y, long lon
               float eps, hipStream_t s, const LnAdd& a = LnAdd()) {
   constexpr int RPB = 256 / G;
   hipLaunchKernelGGL((layernorm_kernel<G, IT>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, x, g, b, y,
-                     rows, C, ldx, ldy, eps, a.br, a.ldb, a.scale, a.rpi, a.sum_out, a.lds, a.pairs, a.amax, a.amax_rows);
+                     rows, C, ldx, ldy, eps, a.br, a.ldb, a.scale, a.rpi, a.sum_out, a.lds);
   return (int)hipGetLastError();
 }
 
@@ -466,22 +536,22 @@ extern "C" int segmif_layernorm_f32(const float* x, const float* gamma, const fl
 }
 
 extern "C" int segmif_layernorm_pairs_f32(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int C, int ldx,
-                                          int ldy, float eps, uint32_t* amax, int amax_images, void* stream) {
+                                          int ldy, float eps, uint32_t* amax, int amax_images, int amax_sub, void* stream) {
   if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0 || (C & 15) || C > 1024 || (ldx & 3) || (ldy & 3) || ldy < C)
     return SEGMIF_EINVAL;
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return SEGMIF_EINVAL;
-  if (amax && (amax_images < 1 || rows % amax_images)) return SEGMIF_EINVAL;
+  if (amax && (amax_images < 1 || rows % amax_images || amax_sub < 1 || (amax_sub & (amax_sub - 1)))) return SEGMIF_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  LnAdd a;
-  a.pairs = 1; a.amax = amax; a.amax_rows = rows / (amax ? amax_images : 1);
-  float* yf = reinterpret_cast<float*>(y);
+  const long long ar = rows / (amax ? amax_images : 1);
+  const int ns = amax ? amax_sub : 1;
+  const long long st = amax ? amax_images : 1;  // slot rows lie `amax_images` words apart (ops.Planes16Guard)
   const int nvec = C >> 2;
-  if (nvec <= 8) return launch_ln<8, 1>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
-  if (nvec <= 16) return launch_ln<16, 1>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
-  if (nvec <= 32) return launch_ln<32, 1>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
-  if (nvec <= 64) return launch_ln<64, 1>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
-  if (nvec <= 128) return launch_ln<64, 2>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
-  return launch_ln<64, 4>(x, gamma, beta, yf, rows, C, ldx, ldy, eps, s, a);
+  if (nvec <= 8) return launch_ln_pairs<8, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, amax, ar, ns, st, s);
+  if (nvec <= 16) return launch_ln_pairs<16, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, amax, ar, ns, st, s);
+  if (nvec <= 32) return launch_ln_pairs<32, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, amax, ar, ns, st, s);
+  if (nvec <= 64) return launch_ln_pairs<64, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, amax, ar, ns, st, s);
+  if (nvec <= 128) return launch_ln_pairs<64, 2>(x, gamma, beta, y, rows, C, ldx, ldy, eps, amax, ar, ns, st, s);
+  return launch_ln_pairs<64, 4>(x, gamma, beta, y, rows, C, ldx, ldy, eps, amax, ar, ns, st, s);
 }
 
 extern "C" int segmif_add_layernorm_f32(const float* x, const float* branch, const float* scale, int64_t rows_per_image,
@@ -515,9 +585,16 @@ __global__ __launch_bounds__(256) void dwconv3x3_xt_kernel(const float* __restri
   // PAIRS (r5): y receives the tokens in PAIRS format (gemm_pairs.hip; same byte count), max |y| goes to the image's range slot
   const int c4n = C >> 2;
   const int wp = (W + XT - 1) / XT;
-  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  unsigned idx = blockIdx.x * 256 + threadIdx.x;
   uint32_t amx = 0u;
-  if (idx >= (unsigned)(wp * c4n)) return;  // (a tail wave's remaining lanes form a prefix: the range report's butterfly still reaches lane 0)
+  bool live = true;
+  if (idx >= (unsigned)(wp * c4n)) {
+    if constexpr (!PAIRS) return;
+    // PAIRS: the workgroup's range report ends in barriers, which every wave must reach the same number of times: a thread
+    // past the end recomputes the last valid column and stores nothing
+    live = false;
+    idx = (unsigned)(wp * c4n) - 1;
+  }
   const int xp = (int)(idx / (unsigned)c4n), c = (int)(idx - (unsigned)xp * c4n) * 4;
   const int x0 = XT * xp;
   const int y0 = blockIdx.y * DW2_TY;
@@ -558,13 +635,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_xt_kernel(const float* __restri
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = GELU ? gelu_exact(a[e]) : a[e];
       if constexpr (PAIRS) {
-        if (x0 + j < W) {
+        if (live && x0 + j < W) {
           uint32_t ha, la, hb, lb;
           segmif::p16::split2(o[0], o[1], ha, la);
           segmif::p16::split2(o[2], o[3], hb, lb);
-          unsigned char* d8 = reinterpret_cast<unsigned char*>(dst + (long long)j * C - c) + (c >> 4) * 64 + (c & 15) * 2;
-          *reinterpret_cast<u32x2*>(d8) = u32x2{ha, hb};
-          *reinterpret_cast<u32x2*>(d8 + 32) = u32x2{la, lb};
+          // (threads c, c + 4, c + 8, c + 12 of one 16-channel group are four consecutive lanes with the same x0, j, live)
+          unsigned char* d16 = reinterpret_cast<unsigned char*>(dst + (long long)j * C - c) + (c >> 4) * 64 + ((c >> 2) & 3) * 16;
+          *reinterpret_cast<segmif::p16::u4*>(d16) = segmif::p16::quad_piece(ha, hb, la, lb);
           amx = segmif::p16::absmax_pk(segmif::p16::absmax_pk(amx, ha), hb);
         }
       } else {
@@ -578,7 +655,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_xt_kernel(const float* __restri
     }
   }
   if constexpr (PAIRS) {
-    if (amax) segmif::p16::fold_pat(amax, amax_images > 1 ? blockIdx.z : 0, amax_images > 1 ? blockIdx.z : 0, amx);
+    if (amax) segmif::p16::fold_pat_block(amax, amax_images > 1 ? blockIdx.z : 0, amx);  // one slot access per workgroup
   }
 }
 

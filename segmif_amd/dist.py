@@ -130,6 +130,17 @@ def max_over_ranks(value):
     return float(t.item())
 
 
+def gather_over_ranks(value):
+    """-> list of every rank's python float, in rank order (one all_gather: per-rank spread of a timing)."""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return [float(value)]
+    dev = "cuda" if torch.distributed.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(torch.distributed.get_world_size())]
+    torch.distributed.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def sum_over_ranks(value):
     if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
         return float(value)

@@ -206,7 +206,7 @@ class Planes16Guard:
     guard's reports to column 0 and stands for every image).  tripped() reads the rows back (one host sync) and says which
     images left [2^-13, 65504) somewhere - the range in which a half pair carries an fp32 value to within one bit.  All-zero
     tensors pass; inf and NaN read as overflow (the slots hold integer maxima of bit patterns: a NaN cannot be dropped)."""
-    SLOTS = 1024
+    SLOTS = 4096  # (r5: 1024 -> 4096 rows - a pairs LayerNorm takes LN_SUB rows; 1 MB at 64 images, read back once per forward)
     LO, HI = 2.0 ** -13, 65504.0
     # (r5) conditioning bound: an image whose CrossPath context softmax reports kappa = max |logit| (1 - p_max) above this is
     # repeated with the 3x3 convs in exact fp32 (saturated()).  Calibrated in profiles/r05_cond_calibration.txt: the pair
@@ -237,6 +237,19 @@ class Planes16Guard:
             self.whole.add(row)
         return self.amax.data_ptr() + 4 * self.images * row, (self.images if per_image else 1)
 
+    def slot_rows(self, images, n):
+        """-> (address of n CONSECUTIVE rows of range slots, amax_images, rows actually granted): for a launch that spreads its
+        reports (n a power of two).  Near the end of the table a single row is granted."""
+        if self.used + n > self.SLOTS:
+            ptr, nimg = self.slot(images)
+            return ptr, nimg, 1
+        ptr, nimg = self.slot(images)
+        first = self.used - 1
+        for _ in range(n - 1):
+            self.slot(images)
+        assert self.used - 1 == first + n - 1
+        return ptr, nimg, n
+
     def cond_slot(self, images):
         """-> device address of the conditioning words for a launch over `images` images (segmif_crosspath_fold_f32's `cond`):
         the guard's own row when the launch indexes the guard's batch, else None (pooled reporting needs one word per launch
@@ -253,8 +266,8 @@ class Planes16Guard:
 
     def _read(self):
         """ONE device read-back: (range maxima of the used rows, conditioning words) as float32."""
-        host = self.amax.cpu().view(torch.float32)
-        return host[:self.used], host[self.SLOTS]
+        host = torch.cat((self.amax[:self.used], self.amax[self.SLOTS:self.SLOTS + 1])).cpu().view(torch.float32)
+        return host[:self.used], host[self.used]
 
     def maxima(self):
         return self._read()[0]
@@ -589,6 +602,7 @@ def set_linear_mode(mode):
 _PAIRS = os.environ.get("SEGMIF_GEMM_PAIRS", "on")  # "off": round 4's gemm_split<f16x3> everywhere (A/B switch)
 if _PAIRS not in ("on", "off"):
     raise RuntimeError(f"SEGMIF_GEMM_PAIRS must be 'on' or 'off', got {_PAIRS!r}")
+LN_SUB = 8             # rows of range slots a pairs LayerNorm spreads its reports over (csrc/rowops.hip, layernorm_pairs_kernel)
 PAIRS_MIN_ROWS = 8192  # below this a transformer block's GEMMs stay on round 4's kernels (fp32 tiles with split-K for the short ones)
 
 
@@ -667,9 +681,13 @@ def layernorm_pairs(x, gamma, beta, eps):
     out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     if not aligned16(gamma, beta):
         gamma, beta = gamma.detach().clone(), beta.detach().clone()
-    amax, nimg = _guard_slot(x.shape[0] if x.dim() == 3 else None)
+    guard = _scope.guard
+    if guard is None:
+        raise RuntimeError("PAIRS tensors exist inside a guarded f16x3 scope only (ops.run_guarded / install_guard)")
+    # (the kernel's waves are short and many: its range reports are spread over LN_SUB consecutive rows of slots)
+    amax, nimg, nsub = guard.slot_rows(x.shape[0] if x.dim() == 3 else None, LN_SUB)
     _lib.check(_lib.load().segmif_layernorm_pairs_f32(x.data_ptr(), _req(gamma).data_ptr(), _req(beta).data_ptr(), out.data_ptr(),
-                                                      rows, C, ldx, C, float(eps), amax, nimg, _stream()), "segmif_layernorm_pairs_f32")
+                                                      rows, C, ldx, C, float(eps), amax, nimg, nsub, _stream()), "segmif_layernorm_pairs_f32")
     return Pairs(out)
 
 

@@ -47,6 +47,7 @@ class GradAllReducer:
         self._stream = None
         self.time_exposed_wait = False  # measure the non-overlapped part of the all-reduce in finish() (adds device syncs)
         self.exposed_wait_s = 0.0
+        self.exposed_wait_per_bucket_s = []  # (launch order = reverse parameter order) how long each bucket's wait blocked
 
     # ---- bucket layout ------------------------------------------------------------------------
     def _build(self, active, hooks=True):
@@ -116,10 +117,14 @@ class GradAllReducer:
             cur = torch.cuda.current_stream()
             cur.synchronize()  # backward's kernels only: RCCL runs on its own stream and keeps going
             t0 = time.perf_counter()
+            per = []
             for h in self._handles:
-                h.wait()  # the compute stream now depends on the collectives
-            cur.synchronize()
+                t1 = time.perf_counter()
+                h.wait()  # the compute stream now depends on this collective
+                cur.synchronize()
+                per.append(time.perf_counter() - t1)
             self.exposed_wait_s = time.perf_counter() - t0
+            self.exposed_wait_per_bucket_s = per  # (a bucket that finished under backward costs ~0: the first ones launched)
         else:
             for h in self._handles:
                 h.wait()

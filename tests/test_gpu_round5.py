@@ -137,9 +137,9 @@ def test_pairs_producers_match_their_fp32_kernels_and_report_ranges(ops):
         yp = ops.layernorm_pairs(x.cuda(), g.cuda(), bt.cuda(), 1e-5)
         close(ops.pairs_to_f32(yp), ops.layernorm(x.cuda(), g.cuda(), bt.cuda(), 1e-5), "layernorm")
     m = gd.maxima()
-    assert m.shape == (1, B) and not gd.tripped().any()
+    assert m.shape == (ops.LN_SUB, B) and not gd.tripped().any()  # (its reports are spread over LN_SUB rows of slots)
     ref_max = ops.layernorm(x.cuda(), g.cuda(), bt.cuda(), 1e-5).abs().amax(dim=(1, 2)).cpu()
-    assert torch.allclose(m[0], ref_max.half().float(), rtol=2e-3), (m, ref_max)
+    assert torch.allclose(m.max(0).values, ref_max.half().float(), rtol=2e-3), (m, ref_max)
     big = g.clone() * 1.0e5  # image-independent blow-up: every image trips; a NaN in one image: that image only
     with scope(ops, B) as gd:
         ops.layernorm_pairs(x.cuda(), big.cuda(), bt.cuda(), 1e-5)
@@ -223,8 +223,11 @@ def test_mit_b3_pair_in_batch_on_the_pairs_path_vs_reference(ops, golden_dir):
     against the recorded ones, with the pairs path on and off.  (The 64-pair bench batch is covered by
     tests/test_gpu_round3.py::test_bench_batch_of_64_with_the_golden_pair_vs_reference, which now runs on this path too.)"""
     import numpy as np
+    from segmif_amd.core import Network3
     g = np.load(os.path.join(golden_dir, "pair_b3_480x640_checksum.npz"))
-    enc = _encoder("mit_b3")
+    net = Network3("mit_b3", 9, pretrained=None)  # (the record's weights are named through Network3: denoise_net.encoder.*)
+    dw.load_det_weights(net, seed=0)
+    enc = net.cuda().eval().denoise_net.encoder
     gold = dw.det_input("b3_mask", (1, 1, 480, 640))
     fill = dw.det_input("b64_m", (4, 1, 480, 640))
     mask = torch.cat([gold] + [fill[k % 4:k % 4 + 1].roll(7 * (k // 4 + 1), dims=2) for k in range(7)]).repeat(1, 3, 1, 1).cuda()

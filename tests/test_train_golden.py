@@ -371,3 +371,62 @@ def test_config2_full_size_train_steps_property_run():
         if g is not None:
             worst = max(worst, float((p.grad - g).abs().max() / (g.abs().max() + 1e-30)))
     assert worst < 2e-3, worst  # (fp32 reductions over 4x the pixels in another order)
+
+
+@pytest.mark.gpu
+def test_full_size_fusion_step_gradients_vs_reference_record():
+    """(r5) One iteration of train.py:351-385 at BASELINE config[2]'s backbone and image size - mit_b3,
+    1 x 480 x 640 - against a record made by the REAL reference's autograd (oracle/make_golden_r5.py ->
+    tests/golden/grads_fusion_step_b3_480x640.npz): the three loss values, which parameters receive gradients, and for every
+    parameter of the fusion net the gradient's norm and its first 2048 entries.  Until now full-size gradients were checked
+    against themselves only (batch 8 vs batch 2).  Tolerance: 2e-3 of max(rms, max |head|) of each tensor - the norm of the other
+    gradient fixtures (fp32 reductions over 307 200 pixels in another order than torch's)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import detweights as dw
+    from segmif_amd.core import Fusion_Network3_ac, Network3
+    from segmif_amd.train import FusionTrainer
+    from segmif_amd.utils.optimizer import PolyWarmupAdamW
+    g = load("grads_fusion_step_b3_480x640.npz")
+    B, H, W, iter_ = 1, 480, 640, 2
+    net = Network3("mit_b3", 9, pretrained=None)
+    dw.load_det_weights(net, seed=0)
+    fus = Fusion_Network3_ac()
+    dw.load_det_weights(fus, seed=0)
+    net, fus = net.cuda().eval(), fus.cuda().eval()
+    ir3 = dw.det_input("r5g_ir", (B, 1, H, W)).repeat(1, 3, 1, 1)
+    vis3 = dw.det_input("r5g_vis", (B, 3, H, W))
+    mask3 = dw.det_input("r5g_mask", (B, 1, H, W)).repeat(1, 3, 1, 1)
+    labels = dw.det_labels("r5g_lab", (B, H, W), 9)
+    labels[0, 11:40, 100:300] = 255
+    opt = PolyWarmupAdamW([{"params": fus.parameters(), "lr": 8e-5 / iter_, "weight_decay": 0.01}], **fus_kw(iter_))
+    tr = FusionTrainer(net, fus, opt, torch.nn.CrossEntropyLoss(ignore_index=255), iter_=iter_)
+    total = tr.step(ir3.cuda(), vis3.cuda(), mask3.cuda(), labels.cuda())
+    l1, l2 = tr.history[0][0], tr.history[0][1]
+    assert abs(l1 - float(g["loss1"])) < 2e-4 * abs(float(g["loss1"])), (l1, float(g["loss1"]))
+    assert abs(l2 - float(g["loss2"])) < 2e-4 * abs(float(g["loss2"])), (l2, float(g["loss2"]))
+    assert abs(float(total) - float(g["total"])) < 2e-4 * abs(float(g["total"]))
+    names = sorted(k[:-5] for k in g.files if k.endswith("|norm"))
+    produced = sorted(n for n, p in fus.named_parameters() if p.grad is not None)
+    assert produced == names and sorted(g["no_grad_params"].tolist()) == sorted(n for n, p in fus.named_parameters() if p.grad is None)
+    worst, worst_norm, bad = 0.0, 0.0, []
+    for n, p in fus.named_parameters():
+        if p.grad is None:
+            continue
+        got = p.grad.detach().double().cpu().reshape(-1)
+        head = torch.from_numpy(g[n + "|head"]).double()
+        k = head.numel()
+        rms = float(g[n + "|norm"]) / max(got.numel(), 1) ** 0.5 + TINY
+        scale = max(rms, float(head.abs().max()))
+        e = float((got[:k] - head).abs().max()) / scale
+        en = abs(float(got.norm()) - float(g[n + "|norm"])) / (float(g[n + "|norm"]) + TINY)
+        worst, worst_norm = max(worst, e), max(worst_norm, en)
+        if e >= 2e-3 or en >= 2e-3:
+            bad.append((n, e, en))
+    try:
+        from _observed import observed
+        observed("full_size_fusion_step_gradients_vs_reference", {"worst_head_err": worst, "worst_norm_err": worst_norm,
+                                                                  "tensors": len(names), "loss1": l1, "loss2": l2})
+    except ImportError:
+        pass
+    assert not bad, bad
