@@ -287,7 +287,9 @@ def config_leg(backbone, B, H, W, steps):
     gf = GFLOP_PER_PAIR.get((backbone, H, W))
     rec = {"backbone": backbone, "height": H, "width": W, "pairs_per_step": B, "steps": steps, "warmup": 2,
            "value": B / dt, "unit": "img-pairs/s", "ms_per_step": 1e3 * dt,
-           "f16x3_pairs_repeated": s1["images_repeated"] - s0["images_repeated"]}
+           "f16x3_pairs_repeated": s1["images_repeated"] - s0["images_repeated"],
+           "f16x3_pairs_repeated_fp32conv": s1["images_repeated_fp32conv"] - s0["images_repeated_fp32conv"],
+           "f16x3_pairs_seen": s1["images"] - s0["images"]}
     if gf is not None:
         rec["gflop_per_pair"] = {"executed": gf - gflop_removed_by_n4(H, W), "textbook_order": gf}
         rec["whole_path_tflops"] = B / dt * (gf - gflop_removed_by_n4(H, W)) / 1e3

@@ -459,10 +459,11 @@ int segmif_linattn_fold_f32(const double* partial, const float* wend, float* wef
  *  - segmif_crosspath_fold_f32: K^T V = Wk G Wv^T per head from the Gram partials ([Wk; Wv] = the raw (128, 64) kv
  *    weight), softmax over the k index of (K^T V) * scale, folded into end_proj exactly like segmif_linattn_fold_f32.
  *    cond (or NULL): B words, one per image; the launch raises cond[b] (integer atomic max over fp32 bit patterns) to
- *    kappa = max over its 64 softmax columns of sum_i p_i (1 - p_i) A_i, A_i = |scale| sum_ab |Wk[i][a]| G[a][b] |Wv[j][b]|
- *    (the logit without its cancellation) - the factor by which this softmax amplifies a RELATIVE error of the Gram
- *    entries.  The host's f16x3 guard reads it beside the range slots: an image whose kappa passes a calibrated bound is
- *    computed again with the 3x3 convs in exact fp32 (round 5; core/model_fusion.py:281-286, :316-326).
+ *    kappa = max over its 64 softmax columns of max_i |p_i (dL_i - sum_k p_k dL_k)|, dL the derivative of the logits with
+ *    respect to a relative perturbation G -> G o (1 + eps S) of the Gram entries under one fixed symmetric +-1 pattern S - how
+ *    far this softmax moves per unit RELATIVE error of its input.  The host's f16x3 guard reads it beside the range slots: an
+ *    image whose kappa passes a calibrated bound is computed again with the 3x3 convs in exact fp32 (round 5;
+ *    core/model_fusion.py:281-286, :316-326).
  *  - segmif_crosspath_tail_f32: out = LayerNorm_64(x_i + Weff_b . [ReLU(W3 x_3 + b3) | ReLU(Wi x_i + bi)] + bend):
  *    channel_proj halves, the context-folded end_proj (Weff: (B, 64, 128)), residual and norm in one pass over the
  *    tokens; optionally also emits out as planes chunks 0..3 (conv3x3_planes format, H * W == N) for the next DRDB.

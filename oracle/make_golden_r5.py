@@ -70,6 +70,36 @@ def main():
         rec[name + "|norm"] = np.float64(g.double().norm())
         rec[name + "|head"] = mgt.npy(g.reshape(-1)[:2048])
     rec["no_grad_params"] = np.array([n for n, p in fus.named_parameters() if p.grad is None])
+    # Scalar parameters (the shared PReLU slope): their gradient is ONE fp32 sum over every pixel of every layer that uses them -
+    # 2e8 terms in whatever order torch's CPU reductions take - so the float32 record above carries a summation error of its own.
+    # The same step with the reference's modules in float64 gives the value both implementations are approximating.
+    small = [n for n, p in fus.named_parameters() if p.grad is not None and p.numel() <= 4]
+    if small:
+        net64, fus64 = net.double(), fus.double()
+        torch.set_default_dtype(torch.float64)  # (the reference's colour / loss code builds its constant matrices with torch.tensor(..))
+        with mgt.cuda_is_identity():
+            floss64 = loss_mod.Fusionloss_grad3()
+            for m in floss64.modules():
+                m.double()
+            for k, v in list(vars(floss64).items()):
+                if torch.is_tensor(v) and v.is_floating_point():
+                    setattr(floss64, k, v.double())
+            vis64 = mf.RGB2YCrCb(vis3.double())
+            with torch.no_grad():
+                o0, o1 = net64.denoise_net.encoder.forward_fusion(mask3.double())
+            fusion64 = fus64(ir.double(), vis64, o0, o1)
+            ycc64 = vis64.clone()
+            ycc64[:, 0:1] = fusion64
+            rgb64 = mf.YCrCb2RGB(ycc64)
+            l1 = floss64(ir.double(), vis64, fusion64, mask3.double())
+            l2 = net64._loss(rgb64, labels, crit)
+        fus64.zero_grad()
+        ((0.4 / iter_) * l1 + 0.8 * l2).backward()
+        for name, p in fus64.named_parameters():
+            if name in small:
+                rec[name + "|f64"] = mgt.npy(p.grad.detach().reshape(-1))
+        rec["loss1_f64"], rec["loss2_f64"] = np.float64(l1.detach()), np.float64(l2.detach())
+        torch.set_default_dtype(torch.float32)
     path = os.path.join(OUT, "grads_fusion_step_b3_480x640.npz")
     np.savez_compressed(path, **rec)
     print(f"  {os.path.basename(path)}: {os.path.getsize(path) / 1024:.1f} KiB, {time.time() - t0:.0f} s of reference CPU time, "

@@ -164,9 +164,12 @@ class SegFormerHead(nn.Module):
             # few KB - instead of two full passes over the (B, H/4, W/4, E) tensor (forward multiply + its backward)
             E = y.shape[-1]
             keep = 1.0 - self.dropout.p
-            mask = torch.empty((B, 1, E), device=y.device, dtype=torch.float32).bernoulli_(keep) / keep
+            if keep <= 0.0:  # Dropout2d(p = 1): every channel dropped - zeros, not 0 / 0
+                mask = torch.zeros((B, 1, E), device=y.device, dtype=torch.float32)
+            else:
+                mask = torch.empty((B, 1, E), device=y.device, dtype=torch.float32).bernoulli_(keep) / keep
             wb = self.linear_pred.weight.flatten(1).unsqueeze(0) * mask
-            return ag.batched_linear(y.reshape(B, H1 * W1, E), wb, self.linear_pred.bias).view(B, H1, W1, -1)
+            return ag.batched_linear(y.contiguous().reshape(B, H1 * W1, E), wb, self.linear_pred.bias).view(B, H1, W1, -1)
         return ag.linear(y, self.linear_pred.weight, self.linear_pred.bias)
 
     def forward_nhwc(self, feats):

@@ -12,7 +12,18 @@
 #include <stdint.h>
 #include <string.h>
 
+// The few RCCL types and constants these entry points use.  With the RCCL development headers present they come from
+// <rccl/rccl.h>; without them (a box that only runs the kernels) the same ABI-stable declarations are made here, so the kernel
+// library still BUILDS there as the paragraph above promises - the functions are resolved with dlsym either way.
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7, ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+#endif
 
 #include "segmif_hip.h"
 

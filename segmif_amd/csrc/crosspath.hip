@@ -253,30 +253,32 @@ __global__ __launch_bounds__(1024) void crosspath_fold_kernel(const double* __re
     G[u] = s;
   }
   __syncthreads();
-  double* T1a = ctx + 512;    // [64][64]  |Wk| G   (cond only)
-  double* actx = T1a + 4096;  // [8][8][8]  absolute-value logits (cond only)
+  double* D1 = ctx + 512;     // [64][64]  Wk (G o S): the Gram matrix under the probe pattern S (cond only)
+  double* dctx = D1 + 4096;   // [8][8][8]  d logit / d eps under that pattern (cond only)
   for (int u = tid; u < 4096; u += 1024) {  // T1[c][bq] = sum_a Wk[c][a] G[a][bq]
     const int c = u >> 6, bq = u & 63;
-    double s = 0.0, sa = 0.0;
+    double s = 0.0, sd = 0.0;
     for (int a = 0; a < 64; ++a) {
-      const double w = (double)wkv[c * 64 + a], g = G[a * 64 + bq];
-      s += w * g;
-      sa += fabs(w) * fabs(g);
+      const double wg = (double)wkv[c * 64 + a] * G[a * 64 + bq];
+      s += wg;
+      // S[a][bq] = +-1, symmetric (the Gram matrix and the errors of its entries are), fixed: a multiplicative hash of (min, max)
+      const unsigned lo = a < bq ? a : bq, hi = a < bq ? bq : a;
+      sd += (((lo * 64u + hi + 1u) * 2654435761u) >> 16) & 1u ? wg : -wg;
     }
     T1[u] = s;
-    if (cond) T1a[u] = sa;
+    if (cond) D1[u] = sd;
   }
   __syncthreads();
   if (tid < 512) {  // (K^T V)[h][i][j] = sum_b T1[h*8+i][b] Wv[h*8+j][b]
     const int hh = tid >> 6, i = (tid >> 3) & 7, j = tid & 7;
-    double s = 0.0, sa = 0.0;
+    double s = 0.0, sd = 0.0;
     for (int q = 0; q < 64; ++q) {
       const double w = (double)wkv[(64 + hh * 8 + j) * 64 + q];
       s += T1[(hh * 8 + i) * 64 + q] * w;
-      if (cond) sa += T1a[(hh * 8 + i) * 64 + q] * fabs(w);
+      if (cond) sd += D1[(hh * 8 + i) * 64 + q] * w;
     }
     ctx[tid] = s * (double)scale;
-    if (cond) actx[tid] = sa * fabs((double)scale);
+    if (cond) dctx[tid] = sd * (double)scale;
   }
   __syncthreads();
   if (tid < 64) {  // one (h, j) column per thread: softmax over i (dim = -2)
@@ -288,20 +290,23 @@ __global__ __launch_bounds__(1024) void crosspath_fold_kernel(const double* __re
       ev[i] = exp(ctx[hh * 64 + i * 8 + j] - mx);
       sum += ev[i];
     }
-    double kap = 0.0;
+    double mean_d = 0.0;
     for (int i = 0; i < 8; ++i) {
       const double pi = ev[i] / sum;
       ctx[hh * 64 + i * 8 + j] = pi;
-      if (cond) kap += pi * (1.0 - pi) * actx[hh * 64 + i * 8 + j];
+      if (cond) mean_d += pi * dctx[hh * 64 + i * 8 + j];
     }
     if (cond) {
-      // Conditioning of this softmax column.  A logit is L_i = scale * sum_ab Wk[i][a] G[a][b] Wv[j][b] with G >= 0 (a Gram
-      // matrix of ReLU outputs): what the producers' arithmetic leaves on it is a RELATIVE error eps of the Gram entries, i.e.
-      // |dL_i| <= eps A_i with A_i = |scale| sum_ab |Wk[i][a]| G[a][b] |Wv[j][b]| - the logit without its cancellation, which
-      // can be orders of magnitude above |L_i|.  The softmax turns it into d p_i = p_i (dL_i - sum_k p_k dL_k), so a column's
-      // probabilities move by at most ~2 eps kappa, kappa = sum_i p_i (1 - p_i) A_i: large only while the column is undecided AND
-      // its logits are small differences of large sums.  A decided (one-hot) column reports ~0 whatever its magnitude; NaN
-      // logits report NaN (top of the integer order).  Non-negative floats order like their bit patterns: integer atomic max.
+      // Conditioning probe of this softmax column.  What the producers' arithmetic leaves on the Gram entries is a RELATIVE
+      // error; the probe asks how far the context moves per unit of it under ONE fixed sign pattern S: G -> G o (1 + eps S) moves
+      // the logits by eps dL (dL formed above beside the logits themselves) and the softmax, to first order, by
+      // d p_i = p_i (dL_i - sum_k p_k dL_k) eps.  kappa = max_i |p_i (dL_i - sum_k p_k dL_k)| over the launch's 64 columns:
+      // ~1 for a well-conditioned context, hundreds where two large, cancelling logits compete (tools/cond_probe.py: 300 - 400
+      // on the over-exposed pair whose f16x3 error was 6e-3, below 10 on its neighbours).  A worst-case bound (absolute values
+      // instead of S) sits at 1e4 for nearly every input and separates nothing - profiles/r05_cond_calibration_abs.txt.
+      // A decided (one-hot) column reports ~0 whatever its magnitude; NaN logits report NaN (top of the integer order).
+      double kap = 0.0;
+      for (int i = 0; i < 8; ++i) kap = fmax(kap, fabs(ctx[hh * 64 + i * 8 + j] * (dctx[hh * 64 + i * 8 + j] - mean_d)));
       const float kappa = (float)kap;
       uint32_t bits = __float_as_uint(kappa);
       if (kappa != kappa) bits = 0x7fc00000u;

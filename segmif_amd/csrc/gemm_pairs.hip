@@ -247,40 +247,51 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM == 
   __syncthreads();  // the ring is free: the epilogue stages its rows there
   PAIRS_TL(30, 1);
 
-  // ---- epilogue (gemm_split's): row scale, bias, activation into a wave-private [32][68] tile, then 4 rows x 256 contiguous
-  // bytes per instruction with the residual read the same way
+  // ---- epilogue.  The products ran transposed (a lane owns an output ROW), so the accumulators go through a wave-private
+  // [32][68] LDS tile and leave as 4 rows x 256 contiguous bytes per instruction (gemm_split's scheme).  Two things differ,
+  // both about vmcnt counting stores as well as loads on gfx9: a load issued AFTER a store cannot be waited for without
+  // draining that store (tools/pairs_timeline.py: the first version's epilogue was 34 % of a workgroup's life, a chain of such
+  // drains).  (1) Row scale, bias and activation are applied AFTER the transposition, where a lane's four columns are the
+  // same for every row: two 16-byte loads per lane for the whole tile, issued before any store.  (2) The residual rows of BOTH
+  // halves are requested before the first store (64 registers: half of the accumulators are dead by then).
   const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
   float* T = reinterpret_cast<float*>(smem_p) + wave * (32 * 68);
+  const int ecl = (lane & 15) * 4, en = n0 + wn * 64 + ecl;  // this lane's four columns in the store phase
+  const bool en_ok = en < p.N;
+  const f32x4 esc = *reinterpret_cast<const f32x4*>(p.wscale + en);  // (the scale array covers the padded columns)
+  const f32x4 ebi = (p.bias && en_ok) ? *reinterpret_cast<const f32x4*>(p.bias + en) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 rres[2][8];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cl = j * 32 + 8 * g + 4 * h;
-        const int n = n0 + wn * 64 + cl;
-        f32x4 y = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        y *= *reinterpret_cast<const f32x4*>(p.wscale + n);  // (the scale array covers the padded columns)
-        if (p.bias && n < p.N) y += *reinterpret_cast<const f32x4*>(p.bias + n);
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(T + r * 68 + j * 32 + 8 * g + 4 * h) =
+            f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+    if (i == 0 && p.res) {  // (uniform) both halves' residual rows, while nothing has been stored yet
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (p.act == SEGMIF_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
-          else if (p.act == SEGMIF_ACT_PRELU) y[e] = y[e] >= 0.f ? y[e] : slope * y[e];
-          else if (p.act == SEGMIF_ACT_GELU) y[e] = gelu_exact(y[e]);
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const long long m = m0 + wm * 64 + ii * 32 + t * 4 + (lane >> 4);
+          rres[ii][t] = (m < p.M && en_ok) ? *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + en) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        *reinterpret_cast<f32x4*>(T + r * 68 + cl) = y;
-      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: the wave's own LDS writes have landed
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const int row = t * 4 + (lane >> 4), cl = (lane & 15) * 4;
+      const int row = t * 4 + (lane >> 4);
       const long long m = m0 + wm * 64 + i * 32 + row;
-      const int n = n0 + wn * 64 + cl;
-      f32x4 y = *reinterpret_cast<const f32x4*>(T + row * 68 + cl);
-      if (m < p.M && n < p.N) {
-        if (p.res) y += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n);
-        *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = y;
+      f32x4 y = *reinterpret_cast<const f32x4*>(T + row * 68 + ecl) * esc + ebi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (p.act == SEGMIF_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+        else if (p.act == SEGMIF_ACT_PRELU) y[e] = y[e] >= 0.f ? y[e] : slope * y[e];
+        else if (p.act == SEGMIF_ACT_GELU) y[e] = gelu_exact(y[e]);
       }
+      if (p.res) y += rres[i][t];
+      if (m < p.M && en_ok) *reinterpret_cast<f32x4*>(p.out + m * p.ldo + en) = y;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites the tile
   }

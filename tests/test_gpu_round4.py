@@ -154,10 +154,11 @@ def _image_like(B, H, W, seed):
 def _check_against_oracle(ops, pipe, sd_seg, sd_fus, ir, vis, mask, name):
     """The guarded pair forward against the oracle, with the input's CONDITIONING measured beside it: the oracle evaluated in
     float64 is the truth, the oracle in float32 (= the reference's arithmetic) sits e_ref away from it.  On well-conditioned
-    inputs e_ref is ~1e-6 .. 1e-4 and the 1e-3 tolerance binds; on over-exposed images the CrossPath softmax logits grow with
-    the squared exposure and the reference's own fp32 result is 1.5e-3 from the truth (profiles/r04_stats_bisect.txt) - there
-    no fp32 implementation can agree with another to 1e-3, and the HIP path is held to a multiple of e_ref instead.  Recorded
-    beside it: the same pairs on the bf16x6 kernels (what a tripped pair gets) and on exact-fp32 MFMA."""
+    inputs e_ref is ~1e-6 .. 1e-4 and the 1e-3 tolerance binds; on over-exposed images the function is ill-conditioned and the
+    reference's own fp32 result is 1.2e-3 from the truth (profiles/r04_stats_bisect.txt) - there no fp32 implementation can
+    agree with another to 1e-3, and the HIP path is held to 1.5 x the error of the repo's own exact-fp32 MFMA path (r5; the guard
+    repeats such a pair with exact-fp32 convs).  Recorded beside it: the same pairs on the bf16x6 kernels (what a range-tripped
+    pair gets) and on exact-fp32 MFMA."""
     import segmif_oracle as so
     s0 = ops.range_stats()
     with torch.no_grad():
@@ -191,7 +192,9 @@ def _check_against_oracle(ops, pipe, sd_seg, sd_fus, ir, vis, mask, name):
     observed(f"r4_stats_{name}", {"fused_err_vs_fp64": e, "reference_fp32_err_vs_fp64": e_ref, "bf16x6_err_vs_fp64": e6,
                                  "fp32_mfma_err_vs_fp64": e32, "pairs": int(ir.shape[0]), "pairs_repeated_on_bf16x6": tripped,
                                  "labels_equal_above_margin": same, "stable_fraction": float(stable.float().mean())})
-    assert e < max(TOL, 5.0 * e_ref), (name, e, e_ref, e6, e32)
+    # (r5) the yardstick is the repo's OWN exact-fp32 MFMA path, not a multiple of the reference's error: an ill-conditioned pair is
+    # caught by the guard's conditioning word and repeated with exact-fp32 convs (tests/test_gpu_round5.py)
+    assert e <= max(TOL, 1.5 * e32), (name, e, e_ref, e6, e32)
     assert same, name
     return tripped
 

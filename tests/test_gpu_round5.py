@@ -253,10 +253,11 @@ def test_mit_b3_pair_in_batch_on_the_pairs_path_vs_reference(ops, golden_dir):
 
 def test_crosspath_fold_reports_the_softmax_conditioning(ops):
     """crosspath_fold's conditioning word against a float64 restatement: kappa = max over (head, column) of
-    sum_i p_i (1 - p_i) A_i with A the logits formed from |Wk|, G, |Wv| (no cancellation); a decided softmax reports ~0."""
+    max_i |p_i (dL_i - sum_k p_k dL_k)| with dL the logits formed from G o S (S the kernel's fixed symmetric +-1 pattern) - and
+    against a FINITE perturbation: softmax(L(G o (1 + eps S))) really moves by eps * kappa.  A decided softmax reports ~0."""
     B, nblk = 3, 2
     torch.manual_seed(5)
-    y = torch.rand(B, 4000, 64) * torch.tensor([0.2, 1.0, 30.0]).view(B, 1, 1)  # image 2: large logits
+    y = torch.rand(B, 4000, 64) * torch.tensor([0.02, 0.2, 30.0]).view(B, 1, 1)  # image 2: large logits, decided columns
     G = torch.einsum("bni,bnj->bij", y.double(), y.double())
     part = torch.zeros(B, nblk, 3072, dtype=torch.float64)
     for a, (ti, tj) in enumerate(((0, 0), (0, 1), (1, 1))):
@@ -267,16 +268,27 @@ def test_crosspath_fold_reports_the_softmax_conditioning(ops):
     with scope(ops, B) as g:
         ops.crosspath_fold(part.cuda(), wkv.cuda(), wend.cuda(), weff, wofs=64, kofs=64, scale=scale)
     kap = g.kappa()
+    ia, ib = torch.meshgrid(torch.arange(64), torch.arange(64), indexing="ij")
+    lo, hi = torch.minimum(ia, ib), torch.maximum(ia, ib)
+    S = (((((lo * 64 + hi + 1) * 2654435761) & 0xffffffff) >> 16) & 1).double() * 2 - 1
     Wk, Wv = wkv[:64].double(), wkv[64:].double()
-    L = torch.einsum("ia,bac,jc->bij", Wk, G, Wv) * scale
-    A = torch.einsum("ia,bac,jc->bij", Wk.abs(), G, Wv.abs()) * abs(scale)
+
+    def ctx_of(Gm):
+        L = torch.einsum("ia,bac,jc->bij", Wk, Gm, Wv) * scale
+        return L, torch.stack([torch.softmax(L[:, 8 * h:8 * h + 8, 8 * h:8 * h + 8], dim=1) for h in range(8)], dim=1)
+
+    L, P = ctx_of(G)
+    dL = torch.einsum("ia,bac,jc->bij", Wk, G * S, Wv) * scale
     ref = torch.zeros(B, dtype=torch.float64)
     for h in range(8):
-        l, a = L[:, 8 * h:8 * h + 8, 8 * h:8 * h + 8], A[:, 8 * h:8 * h + 8, 8 * h:8 * h + 8]
-        p = torch.softmax(l, dim=1)
-        ref = torch.maximum(ref, (p * (1 - p) * a).sum(1).max(1).values)
+        p, d = P[:, h], dL[:, 8 * h:8 * h + 8, 8 * h:8 * h + 8]
+        ref = torch.maximum(ref, (p * (d - (p * d).sum(1, keepdim=True))).abs().flatten(1).max(1).values)
     assert torch.allclose(kap.double(), ref, rtol=1e-4, atol=1e-30), (kap, ref)
-    observed("crosspath_fold_kappa", {"device": kap.tolist(), "fp64": ref.tolist()})
+    eps = 2.0 ** -26
+    _, P2 = ctx_of(G * (1 + eps * S))
+    moved = (P2 - P).abs().flatten(1).max(1).values / eps
+    assert torch.allclose(moved, ref, rtol=5e-2, atol=1e-6), (moved, ref)
+    observed("crosspath_fold_kappa", {"device": kap.tolist(), "fp64": ref.tolist(), "finite_difference": moved.tolist()})
 
 
 def test_ill_conditioned_pair_is_repeated_with_exact_convs(ops):

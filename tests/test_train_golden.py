@@ -409,7 +409,7 @@ def test_full_size_fusion_step_gradients_vs_reference_record():
     names = sorted(k[:-5] for k in g.files if k.endswith("|norm"))
     produced = sorted(n for n, p in fus.named_parameters() if p.grad is not None)
     assert produced == names and sorted(g["no_grad_params"].tolist()) == sorted(n for n, p in fus.named_parameters() if p.grad is None)
-    worst, worst_norm, bad = 0.0, 0.0, []
+    worst, worst_norm, bad, scalar_note = 0.0, 0.0, [], {}
     for n, p in fus.named_parameters():
         if p.grad is None:
             continue
@@ -420,13 +420,22 @@ def test_full_size_fusion_step_gradients_vs_reference_record():
         scale = max(rms, float(head.abs().max()))
         e = float((got[:k] - head).abs().max()) / scale
         en = abs(float(got.norm()) - float(g[n + "|norm"])) / (float(g[n + "|norm"]) + TINY)
+        if n + "|f64" in g.files and (e >= 2e-3 or en >= 2e-3):
+            # a scalar gradient = one fp32 sum over ~2e8 terms: the float32 record carries its own summation error; the record
+            # also holds the same gradient from the reference run in float64 - be as close to THAT as the record itself (x3)
+            truth = torch.from_numpy(g[n + "|f64"]).double()
+            e_fix = float((head - truth).abs().max() / truth.abs().max())
+            e_hip = float((got[:k] - truth).abs().max() / truth.abs().max())
+            scalar_note[n] = {"hip_vs_f64": e_hip, "fp32_record_vs_f64": e_fix}
+            if e_hip <= max(2e-3, 3.0 * e_fix):
+                continue
         worst, worst_norm = max(worst, e), max(worst_norm, en)
         if e >= 2e-3 or en >= 2e-3:
             bad.append((n, e, en))
     try:
         from _observed import observed
         observed("full_size_fusion_step_gradients_vs_reference", {"worst_head_err": worst, "worst_norm_err": worst_norm,
-                                                                  "tensors": len(names), "loss1": l1, "loss2": l2})
+                                                                  "tensors": len(names), "loss1": l1, "loss2": l2, "scalars": scalar_note})
     except ImportError:
         pass
     assert not bad, bad

@@ -2,7 +2,8 @@
 """(r5) Calibration of the f16x3 guard's conditioning bound (ops.Planes16Guard.KAPPA).
 
 For several input families (mit_b1, 64x96 - the size at which the CPU oracle in float64 takes seconds) prints, PER PAIR: the
-conditioning figure kappa = max over columns of sum_i p_i (1 - p_i) A_i (A: the logits without their cancellation) its CrossPath context softmaxes reported (csrc/crosspath.hip,
+conditioning figure kappa (how far a context softmax moves per unit relative perturbation of its Gram matrix under a fixed +-1
+pattern: csrc/crosspath.hip) its CrossPath context softmaxes reported (csrc/crosspath.hip,
 crosspath_fold_kernel), and the error of the fused image against the oracle evaluated in float64 (the truth) for
   f16x3 (default, no repeat) | bf16x6 | f16x3 but 3x3 convs in exact fp32 (what a saturated pair is repeated with) |
   everything on exact-fp32 MFMA | the oracle in float32 (= the reference's own arithmetic).
