@@ -214,6 +214,20 @@ int segmif_gemm_pairs_f32(const SegmifGemmPairs* desc, void* stream);
 int segmif_pairs_from_f32(const float* x, int64_t ldx, void* y, int64_t ldy_bytes, int64_t rows, int C, uint32_t* amax,
                           int amax_images, void* stream);
 int segmif_pairs_to_f32(const void* x, int64_t ldx_bytes, float* y, int64_t ldy, int64_t rows, int C, void* stream);
+/*
+ * (r5) Backward of the spatial-reduction attention without the score matrix (csrc/attention_bwd.hip; the autograd of
+ * core/mix_transformer.py:107-111 - softmax(q k^T scale) v): q, out, dout, dq are (B, N, heads * 64) rows, k / v the two
+ * halves of a (B, Nk, ldkv >= 2 heads 64) tensor, dkv receives (B, Nk, 2 heads 64) = (dk | dv).  Scores are recomputed per
+ * 32 x 32 tile on the exact-fp32 matrix pipe; dk / dv are formed per chunk of queries (segmif_sr_attention_bwd_chunks of them:
+ * about one round of workgroups on the chip) and summed in a fixed order
+ * (deterministic).  workspace: segmif_sr_attention_bwd_workspace_floats floats (row statistics + the chunk partials).
+ */
+int segmif_sr_attention_bwd_chunks(int B, int heads, int N, int Nk);
+int64_t segmif_sr_attention_bwd_workspace_floats(int B, int heads, int N, int Nk, int C);
+int segmif_sr_attention_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* dout, float* dq,
+                                float* dkv, float* workspace, int B, int heads, int N, int Nk, int hd, int ldkv, float scale,
+                                void* stream);
+
 /* Producers of PAIRS rows (r5): LayerNorm (core/mix_transformer.py:152-155 norm1 / norm2, :113 the norm after the sr conv),
  * depthwise 3x3 + bias + GELU (:46-53, :376-387) and the fused attention kernel (:107-111) with their result written as half
  * pairs - 16-channel groups of [16 hi | 16 lo], the fp32 row's byte count - and max |y| folded into the f16x3 range slot of the

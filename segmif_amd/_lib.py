@@ -124,6 +124,10 @@ SIGNATURES = {
                                               c_void_p]),
     "segmif_sr_attention_split16_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                                     c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
+    "segmif_sr_attention_bwd_chunks": (c_int, [c_int, c_int, c_int, c_int]),
+    "segmif_sr_attention_bwd_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "segmif_sr_attention_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "segmif_crosspath_gram_blocks": (c_int, [c_int64]),
     "segmif_crosspath_gram_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "segmif_crosspath_fold_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

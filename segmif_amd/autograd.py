@@ -538,21 +538,28 @@ def _batched_heads_gemm(a, a_ld, a_bs, a_hs, w, w_ld, w_bs, w_hs, out, o_ld, o_b
 
 
 class SrAttentionFn(torch.autograd.Function):
-    """softmax(q k^T scale) v per (batch, head); forward = the fused kernel, backward = score
-    recomputation with batched fp32-MFMA GEMMs + row-softmax kernels (Nk is a few hundred keys)."""
+    """softmax(q k^T scale) v per (batch, head); forward = the fused kernel.  Backward (r5): head_dim 64 - the fused
+    flash-style kernels of csrc/attention_bwd.hip (scores recomputed per tile in registers, nothing of size N x Nk in HBM;
+    SEGMIF_ATTN_BWD=materialize restores round 4's); other head sizes - score recomputation with batched fp32-MFMA GEMMs +
+    row-softmax kernels over materialised (B, heads, N, Nk) tensors."""
+    FUSED = __import__("os").environ.get("SEGMIF_ATTN_BWD", "fused") != "materialize"
 
     @staticmethod
     def forward(ctx, q, kv, heads, scale):
         ctx.heads, ctx.scale = heads, scale
-        ctx.save_for_backward(q, kv)
-        return ops.sr_attention(q, kv, heads, scale)
+        out = ops.sr_attention(q, kv, heads, scale)
+        ctx.save_for_backward(q, kv, out)  # (the output: D_i = dO_i . O_i of the fused backward; alive anyway - proj's input)
+        return out
 
     @staticmethod
     def backward(ctx, do):
-        q, kv = ctx.saved_tensors
+        q, kv, out = ctx.saved_tensors
         heads, scale = ctx.heads, ctx.scale
         do = do.contiguous()
         B, N, C = q.shape
+        if SrAttentionFn.FUSED and C == heads * 64 and q.is_contiguous() and kv.is_contiguous() and out.is_contiguous():
+            dq, dkv = ops.sr_attention_bwd(q, kv, out, do, heads, scale)
+            return dq, dkv, None, None
         Nk = kv.shape[1]
         hd = C // heads
         dev = q.device

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libsegmif_hip.so")
-SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_split.hip", "conv3x3_planes.hip", "gemm_split.hip", "gemm_pairs.hip", "wgrad.hip", "backward.hip", "attention.hip", "attention_split.hip", "rowops.hip", "linattn.hip", "crosspath.hip", "metrics.hip", "losses.hip", "common.hip", "comm.hip", "mixffn.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv3x3_split.hip", "conv3x3_planes.hip", "gemm_split.hip", "gemm_pairs.hip", "wgrad.hip", "backward.hip", "attention.hip", "attention_split.hip", "attention_bwd.hip", "rowops.hip", "linattn.hip", "crosspath.hip", "metrics.hip", "losses.hip", "common.hip", "comm.hip", "mixffn.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(ROOT, "include")]
 

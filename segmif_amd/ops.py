@@ -1384,6 +1384,25 @@ def sr_attention(q, kv, heads, scale, pairs=False):
     return out
 
 
+def sr_attention_bwd(q, kv, out, dout, heads, scale):
+    """Backward of sr_attention for head_dim 64 without materialising the scores (csrc/attention_bwd.hip): q, out, dout (B, N, C)
+    contiguous, kv (B, Nk, 2C) contiguous -> (dq (B, N, C), dkv (B, Nk, 2C))."""
+    B, N, C = q.shape
+    Nk = kv.shape[1]
+    if C != heads * 64 or not (q.is_contiguous() and kv.is_contiguous() and out.is_contiguous() and dout.is_contiguous()) \
+            or kv.shape[2] != 2 * C:
+        raise RuntimeError("sr_attention_bwd expects contiguous q / out / dout (B, N, 64 heads) and kv (B, Nk, 128 heads)")
+    lib = _lib.load()
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    ws = torch.empty((lib.segmif_sr_attention_bwd_workspace_floats(B, heads, N, Nk, C),), device=q.device, dtype=torch.float32)
+    kptr = kv.data_ptr()
+    _lib.check(lib.segmif_sr_attention_bwd_f32(_req(q, "q").data_ptr(), kptr, kptr + 4 * C, _req(out, "out").data_ptr(),
+                                               _req(dout, "dout").data_ptr(), dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(), B, heads, N,
+                                               Nk, 64, 2 * C, float(scale), _stream()), "segmif_sr_attention_bwd_f32")
+    return dq, dkv
+
+
 def linattn_partial(kv, heads=8):
     """kv: (B, N, 2C) contiguous -> fp64 partial sums (B, nblk, heads*d*d)."""
     _req(kv, "kv")
