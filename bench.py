@@ -390,9 +390,9 @@ def main():
     elapsed = dist.max_over_ranks(elapsed)
     trip = ops.range_stats()  # (warm-up + timed steps of the headline configuration)
     trip["granularity"] = ("one pair: range slots and a CrossPath-softmax conditioning word per image; pairs that left the half's range are "
-                           "repeated on bf16x6 (trip_rate), pairs whose softmax is ill-conditioned beyond Planes16Guard.KAPPA with "
+                           "repeated on bf16x6 (trip_rate), pairs whose context softmaxes are ill-conditioned (Planes16Guard.cond_estimate > COND_BOUND) with "
                            "exact-fp32 3x3 convs (cond_repeat_rate)")
-    trip["kappa_bound"] = ops.Planes16Guard.KAPPA
+    trip["cond_bound"], trip["cond_eps"] = ops.Planes16Guard.COND_BOUND, ops.Planes16Guard.COND_EPS
 
     # for continuity with rounds 1-2: the same step on bf16 triples throughout (6 products per MAC, no range guard)
     elapsed_bf16 = None

@@ -418,6 +418,9 @@ class FeatureFusionModule(nn.Module):
         ops.Planes that also receive out_i pre-split (inference on the Gram path only); planes_only: the planes are the only
         output (returns None, None)."""
         B, H, W, C = x1.shape
+        guard = ops.active_guard()
+        if guard is not None:  # (r5) the conditioning words of this interaction's context softmaxes go to their own row
+            guard.next_interaction()
         if wants_grad(self, x1, x2, seg):
             # (out_i: ag.Out placements here - the next DRDB's buffer or the halves of conv2's input)
             r1, r2 = self.cross.forward_tokens_train(x1.reshape(B, H * W, C), x2.reshape(B, H * W, C),

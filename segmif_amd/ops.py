@@ -212,26 +212,33 @@ class Planes16Guard:
     below fp32's own resolution of anything it is added to, but not the "one bit of fp32" the in-range contract states."""
     SLOTS = 4096  # (r5: 1024 -> 4096 rows - a pairs LayerNorm takes LN_SUB rows; 1 MB at 64 images, read back once per forward)
     LO, HI = 2.0 ** -13, 65504.0
-    # (r5) conditioning bound.  crosspath_fold reports, per image, kappa = how far a CrossPath context softmax moves per unit
-    # RELATIVE perturbation of its Gram matrix (csrc/crosspath.hip).  An image above KAPPA is repeated with the 3x3 convs in exact
-    # fp32 (verdict()).  Calibration: profiles/r05_cond_calibration.txt - every input on which the f16x3 convs' rounding was
-    # amplified past the exact-fp32 path's own error (over-exposed image-like pairs: 4.6e-3 against 1.6e-3, 3.9e-4 against
-    # 3e-5 ...) reports kappa >= 337; 256 catches them all.  The signal is LOCAL (one softmax; the amplification that hurts is a
-    # product along the network), so it is necessary, not sufficient: on 64 x 96 images most pairs pass 256 without any loss of
-    # accuracy and are repeated needlessly (correct, slower); at 480 x 640 the contexts are decided (kappa < 1 on the bench's
-    # inputs, x2 and x4 included) and nothing is repeated.  The bench line reports the rate (f16x3_cond_repeat_rate).
-    KAPPA = float(os.environ.get("SEGMIF_GUARD_KAPPA", "256"))
+    # (r5) conditioning bound.  crosspath_fold reports, per image and per INTERACTION (the fusion net runs its FeatureFusionModule
+    # twice, in series), kappa = how far a CrossPath context softmax moves per unit RELATIVE perturbation of its Gram matrix
+    # (csrc/crosspath.hip).  What the f16x3 convs leave on the features entering an interaction is ~COND_EPS relative; the first
+    # interaction turns it into COND_EPS kappa_1, which the second amplifies again: the estimate of what reaches the fused image is
+    #     est = COND_EPS (kappa_1 + kappa_2 + kappa_1 kappa_2),
+    # and an image with est > COND_BOUND is repeated with the 3x3 convs in exact fp32 (verdict()).  One large kappa alone is
+    # harmless (1e-7 x 2 000 = 2e-4); the inputs on which f16x3 really lost accuracy - over-exposed image-like pairs, 4.6e-3 against
+    # the exact-fp32 path's 1.6e-3 - have BOTH in the hundreds (tools/cond_probe.py: 300 x 366).  The estimate is an upper-ish one
+    # (the probe pattern is not the real error pattern): over 30 calibration pairs at 64 x 96 (profiles/r05_cond_calibration.txt)
+    # every pair whose f16x3 error exceeded 3 x the exact-fp32-conv result's AND 1e-4 sits at est >= 3.5e-3 (the one that breaks
+    # the 1e-3 tolerance at 8.4e-3), while 4 of the 8 pairs above 2e-3 lose nothing and are repeated needlessly (correct, slower);
+    # below the bound the largest f16x3 error is 1.2e-4 and equals the exact-fp32 path's.  At 480 x 640 (r05_cond_fullsize.txt:
+    # mit_b1 / mit_b3, inputs x1 and x4) the contexts are decided - est <= 1.8e-4, f16x3 and exact-fp32 convs agree to 7e-6 on
+    # every pair - and nothing is repeated.  The bench line reports the repeat rate (f16x3_cond_repeat_rate).
+    COND_EPS = 1.0e-7
+    COND_BOUND = float(os.environ.get("SEGMIF_GUARD_COND_BOUND", "2e-3"))
 
     def __init__(self, device, images=1):
         if os.environ.get("SEGMIF_GUARD_PER_IMAGE") == "0":  # A/B switch: one slot per launch, whole-batch repeats (round 3)
             images = 1
         self.images = max(1, int(images))
-        # rows 0 .. SLOTS-1: range slots; row SLOTS: the conditioning words (one per image; crosspath_fold raises them);
-        # row SLOTS + 1: one pooled conditioning word for launches whose batch is not the guard's
+        # rows 0 .. SLOTS-1: range slots; rows SLOTS, SLOTS + 1: the conditioning words of the first / every later interaction
+        # (one per image; crosspath_fold raises them)
         self.amax = torch.zeros((self.SLOTS + 2, self.images), device=device, dtype=torch.int32)
         self.used = 0
         self.whole = set()  # rows written by a launch that did not index by image
-        self.cond_pooled = False
+        self.interaction = 0  # FeatureFusionModule calls seen by this scope (next_interaction())
 
     def slot(self, images=None):
         """-> (device address of the next launch's row of range slots, amax_images for the kernel).  images: the batch the
@@ -259,44 +266,57 @@ class Planes16Guard:
         assert self.used - 1 == first + n - 1
         return ptr, nimg, n
 
+    def next_interaction(self):
+        """Called by FeatureFusionModule at the start of each forward inside the scope: the folds that follow report to the
+        conditioning row of that interaction (first / later)."""
+        self.interaction += 1
+
     def cond_slot(self, images):
         """-> device address of the conditioning words for a launch over `images` images (segmif_crosspath_fold_f32's `cond`):
-        the guard's own row when the launch indexes the guard's batch, else None (pooled reporting needs one word per launch
-        image: such callers - a module run on its own with a batch the scope does not know - get no conditioning check)."""
+        the row of the running interaction when the launch indexes the guard's batch, else None (a module run on its own with
+        a batch the scope does not know gets no conditioning check)."""
         if images == self.images:
-            return self.amax.data_ptr() + 4 * self.images * self.SLOTS
+            return self.amax.data_ptr() + 4 * self.images * (self.SLOTS + (1 if self.interaction > 1 else 0))
         return None
 
     def reset(self):
         """Forget every launch (a recorded hipGraph re-fills the same rows on each replay)."""
         self.used = 0
+        self.interaction = 0
         self.whole.clear()
         self.amax.zero_()
 
     def _read(self):
         """ONE device read-back: (range maxima of the used rows, conditioning words) as float32."""
-        host = torch.cat((self.amax[:self.used], self.amax[self.SLOTS:self.SLOTS + 1])).cpu().view(torch.float32)
-        return host[:self.used], host[self.used]
+        host = torch.cat((self.amax[:self.used], self.amax[self.SLOTS:self.SLOTS + 2])).cpu().view(torch.float32)
+        return host[:self.used], host[self.used:self.used + 2]
 
     def maxima(self):
         return self._read()[0]
 
     def kappa(self):
-        """-> float tensor (images,): the largest softmax conditioning figure each image's CrossPath contexts reported."""
+        """-> float tensor (2, images): the largest softmax conditioning figure each image's CrossPath contexts reported in the
+        first interaction (row 0) and in the later one(s) (row 1)."""
         return self._read()[1]
+
+    def cond_estimate(self, k=None):
+        """-> float tensor (images,): COND_EPS (k1 + k2 + k1 k2), the estimated relative error the f16x3 convs' rounding leaves on
+        the fused image after both interactions (NaN kappa: NaN)."""
+        k = self.kappa() if k is None else k
+        return self.COND_EPS * (k[0] + k[1] + k[0] * k[1])
 
     def verdict(self):
         """-> (tripped, saturated): bool tensors (images,).  tripped: some tensor of that image left the half's range (or held
-        inf / NaN) - repeat on bf16x6.  saturated: in range, but a CrossPath context softmax is ill-conditioned beyond KAPPA (or
-        its logits are NaN): the f16x3 convs' operand rounding would be amplified past the 1e-3 tolerance - repeat with the
-        3x3 convs in exact fp32.  One read-back for both."""
+        inf / NaN) - repeat on bf16x6.  saturated: in range, but the CrossPath context softmaxes are ill-conditioned enough that
+        the f16x3 convs' operand rounding is estimated (cond_estimate) to reach COND_BOUND on the fused image, or their logits
+        are NaN - repeat with the 3x3 convs in exact fp32.  One read-back for both."""
         m, k = self._read()
         bad = ~((m == 0) | ((m >= self.LO) & (m < self.HI)))  # NaN fails every comparison: bad
         out = bad.any(0) if bad.shape[0] else torch.zeros(self.images, dtype=torch.bool)
         for row in self.whole:
             if row < bad.shape[0] and bool(bad[row, 0]):
                 out[:] = True
-        sat = ~(k <= self.KAPPA)  # NaN: saturated
+        sat = ~(self.cond_estimate(k) <= self.COND_BOUND)  # NaN: saturated
         return out, sat & ~out
 
     def tripped(self):

@@ -28,7 +28,7 @@ class PairForward:
         tall GEMMs and the fusion net's 3x3 convs run on f16x3 operands, their range slots - one per pair - are read back once
         at the end and exactly the pairs whose activations left the half's exponent range are computed again on the bf16x6
         kernels (a pair's result does not depend on what else is in the batch); (r5) pairs whose CrossPath context softmax
-        reports an ill-conditioned column (Planes16Guard.KAPPA) are computed again with the 3x3 convs in exact fp32."""
+        report ill-conditioned columns in both interactions (Planes16Guard.cond_estimate > COND_BOUND) are computed again with the 3x3 convs in exact fp32."""
         return ops.run_guarded(lambda: self._eager_body(ir, vis, mask3), ir.device, images=ir.shape[0],
                                redo=lambda out, idx: self._redo(out, idx, ir, vis, mask3))
 

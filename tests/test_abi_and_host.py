@@ -179,27 +179,34 @@ def test_guarded_scope_repeats_only_the_images_that_tripped():
 
 
 def test_guarded_scope_repeats_ill_conditioned_images_with_exact_convs():
-    """(r5) The conditioning half of the guard on the host: crosspath_fold raises one word per image to the softmax's
-    kappa; an image above Planes16Guard.KAPPA (or NaN) that stayed in range is handed to `redo` with the 3x3 convs switched to
-    exact fp32 and the f16x3 kernels off; a range trip of the same image wins (bf16x6 repeat only); images below the bound keep
-    their first result; the statistics count the two kinds separately."""
+    """(r5) The conditioning half of the guard on the host: crosspath_fold raises one word per image and interaction to the
+    softmax's kappa; an image whose estimate COND_EPS (k1 + k2 + k1 k2) passes COND_BOUND (or is NaN) and that stayed in range is
+    handed to `redo` with the 3x3 convs switched to exact fp32 and the f16x3 kernels off; ONE large kappa alone does not trip; a
+    range trip of the same image wins (bf16x6 repeat only); the statistics count the two kinds separately."""
     from segmif_amd import ops
     B = 4
 
     def bits(v):
         return int(torch.tensor([v], dtype=torch.float32).view(torch.int32))
 
-    def producer(ranges, kappas):
+    def producer(ranges, k1, k2):
         g = ops.active_guard()
         if g is None:
             return [ops.conv3x3_mode()] * B
         ptr, _ = g.slot(B)
         row = (ptr - g.amax.data_ptr()) // (4 * g.images)
-        cond = g.cond_slot(B)
-        assert cond == g.amax.data_ptr() + 4 * g.images * g.SLOTS and g.cond_slot(B + 1) is None
+        base = g.amax.data_ptr() + 4 * g.images * g.SLOTS
+        assert g.cond_slot(B + 1) is None
+        g.next_interaction()
+        assert g.cond_slot(B) == base
+        g.next_interaction()
+        assert g.cond_slot(B) == base + 4 * g.images
+        g.next_interaction()
+        assert g.cond_slot(B) == base + 4 * g.images      # every later interaction shares the second row
         for b in range(B):
             g.amax[row, b] = bits(ranges[b])
-            g.amax[g.SLOTS, b] = bits(kappas[b])
+            g.amax[g.SLOTS, b] = bits(k1[b])
+            g.amax[g.SLOTS + 1, b] = bits(k2[b])
         return ["f16x3"] * B
 
     seen = []
@@ -211,18 +218,20 @@ def test_guarded_scope_repeats_ill_conditioned_images_with_exact_convs():
             out[i] = ops.conv3x3_mode()
         return out
 
-    K = ops.Planes16Guard.KAPPA
+    G = ops.Planes16Guard
+    big = (G.COND_BOUND / G.COND_EPS) ** 0.5 * 2.0   # k1 = k2 = big: estimate ~ 4 x the bound
+    alone = 0.5 * G.COND_BOUND / G.COND_EPS          # one interaction alone at half the bound
     mode0 = ops.conv3x3_mode()
     s0 = ops.range_stats()
-    out = ops.run_guarded(lambda: producer([1.0, 1.0, 7.0e4, 1.0], [0.5 * K, 2.0 * K, 3.0 * K, float("nan")]), "cpu",
+    out = ops.run_guarded(lambda: producer([1.0, 1.0, 7.0e4, 1.0], [alone, big, big, float("nan")], [0.0, big, big, 1.0]), "cpu",
                           enabled=True, images=B, redo=redo)
     assert out == ["f16x3", "fp32", mode0, "fp32"] and seen == [(mode0, [2]), ("fp32", [1, 3])]
     assert ops.conv3x3_mode() == mode0
-    out = ops.run_guarded(lambda: producer([1.0] * B, [0.0, K, 0.25 * K, 0.0]), "cpu", enabled=True, images=B, redo=redo)
-    assert out == ["f16x3"] * B and len(seen) == 2                      # kappa == KAPPA still passes
-    out = ops.run_guarded(lambda: producer([1.0] * B, [9.0 * K] * B), "cpu", enabled=True, images=B, redo=redo)
+    out = ops.run_guarded(lambda: producer([1.0] * B, [0.0, alone, 3.0, 0.0], [alone, 0.0, 3.0, 0.0]), "cpu", enabled=True, images=B, redo=redo)
+    assert out == ["f16x3"] * B and len(seen) == 2
+    out = ops.run_guarded(lambda: producer([1.0] * B, [big] * B, [big] * B), "cpu", enabled=True, images=B, redo=redo)
     assert out == ["fp32"] * B and len(seen) == 2                       # every image: one whole repeat, exact convs
-    out = ops.run_guarded(lambda: producer([1.0] * B, [9.0 * K] * B), "cpu", enabled=True, images=B)
+    out = ops.run_guarded(lambda: producer([1.0] * B, [big] * B, [big] * B), "cpu", enabled=True, images=B)
     assert out == ["fp32"] * B and ops.conv3x3_mode() == mode0          # no redo given: the same
     s1 = ops.range_stats()
     assert s1["images_repeated"] - s0["images_repeated"] == 1 and s1["images_repeated_fp32conv"] - s0["images_repeated_fp32conv"] == 2 + B + B

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""(r5) Calibration of the f16x3 guard's conditioning bound (ops.Planes16Guard.KAPPA).
+"""(r5) Calibration of the f16x3 guard's conditioning bound (ops.Planes16Guard.COND_BOUND).
 
 For several input families (mit_b1, 64x96 - the size at which the CPU oracle in float64 takes seconds) prints, PER PAIR: the
 conditioning figure kappa (how far a context softmax moves per unit relative perturbation of its Gram matrix under a fixed +-1
@@ -34,7 +34,7 @@ def per_pair_err(t, truth):
 
 
 def main():
-    ops.Planes16Guard.KAPPA = math.inf  # observe, never repeat
+    ops.Planes16Guard.COND_BOUND = math.inf  # observe, never repeat
     seg, fus = Network3("mit_b1", 9, pretrained=None), Fusion_Network3_ac()
     sd_seg, sd_fus = dw.load_det_weights(seg, seed=0), dw.load_det_weights(fus, seed=0)
     seg, fus = seg.cuda().eval(), fus.cuda().eval()
@@ -45,7 +45,7 @@ def main():
     fams += [(f"image-like x{s:g}", img, s) for s in (1.0, 1.5, 2.0, 3.0, 4.0, 6.0)]
     fams += [("U[0,1) det x3", _inputs(3, 64, 96, 2), 3.0)]
     fams += [(f"image-like(seed 12) x{s:g}", _image_like(3, 64, 96, 12), s) for s in (2.0, 4.0)]
-    print("# family | pair | kappa | err f16x3 | err bf16x6 | err f16x3+fp32 convs | err all-fp32-MFMA | err oracle fp32 (reference arithmetic)")
+    print("# family | pair | kappa_1 kappa_2 -> estimate | err f16x3 | err bf16x6 | err f16x3+fp32 convs | err all-fp32-MFMA | err oracle fp32 (reference arithmetic)")
     for name, (ir, vis, mask), s in fams:
         ir, vis, mask = ir * s, vis * s, mask * s
         with torch.no_grad():
@@ -57,7 +57,9 @@ def main():
                 f16 = pipe._eager_body(ir.cuda(), vis.cuda(), mask.cuda())[0]
             finally:
                 ops.install_guard(prev)
-            kappa = g.kappa().tolist()
+            kap = g.kappa()
+            est = g.cond_estimate(kap).tolist()
+            kappa = [f"{kap[0, b]:8.3g} {kap[1, b]:8.3g} -> {est[b]:8.2e}" for b in range(ir.shape[0])]
             tripped = g.tripped().tolist()
             b6 = ops.run_unguarded(lambda: pipe._eager_body(ir.cuda(), vis.cuda(), mask.cuda()), images=0, repeated=0)[0]
             prev = ops.set_conv3x3_mode("fp32")
@@ -72,7 +74,7 @@ def main():
                 ops.set_conv3x3_mode(prev[0]), ops.set_linear_mode(prev[1]), ops.set_attention_mode(prev[2])
         cols = [per_pair_err(t, truth) for t in (f16, b6, c32, a32, ref["fused"])]
         for b in range(ir.shape[0]):
-            print(f"{name:24s} | {b} | {kappa[b]:9.3g} | " + " | ".join(f"{c[b]:.2e}" for c in cols) + (" | RANGE-TRIPPED" if tripped[b] else ""),
+            print(f"{name:24s} | {b} | {kappa[b]} | " + " | ".join(f"{c[b]:.2e}" for c in cols) + (" | RANGE-TRIPPED" if tripped[b] else ""),
                   flush=True)
     # the bench workload: mit_b3, 480x640, U[0,1) inputs (bench.py's generator) - kappa only
     del seg, fus, pipe
@@ -93,7 +95,8 @@ def main():
                 pipe._eager_body(ir, vis, mask)
             finally:
                 ops.install_guard(prev)
-        print(f"# {name}: kappa per pair {[float('%.3g' % k) for k in g.kappa().tolist()]}  range-tripped {g.tripped().tolist()}", flush=True)
+        print(f"# {name}: estimate per pair {[float('%.3g' % k) for k in g.cond_estimate().tolist()]}  kappa_1 {[float('%.3g' % k) for k in g.kappa()[0].tolist()]} "
+              f"kappa_2 {[float('%.3g' % k) for k in g.kappa()[1].tolist()]}  range-tripped {g.tripped().tolist()}", flush=True)
 
 
 if __name__ == "__main__":

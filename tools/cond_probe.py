@@ -24,7 +24,7 @@ from test_gpu_round4 import _image_like  # noqa: E402
 
 def main():
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
-    ops.Planes16Guard.KAPPA = math.inf
+    ops.Planes16Guard.COND_BOUND = math.inf
     seg, fus = Network3("mit_b1", 9, pretrained=None), Fusion_Network3_ac()
     dw.load_det_weights(seg, seed=0), dw.load_det_weights(fus, seed=0)
     seg, fus = seg.cuda().eval(), fus.cuda().eval()
@@ -66,7 +66,7 @@ def main():
         finally:
             ops.set_conv3x3_mode(prev)
         runs["fp32conv"] = (log[:], c32)
-    print(f"# image-like x{scale:g}; kappa {g.kappa().tolist()}")
+    print(f"# image-like x{scale:g}; kappa (interaction 1, 2) {g.kappa().tolist()} -> estimate {g.cond_estimate().tolist()}")
     a, b = runs["f16x3"], runs["fp32conv"]
     print("# per pair: max |f16x3 - fp32conv| / max |fp32conv|")
     assert len(a[0]) == len(b[0]), (len(a[0]), len(b[0]))
