@@ -242,6 +242,10 @@ def load():
         raise HipLibraryMissing(
             f"{path} not found: build it with `python -m segmif_amd.build` "
             "(hipcc --offload-arch=gfx950). segmif_amd has no CPU or torch fallback.")
+    # torch FIRST: it ships its own libamdhip64, and the HIP runtime this library binds to must be the one torch initialises.
+    # Loaded the other way round (python __graft_entry__.py smoke: build() binds the symbols before anything imported torch) the
+    # kernels' library came up on the system ROCm's runtime and its first launch failed with hipErrorNoDevice (r5).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design

@@ -25,7 +25,7 @@ def _hipcc():
 
 
 def _digest():
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256(" ".join(FLAGS).replace(ROOT, ".").encode())  # (not the checkout's absolute path: the same tree on the GPU box is the same build)
     for f in SOURCES + ["igemm_common.h", "device_once.h", "planes16.h", os.path.join(ROOT, "include", "segmif_hip.h")]:
         p = f if os.path.isabs(f) else os.path.join(CSRC, f)
         with open(p, "rb") as fh:
