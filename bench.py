@@ -494,7 +494,9 @@ def main():
             traffic, traffic_src = None, None
             mode = ops.conv3x3_mode()
             peak = PEAK_FP32_MFMA_TFLOPS if mode == "fp32" else (PEAK_BF16X6_TFLOPS * 2.0 if mode == "planes16" else PEAK_BF16X6_TFLOPS)
-            pmc_name = {"planes16": f"r04_pmc_dominant_b{B}_planes16.json" if os.path.exists(os.path.join(ROOT, "profiles", f"r04_pmc_dominant_b{B}_planes16.json")) else f"r03_pmc_dominant_b{B}_planes16.json", "planes": f"r03_pmc_dominant_b{B}_planes.json" if os.path.exists(os.path.join(ROOT, "profiles", f"r03_pmc_dominant_b{B}_planes.json")) else f"r02_pmc_dominant_b{B}_planes.json", "bf16x6": f"r01_pmc_dominant_b{B}_bf16x6.json",
+            p16_name = next((n for n in (f"r05_pmc_dominant_b{B}_planes16.json", f"r04_pmc_dominant_b{B}_planes16.json")
+                             if os.path.exists(os.path.join(ROOT, "profiles", n))), f"r03_pmc_dominant_b{B}_planes16.json")
+            pmc_name = {"planes16": p16_name, "planes": f"r03_pmc_dominant_b{B}_planes.json" if os.path.exists(os.path.join(ROOT, "profiles", f"r03_pmc_dominant_b{B}_planes.json")) else f"r02_pmc_dominant_b{B}_planes.json", "bf16x6": f"r01_pmc_dominant_b{B}_bf16x6.json",
                         "fp32": "r01_pmc_dominant.json" if B == 8 else f"r01_pmc_dominant_b{B}.json"}[mode]
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and (H, W) == (480, 640):

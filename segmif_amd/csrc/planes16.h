@@ -38,7 +38,7 @@ __device__ __forceinline__ void split8(const float* y, u4& hi, u4& lo) {
 
 // PAIRS rows (gemm_pairs.hip): a 16-channel group is 64 bytes, [16 hi | 16 lo].  Four consecutive lanes that hold 4 consecutive
 // channels each (split into ha, hb / la, lb by split2) own one group; storing 8 bytes per lane and plane would be 32-byte
-// partial writes with 32-byte holes - measured 10x slower than the fp32 store on the LayerNorm (profiles/r05_block_kernel_stats*).
+// partial writes with 32-byte holes - measured 10x slower than the fp32 store on the LayerNorm (profiles/r05_pairs_producers_log.txt).
 // Instead the quad trades dwords (DPP quad_perm, no LDS) so that lane q stores the 16-byte piece q of the group: one fully
 // coalesced dwordx4 store per lane.  -> the piece of lane (threadIdx.x & 3); all four lanes of the quad must be active.
 __device__ __forceinline__ u4 quad_piece(uint32_t ha, uint32_t hb, uint32_t la, uint32_t lb) {
@@ -87,11 +87,12 @@ __device__ __forceinline__ float wave_max(float v) {  // (weights' row scales: f
 }
 
 // The look before the atomic: an atomic load (hipcc emits it with the cache-bypassing sc0 sc1 bits, so it sees other CUs'
-// atomics; a plain load would keep hitting a stale line in the CU's L1 and every wave would go on to the atomic).  Either way a
-// slot access costs ~5 ns of a memory channel's time and they serialise: a kernel must make FEW of them relative to its run
-// time.  (r5: the first LayerNorm that wrote half pairs folded once per wave - 76 800 accesses in a 20 us kernel - and took
-// 330 us, profiles/r05_block_kernel_stats_first.txt; it now walks a contiguous range of rows per workgroup and folds when the
-// image changes.  One access per wave is fine for kernels that run >= 10 ns per wave: the convs, attention.)
+// atomics; a plain load would keep hitting a stale line in the CU's L1 and every wave would go on to the atomic).  It has a
+// price: its LATENCY (several microseconds under load) is what the reporting wave ends on, and atomics on one cache line queue
+// (~10 ns each; the slot words of 16 neighbouring images share a line).  Fine for kernels whose waves live for tens of
+// microseconds - the convs, attention, the CrossPath tail: one look per wave or per persistent workgroup.  NOT for row
+// kernels whose waves live for a microsecond: the first LayerNorm that wrote half pairs spent 330 us instead of 22 this way
+// (profiles/r05_pairs_producers_log.txt) - those use fold_pat_block / fold_pat_async below.
 __device__ __forceinline__ uint32_t slot_peek(const uint32_t* slot) {
   return __atomic_load_n(slot, __ATOMIC_RELAXED);
 }
