@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Step timeline of csrc/gemm_pairs.hip built with -DPAIRS_DBG=1 (tools/pairs_timeline.sh): s_memtime stamps (100 MHz) of thread 0
+"""Step timeline of csrc/gemm_pairs.hip built with -DPAIRS_DBG=1 (tools/pairs_timeline.sh): s_memtime stamps of thread 0
 of the first 1024 workgroups.  Per K step: 0 before the wait + barrier | 1 past the barrier | 2 next stage's DMA issued | 3 MFMAs
 issued.  [29]: 0 kernel start, 1 prologue DMA issued; [30]: 0 K loop done, 1 past the closing barrier; [31][0]: stores drained.
     SEGMIF_HIP_LIB=$PWD/segmif_amd/lib/variants/lib_pairs_dbg.so python tools/pairs_timeline.py M N K [tile]"""
@@ -37,7 +37,7 @@ t = buf.astype(np.int64)
 live = t[:, 29, 0] > 0
 t = t[live]
 nwg = t.shape[0]
-print(f"M {M} N {N} K {K} tile {tile or 'auto'}: {nwg} workgroups stamped, {K // 16} K steps (first {nks} stamped); ticks of 10 ns, mean / p10 / p90")
+print(f"M {M} N {N} K {K} tile {tile or 'auto'}: {nwg} workgroups stamped, {K // 16} K steps (first {nks} stamped); s_memtime ticks (they advance at about the shader clock on this part: a 254 us kernel spans ~5.6e5 of them), mean / p10 / p90")
 
 
 def row(name, v):
@@ -57,4 +57,4 @@ row("closing barrier", t[:, 30, 1] - t[:, 30, 0])
 row("epilogue (incl. store drain)", t[:, 31, 0] - t[:, 30, 1])
 row("workgroup life", t[:, 31, 0] - t[:, 29, 0])
 print(f"  kernel span over the stamped workgroups: {t[:, 31, 0].max() - t[:, 29, 0].min()} ticks; start spread {t[:, 29, 0].max() - t[:, 29, 0].min()}")
-print("  (96 MFMAs per workgroup step = 768 CU cycles; two workgroups per CU: 1536 cycles = 64-73 ticks at 2.1-2.4 GHz if the matrix pipe were the limit)")
+print("  (96 MFMAs per workgroup step = 768 CU cycles; two workgroups per CU: 1536 cycles if the matrix pipe were the limit)")
