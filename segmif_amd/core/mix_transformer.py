@@ -427,8 +427,22 @@ class MixVisionTransformer(nn.Module):
     def forward_fusion(self, x):
         """Stage-1 / stage-2 features bilinearly resized to the input resolution (ref :358-375)."""
         H, W = x.shape[2], x.shape[3]
-        feats = self.forward_features_nhwc(x, 2 if self.skip_unused_fusion_stages else 4)
-        return ops.as_nchw(ops.bilinear(feats[0], H, W)), ops.as_nchw(ops.bilinear(feats[1], H, W))
+
+        def body(inp):
+            feats = self.forward_features_nhwc(inp, 2 if self.skip_unused_fusion_stages else 4)
+            return ops.as_nchw(ops.bilinear(feats[0], H, W)), ops.as_nchw(ops.bilinear(feats[1], H, W))
+
+        if torch.is_grad_enabled() or not x.is_cuda:
+            return body(x)
+        # (r5) inference, also when called on its own (test_fusion.py:100): a guarded f16x3 scope of its own unless the caller
+        # opened one (then this joins it); images that leave the half's range are repeated on bf16x6, alone
+        def redo(out, idx):
+            sub = body(x.index_select(0, idx))
+            out[0].index_copy_(0, idx, sub[0])
+            out[1].index_copy_(0, idx, sub[1])
+            return out
+
+        return ops.run_guarded(lambda: body(x), x.device, images=x.shape[0], redo=redo)
 
 
 def _variant(dims, depths):

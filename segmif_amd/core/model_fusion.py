@@ -672,7 +672,19 @@ class Network3(nn.Module):
             std = fused.new_tensor(self.std).view(1, 3, 1, 1)
             return self.denoise_net.forward_nhwc((fused * 255 - mean) / std)
         # (x*255 - mean)/std fused with the NCHW -> NHWC transpose (ref :1083-1085)
-        return self.denoise_net.forward_nhwc(ops.as_nchw(ops.seg_normalize(fused)))
+        def body(x):
+            return self.denoise_net.forward_nhwc(ops.as_nchw(ops.seg_normalize(x)))
+
+        if torch.is_grad_enabled():
+            return body(fused)  # (training path: its kernels make their own ranges; no guarded scope)
+        # (r5) plain inference, also when the net is called on its own (test_segmentation.py:169): a guarded scope of its own -
+        # f16x3 GEMMs / attention / Mix-FFN on half pairs, images that leave the half's range repeated on bf16x6 - unless a
+        # caller (pipeline.PairForward) already opened one, which this call then joins
+        def redo(out, idx):
+            out.index_copy_(0, idx, body(fused.index_select(0, idx)))
+            return out
+
+        return ops.run_guarded(lambda: body(fused), fused.device, images=fused.shape[0], redo=redo)
 
     def forward(self, fused_seg1):
         return fused_seg1, fused_seg1, ops.as_nchw(self._segment_nhwc(fused_seg1))

@@ -373,3 +373,37 @@ def test_fused_attention_backward_vs_fp64_autograd(ops, B, N, heads, Nk):
                       "out": float((out.double().cpu() - o.detach()).abs().max() / o.detach().abs().max())}
     observed(f"attention_bwd_vs_fp64[{B}x{N}x{heads}x{Nk}]", errs)
     assert errs["fused"]["dq"] < 2e-5 and errs["fused"]["dkv"] < 2e-5, errs
+
+
+def test_standalone_inference_calls_open_their_own_guarded_scope(ops):
+    """(r5) The reference's scripts call `encoder.forward_fusion(mask)` (test_fusion.py:100) and `Network3.forward(fused)`
+    (test_segmentation.py:169) on their own: under no_grad each now opens a guarded f16x3 scope of its own (one scope per call in
+    ops.range_stats; inside pipeline.PairForward they join the caller's), an image that leaves the half's range is repeated alone
+    on bf16x6, and with gradients enabled no scope is opened (the training kernels make their own ranges).  Results against the
+    same calls on bf16x6: within 2e-5 of the range."""
+    from segmif_amd.core import Network3
+    net = Network3("mit_b1", 9, pretrained=None)
+    dw.load_det_weights(net, seed=0)
+    net = net.cuda().eval()
+    x = dw.det_input("r5_standalone", (3, 3, 128, 160)).cuda()
+    enc = net.denoise_net.encoder
+    s0 = ops.range_stats()
+    with torch.no_grad():
+        o0, o1 = enc.forward_fusion(x)
+        _, _, seg = net(x)
+    s1 = ops.range_stats()
+    assert s1["scopes"] - s0["scopes"] == 2 and s1["images"] - s0["images"] == 6 and s1["images_repeated"] == s0["images_repeated"]
+    with torch.no_grad():
+        r0, r1 = ops.run_unguarded(lambda: enc.forward_fusion(x), images=0, repeated=0)
+        rseg = ops.run_unguarded(lambda: net(x)[2], images=0, repeated=0)
+    for a, b in ((o0, r0), (o1, r1), (seg, rseg)):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-5
+    hot = x.clone()
+    hot[1, 0, 5, 7] = float("nan")  # (a scaled image would be normalised away by the first LayerNorm; a NaN is not)
+    with torch.no_grad():
+        h0, _ = enc.forward_fusion(hot)
+    s2 = ops.range_stats()
+    assert s2["images_repeated"] - s1["images_repeated"] == 1
+    assert torch.equal(h0[0], o0[0]) and torch.equal(h0[2], o0[2])  # the other images keep their f16x3 results
+    _, _, seg_g = net(x)  # gradients enabled: the functional path, no scope
+    assert ops.range_stats()["scopes"] == s2["scopes"] and seg_g.requires_grad
