@@ -421,8 +421,20 @@ class MixVisionTransformer(nn.Module):
         """The two feature maps forward_fusion() up-samples, still at their own resolution and NHWC:
         (B, H/4, W/4, C1), (B, H/8, W/8, C2).  For consumers that apply a 1x1 conv next and can do it
         BEFORE the bilinear resize (Fusion_Network3_ac.forward_from_features)."""
-        feats = self.forward_features_nhwc(x, 2 if self.skip_unused_fusion_stages else 4)
-        return feats[0], feats[1]
+        def body(inp):
+            feats = self.forward_features_nhwc(inp, 2 if self.skip_unused_fusion_stages else 4)
+            return feats[0], feats[1]
+
+        if torch.is_grad_enabled() or not x.is_cuda:
+            return body(x)
+
+        def redo(out, idx):  # (r5: as forward_fusion - a guarded f16x3 scope of its own unless the caller opened one)
+            sub = body(x.index_select(0, idx))
+            out[0].index_copy_(0, idx, sub[0])
+            out[1].index_copy_(0, idx, sub[1])
+            return out
+
+        return ops.run_guarded(lambda: body(x), x.device, images=x.shape[0], redo=redo)
 
     def forward_fusion(self, x):
         """Stage-1 / stage-2 features bilinearly resized to the input resolution (ref :358-375)."""
