@@ -188,6 +188,9 @@ class Attention(nn.Module):
         names = [("q", self.q.weight, ops.pack_linear), ("kv", self.kv.weight, ops.pack_linear)]
         if self.sr_ratio > 1:
             names.append(("sr", self.sr.weight, ops.pack_sr_conv))
+        biases = [self.q.bias, self.kv.bias, self.proj.bias] + ([self.sr.bias, self.norm.weight, self.norm.bias] if self.sr_ratio > 1 else [])
+        if not ops.aligned16(*biases):  # (the pairs kernels read them 16 bytes at a time; odd offsets of a flattened buffer: old path)
+            return False
         return all(p[1] is not None and p[1].pairs is not None for p in (pk.get(n + ":" + lm, w, f) for n, w, f in names))
 
     def forward(self, x, H, W, residual=None):
