@@ -497,11 +497,23 @@ typedef struct SegmifCrossTail {
   int32_t planes_f16;                               /* != 0: an f16x3 buffer (segmif_planes16_*) */
   uint32_t* planes_amax;                            /* f16x3: range slot(s) for max |out|, or NULL */
   int32_t planes_amax_images;                       /* == B: planes_amax[image]; <= 1: planes_amax[0] */
+  /* (r5) x3_ih > 0: x_3 is NOT a full-resolution tensor.  x3 then points at the (B, x3_ih * x3_iw, ld3) LOW-resolution map
+   * of channel_proj3's y half ALREADY APPLIED (w3 x + b3, no ReLU; w3 / b3 here are ignored), and the kernel resizes it to
+   * H x W (bilinear, align_corners = False: segmif_bilinear_nhwc_f32's arithmetic) row by row as it consumes it - a resize
+   * is a convex combination per channel, so it commutes with the Linear.  H, W must be set (H * W == N).  Replaces
+   * F.interpolate at core/mix_transformer.py:364-373 for this consumer: the resized tensor never exists. */
+  int32_t x3_ih, x3_iw;
 } SegmifCrossTail;
 
 int segmif_crosspath_gram_blocks(int64_t N);
 int segmif_crosspath_gram_f32(const float* x, int ldx, const float* w, const float* bias, double* partial, int B, int64_t N,
                               void* stream);
+/* (r5) the Gram partials of relu(resize(s_low -> H x W)) for s_low = the (B, ih * iw, lds) low-resolution map of a channel_proj
+ * half ALREADY APPLIED (W x + c, no ReLU): same (B, segmif_crosspath_gram_blocks(H * W), 3072) fp64 output as
+ * segmif_crosspath_gram_f32 on the resized tensor (bilinear, align_corners = False), which is never formed.  Needs
+ * W % 4 == 0 and an enlargement by three or more (3 iw <= W), else SEGMIF_EINVAL (the caller resizes first).  Replaces
+ * F.interpolate (core/mix_transformer.py:364-373) + channel_proj3 (core/model_fusion.py:353) for cross_attn's context. */
+int segmif_crosspath_gram_lazy_f32(const float* s_low, int lds, int ih, int iw, int H, int W, double* partial, int B, void* stream);
 int segmif_crosspath_fold_f32(const double* partial, int nblk, const float* wkv, const float* wend, float* weff, int B,
                               int Nout, int ldw, int wofs, int ldweff, int kofs, float scale, uint32_t* cond, void* stream);
 int segmif_crosspath_tail_f32(const SegmifCrossTail* desc, void* stream);

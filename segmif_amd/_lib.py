@@ -70,6 +70,7 @@ class SegmifCrossTail(ctypes.Structure):
         ("B", c_int32), ("N", c_int64),
         ("planes_out", c_void_p), ("H", c_int32), ("W", c_int32), ("planes_chunks", c_int32),
         ("planes_f16", c_int32), ("planes_amax", c_void_p), ("planes_amax_images", c_int32),
+        ("x3_ih", c_int32), ("x3_iw", c_int32),
     ]
 
 
@@ -130,6 +131,7 @@ SIGNATURES = {
                                           c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "segmif_crosspath_gram_blocks": (c_int, [c_int64]),
     "segmif_crosspath_gram_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "segmif_crosspath_gram_lazy_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "segmif_crosspath_fold_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_float, c_void_p, c_void_p]),
     "segmif_crosspath_tail_f32": (c_int, [POINTER(SegmifCrossTail), c_void_p]),

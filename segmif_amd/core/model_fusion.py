@@ -350,7 +350,16 @@ class CrossPath(nn.Module):
         bias = [(m.bias[:C], m.bias[C:]) if m.bias is not None else (None, None) for m in cp]
         g1 = ops.crosspath_gram(x1, halves[0][0], bias[0][0])   # y1 -> ctx1 (cross_attn2.kv1)
         g2 = ops.crosspath_gram(x2, halves[1][0], bias[1][0])   # y2 -> ctx2 (cross_attn2.kv2)
-        g3 = ops.crosspath_gram(seg, halves[2][1], bias[2][1])  # u3 -> ctx3 (cross_attn.kv3)
+        lazy = isinstance(seg, ops.LazySeg)
+        if lazy:
+            # (r5) the segmentation feature stays at its own resolution: channel_proj3 (both halves, no ReLU yet) runs on the low-
+            # resolution map - a resize is a convex combination per channel, so Linear(resize(x)) = resize(Linear(x)) - and the
+            # Gram / tail kernels resize the projected rows as they read them (csrc/crosspath.hip, LAZY)
+            proj3 = ops.linear(seg.low, self._pk.get("cp3", cp[2].weight, ops.pack_weight), 2 * C, bias=cp[2].bias)
+            seg = proj3[..., :C]  # y half: the tails' x3
+            g3 = ops.crosspath_gram_lazy(proj3[..., C:], hw[0], hw[1])  # u3 -> ctx3 (cross_attn.kv3)
+        else:
+            g3 = ops.crosspath_gram(seg, halves[2][1], bias[2][1])  # u3 -> ctx3 (cross_attn.kv3)
         B = x1.shape[0]
         outs = []
         for i, (x, g, kv, o, pl) in enumerate(((x1, g1, self.cross_attn2.kv1, out1, planes1),
@@ -362,7 +371,7 @@ class CrossPath(nn.Module):
             ops.crosspath_fold(g3, self.cross_attn.kv3.weight, end.weight, weff, wofs=C, kofs=C, scale=self.cross_attn.scale)
             outs.append(ops.crosspath_tail(seg, x, halves[2][0], bias[2][0], halves[i - 1][1], bias[i - 1][1], weff, end.bias,
                                            (norm.weight, norm.bias, norm.eps), out=o, planes=pl, hw=hw,
-                                           planes_only=planes_only))
+                                           planes_only=planes_only, lazy=lazy))
         return outs[0], outs[1]
 
     def gram_ok(self):
@@ -421,6 +430,17 @@ class FeatureFusionModule(nn.Module):
         guard = ops.active_guard()
         if guard is not None:  # (r5) the conditioning words of this interaction's context softmaxes go to their own row
             guard.next_interaction()
+        lazy = isinstance(seg, ops.LazySeg)
+        if lazy and (seg.H, seg.W) != (H, W):
+            raise RuntimeError("FeatureFusionModule: the lazy segmentation feature targets another image size")
+        if lazy and not (self.cross.gram_ok() and seg.fits() and not wants_grad(self, x1, x2)):
+            seg, lazy = seg.materialise(), False  # (only the Gram-form inference kernels resize as they read)
+        if lazy:
+            r1, r2 = self.cross.forward_tokens_gram(x1.view(B, H * W, C), x2.view(B, H * W, C), seg,
+                                                    None if out1 is None else out1.view(B, H * W, out1.shape[-1]),
+                                                    None if out2 is None else out2.view(B, H * W, out2.shape[-1]),
+                                                    planes1, planes2, (H, W), planes_only=planes_only)
+            return (None, None) if planes_only else (r1.view(B, H, W, C), r2.view(B, H, W, C))
         if wants_grad(self, x1, x2, seg):
             # (out_i: ag.Out placements here - the next DRDB's buffer or the halves of conv2's input)
             r1, r2 = self.cross.forward_tokens_train(x1.reshape(B, H * W, C), x2.reshape(B, H * W, C),
@@ -545,10 +565,13 @@ class Fusion_Network3_ac(nn.Module):
             raise RuntimeError(f"Fusion_Network3_ac expects 64/128-channel segmentation features, got "
                                f"{f1.shape[-1]}/{f2.shape[-1]} channels")
         H, W = ir.shape[2], ir.shape[3]
+        # (r5, SURVEY §8(f) N4 second half) the resized features are not formed either: CrossPath's kernels read the low-resolution
+        # maps through ops.LazySeg (SEGMIF_LAZY_SEG=0: resize first, as before)
+        up = (lambda low: ops.LazySeg(low, H, W)) if ops.lazy_seg_mode() else (lambda low: ops.bilinear(low, H, W))
         return self._forward_eval(
             ir, vis,
-            lambda: ops.bilinear(ops.linear(f1, self._w("conv3"), 64, bias=self.conv3.bias), H, W),
-            lambda: ops.bilinear(ops.linear(f2, self._w("conv4"), 64, bias=self.conv4.bias), H, W))
+            lambda: up(ops.linear(f1, self._w("conv3"), 64, bias=self.conv3.bias)),
+            lambda: up(ops.linear(f2, self._w("conv4"), 64, bias=self.conv4.bias)))
 
     def _forward_eval(self, ir, vis, seg1_fn, seg2_fn):
         B, _, H, W = ir.shape

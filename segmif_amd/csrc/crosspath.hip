@@ -130,6 +130,30 @@ __device__ __forceinline__ void wfrag(const unsigned char* base, int row, int pi
   for (int k = 0; k < 3; ++k) out[k] = *reinterpret_cast<const u32x4*>(a + k * plane_bytes);
 }
 
+// deterministic reduction of the waves' Gram accumulators, then one fp64 partial per workgroup (shared by the two Gram kernels)
+__device__ __forceinline__ void gram_reduce_store(const f32x16* g, double* Red, double* __restrict__ partial, int b, int tid, int lane,
+                                                  int wave) {
+  for (int wv = 0; wv < CP_WAVES; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          double* p = Red + (a * 16 + v) * 64 + lane;
+          *p = wv == 0 ? (double)g[a][v] : *p + (double)g[a][v];
+        }
+    }
+    __syncthreads();
+  }
+  // canonical layout: tile a in {(0,0), (0,1), (1,1)}, element (i, j) at a*1024 + i*32 + j
+  double* dst = partial + ((long long)b * gridDim.x + blockIdx.x) * 3072;
+  for (int u = tid; u < 3072; u += 512) {
+    const int a = u >> 10, i = (u >> 5) & 31, j = u & 31;
+    const int hh = (i >> 2) & 1, v = (i & 3) + 4 * (i >> 3);
+    dst[u] = Red[(a * 16 + v) * 64 + hh * 32 + j];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                              const float* __restrict__ bias, double* __restrict__ partial,
@@ -209,26 +233,129 @@ __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __rest
     if (t + stride < ntiles) tile(t + stride, xb2, xa, t + 3 * stride);
     if (t + 2 * stride < ntiles) tile(t + 2 * stride, xc, xb2, t + 4 * stride);
   }
-  // deterministic reduction over the 8 waves, then one partial per workgroup
-  for (int wv = 0; wv < CP_WAVES; ++wv) {
-    if (wave == wv) {
+  gram_reduce_store(g, Red, partial, b, tid, lane, wave);
+}
+
+// LAZY Gram (r5): G_b = sum_px relu(u_px) relu(u_px)^T where u = bilinear(s_low -> H x W) and s_low is the
+// (B, ih x iw, lds) LOW-resolution map of channel_proj3's u half already applied (W x + c, no ReLU): the resize is a convex
+// combination per channel, so it commutes with the Linear, and the full-resolution segmentation feature is never formed (see
+// crosspath_tail_kernel<., LAZY>).  Stage 1 of crosspath_gram_kernel (48 MFMAs, the 3-way split of x, 256 B of HBM per pixel)
+// becomes: source values from an L2-resident map, three multiply-adds, a ReLU - produced directly in the layout stage 2 wants
+// (lane = channel, register = pixel).
+//  * The pixel -> source arithmetic (bilinear_kernel's, csrc/rowops.hip) is the same for the 32 lanes of a half, so it is done once
+//    per pixel with lane = pixel and handed over through a per-wave LDS table instead of ~40 vector instructions per pixel per lane.
+//  * The four pixels of an aligned group of four share their source rows (W % 4 == 0) and - the resize being an enlargement by
+//    three or more (3 iw <= W) - touch at most three adjacent source columns c0 .. c0 + 2: six loads serve a group's 16 taps; a
+//    pixel selects (c0, c0 + 1) or (c0 + 1, c0 + 2).  The first version loaded every tap (128 dword loads per 32-pixel tile) and
+//    ran at the texture path's instruction rate: 1.69 ms against 1.57 ms for the kernel that reads the full tensor from HBM.
+//  * Two 24-register buffers (one K step = 8 pixels x 2 channel tiles each) are requested one tile ahead; GFENCE: see FENCE in
+//    crosspath_tail_kernel.
+__global__ __launch_bounds__(512) void crosspath_gram_lazy_kernel(const float* __restrict__ s, int lds, int ih, int iw, int W, float sy,
+                                                                  float sx, double* __restrict__ partial, long long N) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* Red = reinterpret_cast<double*>(smem_raw);                                  // [3][16][64]
+  // [wave][slot][32 pixels]; TapO (read for group leaders only): offsets of (y0, c0), (y1, c0), and of columns c0 + 1, c0 + 2
+  // relative to c0 (clamped at the right edge); TapW: (ly, lx, pixel uses columns c0 + 1 / c0 + 2 ? 1 : 0, -)
+  u32x4* TapO = reinterpret_cast<u32x4*>(smem_raw + 3 * 16 * 64 * sizeof(double));
+  f32x4* TapW = reinterpret_cast<f32x4*>(smem_raw + 3 * 16 * 64 * sizeof(double) + CP_WAVES * 2 * 32 * sizeof(u32x4));
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const float* __restrict__ sb = s + (long long)b * ih * iw * lds;
+  f32x16 g[3] = {zero16(), zero16(), zero16()};
+  const long long ntiles = (N + 31) / 32;
+  const long long stride = (long long)gridDim.x * CP_WAVES;
+
+  // lane = pixel r of tile tt -> table slot `slot` of this wave
+  auto table = [&](long long tt, int slot) {
+    long long px = tt * 32 + r;
+    px = px < N ? px : N - 1;  // (clamped into the image: the loads are unconditional, pixels past N are masked in `consume`)
+    const unsigned yy = (unsigned)px / (unsigned)W, xx = (unsigned)px - yy * (unsigned)W;
+    const float fy = fmaxf(sy * ((float)yy + 0.5f) - 0.5f, 0.f);
+    const float fx = fmaxf(sx * ((float)xx + 0.5f) - 0.5f, 0.f);
+    const float fl = fmaxf(sx * ((float)(xx & ~3u) + 0.5f) - 0.5f, 0.f);  // the group's first pixel
+    const int y0 = (int)fy, x0 = (int)fx, c0 = (int)fl;
+    const int y1 = min(y0 + 1, ih - 1);
+    u32x4 o;
+    o[0] = (unsigned)((y0 * iw + c0) * lds);
+    o[1] = (unsigned)((y1 * iw + c0) * lds);
+    o[2] = (unsigned)((min(c0 + 1, iw - 1) - c0) * lds);
+    o[3] = (unsigned)((min(c0 + 2, iw - 1) - c0) * lds);
+    TapO[(wave * 2 + slot) * 32 + r] = o;  // (both lane halves write the same values)
+    TapW[(wave * 2 + slot) * 32 + r] = f32x4{fy - (float)y0, fx - (float)x0, x0 > c0 ? 1.f : 0.f, 0.f};
+  };
+  // register j of K step ks is pixel 16 ks + 8 (j >> 2) + (j & 3) + 4 h of the tile (v = 8 ks + j: (v & 3) + 8 (v >> 2) + 4 h);
+  // group gq = j >> 2 starts at pixel 16 ks + 8 gq + 4 h.   buf[((gq * 2 + nt) * 2 + row) * 3 + col]
+  auto issue = [&](int slot, int ks, float* buf) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
+    for (int gq = 0; gq < 2; ++gq) {
+      const u32x4 o = TapO[(wave * 2 + slot) * 32 + 16 * ks + 8 * gq + 4 * h];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          double* p = Red + (a * 16 + v) * 64 + lane;
-          *p = wv == 0 ? (double)g[a][v] : *p + (double)g[a][v];
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          const unsigned base = o[row] + (unsigned)(32 * nt + r);
+          float* q = buf + ((gq * 2 + nt) * 2 + row) * 3;
+          q[0] = sb[base];
+          q[1] = sb[base + o[2]];
+          q[2] = sb[base + o[3]];
         }
     }
-    __syncthreads();
+  };
+  auto consume = [&](long long t, int slot, int ks, const float* buf) {
+    f32x4 y[2][2];  // [nt][low / high four registers of the K step]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int gq = j >> 2, l = 16 * ks + 8 * gq + (j & 3);
+      const f32x4 w = TapW[(wave * 2 + slot) * 32 + l + 4 * h];
+      const float ly = w[0], lx = w[1], hy = 1.f - ly, hx = 1.f - lx;
+      const bool right = w[2] != 0.f;
+      const bool pv = t * 32 + l + 4 * h < N;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const float* q = buf + ((gq * 2 + nt) * 2) * 3;  // row 0: q[0..2], row 1: q[3..5]
+        const float a0 = right ? q[1] : q[0], b0 = right ? q[2] : q[1];
+        const float a1 = right ? q[4] : q[3], b1 = right ? q[5] : q[4];
+        const float v = fmaxf(hy * (hx * a0 + lx * b0) + ly * (hx * a1 + lx * b1), 0.f);
+        y[nt][gq][j & 3] = pv ? v : 0.f;
+      }
+    }
+    const Op3 y0 = split8(y[0][0], y[0][1]), y1 = split8(y[1][0], y[1][1]);
+    g[0] = mma6(y0.p, y0.p, g[0]);
+    g[1] = mma6(y0.p, y1.p, g[1]);
+    g[2] = mma6(y1.p, y1.p, g[2]);
+  };
+  float bufA[24], bufB[24];
+  long long t = (long long)blockIdx.x * CP_WAVES + wave;
+  int slot = 0;
+  int never = 0;
+  asm volatile("" : "+s"(never));
+#define GFENCE() do { if (never) asm volatile("s_nop 0"); } while (0)
+  if (t < ntiles) {
+    table(t, 0);
+    GFENCE();
+    issue(0, 0, bufA);
+    GFENCE();
+    issue(0, 1, bufB);
+    GFENCE();
   }
-  // canonical layout: tile a in {(0,0), (0,1), (1,1)}, element (i, j) at a*1024 + i*32 + j
-  double* dst = partial + ((long long)b * gridDim.x + blockIdx.x) * 3072;
-  for (int u = tid; u < 3072; u += 512) {
-    const int a = u >> 10, i = (u >> 5) & 31, j = u & 31;
-    const int hh = (i >> 2) & 1, v = (i & 3) + 4 * (i >> 3);
-    dst[u] = Red[(a * 16 + v) * 64 + hh * 32 + j];
+  for (; t < ntiles; t += stride, slot ^= 1) {
+    // (unconditional requests - the last iteration re-requests its own tile: with a branch around them the compiler cannot count
+    // what is in flight and the second K step's wait drains the requests just made)
+    table(t + stride < ntiles ? t + stride : t, slot ^ 1);
+    GFENCE();
+    consume(t, slot, 0, bufA);
+    GFENCE();
+    issue(slot ^ 1, 0, bufA);
+    GFENCE();
+    consume(t, slot, 1, bufB);
+    GFENCE();
+    issue(slot ^ 1, 1, bufB);
+    GFENCE();
   }
+#undef GFENCE
+  __syncthreads();
+  gram_reduce_store(g, Red, partial, b, tid, lane, wave);
 }
 
 // G = sum of the partial Gram matrices (fp64), ctx_h = softmax_{dim -2}((Wk_h G Wv_h^T) scale), folded into end_proj:
@@ -344,20 +471,36 @@ struct TailK {
   int ld3, ldi, ldo;
   int W, Hp, Wp, chunks;              // planes geometry (image width, padded dims, chunk images per batch element)
   float eps;
+  int ih, iw;                         // LAZY: x3 is the (B, ih x iw, ld3) low-resolution map of PROJECTED rows (see below); W = image width
+  float sy, sx;                       // LAZY: ih / H, iw / W (the resize's source step, as segmif_bilinear_nhwc_f32 forms it)
 };
 
 // F16: the planes copy is an f16x3 one (its own instantiation: the bf16 kernel sits at the register limit).
-template <bool F16>
+// LAZY (r5): x_3 = bilinear(seg_low -> H x W) is never materialised.  A bilinear resize is a per-channel convex
+// combination of four source pixels, so it commutes with channel_proj3's Linear: W3 x_3 + b3 = bilinear(W3 seg_low + b3).  The host
+// runs that Linear at LOW resolution (1/16 or 1/64 of the pixels) and hands the result as x3; here a lane interpolates its pixel's
+// row of it (the arithmetic of bilinear_kernel, csrc/rowops.hip), applies the ReLU and has - in the registers the MFMA wants - what
+// stage 1 of source 0 produced before: 48 of the tile's 192 MFMAs, the 3-way split of x_3 and 256 of the 768 bytes per pixel of
+// HBM traffic go away (the low-resolution map is L2 / MALL resident: 4.9 MB per image at 120 x 160).  The four source rows of one
+// K step (16 channels: 8 loads of 16 bytes) travel in the 32 registers that held the prefetched x_3 rows; the four K steps of
+// source 0 are spread between the phases of source 1 so that each step's rows are in flight during 24-48 MFMAs of other work.
+// LAZY tiles issue a FIXED number of vector-memory operations: rows are read from addresses clamped into the image and lanes past
+// the image's last pixel recompute and re-store that pixel (identical bytes to the same address) instead of being predicated.  With
+// branches around loads or stores the compiler cannot count what is in flight and every wait for one K step's rows becomes
+// s_waitcnt vmcnt(0) - draining the x_i prefetch (HBM latency) four times per tile and the previous tile's stores at its top; that
+// made the first LAZY version 11 % faster instead of the third its traffic promised.  OUT = false: no fp32 output exists in the
+// instantiation at all (the planes copy is the only consumer - the forward's hot case); OUT = true: p.out is checked at run time.
+template <bool F16, bool LAZY, bool OUT>
 __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* W3s = smem_raw;             // [64][WPB]
   unsigned char* Wis = W3s + 64 * WPB;       // [64][WPB]
   unsigned char* Wes = Wis + 64 * WPB;       // [64][WPB2]
   float* Cst = reinterpret_cast<float*>(Wes + 64 * WPB2);  // b3[64] bi[64] bend[64] gamma[64] beta[64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the tile loop's branches are then scalar too)
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
-  stage_split64(p.w3, 64, 0, W3s, WPB, 0, 128, tid, 512);
+  if constexpr (!LAZY) stage_split64(p.w3, 64, 0, W3s, WPB, 0, 128, tid, 512);
   stage_split64(p.wi, 64, 0, Wis, WPB, 0, 128, tid, 512);
   {
     const float* we = p.weff + (long long)b * 64 * 128;
@@ -370,7 +513,7 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
     }
   }
   __syncthreads();
-  const float* __restrict__ x3b = p.x3 + (long long)b * p.N * p.ld3;
+  const float* __restrict__ x3b = p.x3 + (long long)b * (LAZY ? (long long)p.ih * p.iw : p.N) * p.ld3;
   const float* __restrict__ xib = p.xi + (long long)b * p.N * p.ldi;
   float* __restrict__ outb = p.out + (long long)b * p.N * p.ldo;
 
@@ -394,6 +537,80 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
       for (int e = 0; e < 4; ++e) a[4 * g + e] = cb[e];
     }
     return a;
+  };
+  // a tile's epilogue: + residual x_i, LayerNorm, stores (shared by the two tile bodies below)
+  auto finish = [&](const f32x16* z, const f32x4* ci, long long px, bool ok, int zo) {
+    // epilogue: + residual x_i (same channel layout: channel 32 mt + 8 g + 4 h + e = ci[4 mt + g][e]), LayerNorm over the
+    // pixel's 64 channels (32 in this lane, 32 in lane ^ 32)
+    float o[32];
+    float s1 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = z[mt][4 * g + e] + ci[4 * mt + g][e];
+          o[mt * 16 + 4 * g + e] = v;
+          s1 += v;
+        }
+    s1 += __shfl_xor(s1, 32);
+    const float mean = s1 * (1.0f / 64.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      o[k] -= mean;
+      s2 = fmaf(o[k], o[k], s2);
+    }
+    s2 += __shfl_xor(s2, 32);
+    const float rstd = 1.0f / sqrtf(s2 * (1.0f / 64.0f) + p.eps);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(Cst + zo + 192 + mt * 32 + 8 * g + 4 * h);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(Cst + zo + 256 + mt * 32 + 8 * g + 4 * h);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = o[mt * 16 + 4 * g + e] * rstd * ga[e] + bt[e];
+          o[mt * 16 + 4 * g + e] = v[e];
+        }
+        if constexpr (OUT) {
+          if (ok && p.out) *reinterpret_cast<f32x4*>(outb + px * p.ldo + mt * 32 + 8 * g + 4 * h) = v;
+        }
+      }
+    if constexpr (F16) {
+      if (ok) {
+        // (r5) 32-bit pixel arithmetic and byte offsets from a wave-uniform image base: the launcher bounds N and the image's
+        // planes bytes below 2^31 (a 64-bit division and 64-bit addresses per store held registers the LAZY body needs)
+        const unsigned upx = (unsigned)px;
+        const unsigned yy = upx / (unsigned)p.W, xx = upx - yy * (unsigned)p.W;
+        unsigned char* __restrict__ pb = p.planes + (long long)b * p.chunks * p.Hp * p.Wp * p16::PIXEL_BYTES;
+        const unsigned off = ((yy + 2u) * (unsigned)p.Wp + xx + 2u) * (unsigned)p16::PIXEL_BYTES + (unsigned)h * 16u;
+        const unsigned cstride = (unsigned)p.Hp * (unsigned)p.Wp * (unsigned)p16::PIXEL_BYTES;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          u32x4 hi, lo;
+          p16::split8(o + 8 * c, hi, lo);
+          *reinterpret_cast<u32x4*>(pb + (size_t)(off + c * cstride)) = hi;
+          *reinterpret_cast<u32x4*>(pb + (size_t)(off + c * cstride + 32u)) = lo;
+          pl_amx = p16::absmax_pk4(pl_amx, hi);
+        }
+      }
+    } else if (p.planes && ok) {  // (F16 implies a planes buffer) positions 8h .. 8h+7 of chunk c = channels 16c + {4h..4h+3, 8+4h..8+4h+3}: this lane's o[8c .. 8c+7]
+      const int yy = (int)(px / p.W), xx = (int)(px - (long long)yy * p.W);
+      unsigned char* dst = p.planes + ((((long long)b * p.chunks) * p.Hp + yy + 2) * p.Wp + xx + 2) * 96 + h * 16;
+      const long long cstride = (long long)p.Hp * p.Wp * 96;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const Op3 pl = split8(f32x4{o[8 * c], o[8 * c + 1], o[8 * c + 2], o[8 * c + 3]},
+                              f32x4{o[8 * c + 4], o[8 * c + 5], o[8 * c + 6], o[8 * c + 7]});
+        *reinterpret_cast<u32x4*>(dst + c * cstride) = pl.p[0];
+        *reinterpret_cast<u32x4*>(dst + c * cstride + 32) = pl.p[1];
+        *reinterpret_cast<u32x4*>(dst + c * cstride + 64) = pl.p[2];
+      }
+    }
   };
   // one 32-pixel tile; c3 / ci hold its rows of x_3 / x_i.  The next tile's x_i rows are requested into ni while this one is
   // computed (two register sets used alternately: ci is live until the residual add of the epilogue); the next tile's x_3 rows go
@@ -449,80 +666,168 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
           }
         }
     }
-    // epilogue: + residual x_i (same channel layout: channel 32 mt + 8 g + 4 h + e = ci[4 mt + g][e]), LayerNorm over the
-    // pixel's 64 channels (32 in this lane, 32 in lane ^ 32)
-    float o[32];
-    float s1 = 0.f;
+    finish(z, ci, px, ok, zo);
+  };
+  // ---- LAZY: x_3's projected rows interpolated from the low-resolution map ----
+  struct Taps {
+    int o00, o01, o10, o11;  // element offsets of the four source rows (channel 4h included)
+    float ly, lx;
+  };
+  auto taps = [&](long long tt) {  // of this lane's pixel of tile tt (clamped into the image: the loads are unconditional)
+    long long px = tt * 32 + r;
+    px = px < p.N ? px : p.N - 1;
+    const int yy = (int)((unsigned)px / (unsigned)p.W), xx = (int)px - yy * p.W;
+    const float fy = fmaxf(p.sy * ((float)yy + 0.5f) - 0.5f, 0.f);  // (bilinear_kernel's arithmetic, csrc/rowops.hip)
+    const float fx = fmaxf(p.sx * ((float)xx + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, p.ih - 1), x1 = min(x0 + 1, p.iw - 1);
+    Taps tp;
+    tp.ly = fy - (float)y0;
+    tp.lx = fx - (float)x0;
+    tp.o00 = (y0 * p.iw + x0) * p.ld3 + 4 * h;
+    tp.o01 = (y0 * p.iw + x1) * p.ld3 + 4 * h;
+    tp.o10 = (y1 * p.iw + x0) * p.ld3 + 4 * h;
+    tp.o11 = (y1 * p.iw + x1) * p.ld3 + 4 * h;
+    return tp;
+  };
+  // the four source rows' pieces q = 2 ks, 2 ks + 1 (16 channels = one K step of stage 2): buf[2 tap + j]
+  auto issue = [&](const Taps& tp, int ks, f32x4* buf) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = z[mt][4 * g + e] + ci[4 * mt + g][e];
-          o[mt * 16 + 4 * g + e] = v;
-          s1 += v;
-        }
-    s1 += __shfl_xor(s1, 32);
-    const float mean = s1 * (1.0f / 64.0f);
-    float s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      o[k] -= mean;
-      s2 = fmaf(o[k], o[k], s2);
+    for (int j = 0; j < 2; ++j) {
+      const int c = 8 * (2 * ks + j);
+      buf[0 + j] = *reinterpret_cast<const f32x4*>(x3b + tp.o00 + c);
+      buf[2 + j] = *reinterpret_cast<const f32x4*>(x3b + tp.o01 + c);
+      buf[4 + j] = *reinterpret_cast<const f32x4*>(x3b + tp.o10 + c);
+      buf[6 + j] = *reinterpret_cast<const f32x4*>(x3b + tp.o11 + c);
     }
-    s2 += __shfl_xor(s2, 32);
-    const float rstd = 1.0f / sqrtf(s2 * (1.0f / 64.0f) + p.eps);
+  };
+  // K step ks of source 0: T = relu(interpolated rows) is already in stage 2's operand layout (registers 8 sp .. 8 sp + 7 of tile nt,
+  // ks = 2 nt + sp, are pieces 2 ks and 2 ks + 1)
+  auto step0 = [&](const Taps& tp, int ks, const f32x4* buf, f32x16* z, int zo) {
+    const float hy1 = 1.f - tp.ly, hx1 = 1.f - tp.lx;
+    const f32x2 hy = {hy1, hy1}, hx = {hx1, hx1}, ly = {tp.ly, tp.ly}, lx = {tp.lx, tp.lx};
+    f32x4 pc[2];
+    // packed arithmetic on the register pairs AS LOADED (elements 0-1 and 2-3 of each 16-byte piece): written per element, the
+    // compiler paired values of different source rows for v_pk_mul_f32 and copied them together right behind the loads - a wait
+    // on requests issued a few instructions earlier
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(Cst + zo + 192 + mt * 32 + 8 * g + 4 * h);
-        const f32x4 bt = *reinterpret_cast<const f32x4*>(Cst + zo + 256 + mt * 32 + 8 * g + 4 * h);
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = o[mt * 16 + 4 * g + e] * rstd * ga[e] + bt[e];
-          o[mt * 16 + 4 * g + e] = v[e];
-        }
-        if (ok && p.out) *reinterpret_cast<f32x4*>(outb + px * p.ldo + mt * 32 + 8 * g + 4 * h) = v;
+      for (int e = 0; e < 4; e += 2) {
+        const f32x2 v00 = {buf[0 + j][e], buf[0 + j][e + 1]}, v01 = {buf[2 + j][e], buf[2 + j][e + 1]};
+        const f32x2 v10 = {buf[4 + j][e], buf[4 + j][e + 1]}, v11 = {buf[6 + j][e], buf[6 + j][e + 1]};
+        const f32x2 v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        pc[j][e] = fmaxf(v[0], 0.f);
+        pc[j][e + 1] = fmaxf(v[1], 0.f);
       }
-    if constexpr (F16) {
-      if (ok) {
-        const int yy = (int)(px / p.W), xx = (int)(px - (long long)yy * p.W);
-        unsigned char* dst = p.planes + ((((long long)b * p.chunks) * p.Hp + yy + 2) * p.Wp + xx + 2) * p16::PIXEL_BYTES + h * 16;
-        const long long cstride = (long long)p.Hp * p.Wp * p16::PIXEL_BYTES;
+    const Op3 tk = split8(pc[0], pc[1]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          u32x4 hi, lo;
-          p16::split8(o + 8 * c, hi, lo);
-          *reinterpret_cast<u32x4*>(dst + c * cstride) = hi;
-          *reinterpret_cast<u32x4*>(dst + c * cstride + 32) = lo;
-          pl_amx = p16::absmax_pk4(pl_amx, hi);
-        }
-      }
-    } else if (p.planes && ok) {  // (F16 implies a planes buffer) positions 8h .. 8h+7 of chunk c = channels 16c + {4h..4h+3, 8+4h..8+4h+3}: this lane's o[8c .. 8c+7]
-      const int yy = (int)(px / p.W), xx = (int)(px - (long long)yy * p.W);
-      unsigned char* dst = p.planes + ((((long long)b * p.chunks) * p.Hp + yy + 2) * p.Wp + xx + 2) * 96 + h * 16;
-      const long long cstride = (long long)p.Hp * p.Wp * 96;
+    for (int mt = 0; mt < 2; ++mt) {
+      u32x4 wf[3];
+      wfrag(Wes + zo, mt * 32 + r, WPB2, 256, ks, h, wf);
+      z[mt] = mma6(wf, tk.p, z[mt]);
+    }
+  };
+  // one tile: c3 holds the source rows of its K step 0 (requested by the previous tile); ci / ni as above
+  auto load_clamped = [&](long long tt, f32x4* dst) {  // x_i rows, unconditional
+    long long px = tt * 32 + r;
+    px = px < p.N ? px : p.N - 1;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const Op3 pl = split8(f32x4{o[8 * c], o[8 * c + 1], o[8 * c + 2], o[8 * c + 3]},
-                              f32x4{o[8 * c + 4], o[8 * c + 5], o[8 * c + 6], o[8 * c + 7]});
-        *reinterpret_cast<u32x4*>(dst + c * cstride) = pl.p[0];
-        *reinterpret_cast<u32x4*>(dst + c * cstride + 32) = pl.p[1];
-        *reinterpret_cast<u32x4*>(dst + c * cstride + 64) = pl.p[2];
+    for (int q = 0; q < 8; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xib + px * p.ldi + 8 * q + 4 * h);
+  };
+  // Scheduling fences of the LAZY tile: a branch the compiler cannot fold (never taken) ends a basic block, and the instruction
+  // scheduler works inside blocks.  Without them it either sinks a K step's requests down to their first use or lifts that use
+  // (the interpolation) up to just behind the requests to free their 32 registers - both wait on rows requested a few instructions
+  // earlier.  (sched_barrier masks and fake register dependencies each stopped one of the two motions and provoked the other.)
+  // The fenced blocks hold no vector-memory operation of their own, so the in-flight counts the waits are built from stay exact.
+  int never = 0;
+  asm volatile("" : "+s"(never));
+#define FENCE() do { if (never) asm volatile("s_nop 0"); } while (0)
+  auto tile_lazy = [&](long long t, f32x4* c3, const f32x4* ci, f32x4* ni) {
+    long long px = t * 32 + r;
+    px = px < p.N ? px : p.N - 1;  // (lanes past the end redo the last pixel: see the template's header)
+    constexpr bool ok = true;
+    int zo = 0;
+    asm volatile("" : "+v"(zo));
+    const Taps tp = taps(t);
+    f32x16 z[2];
+    z[0] = rows16(Cst + zo + 128);
+    z[1] = rows16(Cst + zo + 160);
+    step0(tp, 0, c3, z, zo);
+    issue(tp, 1, c3);
+    FENCE();  // (the x_i rows AFTER this K step's rows: the wait below may then leave them in flight)
+    load_clamped(t + stride, ni);
+    FENCE();
+    // source 1 = x_i -> u_i half, stage 1 (as in tile())
+    f32x16 tt[2];
+    tt[0] = rows16(Cst + zo + 64);
+    tt[1] = rows16(Cst + zo + 96);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const Op3 xs = split8(ci[2 * s], ci[2 * s + 1]);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        u32x4 wf[3];
+        wfrag(Wis + zo, nt * 32 + r, WPB, 128, s, h, wf);
+        tt[nt] = mma6(wf, xs.p, tt[nt]);
       }
     }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) tt[nt][v] = fmaxf(tt[nt][v], 0.f);
+    }
+    FENCE();
+    step0(tp, 1, c3, z, zo);
+    issue(tp, 2, c3);
+    FENCE();
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        const Op3 tk = split8(tt[nt], sp);
+        const int ks = 4 + nt * 2 + sp;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          u32x4 wf[3];
+          wfrag(Wes + zo, mt * 32 + r, WPB2, 256, ks, h, wf);
+          z[mt] = mma6(wf, tk.p, z[mt]);
+        }
+      }
+      if (nt == 0) {
+        FENCE();
+        step0(tp, 2, c3, z, zo);
+        issue(tp, 3, c3);
+        FENCE();
+      }
+    }
+    FENCE();
+    step0(tp, 3, c3, z, zo);
+    issue(taps(t + stride), 0, c3);  // the next tile's first K step
+    FENCE();
+    finish(z, ci, px, ok, zo);
   };
   f32x4 a3[8], ai[8], bi[8];
   long long t = (long long)blockIdx.x * CP_WAVES + wave;
-  load(t, x3b, p.ld3, a3);
-  load(t, xib, p.ldi, ai);
-  for (; t < ntiles; t += 2 * stride) {
-    tile(t, a3, ai, bi);
-    if (t + stride < ntiles) tile(t + stride, a3, bi, ai);
+  if constexpr (LAZY) {
+    issue(taps(t), 0, a3);
+    FENCE();  // (same order and counts as a tile leaves behind: eight operations after the K step's rows)
+    load_clamped(t, ai);
+    FENCE();
+  } else {
+    load(t, x3b, p.ld3, a3);
+    load(t, xib, p.ldi, ai);
   }
+  for (; t < ntiles; t += 2 * stride) {
+    if constexpr (LAZY) {
+      tile_lazy(t, a3, ai, bi);
+      if (t + stride < ntiles) tile_lazy(t + stride, a3, bi, ai);
+    } else {
+      tile(t, a3, ai, bi);
+      if (t + stride < ntiles) tile(t + stride, a3, bi, ai);
+    }
+  }
+#undef FENCE
   if constexpr (F16) {
     if (p.pl_amax) p16::fold_pat(p.pl_amax, p.pl_amax_images > 1 ? b : 0, p.pl_amax_images > 1 ? b : 0, pl_amx);
   }
@@ -549,6 +854,20 @@ extern "C" int segmif_crosspath_gram_f32(const float* x, int ldx, const float* w
   return (int)hipGetLastError();
 }
 
+extern "C" int segmif_crosspath_gram_lazy_f32(const float* s_low, int lds, int ih, int iw, int H, int W, double* partial, int B,
+                                              void* stream) {
+  if (!s_low || !partial || B <= 0 || ih <= 0 || iw <= 0 || H <= 0 || W <= 0 || lds < 64) return SEGMIF_EINVAL;
+  if (((uintptr_t)s_low & 3) || ((uintptr_t)partial & 7)) return SEGMIF_EINVAL;
+  const long long N = (long long)H * W;
+  if (N >= (1ll << 31) || (long long)ih * iw * lds >= (1ll << 31)) return SEGMIF_EINVAL;  // 32-bit offsets inside an image
+  if ((W & 3) || 3ll * iw > W) return SEGMIF_EINVAL;  // aligned groups of four pixels share <= 3 source columns (kernel header)
+  const int nblk = segmif_crosspath_gram_blocks(N);
+  constexpr size_t smem = 3 * 16 * 64 * sizeof(double) + CP_WAVES * 2 * 32 * (sizeof(u32x4) + sizeof(f32x4));
+  hipLaunchKernelGGL(crosspath_gram_lazy_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(512), smem, (hipStream_t)stream, s_low, lds,
+                     ih, iw, W, (float)ih / (float)H, (float)iw / (float)W, partial, N);
+  return (int)hipGetLastError();
+}
+
 extern "C" int segmif_crosspath_fold_f32(const double* partial, int nblk, const float* wkv, const float* wend, float* weff, int B,
                                          int Nout, int ldw, int wofs, int ldweff, int kofs, float scale, uint32_t* cond,
                                          void* stream) {
@@ -567,7 +886,7 @@ extern "C" int segmif_crosspath_fold_f32(const double* partial, int nblk, const 
 }
 
 extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream) {
-  if (!d || !d->x3 || !d->xi || !d->w3 || !d->wi || !d->weff || (!d->out && !d->planes_out) || d->B <= 0 || d->N <= 0) return SEGMIF_EINVAL;  // (out may be NULL when the planes copy is the only consumer)
+  if (!d || !d->x3 || !d->xi || (!d->w3 && d->x3_ih <= 0) || !d->wi || !d->weff || (!d->out && !d->planes_out) || d->B <= 0 || d->N <= 0) return SEGMIF_EINVAL;  // (out may be NULL when the planes copy is the only consumer)
   if (d->ld3 < 64 || d->ldi < 64 || d->ldo < 64 || ((d->ld3 | d->ldi | d->ldo) & 3)) return SEGMIF_EINVAL;
   if (((uintptr_t)d->x3 | (uintptr_t)d->xi | (uintptr_t)d->w3 | (uintptr_t)d->wi | (uintptr_t)d->weff | (uintptr_t)d->out) & 15)
     return SEGMIF_EINVAL;
@@ -586,8 +905,17 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
     int hp, wp;
     if (segmif_planes_dims(d->H, d->W, &hp, &wp) != 0) return SEGMIF_EINVAL;
     k.W = d->W; k.Hp = hp; k.Wp = wp; k.chunks = d->planes_chunks;
+    if (d->N >= (1ll << 31) || (long long)d->planes_chunks * hp * wp * 96 >= (1ll << 31)) return SEGMIF_EINVAL;  // 32-bit offsets inside an image
   }
   k.eps = d->ln_eps;
+  k.ih = k.iw = 0; k.sy = k.sx = 0.f;
+  const bool lazy = d->x3_ih > 0 || d->x3_iw > 0;
+  if (lazy) {  // x3 = the low-resolution map of projected rows (header): H x W is the resize's target
+    if (d->x3_ih <= 0 || d->x3_iw <= 0 || d->H <= 0 || d->W <= 0 || (int64_t)d->H * d->W != d->N || d->N >= (1ll << 31)) return SEGMIF_EINVAL;
+    if ((int64_t)d->x3_ih * d->x3_iw * d->ld3 >= (1ll << 31)) return SEGMIF_EINVAL;  // 32-bit element offsets inside an image
+    k.ih = d->x3_ih; k.iw = d->x3_iw; k.W = d->W;
+    k.sy = (float)d->x3_ih / (float)d->H; k.sx = (float)d->x3_iw / (float)d->W;
+  }
   const long long ntiles = (d->N + 31) / 32;
   long long wgs = (ntiles + CP_WAVES - 1) / CP_WAVES;
   const long long per_image = (2 * 256 + d->B - 1) / d->B;  // 100 KB of LDS: one workgroup per CU, two rounds of them
@@ -596,14 +924,23 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
   static segmif::PerDeviceFlag raised_flag;
   bool& raised = raised_flag.here();
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)crosspath_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)crosspath_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipSuccess;
+    for (const void* fn : {(const void*)crosspath_tail_kernel<false, false, true>, (const void*)crosspath_tail_kernel<true, false, true>,
+                           (const void*)crosspath_tail_kernel<false, true, true>, (const void*)crosspath_tail_kernel<true, true, true>,
+                           (const void*)crosspath_tail_kernel<true, true, false>})
+      if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
   const dim3 grid((unsigned)wgs, (unsigned)d->B);
   hipStream_t st = (hipStream_t)stream;
-  if (k.pl_f16) hipLaunchKernelGGL(crosspath_tail_kernel<true>, grid, dim3(512), smem, st, k);
-  else hipLaunchKernelGGL(crosspath_tail_kernel<false>, grid, dim3(512), smem, st, k);
+  if (lazy) {
+    if (k.pl_f16 && !k.out) hipLaunchKernelGGL((crosspath_tail_kernel<true, true, false>), grid, dim3(512), smem, st, k);
+    else if (k.pl_f16) hipLaunchKernelGGL((crosspath_tail_kernel<true, true, true>), grid, dim3(512), smem, st, k);
+    else hipLaunchKernelGGL((crosspath_tail_kernel<false, true, true>), grid, dim3(512), smem, st, k);
+  } else {
+    if (k.pl_f16) hipLaunchKernelGGL((crosspath_tail_kernel<true, false, true>), grid, dim3(512), smem, st, k);
+    else hipLaunchKernelGGL((crosspath_tail_kernel<false, false, true>), grid, dim3(512), smem, st, k);
+  }
   return (int)hipGetLastError();
 }

@@ -1462,6 +1462,67 @@ def linattn_fold(part, wend, weff, wofs, kofs, scale, heads=8):
     return weff
 
 
+_LAZY_SEG = os.environ.get("SEGMIF_LAZY_SEG", "1") != "0"
+
+
+def lazy_seg_mode():
+    return _LAZY_SEG
+
+
+def set_lazy_seg_mode(on):
+    """A/B switch (env SEGMIF_LAZY_SEG=0): Fusion_Network3_ac.forward_from_features hands CrossPath the LOW-resolution
+    segmentation feature and the kernels resize it as they read (on), or the feature is resized to H x W first (off)."""
+    global _LAZY_SEG
+    prev, _LAZY_SEG = _LAZY_SEG, bool(on)
+    return prev
+
+
+class LazySeg:
+    """The segmentation feature CrossPath consumes, NOT yet resized: `low` = (B, ih, iw, 64) contiguous NHWC (conv3 / conv4 already
+    applied), to be read as bilinear(low -> H x W) (align_corners = False; core/mix_transformer.py:364-373).  The Gram-form
+    CrossPath reads it through segmif_crosspath_gram_lazy_f32 / SegmifCrossTail.x3_ih - the (B, H, W, 64) tensor (5 GB at 64 x 480
+    x 640, written once and read three times per interaction) never exists; any other consumer calls materialise()."""
+
+    def __init__(self, low, H, W):
+        _req(low, "low")
+        if low.dim() != 4 or low.shape[-1] != 64 or not low.is_contiguous():
+            raise RuntimeError("LazySeg expects a contiguous (B, ih, iw, 64) map")
+        self.low, self.H, self.W = low, int(H), int(W)
+        self._full = None
+
+    @property
+    def shape(self):
+        return torch.Size((self.low.shape[0], self.H, self.W, 64))
+
+    requires_grad = False
+
+    def fits(self):
+        """segmif_crosspath_gram_lazy_f32's geometry: aligned groups of four pixels in one row, an enlargement by three or more."""
+        return self.W % 4 == 0 and 3 * self.low.shape[2] <= self.W
+
+    def materialise(self):
+        if self._full is None:
+            self._full = bilinear(self.low, self.H, self.W)
+        return self._full
+
+
+def crosspath_gram_lazy(s_low, H, W):
+    """Gram partials of relu(bilinear(s_low -> H x W)): s_low (B, ih, iw, 64) rows view (a channel slice of the projected low-
+    resolution map: pitch = its last stride) -> (B, nblk, 3072) fp64, as crosspath_gram gives on the resized tensor."""
+    _req(s_low, "s_low")
+    if s_low.dim() != 4 or s_low.shape[3] != 64 or s_low.stride(3) != 1 or s_low.stride(1) != s_low.shape[2] * s_low.stride(2) \
+            or s_low.stride(0) != s_low.shape[1] * s_low.stride(1):
+        raise RuntimeError("crosspath_gram_lazy expects a (B, ih, iw, 64) rows view")
+    B, ih, iw, _ = s_low.shape
+    lib = _lib.load()
+    nblk = lib.segmif_crosspath_gram_blocks(H * W)
+    part = torch.empty((B, nblk, 3072), device=s_low.device, dtype=torch.float64)
+    _side("cp_gram", lambda: _lib.check(lib.segmif_crosspath_gram_lazy_f32(
+        s_low.data_ptr(), s_low.stride(2), ih, iw, H, W, part.data_ptr(), B, _stream()), "segmif_crosspath_gram_lazy_f32"),
+        256.0 * B * ih * iw)
+    return part
+
+
 def crosspath_gram(x, w_half, b_half):
     """Per-image Gram partials of relu(x @ w_half^T + b_half): x (B, N, 64) rows view, w_half a contiguous (64, 64) slice
     of a channel_proj weight -> (B, nblk, 3072) fp64 (segmif_crosspath_gram_f32)."""
@@ -1494,16 +1555,23 @@ def crosspath_fold(part, wkv, wend, weff, wofs, kofs, scale):
     return weff
 
 
-def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None, hw=None, planes_only=False):
+def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None, hw=None, planes_only=False, lazy=False):
     """out = LN(x_i + weff_b @ [relu(w3 x_3 + b3) | relu(wi x_i + bi)] + bend): x3, xi (B, N, 64) rows views, w3 / wi
     contiguous (64, 64) slices, weff (B, 64, 128), ln = (gamma, beta, eps).  planes: optional ops.Planes that receives
     out as chunks 0..3 (hw = (H, W) with H * W == N); planes_only: write nothing else (the fp32 tensor has no reader:
-    the second interaction of Fusion_Network3_ac, whose consumers are the planes convs) and return None."""
-    for t, nm in ((x3, "x3"), (xi, "xi")):
+    the second interaction of Fusion_Network3_ac, whose consumers are the planes convs) and return None.
+    lazy=True: x3 is the (B, ih, iw, 64) rows view of the LOW-resolution map of channel_proj3's y half already applied (w3 / b3
+    unused); the kernel reads bilinear(x3 -> hw) (SegmifCrossTail.x3_ih)."""
+    for t, nm in ((xi, "xi"),) if lazy else ((x3, "x3"), (xi, "xi")):
         _req(t, nm)
         if t.dim() != 3 or t.shape[2] != 64 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
             raise RuntimeError(f"crosspath_tail: {nm} must be a (B, N, 64) rows view")
     B, N, _ = xi.shape
+    if lazy:
+        _req(x3, "x3")
+        if x3.dim() != 4 or x3.shape[0] != B or x3.shape[3] != 64 or x3.stride(3) != 1 or x3.stride(1) != x3.shape[2] * x3.stride(2) \
+                or x3.stride(0) != x3.shape[1] * x3.stride(1) or hw is None or hw[0] * hw[1] != N:
+            raise RuntimeError("crosspath_tail: lazy x3 must be a (B, ih, iw, 64) rows view, with hw = (H, W) of the tokens")
     if planes_only:
         if planes is None or out is not None:
             raise RuntimeError("crosspath_tail: planes_only needs a planes buffer and no fp32 output")
@@ -1512,15 +1580,17 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
             out = torch.empty((B, N, 64), device=xi.device, dtype=torch.float32)
         if tuple(out.shape) != (B, N, 64) or out.stride(2) != 1 or out.stride(0) != N * out.stride(1):
             raise RuntimeError("crosspath_tail: out must be a (B, N, 64) rows view")
-    for t in (w3, wi):
+    for t in (wi,) if lazy else (w3, wi):
         if tuple(_req(t, "w").shape) != (64, 64) or not t.is_contiguous():
             raise RuntimeError("crosspath_tail expects contiguous (64, 64) weight slices")
     if tuple(_req(weff, "weff").shape) != (B, 64, 128) or not weff.is_contiguous():
         raise RuntimeError("crosspath_tail expects a contiguous (B, 64, 128) folded weight")
     d = _lib.SegmifCrossTail()
-    d.x3, d.xi, d.ld3, d.ldi = x3.data_ptr(), xi.data_ptr(), x3.stride(1), xi.stride(1)
-    d.w3, d.wi, d.weff = w3.data_ptr(), wi.data_ptr(), weff.data_ptr()
-    d.b3 = _req(b3).data_ptr() if b3 is not None else None
+    d.x3, d.xi, d.ld3, d.ldi = x3.data_ptr(), xi.data_ptr(), x3.stride(2 if lazy else 1), xi.stride(1)
+    d.w3, d.wi, d.weff = None if lazy else w3.data_ptr(), wi.data_ptr(), weff.data_ptr()
+    d.b3 = _req(b3).data_ptr() if b3 is not None and not lazy else None
+    if lazy:
+        d.x3_ih, d.x3_iw, d.H, d.W = x3.shape[1], x3.shape[2], hw[0], hw[1]
     d.bi = _req(bi).data_ptr() if bi is not None else None
     d.bend = _req(bend).data_ptr() if bend is not None else None
     d.ln_gamma, d.ln_beta, d.ln_eps = _req(ln[0]).data_ptr(), _req(ln[1]).data_ptr(), float(ln[2])
@@ -1535,7 +1605,7 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
             d.planes_amax, d.planes_amax_images = planes.guard.slot(B)
     _side("cp_tail", lambda: _lib.check(_lib.load().segmif_crosspath_tail_f32(ctypes.byref(d), _stream()),
                                         "segmif_crosspath_tail_f32"),
-          ((512.0 if planes_only else 768.0) + (0.0 if planes is None else 256.0 if planes.f16 else 384.0)) * B * N)  # + the planes copy: 4 | 6 B per element
+          ((512.0 if planes_only else 768.0) - (256.0 if lazy else 0.0) + (0.0 if planes is None else 256.0 if planes.f16 else 384.0)) * B * N)  # + the planes copy: 4 | 6 B per element
     return out
 
 

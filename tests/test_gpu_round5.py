@@ -407,3 +407,114 @@ def test_standalone_inference_calls_open_their_own_guarded_scope(ops):
     assert torch.equal(h0[0], o0[0]) and torch.equal(h0[2], o0[2])  # the other images keep their f16x3 results
     _, _, seg_g = net(x)  # gradients enabled: the functional path, no scope
     assert ops.range_stats()["scopes"] == s2["scopes"] and seg_g.requires_grad
+
+
+# ---- (r5) CrossPath reading the segmentation feature at its own resolution ----
+def _lazy_case(ops, B, ih, iw, H, W, seed):
+    """low-resolution feature, channel_proj3-like weights, the resized tensor (the old path's input) and the projected map."""
+    low = rnd(B, ih, iw, 64, seed=seed, lo=-2.0, hi=2.0).cuda()
+    w = (rnd(128, 64, seed=seed + 1) * 0.25).cuda()
+    b = (rnd(128, seed=seed + 2) * 0.3).cuda()
+    full = ops.bilinear(low, H, W)
+    proj = ops.linear(low, ops.pack_weight(w), 128, bias=b)
+    return low, w, b, full, proj
+
+
+@pytest.mark.parametrize("B,ih,iw,H,W", [(2, 16, 24, 64, 96), (2, 8, 12, 64, 96), (1, 10, 14, 40, 56), (3, 7, 9, 30, 52),
+                                         (1, 30, 40, 120, 160), (2, 5, 4, 17, 12)])
+def test_lazy_gram_equals_gram_of_the_resized_feature(ops, B, ih, iw, H, W):
+    """segmif_crosspath_gram_lazy_f32 on the projected LOW-resolution map against segmif_crosspath_gram_f32 on the resized
+    tensor (Linear and bilinear resize commute to rounding): the 64 x 64 Gram sums, relative to the largest entry.  x 4, x 8,
+    an image whose rows are not multiples of 32 pixels, non-integer scales with a partial last tile (one exactly at the
+    kernel's limit of an enlargement by three)."""
+    low, w, b, full, proj = _lazy_case(ops, B, ih, iw, H, W, seed=3)
+    ref = ops.crosspath_gram(full.view(B, H * W, 64), w[64:].contiguous(), b[64:]).sum(1)
+    got = ops.crosspath_gram_lazy(proj[..., 64:], H, W).sum(1)
+    e = float((got - ref).abs().max() / ref.abs().max())
+    observed(f"lazy_gram_{ih}x{iw}_to_{H}x{W}", e)
+    assert e < 2e-6, e
+    # and against fp64 on the host, from the definition
+    up = torch.nn.functional.interpolate(proj[..., 64:].permute(0, 3, 1, 2).double().cpu(), size=(H, W), mode="bilinear",
+                                         align_corners=False).permute(0, 2, 3, 1).reshape(B, H * W, 64).relu()
+    g64 = torch.einsum("bni,bnj->bij", up, up)
+    tiles = got.view(B, 3, 32, 32).cpu()
+    for a, (i0, j0) in enumerate(((0, 0), (0, 32), (32, 32))):
+        ea = float((tiles[:, a] - g64[:, i0:i0 + 32, j0:j0 + 32]).abs().max() / g64.abs().max())
+        assert ea < 2e-6, (a, ea)
+
+
+@pytest.mark.parametrize("B,ih,iw,H,W,planes", [(2, 16, 24, 64, 96, False), (2, 8, 12, 64, 96, True), (1, 10, 14, 40, 56, True),
+                                                (3, 7, 9, 30, 50, False), (1, 30, 40, 120, 160, True)])
+def test_lazy_tail_equals_tail_on_the_resized_feature(ops, B, ih, iw, H, W, planes):
+    """crosspath_tail with x3 = the projected low-resolution map (SegmifCrossTail.x3_ih) against the same call on the resized
+    tensor: fp32 output and, with planes=True, the f16x3 planes copy (decoded) and the range slots."""
+    low, w, b, full, proj = _lazy_case(ops, B, ih, iw, H, W, seed=5)
+    N = H * W
+    xi = rnd(B, N, 64, seed=9, lo=-1.5, hi=1.5).cuda()
+    wi, bi = (rnd(64, 64, seed=10) * 0.25).cuda(), (rnd(64, seed=11) * 0.2).cuda()
+    weff = (rnd(B, 64, 128, seed=12) * 0.2).cuda()
+    bend, gamma, beta = (rnd(64, seed=13) * 0.1).cuda(), (1.0 + 0.2 * rnd(64, seed=14)).cuda(), (rnd(64, seed=15) * 0.1).cuda()
+    ln = (gamma, beta, 1e-5)
+
+    def run(lazy):
+        x3 = proj[..., :64] if lazy else full.view(B, N, 64)
+        with scope(ops, B) as g:
+            pl = ops.Planes(B, H, W, 4, "cuda", g) if planes else None
+            out = ops.crosspath_tail(x3, xi, None if lazy else w[:64].contiguous(), None if lazy else b[:64], wi, bi, weff, bend, ln,
+                                     planes=pl, hw=(H, W), lazy=lazy)
+            slots = g.amax[0, :B].clone() if planes else None
+        return out, (None if pl is None else pl.data.clone()), slots
+
+    o0, p0, s0 = run(False)
+    o1, p1, s1 = run(True)
+    e = float((o1 - o0).abs().max() / o0.abs().max())
+    observed(f"lazy_tail_{ih}x{iw}_to_{H}x{W}", e)
+    assert e < 5e-6, e   # (LayerNorm output: O(1) values; the two paths differ by fp32 roundings of the 64-channel projection)
+    if planes:
+        dec = lambda p: (lambda hv: hv[:, :16].double() + hv[:, 16:].double() * 2.0 ** -11)(p.view(torch.float16).view(-1, 32))
+        d = float((dec(p1) - dec(p0)).abs().max() / o0.abs().max())  # (64-byte pixels: 16 hi halves | 16 lo halves, x = hi + 2^-11 lo)
+        assert d < 5e-6, d
+        assert torch.equal(s0 > 0, s1 > 0) and bool((s1 > 0).all())
+
+
+def test_lazy_gram_refuses_what_it_cannot_share_and_the_module_resizes_first(ops):
+    """W % 4 != 0 or an enlargement below three: the C entry point returns SEGMIF_EINVAL (RuntimeError here), ops.LazySeg.fits()
+    says so beforehand, and FeatureFusionModule then resizes the feature first - same result as handing it the resized tensor."""
+    low, w, b, full, proj = _lazy_case(ops, 1, 7, 9, 30, 50, seed=3)
+    with pytest.raises(RuntimeError):
+        ops.crosspath_gram_lazy(proj[..., 64:], 30, 50)
+    with pytest.raises(RuntimeError):
+        ops.crosspath_gram_lazy(_lazy_case(ops, 1, 8, 10, 16, 20, seed=3)[4][..., 64:], 16, 20)
+    assert not ops.LazySeg(low, 30, 50).fits() and ops.LazySeg(low, 28, 52).fits()
+    from segmif_amd.core.model_fusion import FeatureFusionModule
+    ffm = FeatureFusionModule(64).cuda().eval()
+    dw.load_det_weights(ffm, seed=0)
+    x1, x2 = rnd(1, 30, 50, 64, seed=21).cuda(), rnd(1, 30, 50, 64, seed=22).cuda()
+    with torch.no_grad():
+        a = ffm.forward_nhwc(x1, x2, ops.LazySeg(low, 30, 50))
+        c = ffm.forward_nhwc(x1, x2, full)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+
+
+def test_pair_forward_with_and_without_the_resized_feature(ops):
+    """Fusion_Network3_ac.forward_from_features with CrossPath reading the low-resolution features (default) against the same
+    forward with the features resized first (SEGMIF_LAZY_SEG=0): the fused image, relative to its range."""
+    from segmif_amd.core import Fusion_Network3_ac, Network3
+    seg, fus = Network3("mit_b1", 9, pretrained=None), Fusion_Network3_ac()
+    dw.load_det_weights(seg, seed=0), dw.load_det_weights(fus, seed=0)
+    seg, fus = seg.cuda().eval(), fus.cuda().eval()
+    B, H, W = 2, 64, 96
+    ir, vis = dw.det_input("lz_ir", (B, 1, H, W)).cuda(), dw.det_input("lz_vis", (B, 1, H, W)).cuda()
+    mask3 = dw.det_input("lz_mask", (B, 1, H, W)).repeat(1, 3, 1, 1).cuda()
+    outs = {}
+    with torch.no_grad():
+        feats = seg.denoise_net.encoder.forward_fusion_features(mask3)
+        for on in (True, False):
+            prev = ops.set_lazy_seg_mode(on)
+            try:
+                outs[on] = fus.forward_from_features(ir, vis, *feats).clone()
+            finally:
+                ops.set_lazy_seg_mode(prev)
+    e = float((outs[True] - outs[False]).abs().max() / outs[False].abs().max())
+    observed("lazy_seg_pair_forward", e)
+    assert e < 2e-5, e
