@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __rest
 //    ran at the texture path's instruction rate: 1.69 ms against 1.57 ms for the kernel that reads the full tensor from HBM.
 //  * Two 24-register buffers (one K step = 8 pixels x 2 channel tiles each) are requested one tile ahead; GFENCE: see FENCE in
 //    crosspath_tail_kernel.
-__global__ __launch_bounds__(512) void crosspath_gram_lazy_kernel(const float* __restrict__ s, int lds, int ih, int iw, int W, float sy,
+__global__ __launch_bounds__(512, 4) void crosspath_gram_lazy_kernel(const float* __restrict__ s, int lds, int ih, int iw, int W, float sy,
                                                                   float sx, double* __restrict__ partial, long long N) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* Red = reinterpret_cast<double*>(smem_raw);                                  // [3][16][64]
