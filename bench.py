@@ -466,12 +466,15 @@ def main():
             "conv3x3_mode": ops.conv3x3_mode(),
             "arithmetic_modes": {"conv3x3": ops.conv3x3_mode(), "linear": ops.linear_mode(), "crosspath": ops.crosspath_mode(),
                                  "attention": ops.attention_mode(), "mixffn": ops.mixffn_mode(),
-                                 "encoder_gemms": "gemm_pairs (A pre-split by its producer)" if ops.pairs_mode() == "on" else "gemm_split"},
+                                 "encoder_gemms": "gemm_pairs (A pre-split by its producer)" if ops.pairs_mode() == "on" else "gemm_split",
+                                 "crosspath_seg_feature": "read at its own resolution by the Gram / tail kernels (ops.LazySeg)"
+                                 if ops.lazy_seg_mode() else "resized to H x W first"},
             "data": "synthetic",
             "config": {"workload": f"{args.backbone} pair forward (forward_fusion + Fusion_Network3_ac + Network3 "
                                    f"+ x4 bilinear + argmax), {H}x{W}, {B} pairs per GPU per step, eval mode, "
                                    "seeded deterministic weights; conv3/conv4 (1x1) applied before the "
-                                   "bilinear resize of forward_fusion (same function, SURVEY 8(f) N4)",
+                                   "bilinear resize of forward_fusion, and that resize done by CrossPath's kernels as they read "
+                                   "(same function, SURVEY 8(f) N4)",
                        "backbone": args.backbone, "height": H, "width": W, "pairs_per_gpu": B,
                        "parallelism": f"replicas x{world} (independent pairs, no collective)",
                        "launch": "hipGraph replay" if args.graph else "eager"},
@@ -540,8 +543,8 @@ def main():
         if side:
             # bandwidth-bound kernels: algorithmic HBM bytes per launch / HIP-event time around the launch (peak 8 TB/s,
             # ~6.3 achievable: MI355X_MICROARCH.md)
-            names = {"dwconv": "dwconv3x3_gelu_kernel (Mix-FFN middle)", "cp_gram": "crosspath_gram_kernel",
-                     "cp_tail": "crosspath_tail_kernel", "bilinear": "bilinear_kernel (forward_fusion / logits resize)",
+            names = {"dwconv": "dwconv3x3_gelu_kernel (Mix-FFN middle)", "cp_gram": "crosspath_gram_kernel (the two modalities' features; the segmentation feature's Gram reads a low-resolution map and is not timed here)",
+                     "cp_tail": "crosspath_tail_kernel (x_i in + planes out: the segmentation feature is an L2-resident low-resolution map)" if ops.lazy_seg_mode() else "crosspath_tail_kernel", "bilinear": "bilinear_kernel (forward_fusion / logits resize)",
                      "mixffn": "mixffn_kernel (norm2 + fc1 + dwconv + GELU + fc2 + residual of a stage-1/2 block in one launch; bytes = x in + out)"}
             hb = {}
             for tag, t in side.items():

@@ -1517,7 +1517,7 @@ def crosspath_gram_lazy(s_low, H, W):
     lib = _lib.load()
     nblk = lib.segmif_crosspath_gram_blocks(H * W)
     part = torch.empty((B, nblk, 3072), device=s_low.device, dtype=torch.float64)
-    _side("cp_gram", lambda: _lib.check(lib.segmif_crosspath_gram_lazy_f32(
+    _side("cp_gram_lazy", lambda: _lib.check(lib.segmif_crosspath_gram_lazy_f32(
         s_low.data_ptr(), s_low.stride(2), ih, iw, H, W, part.data_ptr(), B, _stream()), "segmif_crosspath_gram_lazy_f32"),
         256.0 * B * ih * iw)
     return part
