@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* Ws = smem_raw;                                   // [64][WPB]
   double* Red = reinterpret_cast<double*>(smem_raw + 64 * WPB);   // [3][16][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
   const float* __restrict__ xb = x + (long long)b * N * ldx;
@@ -186,10 +186,14 @@ __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __rest
   };
   // one 32-pixel tile: `cur` holds its rows; the tile TWO steps ahead is requested into `pre` before the arithmetic starts
   // (three register sets in rotation: two tiles of loads in flight per wave)
+  int never = 0;
+  asm volatile("" : "+s"(never));
   auto tile = [&](long long t, const f32x4* cur, f32x4* pre, long long tpre) {
     int zo = 0;  // opaque zero in every LDS address below: the weight fragments are loop invariant, and hoisted out of
     asm volatile("" : "+v"(zo));  // the tile loop they would occupy 100+ registers for the whole kernel
-    if (tpre < ntiles) load(tpre, pre);
+    load(tpre, pre);  // ((r5) unconditional - rows past the image clamp to its last one: a branch around the request hides from
+                      // the compiler how many are in flight, and the first tile of every three then waited for its own prefetch)
+    if (never) asm volatile("s_nop 0");  // (a basic-block end: the scheduler otherwise sinks the request below the tile's MFMAs)
     // stage 1: Y[px][n] = relu(sum_k x[px][k] W[n][k] + c[n]); lane = column n, register v = pixel (v&3)+8(v>>2)+4h
     f32x16 y[2] = {zero16(), zero16()};
 #pragma unroll
@@ -226,8 +230,8 @@ __global__ __launch_bounds__(512) void crosspath_gram_kernel(const float* __rest
   };
   f32x4 xa[8], xb2[8], xc[8];
   long long t = (long long)blockIdx.x * CP_WAVES + wave;
-  if (t < ntiles) load(t, xa);
-  if (t + stride < ntiles) load(t + stride, xb2);
+  load(t, xa);
+  load(t + stride, xb2);
   for (; t < ntiles; t += 3 * stride) {
     tile(t, xa, xc, t + 2 * stride);
     if (t + stride < ntiles) tile(t + stride, xb2, xa, t + 3 * stride);
