@@ -545,3 +545,36 @@ def test_join_node_and_gradient_sink_host_logic():
     assert sink.dz == [None] * 3 and not sink.done
 
 
+
+
+def test_lazy_gram_geometry_holds_for_every_admitted_size():
+    """csrc/crosspath.hip, crosspath_gram_lazy_kernel: an aligned group of four output pixels reads source columns c0, c0 + 1,
+    c0 + 2 (clamped at the right edge), c0 = the first pixel's left tap, and a pixel takes (c0, c0 + 1) or (c0 + 1, c0 + 2).  The C
+    entry point admits W % 4 == 0 and 3 iw <= W.  Here the kernel's fp32 arithmetic (bilinear_kernel's: src = max(s (x + 0.5)
+    - 0.5, 0), s = iw / W in fp32) is replayed in numpy for every admitted (iw, W) up to W = 1024: the pixel's own taps
+    (x0, min(x0 + 1, iw - 1)) are always the pair the group scheme selects.  (The tested sizes on the GPU are a handful; this is
+    the statement for all of them.  The same scan up to W = 16 384 finds no exception either: the real-arithmetic margin to an
+    integer boundary is a multiple of 1 / (2 W), far above fp32's error in the coordinate at these widths.)"""
+    import numpy as np
+    f32 = np.float32
+    checked = 0
+    for W in range(4, 1025, 4):
+        xx = np.arange(W, dtype=np.int64)
+        lead = xx & ~3
+        for iw in sorted({1, 2, 3, W // 8, W // 4, W // 3, max(1, W // 3 - 1), max(1, W // 5), max(1, (W * 3) // 10)}):
+            if iw < 1 or 3 * iw > W:
+                continue
+            s = f32(iw) / f32(W)
+            fx = np.maximum(s * (xx.astype(f32) + f32(0.5)) - f32(0.5), f32(0)).astype(f32)
+            fl = np.maximum(s * (lead.astype(f32) + f32(0.5)) - f32(0.5), f32(0)).astype(f32)
+            x0, c0 = fx.astype(np.int64), fl.astype(np.int64)
+            x1 = np.minimum(x0 + 1, iw - 1)
+            ck = x0 - c0
+            assert ck.min() >= 0 and ck.max() <= 1, (W, iw, ck.min(), ck.max())
+            cols = np.stack([c0, np.minimum(c0 + 1, iw - 1), np.minimum(c0 + 2, iw - 1)])  # what the group loads
+            left = np.where(ck == 1, cols[1], cols[0])
+            right = np.where(ck == 1, cols[2], cols[1])
+            assert np.array_equal(left, x0) and np.array_equal(right, x1), (W, iw)
+            assert x0.max() <= iw - 1
+            checked += 1
+    assert checked > 1500
