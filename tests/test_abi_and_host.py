@@ -578,3 +578,21 @@ def test_lazy_gram_geometry_holds_for_every_admitted_size():
             assert x0.max() <= iw - 1
             checked += 1
     assert checked > 1500
+
+
+def test_resize_commutes_with_the_linears_the_lazy_path_moves_across_it():
+    """What ops.LazySeg rests on (core/mix_transformer.py:364-373 followed by core/model_fusion.py:351-353): a bilinear resize is a
+    convex combination per channel (weights sum to 1), so conv3 / conv4 (1 x 1, bias) and channel_proj3 (Linear, bias) give the
+    same tensor before or after it - in float64 to rounding, at x 4, x 8 and a non-integer enlargement.  The ReLU does NOT commute,
+    which is why the kernels resize the projected rows and apply it afterwards."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(7)
+    for (ih, iw, H, W) in ((6, 8, 24, 32), (5, 7, 40, 56), (7, 9, 30, 52)):
+        x = torch.randn(2, 64, ih, iw, generator=g, dtype=torch.float64)
+        w = torch.randn(128, 64, generator=g, dtype=torch.float64) * 0.2
+        b = torch.randn(128, generator=g, dtype=torch.float64)
+        up = lambda t: F.interpolate(t, size=(H, W), mode="bilinear", align_corners=False)
+        lin = lambda t: F.conv2d(t, w[:, :, None, None], b)
+        a, c = lin(up(x)), up(lin(x))
+        assert float((a - c).abs().max()) < 1e-12 * float(a.abs().max()) + 1e-13
+        assert float((torch.relu(a) - up(torch.relu(lin(x)))).abs().max()) > 1e-3  # (the ReLU has to come after the resize)
