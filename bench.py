@@ -257,7 +257,7 @@ def train_leg(args, rank, world, seg, fus):
     return out
 
 
-def config_leg(backbone, B, H, W, steps):
+def config_leg(backbone, B, H, W, steps, graph=False):
     """A short timed forward leg of another BASELINE config (the same pair forward in the default arithmetic, inputs resident
     in HBM, one warm-up pass that also packs the weights): pairs/s and the whole-path rate."""
     import detweights as dw
@@ -286,10 +286,29 @@ def config_leg(backbone, B, H, W, steps):
     s1 = ops.range_stats()
     gf = GFLOP_PER_PAIR.get((backbone, H, W))
     rec = {"backbone": backbone, "height": H, "width": W, "pairs_per_step": B, "steps": steps, "warmup": 2,
-           "value": B / dt, "unit": "img-pairs/s", "ms_per_step": 1e3 * dt,
+           "value": B / dt, "unit": "img-pairs/s", "ms_per_step": 1e3 * dt, "launch": "eager",
            "f16x3_pairs_repeated": s1["images_repeated"] - s0["images_repeated"],
            "f16x3_pairs_repeated_fp32conv": s1["images_repeated_fp32conv"] - s0["images_repeated_fp32conv"],
            "f16x3_pairs_seen": s1["images"] - s0["images"]}
+    if graph:
+        # (r6) small steps are launch-bound (~900 launches for a 15 ms step at 4 pairs): the same step captured
+        # once into a hipGraph and replayed - same kernels, same guard (the graph carries its own range slots, read back after every
+        # replay; a tripped pair is repeated eagerly) - reported beside the eager figure
+        try:
+            with torch.no_grad():
+                pipe.capture(ir, vis, mask)
+                for _ in range(2):
+                    pipe(ir, vis, mask)
+                dist.fence()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    lab2 = pipe(ir, vis, mask)[1]
+                dist.fence()
+                dtg = (time.perf_counter() - t0) / steps
+            rec["hipgraph_replay"] = {"value": B / dtg, "ms_per_step": 1e3 * dtg, "labels_equal_eager": bool(torch.equal(lab2, labels))}
+            del lab2
+        except Exception as exc:  # (capture refused: the eager figure stands)
+            rec["hipgraph_replay"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     if gf is not None:
         rec["gflop_per_pair"] = {"executed": gf - gflop_removed_by_n4(H, W), "textbook_order": gf}
         rec["whole_path_tflops"] = B / dt * (gf - gflop_removed_by_n4(H, W)) / 1e3
@@ -432,7 +451,7 @@ def main():
         for key, cfg in (("config1_mit_b1_b4_480x640", ("mit_b1", 4, 480, 640)), ("config4_mit_b5_b2_1024x1024", ("mit_b5", 2, 1024, 1024)),
                          ("mit_b1_b64_480x640", ("mit_b1", 64, 480, 640))):
             try:
-                configs[key] = config_leg(*cfg, steps=3)
+                configs[key] = config_leg(*cfg, steps=3, graph=cfg[1] <= 8)
             except Exception as exc:
                 configs[key] = {"error": f"{type(exc).__name__}: {exc}"}
 

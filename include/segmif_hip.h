@@ -233,10 +233,11 @@ int segmif_sr_attention_bwd_f32(const float* q, const float* k, const float* v, 
  * pairs - 16-channel groups of [16 hi | 16 lo], the fp32 row's byte count - and max |y| folded into the f16x3 range slot of the
  * row's image (amax: amax_images words, rows / amax_images rows per image; NULL = no report).  Same arithmetic as
  * segmif_layernorm_f32 / segmif_dwconv3x3_gelu_f32 / segmif_sr_attention_split16_f32; C % 16 == 0.  The LayerNorm's waves are
- * short and numerous: it takes amax_sub (a power of two) consecutive ROWS of slots, amax_images words apart, and spreads its
+ * short and numerous: it takes amax_sub (a power of two) consecutive ROWS of slots, amax_pitch words apart (>= amax_images: the
+ * guard's own image count, which differs from amax_images when the launch reports to column 0 only), and spreads its
  * reports over them (a slot access serialises on its memory channel). */
 int segmif_layernorm_pairs_f32(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int C, int ldx,
-                               int ldy, float eps, uint32_t* amax, int amax_images, int amax_sub, void* stream);
+                               int ldy, float eps, uint32_t* amax, int amax_images, int amax_sub, int amax_pitch, void* stream);
 int segmif_dwconv3x3_gelu_pairs_f32(const float* x, const float* w9, const float* bias, void* y, int B, int H, int W, int C,
                                     uint32_t* amax, int amax_images, void* stream);
 int segmif_sr_attention_split16_pairs_f32(const float* q, const float* k, const float* v, void* out, void* workspace, int B,
@@ -326,6 +327,15 @@ int64_t segmif_planes16_bytes(int B, int H, int W, int chunks);
 int segmif_planes16_zero_border(void* planes, int B, int H, int W, int chunks, void* stream);
 int segmif_planes16_from_f32(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0, int nconv,
                              uint32_t* amax, int amax_images, void* stream);
+/* (r6) The fusion net's first convs, conv1_ir / conv1_vis (core/model_fusion.py:1029-1030, applied at :1051-1053 / :1055-1057 to
+ * ir[:, 0:1] / vis[:, 0:1]): 3 x 3 'same' conv from ONE channel to 64 + bias + activation (SEGMIF_ACT_*; prelu = the shared scalar
+ * slope) as a store-bound stencil.  x: (B, H, W) fp32, w: the raw (64, 1, 3, 3) weight, bias: 64 floats or NULL.  Outputs, at least
+ * one: `planes` - an f16x3 planes buffer of `chunks` chunks per image receiving chunks [chunk0, chunk0 + 4) (half pairs, max |y|
+ * folded into the range slots `amax`: amax_images = B words, one per image, or 1) - and / or `out`, (B, H, W, 64) fp32 rows with
+ * pixel pitch ldo.  Replaces the scalar-gather implicit GEMM for Cin = 1. */
+int segmif_conv3x3_c1_f16x3(const float* x, const float* w, const float* bias, const float* prelu, int act, void* planes,
+                            int chunks, int chunk0, float* out, int ldo, int B, int H, int W, uint32_t* amax, int amax_images,
+                            void* stream);
 int64_t segmif_planes16_weight_bytes(int N, int Cin, int taps);
 int segmif_planes16_pack_weight(const float* packed, int N, int Cin, int taps, int ldw, void* out, void* stream);
 int segmif_conv3x3_planes_f16x3(const SegmifConvPlanes* desc, uint32_t* amax, int amax_images, void* stream);
@@ -444,7 +454,9 @@ int segmif_sr_attention_split16_f32(const float* q, const float* k, const float*
 
 /*
  * Linear ("efficient") cross attention context, step 1: per (batch, head) partial sums of
- * K^T V over row blocks.  kv: (B, N, 2*C), C = heads*d, d == 8: k = cols [0,C), v = [C,2C).
+ * K^T V over row blocks.  kv: (B, N, 2*C), C = heads*d: k = cols [0,C), v = [C,2C).  heads = d = 8 (C = 64: the configuration
+ * Fusion_Network3_ac instantiates) runs the tuned kernels; (r6) any other geometry with C <= 64, d <= 8 - the ablation networks'
+ * dim-32 modules, core/model_fusion.py:363-429, :626-661 - a generic one with the same arithmetic.
  * partial: (B, nblk, heads*d*d) DOUBLES with nblk = segmif_linattn_num_blocks(N) (fp32 inside a
  * 32-row run, fp64 across runs: the sum feeds a softmax).
  * Step 2 (segmif_linattn_fold_f32) reduces the partials in fp64, applies
@@ -503,6 +515,11 @@ typedef struct SegmifCrossTail {
    * is a convex combination per channel, so it commutes with the Linear.  H, W must be set (H * W == N).  Replaces
    * F.interpolate at core/mix_transformer.py:364-373 for this consumer: the resized tensor never exists. */
   int32_t x3_ih, x3_iw;
+  /* (r6) arith_f16 != 0: the kernel's own contractions on f16x3 operands (half pairs x power-of-two-scaled half planes, three MFMA
+   * products per MAC instead of six bf16 ones) - for the lazy (x3_ih > 0), planes-only (out == NULL), f16x3-planes launch, inside a
+   * guarded scope: arith_amax = the range slot(s) receiving max |x_i| and max |interpolated y_3| (arith_amax_images == B: one per
+   * image; <= 1: arith_amax[0]). */
+  int32_t arith_f16; uint32_t* arith_amax; int32_t arith_amax_images;
 } SegmifCrossTail;
 
 int segmif_crosspath_gram_blocks(int64_t N);
@@ -530,6 +547,12 @@ int segmif_seg_normalize_f32(const float* x_nchw, float* y_nhwc, int B, int H, i
 int segmif_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int64_t HW, int ldo, void* stream);
 int segmif_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int64_t HW, int ldx, void* stream);
 int segmif_fuse_ycrcb_f32(const float* vis_nchw, const float* yf, float* out_nchw, int B, int64_t HW, void* stream);
+/* (r6) two-source pointwise pass over rows views (rows x C, pitches in floats, C % 4 == 0, 16-byte aligned) - the glue of the
+ * reference's ablation networks: mode 0 y = a + b (Fusion_Network3_Add, core/model_fusion.py:745-752); mode 1
+ * y = silu(a) + silu(b) (Fusion_Network3_Average's att_i(x) + att_j(seg): AttentionModule ends in sigmoid(z) * z, :769-770,
+ * :807-813); mode 2 y = silu(a) (AttentionModule alone; b may be NULL) */
+int segmif_pointwise2_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int64_t rows, int C, int mode,
+                          void* stream);
 /* RGB2YCrCb / YCrCb2RGB themselves (core/model_fusion.py:69-91, :93-111; called at train.py:355, :365) and their backward, on
  * planar (B, 3, HW) images: mode 0 RGB -> YCrCb; mode 1 YCrCb -> RGB (ysrc != NULL supplies channel 0 from a (B, 1, HW)
  * tensor: train.py:362-364's clone + slice assignment folded in); mode 2 backward of 0 (in = d/dYCrCb -> d/dRGB); mode 3

@@ -98,6 +98,12 @@ def main():
         for name, p in fus64.named_parameters():
             if name in small:
                 rec[name + "|f64"] = mgt.npy(p.grad.detach().reshape(-1))
+            elif p.grad is not None:
+                # (r6) every other tensor too: the gradient is an ill-conditioned function of the forward (it runs back through the
+                # CrossPath context softmaxes), so "distance to the float32 record" is a noisy yardstick at the 2e-3 level - a
+                # last-bit change in one forward kernel moved it from 1.7e-3 to 2.1e-3.  The float64 run is what both approximate.
+                rec[name + "|f64head"] = mgt.npy(p.grad.detach().reshape(-1)[:2048])
+                rec[name + "|f64norm"] = np.float64(p.grad.detach().norm())
         rec["loss1_f64"], rec["loss2_f64"] = np.float64(l1.detach()), np.float64(l2.detach())
         torch.set_default_dtype(torch.float32)
     path = os.path.join(OUT, "grads_fusion_step_b3_480x640.npz")

@@ -290,6 +290,86 @@ def fusion_network3_ac(sd, ir, vis, out1, out2, taps=None):
     return prelu(conv(f, "conv22", 1))
 
 
+# --- (r6) ablation / variant networks (core/model_fusion.py:363-1025) ---------------------------------------------------
+def cross_path_variant(sd, pfx, x1, x2, seg, use, heads=8, want_maps=False):
+    """CrossPath_M (use = 'v', ref :385-395), CrossPath_S ('z', :419-429), CrossPath / CrossPath_showAttention ('zv', :350-361,
+    :560-572): the attention(s) kept, end_proj over what they return."""
+    p1 = F.relu(_lin(x1, sd, pfx + ".channel_proj1"))
+    p2 = F.relu(_lin(x2, sd, pfx + ".channel_proj2"))
+    p3 = F.relu(_lin(seg, sd, pfx + ".channel_proj3"))
+    (y1, u1), (y2, u2), (y3, u3) = p1.chunk(2, dim=-1), p2.chunk(2, dim=-1), p3.chunk(2, dim=-1)
+    parts1, parts2, maps = [], [], {}
+    if "z" in use:
+        ctx1 = _linear_attention_context(_lin(y1, sd, pfx + ".cross_attn2.kv1"), heads)
+        ctx2 = _linear_attention_context(_lin(y2, sd, pfx + ".cross_attn2.kv2"), heads)
+        maps["z1"], maps["z2"] = _apply_context(y3, ctx1, heads), _apply_context(y3, ctx2, heads)
+        parts1.append(maps["z1"])
+        parts2.append(maps["z2"])
+    if "v" in use:
+        ctx3 = _linear_attention_context(_lin(u3, sd, pfx + ".cross_attn.kv3"), heads)
+        maps["v1"], maps["v2"] = _apply_context(u1, ctx3, heads), _apply_context(u2, ctx3, heads)
+        parts1.append(maps["v1"])
+        parts2.append(maps["v2"])
+    o1 = _ln(x1 + _lin(torch.cat(parts1, dim=-1), sd, pfx + ".end_proj1"), sd, pfx + ".norm1", DEFAULT_LN_EPS)
+    o2 = _ln(x2 + _lin(torch.cat(parts2, dim=-1), sd, pfx + ".end_proj2"), sd, pfx + ".norm2", DEFAULT_LN_EPS)
+    if want_maps:
+        return o1, o2, [maps["v1"], maps["z1"], maps["z2"], maps["v2"]]
+    return o1, o2
+
+
+def ffm_variant(sd, pfx, x1, x2, seg, use):
+    """FeatureFusionModule / _SoAM / _MoAM / _ShowAttention (ref :453-463, :490-501, :526-536, :596-605): tokens, CrossPath*, back."""
+    B, C, H, W = x1.shape
+    tok = lambda t: t.flatten(2).transpose(1, 2)
+    o1, o2 = cross_path_variant(sd, pfx + ".cross", tok(x1), tok(x2), tok(seg), use)
+    img = lambda t: t.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+    return img(o1), img(o2)
+
+
+def attention_module(sd, pfx, x):
+    """AttentionModule (ref :759-770): z = conv(relu(conv(x))); sigmoid(z) * z."""
+    z = F.conv2d(F.relu(F.conv2d(x, sd[pfx + ".conv.0.weight"], sd[pfx + ".conv.0.bias"], padding=1)),
+                 sd[pfx + ".conv.2.weight"], sd[pfx + ".conv.2.bias"], padding=1)
+    return torch.sigmoid(z) * z
+
+
+def fusion_variant(sd, name, ir, vis, out1=None, out2=None):
+    """The reference's ablation networks by class name: Fusion_Network3 (:643-660), _S (:838-854), _M (:873-889),
+    _obtainattention (:913-932), _Con (:680-711), _Add (:732-757), _Average (:796-819), Fusion_Network_rmseg (:949-979),
+    Fusion_Network_rmseg_att (:996-1025).  Returns what the class's forward returns."""
+    a = sd["relu.weight"]
+    prelu = lambda t: F.prelu(t, a)
+    conv = lambda t, n, pad: F.conv2d(t, sd[n + ".weight"], sd[n + ".bias"], padding=pad)
+    x1 = drdb(sd, "DRDB1", prelu(conv(ir[:, 0:1], "conv1_ir", 1)))
+    x2 = drdb(sd, "DRDB2", prelu(conv(vis[:, 0:1], "conv1_vis", 1)))
+    if name in ("Fusion_Network_rmseg", "Fusion_Network_rmseg_att"):
+        x1, x2 = drdb(sd, "DRDB3", x1), drdb(sd, "DRDB4", x2)
+        f = prelu(conv(prelu(conv(prelu(conv(torch.cat([x1, x2], dim=1), "conv2", 1)), "conv21", 1)), "conv22", 1))
+        return f if name == "Fusion_Network_rmseg" else (f, [x1, x2])
+    s1, s2 = conv(out1, "conv3", 0), conv(out2, "conv4", 0)
+    a_in = [x1, x2]
+    if name in ("Fusion_Network3", "Fusion_Network3_S", "Fusion_Network3_M", "Fusion_Network3_obtainattention"):
+        use = {"Fusion_Network3_S": "z", "Fusion_Network3_M": "v"}.get(name, "zv")
+        mix = lambda p, q, s, stage: ffm_variant(sd, "ffm", p, q, s, use)
+    elif name == "Fusion_Network3_Con":
+        mix = lambda p, q, s, stage: (conv(torch.cat([p, s], dim=1), ("conv211", "conv411")[stage], 1),
+                                      conv(torch.cat([q, s], dim=1), ("conv221", "conv421")[stage], 1))
+    elif name == "Fusion_Network3_Add":
+        mix = lambda p, q, s, stage: (conv(p + s, ("conv211", "conv411")[stage], 1), conv(q + s, ("conv221", "conv421")[stage], 1))
+    elif name == "Fusion_Network3_Average":
+        mix = lambda p, q, s, stage: (
+            attention_module(sd, f"att{1 + 4 * stage}", p) + attention_module(sd, f"att{2 + 4 * stage}", s),
+            attention_module(sd, f"att{3 + 4 * stage}", q) + attention_module(sd, f"att{4 + 4 * stage}", s))
+    else:
+        raise KeyError(name)
+    x1, x2 = mix(x1, x2, s1, 0)
+    x1, x2 = drdb(sd, "DRDB3", x1), drdb(sd, "DRDB4", x2)
+    x1, x2 = mix(x1, x2, s2, 1)
+    f2 = conv(torch.cat([x1, x2], dim=1), "conv2", 1)
+    f = prelu(conv(prelu(f2), "conv21", 1))
+    return (f, a_in + [f2]) if name == "Fusion_Network3_obtainattention" else f
+
+
 # --- colour transforms ----------------------------------------------------------------------
 def rgb2ycrcb(x):
     """core/model_fusion.py:69-91 (coefficients :75-77)."""

@@ -71,6 +71,7 @@ class SegmifCrossTail(ctypes.Structure):
         ("planes_out", c_void_p), ("H", c_int32), ("W", c_int32), ("planes_chunks", c_int32),
         ("planes_f16", c_int32), ("planes_amax", c_void_p), ("planes_amax_images", c_int32),
         ("x3_ih", c_int32), ("x3_iw", c_int32),
+        ("arith_f16", c_int32), ("arith_amax", c_void_p), ("arith_amax_images", c_int32),
     ]
 
 
@@ -120,7 +121,7 @@ SIGNATURES = {
     "segmif_pairs_from_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "segmif_pairs_to_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "segmif_layernorm_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
-                                         c_int, c_int, c_void_p]),
+                                         c_int, c_int, c_int, c_void_p]),
     "segmif_dwconv3x3_gelu_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                               c_void_p]),
     "segmif_sr_attention_split16_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -224,6 +225,9 @@ SIGNATURES = {
     "segmif_nchw_to_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
     "segmif_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
     "segmif_fuse_ycrcb_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "segmif_conv3x3_c1_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_void_p, c_int, c_void_p]),
+    "segmif_pointwise2_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "segmif_argmax_nhwc_i32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
 }
 

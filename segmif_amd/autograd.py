@@ -557,7 +557,8 @@ class SrAttentionFn(torch.autograd.Function):
         heads, scale = ctx.heads, ctx.scale
         do = do.contiguous()
         B, N, C = q.shape
-        if SrAttentionFn.FUSED and C == heads * 64 and q.is_contiguous() and kv.is_contiguous() and out.is_contiguous():
+        if SrAttentionFn.FUSED and C == heads * 64 and q.is_contiguous() and kv.is_contiguous() and out.is_contiguous() \
+                and ops.aligned16(q, kv, out, do):  # (r6, ADVICE r5: unaligned storage takes the materialising path below instead of EINVAL)
             dq, dkv = ops.sr_attention_bwd(q, kv, out, do, heads, scale)
             return dq, dkv, None, None
         Nk = kv.shape[1]

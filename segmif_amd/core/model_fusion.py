@@ -3,8 +3,8 @@
 Mirror of the classes the reference's scripts use from core/model_fusion.py: WeTr (:9-68),
 RGB2YCrCb / YCrCb2RGB (:69-111), DRDB (:117-157), CrossAttention / CrossAttention2 (:250-328),
 CrossPath (:329-361), FeatureFusionModule (:430-463), Fusion_Network3_ac (:1026-1067),
-Network3 (:1068-1104) — same constructor/forward signatures and state_dict keys.  The ~20 unused
-ablation variants of that file are out of scope.
+Network3 (:1068-1104) — same constructor/forward signatures and state_dict keys.  (r6) The file's
+ablation / variant classes (Fusion_Network3 and the rest) are in .variants and re-exported here.
 
 Layout: every feature map is NHWC.  A DRDB owns one (B, H, W, 224) buffer; each dilated conv reads
 the first Cin channels and writes its 32 output channels in place (the five torch.cat copies of
@@ -13,7 +13,6 @@ softmax and Q@ctx are folded into a per-image end_proj weight (csrc/linattn.hip)
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import autograd as ag
 from .. import ops
@@ -24,6 +23,7 @@ from .segformer_head import SegFormerHead
 import os
 
 _DRDB_RES_PLANES = os.environ.get("SEGMIF_DRDB_RES", "planes") != "fp32"
+_CONV1_STENCIL = os.environ.get("SEGMIF_CONV1", "stencil") != "igemm"  # A/B switch (r6): conv1_ir / conv1_vis as a stencil kernel
 
 __all__ = ["WeTr", "RGB2YCrCb", "YCrCb2RGB", "DRDB", "CrossAttention", "CrossAttention2", "CrossPath",
            "FeatureFusionModule", "Fusion_Network3_ac", "Network3", "Mean", "fuse_to_rgb"]
@@ -574,11 +574,23 @@ class Fusion_Network3_ac(nn.Module):
             lambda: up(ops.linear(f2, self._w("conv4"), 64, bias=self.conv4.bias)))
 
     def _forward_eval(self, ir, vis, seg1_fn, seg2_fn):
+        if all(d.planes_ok() for d in (self.DRDB1, self.DRDB2, self.DRDB3, self.DRDB4)):
+            return self._forward_eval_planes(ir, vis, seg1_fn, seg2_fn)
+        return self._eval_buffers_body(ir, vis, seg1_fn, seg2_fn)
+
+    def _eval_dispatch(self, ir, vis, seg1_fn, seg2_fn):
+        """The body a guarded scope runs and, on a trip, runs AGAIN: re-reads the conv mode each time, so that the repeat
+        finish_guarded makes under set_conv3x3_mode('fp32') (an ill-conditioned CrossPath softmax) really is the exact-fp32
+        buffer path - (r6, ADVICE r5: the planes body ignores the mode, and a standalone call's 'exact' repeat had silently
+        been a bf16x6 planes repeat)."""
+        if all(d.planes_ok() for d in (self.DRDB1, self.DRDB2, self.DRDB3, self.DRDB4)):
+            return self._eval_planes_body(ir, vis, seg1_fn, seg2_fn)
+        return self._eval_buffers_body(ir, vis, seg1_fn, seg2_fn)
+
+    def _eval_buffers_body(self, ir, vis, seg1_fn, seg2_fn):
         B, _, H, W = ir.shape
         dev, slope = ir.device, self.relu.weight
         PRELU = ops.ACT_PRELU
-        if all(d.planes_ok() for d in (self.DRDB1, self.DRDB2, self.DRDB3, self.DRDB4)):
-            return self._forward_eval_planes(ir, vis, seg1_fn, seg2_fn)
         bufs = []
         for x, conv, drdb in ((ir, self.conv1_ir, self.DRDB1), (vis, self.conv1_vis, self.DRDB2)):
             buf = drdb.new_buffer(B, H, W, dev)
@@ -609,8 +621,10 @@ class Fusion_Network3_ac(nn.Module):
         forward): half pairs while a guard is active, and the scope repeats the forward on bf16 triples if a planes tensor
         left the half's exponent range."""
         before = ops.range_fallbacks()
-        out = ops.run_guarded(lambda: self._eval_planes_body(ir, vis, seg1_fn, seg2_fn), ir.device,
-                              enabled=ops.conv3x3_mode() == "planes16")
+        # (images = the batch: the scope's guard then has per-image rows and the conditioning half of the guard sees this call's
+        # CrossPath softmaxes; no per-image redo here - a tripped standalone call repeats as a whole)
+        out = ops.run_guarded(lambda: self._eval_dispatch(ir, vis, seg1_fn, seg2_fn), ir.device,
+                              enabled=ops.conv3x3_mode() == "planes16", images=ir.shape[0])
         self.planes16_fallbacks += ops.range_fallbacks() - before
         return out
 
@@ -629,6 +643,11 @@ class Fusion_Network3_ac(nn.Module):
         for x, conv, name in ((ir, self.conv1_ir, "conv1_ir"), (vis, self.conv1_vis, "conv1_vis")):
             pls.append(ops.Planes(B, H, W, DRDB.PLANES_CHUNKS, dev, guard))
             # conv1 writes its 64 channels split, as the DRDB's first four chunks (and as fp32 - the DRDB's residual input - unless lean)
+            if pls[-1].f16 and _CONV1_STENCIL and conv.weight.is_contiguous():
+                # (r6) Cin = 1: a store-bound stencil, not a K = 9 scalar-gather GEMM (2.4 -> ~1 ms per 64-image launch)
+                xs.append(ops.conv3x3_c1(self._first_channel_nhwc(x), conv.weight, bias=conv.bias, act=PRELU, prelu=slope,
+                                         planes=pls[-1], planes_only=lean))
+                continue
             xs.append(ops.conv2d(self._first_channel_nhwc(x), self._w(name), 64, 3, pad=1, bias=conv.bias, act=PRELU,
                                  prelu=slope, planes=pls[-1], planes_only=lean))
         y1 = self.DRDB1.forward_planes(xs[0], pls[0], preloaded=True)
@@ -676,6 +695,22 @@ class Fusion_Network3_ac(nn.Module):
     planes16_fallbacks = 0  # forwards repeated on the bf16x6 kernels because the f16x3 range guard tripped
 
 
+def seg_criterion_loss(seg, label, criterion):
+    """criterion(bilinear-up(seg -> label size), label) for NHWC logits `seg` (ref :1095-1096, :241-244).  With the criterion
+    train.py builds - nn.CrossEntropyLoss(ignore_index=...), mean reduction, no class weights - the whole chain (x4 bilinear,
+    softmax-CE with ignore_index, their backward) runs in two HIP kernels.  Any other criterion is the CALLER's code: it receives
+    the up-sampled logits as an NCHW view of the HIP bilinear kernel's output (with its HIP backward) - (r6) no F.interpolate, no
+    aten op of this package's own on the way."""
+    H, W = label.shape[1:]
+    up = ag.bilinear(seg, H, W) if seg.requires_grad else ops.bilinear(seg, H, W)
+    # the HIP CE kernel holds a row's logits in 32 registers; labels outside [0, C) other than ignore_index are
+    # treated as ignored there (torch raises), so the data pipeline must already guarantee the range (train.py's does)
+    if isinstance(criterion, nn.CrossEntropyLoss) and criterion.weight is None and criterion.reduction == "mean" \
+            and getattr(criterion, "label_smoothing", 0.0) == 0.0 and seg.shape[-1] <= 32:
+        return ag.softmax_ce(up, label.type(torch.long), criterion.ignore_index)
+    return criterion(ops.as_nchw(up), label.type(torch.long))
+
+
 class Network3(nn.Module):
     def __init__(self, backbone, num_classes=20, embedding_dim=256, pretrained=True):
         super().__init__()
@@ -719,18 +754,8 @@ class Network3(nn.Module):
         return ops.argmax_nhwc(ops.bilinear(seg, H, W))
 
     def _loss(self, fused_seg1, label, criterion):
-        """CE(bilinear-up(seg_map), label) (ref :1090-1097).  With an nn.CrossEntropyLoss criterion the
-        whole chain (x4 bilinear, softmax-CE with ignore_index, their backward) runs in HIP kernels."""
-        seg = self._segment_nhwc(fused_seg1)
-        H, W = label.shape[1:]
-        # the HIP CE kernel holds a row's logits in 32 registers; labels outside [0, C) other than ignore_index are
-        # treated as ignored there (torch raises), so the data pipeline must already guarantee the range (train.py's does)
-        if isinstance(criterion, nn.CrossEntropyLoss) and criterion.weight is None and criterion.reduction == "mean" \
-                and getattr(criterion, "label_smoothing", 0.0) == 0.0 and seg.shape[-1] <= 32:
-            up = ag.bilinear(seg, H, W) if seg.requires_grad else ops.bilinear(seg, H, W)
-            return ag.softmax_ce(up, label.type(torch.long), criterion.ignore_index)
-        outputs = F.interpolate(ops.as_nchw(seg), size=label.shape[1:], mode='bilinear', align_corners=False)
-        return criterion(outputs, label.type(torch.long))
+        """CE(bilinear-up(seg_map), label) (ref :1090-1097): seg_criterion_loss below."""
+        return seg_criterion_loss(self._segment_nhwc(fused_seg1), label, criterion)
 
     def denoise_net_parameters(self):
         return self.denoise_net.parameters()
@@ -754,3 +779,11 @@ class Mean(nn.Module):
         rgb = ops.fuse_ycrcb(vis, mask[:, 0:1])
         lo, hi = rgb.min(), rgb.max()
         return (rgb - lo) / (hi - lo)
+
+
+# (r6) the reference's ablation / variant classes (core/model_fusion.py:158-1025) live in .variants and are part of this module's
+# namespace like upstream: `from core.model_fusion import Fusion_Network3` (val_performance.py:565) resolves here.
+from .variants import *  # noqa: E402,F401,F403
+from . import variants as _variants  # noqa: E402
+
+__all__ += _variants.__all__

@@ -108,16 +108,21 @@ class SegFormerHead(nn.Module):
             p for m in mlps for p in (m.proj.weight, m.proj.bias))
 
         def build():
+            # (r6) weight preparation, once per parameter version, on the HOST in float64 - like the optimizer's bias corrections:
+            # ~1.5 MB down, 1 MB up; the device-side float64 `@` it replaces went through rocBLAS (Cijk_* / gemvt kernels in the
+            # forward table)
+            dev = fuse.conv.weight.device
             E = fuse.conv.out_channels
-            s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
-            wf = fuse.conv.weight.double().flatten(1) * s[:, None]  # (E, 4E), columns in cat order [c4 c3 c2 c1]
-            shift = bn.bias.double() - bn.running_mean.double() * s
+            h = lambda t: t.detach().to("cpu", torch.float64)
+            s = h(bn.weight) / torch.sqrt(h(bn.running_var) + bn.eps)
+            wf = h(fuse.conv.weight).flatten(1) * s[:, None]  # (E, 4E), columns in cat order [c4 c3 c2 c1]
+            shift = h(bn.bias) - h(bn.running_mean) * s
             ws = []
             for slot, m in enumerate(mlps):
                 blk = wf[:, slot * E:(slot + 1) * E]
-                ws.append(ops.pack_weight((blk @ m.proj.weight.double()).float().contiguous()))
-                shift = shift + blk @ m.proj.bias.double()
-            return ws, shift.float().contiguous()
+                ws.append(ops.pack_weight((blk @ h(m.proj.weight)).float().contiguous().to(dev)))
+                shift = shift + blk @ h(m.proj.bias)
+            return ws, shift.float().contiguous().to(dev)
 
         return self._pk.get_multi("per_scale_fused", srcs, build)
 

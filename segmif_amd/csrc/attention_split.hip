@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       // score in the key loop
       if constexpr (F16) {
         qh[s] = split8h(lo * (scale * 1.44269504088896340736f), hi * (scale * 1.44269504088896340736f));
-        amx = p16::absmax_pk4(amx, qh[s].hi);
+        amx = p16::absmax_pk4(amx, qh[s].hi, qh[s].lo);
       } else {
         qp[s] = split8(lo * (scale * 1.44269504088896340736f), hi * (scale * 1.44269504088896340736f));
       }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
           unsigned char* d8 = reinterpret_cast<unsigned char*>(orow) + (c >> 4) * 64 + (c & 15) * 2;
           *reinterpret_cast<u32x2*>(d8) = u32x2{ha, hb};
           *reinterpret_cast<u32x2*>(d8 + 32) = u32x2{la, lb};
-          oamx = p16::absmax_pk(p16::absmax_pk(oamx, ha), hb);
+          oamx = p16::absmax_pk(p16::absmax_pk(oamx, ha, la), hb, lb);
         } else {
           *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) = w;
         }

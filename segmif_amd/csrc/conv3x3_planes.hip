@@ -524,7 +524,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (F16) {
           p16::split8(y + 8 * q, pl[0], pl[1]);
           pl[2] = pl[1];
-          const uint32_t mx = p16::absmax_pk4(amx, pl[0]);
+          const uint32_t mx = p16::absmax_pk4(amx, pl[0], pl[1]);
           amx = ok ? mx : amx;
         } else {
           split8(y + 8 * q, pl[0], pl[1], pl[2]);
@@ -703,7 +703,7 @@ __global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, uns
     }
     if (amax) {  // a wave covers consecutive pixels: images of its first and last lane (conservative when it straddles two)
       const int b_lo = __shfl(b, 0, 64), b_hi = __shfl(b, 63, 64);
-      p16::fold_pat(amax, amax_images > 1 ? b_lo : 0, amax_images > 1 ? b_hi : 0, live ? p16::absmax_pk4(0u, p0) : 0u);
+      p16::fold_pat(amax, amax_images > 1 ? b_lo : 0, amax_images > 1 ? b_hi : 0, live ? p16::absmax_pk4(0u, p0, p1) : 0u);
     }
   } else {
     u32x4 p0, p1, p2;
@@ -712,6 +712,81 @@ __global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, uns
     *reinterpret_cast<u32x4*>(dst + 32) = p1;
     *reinterpret_cast<u32x4*>(dst + 64) = p2;
   }
+}
+
+// (r6) conv1_ir / conv1_vis of the fusion net (core/model_fusion.py:1029-1030, :1051-1053, :1055-1057): a 3 x 3 'same' conv from ONE
+// channel to 64, + bias + the shared PReLU, written as the first DRDB's input planes (half pairs, chunks chunk0 .. chunk0 + 3) and /
+// or as fp32 rows.  As an implicit GEMM this was K = 9 gathered scalar by scalar (igemm<128,64,..,generic>: 2.4 ms per 64-image
+// launch, matrix pipe 11 % busy); it is 18 flops per output value against 4 output bytes - a store-bound stencil.  One wave = one
+// 16-channel chunk x 32 consecutive pixels x the two halves of the chunk: a lane keeps its 8 channels' 72 taps + 8 biases in
+// registers for the workgroup's whole run of pixels (all inside ONE image: a single range report per workgroup), reads its
+// pixel's 3 x 3 window (nine loads shared by the lane pair, neighbours one float apart), and stores one 16-byte piece per plane:
+// a wave's two store instructions together fill 2 KB of contiguous planes memory.  Store traffic 256 B per pixel = 5.0 GB per
+// 64 images: ~0.8 ms at the achievable 6.3 TB/s.
+constexpr int C1_PIX = 32;  // pixels per workgroup step (4 waves = the 4 chunks of the 64 output channels)
+__global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const float* __restrict__ prelu, int act,
+                                                         unsigned char* __restrict__ planes, int total, int chunk0,
+                                                         float* __restrict__ out, int ldo, int H, int W, int Hp, int Wp, int steps,
+                                                         uint32_t* __restrict__ amax, int amax_images) {
+  const int tid = threadIdx.x, lane = tid & 63, c = tid >> 6, hf = lane & 1, pl = lane >> 1;
+  const int b = blockIdx.y;
+  const long long npix = (long long)H * W;
+  float wt[8][9], bs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int n = 16 * c + 4 * hf + (e & 3) + 8 * (e >> 2);  // position 8 hf + e of chunk c (sigma order)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[e][t] = w[n * 9 + t];
+    bs[e] = bias ? bias[n] : 0.f;
+  }
+  const float slope = act == SEGMIF_ACT_PRELU ? prelu[0] : 0.f;
+  const float* xb = x + (long long)b * npix;
+  unsigned char* pb = planes ? planes + ((long long)b * total + chunk0 + c) * Hp * (long long)Wp * PXH : nullptr;
+  float* ob = out ? out + (long long)b * npix * ldo : nullptr;
+  uint32_t amx = 0u;
+  for (int it = 0; it < steps; ++it) {
+    const long long pix = ((long long)blockIdx.x * steps + it) * C1_PIX + pl;
+    const bool live = pix < npix;
+    const long long pc = live ? pix : npix - 1;
+    const int yy = (int)(pc / W), xx = (int)(pc - (long long)yy * W);
+    float win[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int sy = yy + dy - 1, sx = xx + dx - 1;
+        const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+        const float v = xb[(long long)(in ? sy : yy) * W + (in ? sx : xx)];  // (unconditional load from a valid address)
+        win[dy * 3 + dx] = in ? v : 0.f;
+      }
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = bs[e];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) a = fmaf(win[t], wt[e][t], a);
+      if (act == SEGMIF_ACT_RELU) a = fmaxf(a, 0.f);
+      else if (act == SEGMIF_ACT_PRELU) a = a > 0.f ? a : a * slope;
+      y[e] = a;
+    }
+    if (ob && live) {
+      float* o = ob + pix * ldo + 16 * c + 4 * hf;
+      *reinterpret_cast<f32x4*>(o) = f32x4{y[0], y[1], y[2], y[3]};
+      *reinterpret_cast<f32x4*>(o + 8) = f32x4{y[4], y[5], y[6], y[7]};
+    }
+    if (pb) {
+      u32x4 p0, p1;
+      p16::split8(y, p0, p1);
+      if (live) {
+        unsigned char* dst = pb + ((long long)(yy + PB) * Wp + xx + PB) * PXH + hf * 16;
+        *reinterpret_cast<u32x4*>(dst) = p0;
+        *reinterpret_cast<u32x4*>(dst + 32) = p1;
+        amx = p16::absmax_pk4(amx, p0, p1);
+      }
+    }
+  }
+  if (pb && amax) p16::fold_pat(amax, amax_images > 1 ? b : 0, amax_images > 1 ? b : 0, amx);
 }
 
 // zero the border / round-up region of every chunk image: one block per padded row
@@ -844,6 +919,27 @@ extern "C" int segmif_planes_from_f32(const float* x, int ldx, void* planes, int
 extern "C" int segmif_planes16_from_f32(const float* x, int ldx, void* planes, int B, int H, int W, int chunks, int chunk0,
                                         int nconv, uint32_t* amax, int amax_images, void* stream) {
   return planes_from_f32_impl<true>(x, ldx, planes, B, H, W, chunks, chunk0, nconv, amax, amax_images, stream);
+}
+
+extern "C" int segmif_conv3x3_c1_f16x3(const float* x, const float* w, const float* bias, const float* prelu, int act, void* planes,
+                                       int chunks, int chunk0, float* out, int ldo, int B, int H, int W, uint32_t* amax,
+                                       int amax_images, void* stream) {
+  if (!x || !w || (!planes && !out) || B <= 0 || H <= 0 || W <= 0 || act < 0 || act > SEGMIF_ACT_PRELU) return SEGMIF_EINVAL;
+  if (act == SEGMIF_ACT_PRELU && !prelu) return SEGMIF_EINVAL;
+  if (planes && (chunk0 < 0 || chunk0 + 4 > chunks || ((uintptr_t)planes & 15) || (amax && amax_images != 1 && amax_images != B)))
+    return SEGMIF_EINVAL;
+  if (out && (ldo < 64 || (ldo & 3) || ((uintptr_t)out & 15))) return SEGMIF_EINVAL;
+  const long long npix = (long long)H * W;
+  const long long groups = (npix + C1_PIX - 1) / C1_PIX;
+  // workgroups per image: about four per CU over the batch, each a run of `steps` 32-pixel groups inside one image
+  long long per_image = (1024 + B - 1) / B;
+  if (per_image > groups) per_image = groups;
+  if (per_image < 1) per_image = 1;
+  const int steps = (int)((groups + per_image - 1) / per_image);
+  const unsigned gx = (unsigned)((groups + steps - 1) / steps);
+  hipLaunchKernelGGL(conv3x3_c1_kernel, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, prelu, act,
+                     (unsigned char*)planes, chunks, chunk0, out, ldo, H, W, planes_hp(H), planes_wp(W), steps, amax, amax_images);
+  return (int)hipGetLastError();
 }
 
 extern "C" int64_t segmif_planes_weight_bytes(int N, int Cin, int taps) {

@@ -130,6 +130,70 @@ __device__ __forceinline__ void wfrag(const unsigned char* base, int row, int pi
   for (int k = 0; k < 3; ++k) out[k] = *reinterpret_cast<const u32x4*>(a + k * plane_bytes);
 }
 
+// ---- (r6) f16x3 arithmetic for the tail (planes16.h): weights as three half planes W0 | W - W0 | 2^-11 W0 of the row scaled by a
+// power of two, activations as half pairs split in registers; three products per MAC, least significant first: lo W0s, hi Wl, hi W0
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct Op2 {
+  u32x4 hi, lo;
+};
+__device__ __forceinline__ Op2 split8h(const f32x4 a, const f32x4 b) {
+  const float y[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  Op2 o;
+  p16::split8(y, o.hi, o.lo);
+  return o;
+}
+__device__ __forceinline__ Op2 split8h(const f32x16 t, int s) {  // accumulator registers 8s .. 8s+7
+  return split8h(f32x4{t[8 * s], t[8 * s + 1], t[8 * s + 2], t[8 * s + 3]},
+                 f32x4{t[8 * s + 4], t[8 * s + 5], t[8 * s + 6], t[8 * s + 7]});
+}
+__device__ __forceinline__ f16x8 oph(const u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+// acc += W X with the weight planes `w` as the MFMA's first operand (rows) and the half pair `x` as its second
+__device__ __forceinline__ f32x16 mma3(const u32x4* w, const Op2& x, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oph(w[2]), oph(x.lo), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oph(w[1]), oph(x.hi), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oph(w[0]), oph(x.hi), acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ void split3h(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 w0 = {(_Float16)x0, (_Float16)x1};
+  const h2 wl = {(_Float16)(x0 - (float)w0[0]), (_Float16)(x1 - (float)w0[1])};
+  const h2 ws = {(_Float16)((float)w0[0] * (1.f / p16::LSCALE)), (_Float16)((float)w0[1] * (1.f / p16::LSCALE))};
+  p0 = __builtin_bit_cast(uint32_t, w0);
+  p1 = __builtin_bit_cast(uint32_t, wl);
+  p2 = __builtin_bit_cast(uint32_t, ws);
+}
+__device__ __forceinline__ float pow2_scale(float mx) {  // brings mx into [2^14, 2^15); 1 for zero / non-finite
+  int e = 0;
+  if (mx >= 1e-30f && mx <= 3e38f) e = 14 - (int)((__float_as_uint(mx) >> 23) - 127);
+  return ldexpf(1.f, e);
+}
+// f16x3 LDS image of 64 rows x NCOL columns (64 | 128) of a row-major fp32 matrix, same positions as stage_split64; the row
+// scale 2^-e(n) goes to inv[n].  One row per LPR lanes (a half-wave for 64 columns, a wave for 128): its maximum is a
+// shuffle reduction.  Must be called by all `nthreads` threads (a multiple of 64).
+template <int NCOL>
+__device__ __forceinline__ void stage_split_h(const float* __restrict__ w, int ldw, unsigned char* dst, int pitch, float* inv,
+                                              int tid, int nthreads) {
+  constexpr int LPR = NCOL / 2;  // lanes (pairs of columns) per row
+  for (int u = tid; u < 64 * LPR; u += nthreads) {
+    const int row = u / LPR, pp = 2 * (u % LPR);
+    const int s = pp >> 4, hh = (pp >> 3) & 1, j = pp & 7;
+    const int col = 16 * s + 4 * hh + (j & 3) + 8 * (j >> 2);
+    const f32x2 v = *reinterpret_cast<const f32x2*>(w + (long long)row * ldw + col);
+    float mx = fmaxf(fabsf(v[0]), fabsf(v[1]));
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float sc = pow2_scale(mx);
+    uint32_t a, b, c;
+    split3h(v[0] * sc, v[1] * sc, a, b, c);
+    unsigned char* d = dst + row * pitch + pp * 2;
+    *reinterpret_cast<uint32_t*>(d) = a;
+    *reinterpret_cast<uint32_t*>(d + NCOL * 2) = b;
+    *reinterpret_cast<uint32_t*>(d + NCOL * 4) = c;
+    if (u % LPR == 0) inv[row] = 1.f / sc;
+  }
+}
+
 // deterministic reduction of the waves' Gram accumulators, then one fp64 partial per workgroup (shared by the two Gram kernels)
 __device__ __forceinline__ void gram_reduce_store(const f32x16* g, double* Red, double* __restrict__ partial, int b, int tid, int lane,
                                                   int wave) {
@@ -477,6 +541,8 @@ struct TailK {
   float eps;
   int ih, iw;                         // LAZY: x3 is the (B, ih x iw, ld3) low-resolution map of PROJECTED rows (see below); W = image width
   float sy, sx;                       // LAZY: ih / H, iw / W (the resize's source step, as segmif_bilinear_nhwc_f32 forms it)
+  uint32_t* ar_amax;                  // A16: range slot(s) for the operands the kernel splits (x_i, the interpolated y_3) or null
+  int ar_amax_images;
 };
 
 // F16: the planes copy is an f16x3 one (its own instantiation: the bf16 kernel sits at the register limit).
@@ -494,8 +560,16 @@ struct TailK {
 // s_waitcnt vmcnt(0) - draining the x_i prefetch (HBM latency) four times per tile and the previous tile's stores at its top; that
 // made the first LAZY version 11 % faster instead of the third its traffic promised.  OUT = false: no fp32 output exists in the
 // instantiation at all (the planes copy is the only consumer - the forward's hot case); OUT = true: p.out is checked at run time.
-template <bool F16, bool LAZY, bool OUT>
+// A16 (r6; LAZY, planes-only instantiation): the kernel's own contractions on f16x3 operands - Wi and the per-image Weff staged as
+// power-of-two-scaled half planes (row scales in LDS, found while staging), x_i / the interpolated y_3 / relu(channel_proj_i) split
+// into half pairs in registers: 72 MFMAs and the two-way splits per 32-pixel tile instead of 144 and the three-way ones.  Round 4
+// built this for the kernel that still read x_3 from HBM and measured nothing (it moved 768 B per pixel: HBM-bound); with the
+// segmentation feature read at its own resolution the tail is bound by exactly this work.  Inside a guarded scope
+// only: max |x_i| and max |y_3| go to their own range slot (ar_amax), an overflow of the un-tracked relu(channel_proj_i) turns
+// the output into inf / NaN, which the planes copy's slot reports.
+template <bool F16, bool LAZY, bool OUT, bool A16 = false>
 __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
+  static_assert(!A16 || (F16 && LAZY && !OUT), "f16x3 arithmetic: the forward's hot instantiation only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* W3s = smem_raw;             // [64][WPB]
   unsigned char* Wis = W3s + 64 * WPB;       // [64][WPB]
@@ -505,11 +579,18 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
   if constexpr (!LAZY) stage_split64(p.w3, 64, 0, W3s, WPB, 0, 128, tid, 512);
-  stage_split64(p.wi, 64, 0, Wis, WPB, 0, 128, tid, 512);
+  if constexpr (A16) {  // (Cst + 384: 2^-e of Wi's rows, Cst + 448: of this image's Weff rows)
+    stage_split_h<64>(p.wi, 64, Wis, WPB, Cst + 384, tid, 512);
+    stage_split_h<128>(p.weff + (long long)b * 64 * 128, 128, Wes, WPB2, Cst + 448, tid, 512);
+  } else {
+    stage_split64(p.wi, 64, 0, Wis, WPB, 0, 128, tid, 512);
+  }
   {
     const float* we = p.weff + (long long)b * 64 * 128;
-    stage_split64(we, 128, 0, Wes, WPB2, 0, 256, tid, 512);
-    stage_split64(we, 128, 64, Wes, WPB2, 64, 256, tid, 512);
+    if constexpr (!A16) {
+      stage_split64(we, 128, 0, Wes, WPB2, 0, 256, tid, 512);
+      stage_split64(we, 128, 64, Wes, WPB2, 64, 256, tid, 512);
+    }
     if (tid < 320) {
       const int a = tid >> 6, c = tid & 63;
       const float* src = a == 0 ? p.b3 : a == 1 ? p.bi : a == 2 ? p.bend : a == 3 ? p.gamma : p.beta;
@@ -517,6 +598,11 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
     }
   }
   __syncthreads();
+  if constexpr (A16) {  // biases of the two f16x3 contractions divided by their rows' scales 2^-e (exact: powers of two)
+    if (tid < 64) Cst[64 + tid] /= Cst[384 + tid];
+    else if (tid < 128) Cst[128 + tid - 64] /= Cst[448 + tid - 64];
+    __syncthreads();
+  }
   const float* __restrict__ x3b = p.x3 + (long long)b * (LAZY ? (long long)p.ih * p.iw : p.N) * p.ld3;
   const float* __restrict__ xib = p.xi + (long long)b * p.N * p.ldi;
   float* __restrict__ outb = p.out + (long long)b * p.N * p.ldo;
@@ -524,6 +610,13 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
   const long long ntiles = (p.N + 31) / 32;
   const long long stride = (long long)gridDim.x * CP_WAVES;
   uint32_t pl_amx = 0u;  // f16x3 planes copy: largest |out| this lane wrote (p16::absmax_pk patterns)
+  // A16: largest |x_i| this lane split, as an fp32 bit pattern (integer maximum: a NaN stays on top).  The other two operands the kernel
+  // splits are not tracked - y_3 is a convex combination of the low-resolution map's rows, relu(channel_proj_i) is bounded by
+  // |Wi| |x_i| + |bi| -: an overflow of either turns the output into inf / NaN, which the planes copy's own slot reports, and a
+  // half pair's ABSOLUTE error is at most 2^-36 whatever the magnitude, i.e. below fp32's resolution of the residual x_i they are
+  // added to as long as x_i itself is in range (which this slot checks).  (Tracking them on the split halves made hipcc spill 79
+  // registers in this kernel; every spill reload drains the prefetch it sits beside.)
+  uint32_t ar_amx = 0u;
   auto load = [&](long long tt, const float* __restrict__ base, int ld, f32x4* dst) {  // a pixel's channels 8q + 4h .. +3
     const long long px = tt * 32 + r;
     const bool ok = tt < ntiles && px < p.N;
@@ -557,6 +650,7 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
           const float v = z[mt][4 * g + e] + ci[4 * mt + g][e];
           o[mt * 16 + 4 * g + e] = v;
           s1 += v;
+          if constexpr (A16) ar_amx = max(ar_amx, __float_as_uint(ci[4 * mt + g][e]) & 0x7fffffffu);  // (x_i: the operand whose range matters, below)
         }
     s1 += __shfl_xor(s1, 32);
     const float mean = s1 * (1.0f / 64.0f);
@@ -599,7 +693,7 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
           p16::split8(o + 8 * c, hi, lo);
           *reinterpret_cast<u32x4*>(pb + (size_t)(off + c * cstride)) = hi;
           *reinterpret_cast<u32x4*>(pb + (size_t)(off + c * cstride + 32u)) = lo;
-          pl_amx = p16::absmax_pk4(pl_amx, hi);
+          pl_amx = p16::absmax_pk4(pl_amx, hi, lo);
         }
       }
     } else if (p.planes && ok) {  // (F16 implies a planes buffer) positions 8h .. 8h+7 of chunk c = channels 16c + {4h..4h+3, 8+4h..8+4h+3}: this lane's o[8c .. 8c+7]
@@ -724,12 +818,22 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
         pc[j][e] = fmaxf(v[0], 0.f);
         pc[j][e + 1] = fmaxf(v[1], 0.f);
       }
-    const Op3 tk = split8(pc[0], pc[1]);
+    if constexpr (A16) {
+      const Op2 th = split8h(pc[0], pc[1]);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      u32x4 wf[3];
-      wfrag(Wes + zo, mt * 32 + r, WPB2, 256, ks, h, wf);
-      z[mt] = mma6(wf, tk.p, z[mt]);
+      for (int mt = 0; mt < 2; ++mt) {
+        u32x4 wf[3];
+        wfrag(Wes + zo, mt * 32 + r, WPB2, 256, ks, h, wf);
+        z[mt] = mma3(wf, th, z[mt]);
+      }
+    } else {
+      const Op3 tk = split8(pc[0], pc[1]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        u32x4 wf[3];
+        wfrag(Wes + zo, mt * 32 + r, WPB2, 256, ks, h, wf);
+        z[mt] = mma6(wf, tk.p, z[mt]);
+      }
     }
   };
   // one tile: c3 holds the source rows of its K step 0 (requested by the previous tile); ci / ni as above
@@ -755,7 +859,7 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
     asm volatile("" : "+v"(zo));
     const Taps tp = taps(t);
     f32x16 z[2];
-    z[0] = rows16(Cst + zo + 128);
+    z[0] = rows16(Cst + zo + 128);  // (A16: the bias divided by the row's scale 2^-e - exact -, the scale applied at the end)
     z[1] = rows16(Cst + zo + 160);
     step0(tp, 0, c3, z, zo);
     issue(tp, 1, c3);
@@ -764,22 +868,45 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
     FENCE();
     // source 1 = x_i -> u_i half, stage 1 (as in tile())
     f32x16 tt[2];
-    tt[0] = rows16(Cst + zo + 64);
-    tt[1] = rows16(Cst + zo + 96);
+    if constexpr (A16) {
+      tt[0] = rows16(Cst + zo + 64);  // bias / 2^-e(c): relu(2^-e (W' x) + b) = 2^-e relu(W' x + b 2^e)
+      tt[1] = rows16(Cst + zo + 96);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const Op3 xs = split8(ci[2 * s], ci[2 * s + 1]);
+      for (int s = 0; s < 4; ++s) {
+        const Op2 xh = split8h(ci[2 * s], ci[2 * s + 1]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          u32x4 wf[3];
+          wfrag(Wis + zo, nt * 32 + r, WPB, 128, s, h, wf);
+          tt[nt] = mma3(wf, xh, tt[nt]);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)  // ReLU, row scale 2^-e(c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(Cst + zo + 384 + nt * 32 + 8 * g + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tt[nt][4 * g + e] = fmaxf(tt[nt][4 * g + e], 0.f) * sc[e];
+        }
+    } else {
+      tt[0] = rows16(Cst + zo + 64);
+      tt[1] = rows16(Cst + zo + 96);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const Op3 xs = split8(ci[2 * s], ci[2 * s + 1]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          u32x4 wf[3];
+          wfrag(Wis + zo, nt * 32 + r, WPB, 128, s, h, wf);
+          tt[nt] = mma6(wf, xs.p, tt[nt]);
+        }
+      }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        u32x4 wf[3];
-        wfrag(Wis + zo, nt * 32 + r, WPB, 128, s, h, wf);
-        tt[nt] = mma6(wf, xs.p, tt[nt]);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) tt[nt][v] = fmaxf(tt[nt][v], 0.f);
       }
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-      for (int v = 0; v < 16; ++v) tt[nt][v] = fmaxf(tt[nt][v], 0.f);
     }
     FENCE();
     step0(tp, 1, c3, z, zo);
@@ -789,13 +916,23 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
     for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
-        const Op3 tk = split8(tt[nt], sp);
         const int ks = 4 + nt * 2 + sp;
+        if constexpr (A16) {
+          const Op2 th = split8h(tt[nt], sp);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          u32x4 wf[3];
-          wfrag(Wes + zo, mt * 32 + r, WPB2, 256, ks, h, wf);
-          z[mt] = mma6(wf, tk.p, z[mt]);
+          for (int mt = 0; mt < 2; ++mt) {
+            u32x4 wf[3];
+            wfrag(Wes + zo, mt * 32 + r, WPB2, 256, ks, h, wf);
+            z[mt] = mma3(wf, th, z[mt]);
+          }
+        } else {
+          const Op3 tk = split8(tt[nt], sp);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            u32x4 wf[3];
+            wfrag(Wes + zo, mt * 32 + r, WPB2, 256, ks, h, wf);
+            z[mt] = mma6(wf, tk.p, z[mt]);
+          }
         }
       }
       if (nt == 0) {
@@ -809,6 +946,16 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
     step0(tp, 3, c3, z, zo);
     issue(taps(t + stride), 0, c3);  // the next tile's first K step
     FENCE();
+    if constexpr (A16) {  // end_proj: row scale 2^-e(m) (the bias went in divided by it)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(Cst + zo + 448 + mt * 32 + 8 * g + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[mt][4 * g + e] *= sc[e];
+        }
+    }
     finish(z, ci, px, ok, zo);
   };
   f32x4 a3[8], ai[8], bi[8];
@@ -834,6 +981,9 @@ __global__ __launch_bounds__(512) void crosspath_tail_kernel(const TailK p) {
 #undef FENCE
   if constexpr (F16) {
     if (p.pl_amax) p16::fold_pat(p.pl_amax, p.pl_amax_images > 1 ? b : 0, p.pl_amax_images > 1 ? b : 0, pl_amx);
+  }
+  if constexpr (A16) {
+    if (p.ar_amax) p16::fold_bits(p.ar_amax, p.ar_amax_images > 1 ? b : 0, p.ar_amax_images > 1 ? b : 0, ar_amx);
   }
 }
 
@@ -920,6 +1070,13 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
     k.ih = d->x3_ih; k.iw = d->x3_iw; k.W = d->W;
     k.sy = (float)d->x3_ih / (float)d->H; k.sx = (float)d->x3_iw / (float)d->W;
   }
+  // (r6) f16x3 arithmetic: the lazy, planes-only, f16-planes launch inside a guarded scope (arith_amax given)
+  const bool a16 = d->arith_f16 != 0;
+  k.ar_amax = nullptr; k.ar_amax_images = 1;
+  if (a16) {
+    if (!lazy || !k.pl_f16 || k.out || !d->arith_amax || (d->arith_amax_images > 1 && d->arith_amax_images != d->B)) return SEGMIF_EINVAL;
+    k.ar_amax = d->arith_amax; k.ar_amax_images = d->arith_amax_images;
+  }
   const long long ntiles = (d->N + 31) / 32;
   long long wgs = (ntiles + CP_WAVES - 1) / CP_WAVES;
   const long long per_image = (2 * 256 + d->B - 1) / d->B;  // 100 KB of LDS: one workgroup per CU, two rounds of them
@@ -931,7 +1088,7 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
     hipError_t e = hipSuccess;
     for (const void* fn : {(const void*)crosspath_tail_kernel<false, false, true>, (const void*)crosspath_tail_kernel<true, false, true>,
                            (const void*)crosspath_tail_kernel<false, true, true>, (const void*)crosspath_tail_kernel<true, true, true>,
-                           (const void*)crosspath_tail_kernel<true, true, false>})
+                           (const void*)crosspath_tail_kernel<true, true, false>, (const void*)crosspath_tail_kernel<true, true, false, true>})
       if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     raised = true;
@@ -939,7 +1096,8 @@ extern "C" int segmif_crosspath_tail_f32(const SegmifCrossTail* d, void* stream)
   const dim3 grid((unsigned)wgs, (unsigned)d->B);
   hipStream_t st = (hipStream_t)stream;
   if (lazy) {
-    if (k.pl_f16 && !k.out) hipLaunchKernelGGL((crosspath_tail_kernel<true, true, false>), grid, dim3(512), smem, st, k);
+    if (a16) hipLaunchKernelGGL((crosspath_tail_kernel<true, true, false, true>), grid, dim3(512), smem, st, k);
+    else if (k.pl_f16 && !k.out) hipLaunchKernelGGL((crosspath_tail_kernel<true, true, false>), grid, dim3(512), smem, st, k);
     else if (k.pl_f16) hipLaunchKernelGGL((crosspath_tail_kernel<true, true, true>), grid, dim3(512), smem, st, k);
     else hipLaunchKernelGGL((crosspath_tail_kernel<false, true, true>), grid, dim3(512), smem, st, k);
   } else {

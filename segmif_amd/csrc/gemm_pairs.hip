@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void pairs_from_f32_kernel(const float* __rest
     unsigned char* dst = y + row * ldy + (c >> 4) * 64 + (c & 15) * 2;
     *reinterpret_cast<u32x2*>(dst) = u32x2{ha, hb};
     *reinterpret_cast<u32x2*>(dst + 32) = u32x2{la, lb};
-    amx = p16::absmax_pk(p16::absmax_pk(amx, ha), hb);
+    amx = p16::absmax_pk(p16::absmax_pk(amx, ha, la), hb, lb);
   }
   if (amax) {  // a wave's 64 threads cover 256 consecutive values: at most two rows' images when C >= 128 ... report per row range
     const long long r0 = ((long long)blockIdx.x * 256 + (threadIdx.x & ~63)) / c4n;
@@ -432,6 +432,8 @@ extern "C" int segmif_pairs_to_f32(const void* x, int64_t ldx_bytes, float* y, i
   return (int)hipGetLastError();
 }
 
+__device__ __attribute__((aligned(256))) unsigned char g_pairs_zero_page[256];  // all zero, never written
+
 extern "C" int segmif_gemm_pairs_f32(const SegmifGemmPairs* d, void* stream) {
   if (!d || !d->a || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % PBK) return SEGMIF_EINVAL;
   const bool patch = d->patch_k > 0;
@@ -450,11 +452,15 @@ extern "C" int segmif_gemm_pairs_f32(const SegmifGemmPairs* d, void* stream) {
   if (d->act == SEGMIF_ACT_PRELU && !d->prelu) return SEGMIF_EINVAL;
   if (d->res && (d->ldr <= 0 || (d->ldr & 3) || ((uintptr_t)d->res & 15))) return SEGMIF_EINVAL;
   if ((d->N & 3) || (d->ldo & 3) || d->ldo < d->N || ((uintptr_t)d->out & 15) || ((uintptr_t)d->bias & 15)) return SEGMIF_EINVAL;
+  // 64 zero bytes on this device (patch mode's out-of-image taps): a zero-initialised __device__ array - (r6) no
+  // hipMalloc / null-stream hipMemset inside a launch function (unordered against a non-blocking stream, illegal under capture)
   static segmif::PerDeviceValue<unsigned char*> zero_page;
   unsigned char*& zp = zero_page.here();
-  if (!zp) {  // 64 zero bytes on this device (patch mode's out-of-image taps); allocated once, never freed
-    if (hipMalloc((void**)&zp, 256) != hipSuccess) return SEGMIF_EINVAL;
-    if (hipMemset(zp, 0, 256) != hipSuccess) return SEGMIF_EINVAL;
+  if (!zp) {
+    void* sym = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_pairs_zero_page));
+    if (e != hipSuccess || !sym) return e != hipSuccess ? (int)e : SEGMIF_EINVAL;
+    zp = (unsigned char*)sym;
   }
   GemmPairsK k;
   k.a = (const unsigned char*)d->a; k.w = (const unsigned char*)d->w; k.bias = d->bias; k.res = d->res; k.prelu = d->prelu;

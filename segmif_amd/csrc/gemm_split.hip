@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
         p16::split2(x[2], x[3], hb, lb);
         *reinterpret_cast<u32x2*>(As + a_dst[j]) = u32x2{ha, hb};
         *reinterpret_cast<u32x2*>(As + a_dst[j] + 32) = u32x2{la, lb};
-        amx = p16::absmax_pk(p16::absmax_pk(amx, ha), hb);
+        amx = p16::absmax_pk(p16::absmax_pk(amx, ha, la), hb, lb);
       } else {
         uint32_t p0a, p1a, p2a, p0b, p1b, p2b;
         split3(x[0], x[1], p0a, p1a, p2a);

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
               p16::split8(yy, hi, lo);
               *reinterpret_cast<ig_u32x4*>(dst) = hi;
               *reinterpret_cast<ig_u32x4*>(dst + 32) = lo;
-              pl_amx = p16::absmax_pk4(pl_amx, hi);
+              pl_amx = p16::absmax_pk4(pl_amx, hi, lo);
             } else {
               ig_u32x4 pp[3];
 #pragma unroll

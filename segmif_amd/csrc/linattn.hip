@@ -208,15 +208,98 @@ __global__ __launch_bounds__(256) void linattn_kvpartial_kernel(const float* __r
   dst[1] = acc1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// (r6) Any head geometry with heads * d <= 64 and d <= 8 - the reference's ablation networks build their interaction
+// modules at dim 32 (8 heads of 4: model_fusion.py:639-640, :832, :867).  Same arithmetic as the two kernels above (fp32 inside a
+// 32-row run, fp64 across runs and blocks, fixed order), entry e = (h d + i) d + j owned by thread e (and e + 256): these
+// problems are small (32-channel maps), so one generic kernel instead of one instantiation per geometry.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linattn_partial_generic_kernel(const float* __restrict__ kv, double* __restrict__ partial,
+                                                                      long long N, int ldkv, int nblk, int heads, int d) {
+  __shared__ __attribute__((aligned(16))) float rows[LA_CHUNK][128 + 4];
+  const int tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+  const int C = heads * d, E = C * d;
+  const long long r0 = (long long)blk * LA_ROWS;
+  const float* base = kv + ((long long)b * N) * ldkv;
+  int ki[2], vj[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u, hi = e / d;       // hi = h d + i
+    ki[u] = e < E ? hi : 0;
+    vj[u] = e < E ? C + (hi / d) * d + e % d : 0;  // V column h d + j
+  }
+  double acc[2] = {0.0, 0.0};
+  for (int c = 0; c < LA_ROWS / LA_CHUNK; ++c) {
+    for (int u = tid; u < LA_CHUNK * 2 * C; u += 256) {
+      const int r = u / (2 * C), col = u % (2 * C);
+      const long long row = r0 + c * LA_CHUNK + r;
+      rows[r][col] = row < N ? base[row * ldkv + col] : 0.f;
+    }
+    __syncthreads();
+    float s[2] = {0.f, 0.f};
+#pragma unroll 8
+    for (int r = 0; r < LA_CHUNK; ++r) {
+      s[0] = fmaf(rows[r][ki[0]], rows[r][vj[0]], s[0]);
+      s[1] = fmaf(rows[r][ki[1]], rows[r][vj[1]], s[1]);
+    }
+    acc[0] += (double)s[0];
+    acc[1] += (double)s[1];
+    __syncthreads();
+    if (r0 + (c + 1) * LA_CHUNK >= N) break;
+  }
+  double* dst = partial + ((long long)b * nblk + blk) * E;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (tid + 256 * u < E) dst[tid + 256 * u] = acc[u];
+}
+
+__global__ __launch_bounds__(512) void linattn_fold_generic_kernel(const double* __restrict__ partial, const float* __restrict__ wend,
+                                                                   float* __restrict__ weff, int nblk, int Nout, int ldw, int wofs,
+                                                                   int ldweff, int kofs, float scale, int heads, int d) {
+  __shared__ double ctx[512];  // [h][i][j]
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int C = heads * d, E = C * d;
+  if (tid < E) {
+    const double* p = partial + (long long)b * nblk * E + tid;
+    double a = 0.0;
+    for (int k = 0; k < nblk; ++k) a += p[(long long)k * E];  // fixed order: deterministic
+    ctx[tid] = a * (double)scale;
+  }
+  __syncthreads();
+  if (tid < C) {  // one (h, j) column per thread: softmax over i (dim = -2)
+    const int hh = tid / d, j = tid % d;
+    double mx = -1e300, ev[8], sum = 0.0;
+    for (int i = 0; i < d; ++i) mx = fmax(mx, ctx[(hh * d + i) * d + j]);
+    for (int i = 0; i < d; ++i) {
+      ev[i] = exp(ctx[(hh * d + i) * d + j] - mx);
+      sum += ev[i];
+    }
+    for (int i = 0; i < d; ++i) ctx[(hh * d + i) * d + j] = ev[i] / sum;
+  }
+  __syncthreads();
+  for (int o = tid; o < Nout * C; o += 512) {  // Weff[b][n][kofs + h d + i] = sum_j ctx[h][i][j] Wend[n][wofs + h d + j]
+    const int n = o / C, c = o % C, hh = c / d;
+    float acc = 0.f;
+    for (int j = 0; j < d; ++j) acc = fmaf((float)ctx[c * d + j], wend[(long long)n * ldw + wofs + hh * d + j], acc);
+    weff[((long long)b * Nout + n) * ldweff + kofs + c] = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int segmif_linattn_num_blocks(int64_t N) { return (int)((N + LA_ROWS - 1) / LA_ROWS); }
 
 extern "C" int segmif_linattn_partial_f32(const float* kv, double* partial, int B, int64_t N, int heads, int d,
                                           int ldkv, void* stream) {
-  if (!kv || !partial || B <= 0 || N <= 0 || heads != 8 || d != 8 || ldkv < 128 || (ldkv & 3)) return SEGMIF_EINVAL;
-  if (((uintptr_t)kv & 15) || ((uintptr_t)partial & 7)) return SEGMIF_EINVAL;
+  if (!kv || !partial || B <= 0 || N <= 0 || heads <= 0 || d <= 0 || d > 8 || heads * d > 64 || ldkv < 2 * heads * d) return SEGMIF_EINVAL;
   const int nblk = segmif_linattn_num_blocks(N);
+  if (heads != 8 || d != 8) {  // (r6) the ablation networks' geometries (dim 32: 8 heads of 4)
+    if (((uintptr_t)kv & 3) || ((uintptr_t)partial & 7)) return SEGMIF_EINVAL;
+    hipLaunchKernelGGL(linattn_partial_generic_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, kv,
+                       partial, (long long)N, ldkv, nblk, heads, d);
+    return (int)hipGetLastError();
+  }
+  if (ldkv < 128 || (ldkv & 3) || ((uintptr_t)kv & 15) || ((uintptr_t)partial & 7)) return SEGMIF_EINVAL;
   hipLaunchKernelGGL(linattn_partial_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, kv,
                      partial, (long long)N, ldkv, nblk);
   return (int)hipGetLastError();
@@ -225,7 +308,12 @@ extern "C" int segmif_linattn_partial_f32(const float* kv, double* partial, int 
 extern "C" int segmif_linattn_fold_f32(const double* partial, const float* wend, float* weff, int B, int nblk,
                                        int heads, int d, int Nout, int ldw, int wofs, int ldweff, int kofs, float scale,
                                        void* stream) {
-  if (!partial || !wend || !weff || B <= 0 || nblk <= 0 || heads != 8 || d != 8 || Nout <= 0) return SEGMIF_EINVAL;
+  if (!partial || !wend || !weff || B <= 0 || nblk <= 0 || heads <= 0 || d <= 0 || d > 8 || heads * d > 64 || Nout <= 0) return SEGMIF_EINVAL;
+  if (heads != 8 || d != 8) {
+    hipLaunchKernelGGL(linattn_fold_generic_kernel, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, partial, wend, weff, nblk,
+                       Nout, ldw, wofs, ldweff, kofs, scale, heads, d);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(linattn_fold_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream,
                      partial, wend, weff, nblk, Nout, ldw, wofs, ldweff, kofs, scale);
   return (int)hipGetLastError();

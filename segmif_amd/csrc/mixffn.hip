@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int e = 0; e < 4; ++e) y[4 * k + e] = in ? v[2 * s8 + k][e] * rstd * ga[e] + be[e] : 0.f;
       }
       p16::split8(y, a_hi[i][s8], a_lo[i][s8]);
-      amx_a = p16::absmax_pk4(amx_a, a_hi[i][s8]);
+      amx_a = p16::absmax_pk4(amx_a, a_hi[i][s8], a_lo[i][s8]);
     }
   }
 
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         p16::split2(a[0], a[1], g_hi[i][0], g_lo[i][0]);
         p16::split2(a[2], a[3], g_hi[i][1], g_lo[i][1]);
         const bool ok = y0 + yb + i < p.H && x0 + xc < p.W;
-        const uint32_t m = p16::absmax_pk(p16::absmax_pk(amx_g, g_hi[i][0]), g_hi[i][1]);
+        const uint32_t m = p16::absmax_pk(p16::absmax_pk(amx_g, g_hi[i][0], g_lo[i][0]), g_hi[i][1], g_lo[i][1]);
         amx_g = ok ? m : amx_g;
         if constexpr (G::GS_SEPARATE) {
           unsigned char* px = Gs + ((yb + i) * MF_TW + xc) * MF_GP + q4 * 8;

@@ -67,8 +67,20 @@ __device__ __forceinline__ uint32_t absmax_pk(uint32_t m, uint32_t halves) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(a, b));
 }
 
-__device__ __forceinline__ uint32_t absmax_pk4(uint32_t m, const u4& hi) {
-  return absmax_pk(absmax_pk(absmax_pk(absmax_pk(m, hi[0]), hi[1]), hi[2]), hi[3]);
+// (r6) The same with the STICKY bit of the low halves: a value whose high half rounded to zero (|x| < 2^-25) while its low half did
+// not is carried by the low half alone - fewer than 23 bits - yet read 0 on the high halves' patterns, like an exact zero, and
+// passed the guard (the one hole of the range contract).  Such a value now counts as the smallest subnormal
+// (pattern 1 = 2^-24): a tensor whose LARGEST magnitude is that small reports a maximum below the guard's lower bound and is
+// repeated on bf16 triples; a healthy tensor's maximum is unaffected (its patterns are far above 1).  v_and + v_pk_min_u16 +
+// v_pk_max_u16 per pair of values, in epilogues only.
+__device__ __forceinline__ uint32_t absmax_pk(uint32_t m, uint32_t hi, uint32_t lo) {
+  const us2 one = {1, 1};
+  const us2 s = __builtin_elementwise_min(__builtin_bit_cast(us2, lo & 0x7fff7fffu), one);
+  return absmax_pk(__builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, m), s)), hi);
+}
+
+__device__ __forceinline__ uint32_t absmax_pk4(uint32_t m, const u4& hi, const u4& lo) {
+  return absmax_pk(absmax_pk(absmax_pk(absmax_pk(m, hi[0], lo[0]), hi[1], lo[1]), hi[2], lo[2]), hi[3], lo[3]);
 }
 
 __device__ __forceinline__ uint32_t wave_umax(uint32_t v) {

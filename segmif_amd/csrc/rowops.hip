@@ -141,7 +141,7 @@ __global__ __launch_bounds__(1024) void layernorm_pairs_kernel(const float* __re
       segmif::p16::split2(o[2], o[3], hb, lb);
       // (the quad u & ~3 .. u | 3 = one 16-channel group is active as a whole: C % 16 == 0)
       *reinterpret_cast<segmif::p16::u4*>(y + row * ldy_bytes + (u >> 2) * 64 + (u & 3) * 16) = segmif::p16::quad_piece(ha, hb, la, lb);
-      amx = segmif::p16::absmax_pk(segmif::p16::absmax_pk(amx, ha), hb);
+      amx = segmif::p16::absmax_pk(segmif::p16::absmax_pk(amx, ha, la), hb, lb);
     }
   }
   if (amax) {
@@ -345,6 +345,31 @@ __global__ __launch_bounds__(256) void fuse_ycrcb_kernel(const float* __restrict
   out[(b * 3 + 2) * HW + p] = fminf(fmaxf(bl, 0.f), 1.f);
 }
 
+// (r6) Two-source pointwise pass over rows views (the ablation networks' glue, core/model_fusion.py:714-820):
+//   MODE 0  a + b                       Fusion_Network3_Add  (:745-746, :751-752)
+//   MODE 1  silu(a) + silu(b)           Fusion_Network3_Average: att_i(x) + att_j(seg), AttentionModule = sigmoid(z) z  (:769-770)
+//   MODE 2  silu(a)                     AttentionModule alone
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+template <int MODE>
+__global__ __launch_bounds__(256) void pointwise2_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                         float* __restrict__ y, int ldy, long long rows, int C4) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * C4) return;
+  const long long r = idx / C4;
+  const int c = (int)(idx - r * C4) * 4;
+  float4 va = *reinterpret_cast<const float4*>(a + r * lda + c);
+  if (MODE == 0) {
+    const float4 vb = *reinterpret_cast<const float4*>(b + r * ldb + c);
+    va = make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w);
+  } else if (MODE == 1) {
+    const float4 vb = *reinterpret_cast<const float4*>(b + r * ldb + c);
+    va = make_float4(silu_f(va.x) + silu_f(vb.x), silu_f(va.y) + silu_f(vb.y), silu_f(va.z) + silu_f(vb.z), silu_f(va.w) + silu_f(vb.w));
+  } else {
+    va = make_float4(silu_f(va.x), silu_f(va.y), silu_f(va.z), silu_f(va.w));
+  }
+  *reinterpret_cast<float4*>(y + r * ldy + c) = va;
+}
+
 // RGB2YCrCb / YCrCb2RGB (core/model_fusion.py:69-91, :93-111) and their backward, on planar (B, 3, HW) images.
 //   MODE 0  RGB -> YCrCb          Y = .299 R + .587 G + .114 B, Cr = (R - Y) .713 + .5, Cb = (B - Y) .564 + .5
 //   MODE 1  YCrCb -> RGB          ([Y, Cr, Cb] + [0, -.5, -.5]) M, M = [[1, 1, 1], [1.403, -.714, 0], [0, -.344, 1.773]], summed
@@ -536,15 +561,18 @@ extern "C" int segmif_layernorm_f32(const float* x, const float* gamma, const fl
 }
 
 extern "C" int segmif_layernorm_pairs_f32(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int C, int ldx,
-                                          int ldy, float eps, uint32_t* amax, int amax_images, int amax_sub, void* stream) {
+                                          int ldy, float eps, uint32_t* amax, int amax_images, int amax_sub, int amax_pitch, void* stream) {
   if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0 || (C & 15) || C > 1024 || (ldx & 3) || (ldy & 3) || ldy < C)
     return SEGMIF_EINVAL;
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return SEGMIF_EINVAL;
-  if (amax && (amax_images < 1 || rows % amax_images || amax_sub < 1 || (amax_sub & (amax_sub - 1)))) return SEGMIF_EINVAL;
+  if (amax && (amax_images < 1 || rows % amax_images || amax_sub < 1 || (amax_sub & (amax_sub - 1)) || amax_pitch < amax_images))
+    return SEGMIF_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const long long ar = rows / (amax ? amax_images : 1);
   const int ns = amax ? amax_sub : 1;
-  const long long st = amax ? amax_images : 1;  // slot rows lie `amax_images` words apart (ops.Planes16Guard)
+  // (r6) the pitch of the slot rows is the GUARD's image count, given explicitly: a launch whose batch is not the
+  // guard's reports to column 0 (amax_images = 1) of rows that still lie guard.images words apart
+  const long long st = amax ? amax_pitch : 1;
   const int nvec = C >> 2;
   if (nvec <= 8) return launch_ln_pairs<8, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, amax, ar, ns, st, s);
   if (nvec <= 16) return launch_ln_pairs<16, 1>(x, gamma, beta, y, rows, C, ldx, ldy, eps, amax, ar, ns, st, s);
@@ -642,7 +670,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_xt_kernel(const float* __restri
           // (threads c, c + 4, c + 8, c + 12 of one 16-channel group are four consecutive lanes with the same x0, j, live)
           unsigned char* d16 = reinterpret_cast<unsigned char*>(dst + (long long)j * C - c) + (c >> 4) * 64 + ((c >> 2) & 3) * 16;
           *reinterpret_cast<segmif::p16::u4*>(d16) = segmif::p16::quad_piece(ha, hb, la, lb);
-          amx = segmif::p16::absmax_pk(segmif::p16::absmax_pk(amx, ha), hb);
+          amx = segmif::p16::absmax_pk(segmif::p16::absmax_pk(amx, ha, la), hb, lb);
         }
       } else {
         if (x0 + j < W) *reinterpret_cast<f32x4*>(dst + (long long)j * C) = o;
@@ -823,6 +851,19 @@ extern "C" int segmif_seg_normalize_f32(const float* x, float* y, int B, int H, 
   const long long HW = (long long)H * W, total = HW * B;
   hipLaunchKernelGGL(seg_normalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
                      y, HW, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_pointwise2_f32(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int64_t rows, int C, int mode,
+                                     void* stream) {
+  if (!a || !y || rows <= 0 || C <= 0 || (C & 3) || mode < 0 || mode > 2 || (mode != 2 && !b)) return SEGMIF_EINVAL;
+  if ((lda & 3) || (ldy & 3) || (b && (ldb & 3)) || (((uintptr_t)a | (uintptr_t)y | (uintptr_t)b) & 15)) return SEGMIF_EINVAL;
+  const long long total = (long long)rows * (C / 4);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) hipLaunchKernelGGL(pointwise2_kernel<0>, grid, block, 0, s, a, lda, b, ldb, y, ldy, (long long)rows, C / 4);
+  else if (mode == 1) hipLaunchKernelGGL(pointwise2_kernel<1>, grid, block, 0, s, a, lda, b, ldb, y, ldy, (long long)rows, C / 4);
+  else hipLaunchKernelGGL(pointwise2_kernel<2>, grid, block, 0, s, a, lda, b, ldb, y, ldy, (long long)rows, C / 4);
   return (int)hipGetLastError();
 }
 

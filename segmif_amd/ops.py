@@ -100,6 +100,26 @@ def crosspath_mode():
     return _crosspath_mode
 
 
+# (r6) arithmetic of crosspath_tail's own contractions where it can be f16x3 (lazy segmentation feature, planes-only output, guarded
+# scope): "f16x3" (default) | "bf16x6" (A/B switch, SEGMIF_CROSSPATH_ARITH).  Round 4 had built the same for the kernel that still read
+# x_3 from HBM and measured nothing (HBM-bound then); the lazy tail is bound by its vector + matrix work.
+_crosspath_arith = os.environ.get("SEGMIF_CROSSPATH_ARITH", "f16x3")
+if _crosspath_arith not in ("f16x3", "bf16x6"):
+    raise RuntimeError(f"SEGMIF_CROSSPATH_ARITH must be f16x3 or bf16x6, got {_crosspath_arith!r}")
+
+
+def crosspath_arith():
+    return _crosspath_arith
+
+
+def set_crosspath_arith(mode):
+    global _crosspath_arith
+    if mode not in ("f16x3", "bf16x6"):
+        raise ValueError(mode)
+    prev, _crosspath_arith = _crosspath_arith, mode
+    return prev
+
+
 def set_crosspath_mode(mode):
     """'gram' (default): CrossPath in inference on the Gram-matrix kernels of csrc/crosspath.hip; 'gemm': round 1's
     channel_proj GEMMs + fused kv reductions + two-source end_proj GEMM."""
@@ -237,6 +257,7 @@ class Planes16Guard:
         # (one per image; crosspath_fold raises them)
         self.amax = torch.zeros((self.SLOTS + 2, self.images), device=device, dtype=torch.int32)
         self.used = 0
+        self.shared = 0  # launches past SLOTS rows: they share the last row (overflow check exact, vanishing-tensor check pooled)
         self.whole = set()  # rows written by a launch that did not index by image
         self.interaction = 0  # FeatureFusionModule calls seen by this scope (next_interaction())
 
@@ -247,6 +268,9 @@ class Planes16Guard:
         launches is pooled."""
         if self.used < self.SLOTS:
             self.used += 1
+        else:
+            self.shared += 1  # (r6, ADVICE r5: counted and reported - range_stats()["slot_rows_shared"])
+            _note_shared_row()
         row = self.used - 1
         per_image = images is not None and images == self.images and self.images > 1
         if not per_image and self.images > 1:
@@ -282,6 +306,7 @@ class Planes16Guard:
     def reset(self):
         """Forget every launch (a recorded hipGraph re-fills the same rows on each replay)."""
         self.used = 0
+        self.shared = 0
         self.interaction = 0
         self.whole.clear()
         self.amax.zero_()
@@ -340,7 +365,12 @@ class _Scope(threading.local):
 _scope = _Scope()
 _stats_lock = threading.Lock()
 _stats = {"scopes": 0, "fallbacks": 0, "images": 0, "images_repeated": 0, "images_repeated_fp32conv": 0, "streak": 0,
-          "warned": False}
+          "warned": False, "slot_rows_shared": 0}
+
+
+def _note_shared_row():
+    with _stats_lock:
+        _stats["slot_rows_shared"] += 1
 
 
 def _count(images, repeated, exact=0):
@@ -374,7 +404,7 @@ def range_fallbacks():
 def range_stats():
     """-> dict: guarded scopes, scopes with a repeat, images seen, images repeated (f16x3_trip_rate = repeated / seen)."""
     with _stats_lock:
-        d = {k: _stats[k] for k in ("scopes", "fallbacks", "images", "images_repeated", "images_repeated_fp32conv")}
+        d = {k: _stats[k] for k in ("scopes", "fallbacks", "images", "images_repeated", "images_repeated_fp32conv", "slot_rows_shared")}
     d["trip_rate"] = d["images_repeated"] / d["images"] if d["images"] else 0.0
     d["cond_repeat_rate"] = d["images_repeated_fp32conv"] / d["images"] if d["images"] else 0.0
     return d
@@ -394,6 +424,15 @@ def run_guarded(fn, device, enabled=None, images=1, redo=None):
         enabled = f16x3_enabled()
     if _scope.guard is not None or _scope.suppress or not enabled:
         return fn()
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        # (r6) a hipGraph capture cannot hold the scope's host read-back: a standalone call recorded by the CALLER's
+        # graph runs on the bf16x6 kernels (no range to guard, capturable); PairForward.capture installs a guard of its own
+        # and checks it after each replay instead
+        _scope.suppress += 1
+        try:
+            return fn()
+        finally:
+            _scope.suppress -= 1
     _scope.guard = guard = Planes16Guard(device, images)
     try:
         out = fn()
@@ -716,7 +755,8 @@ def layernorm_pairs(x, gamma, beta, eps):
     # (the kernel's waves are short and many: its range reports are spread over LN_SUB consecutive rows of slots)
     amax, nimg, nsub = guard.slot_rows(x.shape[0] if x.dim() == 3 else None, LN_SUB)
     _lib.check(_lib.load().segmif_layernorm_pairs_f32(x.data_ptr(), _req(gamma).data_ptr(), _req(beta).data_ptr(), out.data_ptr(),
-                                                      rows, C, ldx, C, float(eps), amax, nimg, nsub, _stream()), "segmif_layernorm_pairs_f32")
+                                                      rows, C, ldx, C, float(eps), amax, nimg, nsub, guard.images, _stream()),
+               "segmif_layernorm_pairs_f32")
     return Pairs(out)
 
 
@@ -1242,6 +1282,31 @@ def conv3x3_c32to1(x, wt, *, bias=None, act=ACT_NONE, prelu=None):
     return out
 
 
+def conv3x3_c1(x, w, *, bias=None, act=ACT_NONE, prelu=None, planes=None, planes_chunk0=0, planes_only=False):
+    """(r6) 3x3 'same' conv from ONE channel to 64 (+ bias + act) as a store-bound stencil (csrc/conv3x3_planes.hip,
+    conv3x3_c1_kernel): x contiguous (B, H, W, 1), w the RAW (64, 1, 3, 3) weight.  planes: an f16x3 ops.Planes receiving chunks
+    [planes_chunk0, planes_chunk0 + 4); planes_only: no fp32 result (returns None)."""
+    _req(x, "x"), _req(w, "w")
+    if x.dim() != 4 or x.shape[-1] != 1 or not x.is_contiguous() or tuple(w.shape) != (64, 1, 3, 3) or not w.is_contiguous():
+        raise RuntimeError("conv3x3_c1 expects a contiguous (B, H, W, 1) image and the raw contiguous (64, 1, 3, 3) weight")
+    B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    if planes is not None and (not planes.f16 or (planes.B, planes.H, planes.W) != (B, H, W)):
+        raise RuntimeError("conv3x3_c1: planes output needs an f16x3 planes buffer of the image's geometry")
+    if planes_only and planes is None:
+        raise RuntimeError("conv3x3_c1: planes_only needs a planes buffer")
+    out = None if planes_only else torch.empty((B, H, W, 64), device=x.device, dtype=torch.float32)
+    pl_ptr, chunks, amax, nimg = None, 0, None, 1
+    if planes is not None:
+        planes.need(planes_chunk0 + 4, "conv3x3_c1 planes output")
+        pl_ptr, chunks = planes.data.data_ptr(), planes.chunks
+        amax, nimg = planes.guard.slot(B)
+    _lib.check(_lib.load().segmif_conv3x3_c1_f16x3(
+        x.data_ptr(), w.data_ptr(), _req(bias, "bias").data_ptr() if bias is not None else None,
+        _req(prelu, "prelu").data_ptr() if prelu is not None else None, act, pl_ptr, chunks, planes_chunk0,
+        out.data_ptr() if out is not None else None, 64, B, H, W, amax, nimg, _stream()), "segmif_conv3x3_c1_f16x3")
+    return out
+
+
 def conv_ln_fusable(N):
     """True when a conv's LayerNorm can ride in its epilogue: the row (all N channels) must sit in one wave tile - N = 64,
     i.e. the stage-1 patch embed of mit_b1 .. b5 (614 400 rows at 32 images of 480x640: the only patch-embed LayerNorm over
@@ -1603,6 +1668,10 @@ def crosspath_tail(x3, xi, w3, b3, wi, bi, weff, bend, ln, out=None, planes=None
         if planes.f16:
             d.planes_f16 = 1
             d.planes_amax, d.planes_amax_images = planes.guard.slot(B)
+            if lazy and planes_only and _crosspath_arith == "f16x3":
+                # (r6) the kernel's own contractions on half pairs: its operands' range goes to a slot of its own
+                d.arith_f16 = 1
+                d.arith_amax, d.arith_amax_images = planes.guard.slot(B)
     _side("cp_tail", lambda: _lib.check(_lib.load().segmif_crosspath_tail_f32(ctypes.byref(d), _stream()),
                                         "segmif_crosspath_tail_f32"),
           ((512.0 if planes_only else 768.0) - (256.0 if lazy else 0.0) + (0.0 if planes is None else 256.0 if planes.f16 else 384.0)) * B * N)  # + the planes copy: 4 | 6 B per element
@@ -1662,6 +1731,24 @@ def fuse_ycrcb(vis, yf):
     out = torch.empty_like(vis)
     _lib.check(_lib.load().segmif_fuse_ycrcb_f32(vis.data_ptr(), yf.data_ptr(), out.data_ptr(), B, H * W, _stream()),
                "segmif_fuse_ycrcb_f32")
+    return out
+
+
+def pointwise2(a, b, mode, out=None):
+    """(r6) y = a + b (mode 0), silu(a) + silu(b) (mode 1), silu(a) (mode 2; b None) over rows views of equal shape."""
+    rows, C, lda = rows_view(a, "a")
+    ldb = 0
+    if b is not None:
+        rb, cb, ldb = rows_view(b, "b")
+        if (rb, cb) != (rows, C):
+            raise RuntimeError("pointwise2: a and b differ in shape")
+    if out is None:
+        out = torch.empty(a.shape, device=a.device, dtype=torch.float32)
+    ro, co, ldo = rows_view(out, "out")
+    if (ro, co) != (rows, C):
+        raise RuntimeError("pointwise2: out shape mismatch")
+    _lib.check(_lib.load().segmif_pointwise2_f32(a.data_ptr(), lda, b.data_ptr() if b is not None else None, ldb, out.data_ptr(), ldo,
+                                                 rows, C, mode, _stream()), "segmif_pointwise2_f32")
     return out
 
 

@@ -47,6 +47,7 @@ class GradAllReducer:
         self._stream = None
         self.time_exposed_wait = False  # measure the non-overlapped part of the all-reduce in finish() (adds device syncs)
         self.exposed_wait_s = 0.0
+        self.copies = 0  # per-parameter gradient copies into the buckets made by the hook (0 after step 1 under train._zero_grads)
         self.exposed_wait_per_bucket_s = []  # (launch order = reverse parameter order) how long each bucket's wait blocked
 
     # ---- bucket layout ------------------------------------------------------------------------
@@ -79,6 +80,7 @@ class GradAllReducer:
                                "finish() after every backward (gradient accumulation is not supported)")
         dst = self._flat[bi][off:off + p.numel()]
         if p.grad.data_ptr() != dst.data_ptr():
+            self.copies += 1  # (segmif_amd.train zeroes the buckets in place instead - zero_buckets() - and never gets here)
             # (after finish() p.grad IS this slice; with optimizer.zero_grad(set_to_none=False) autograd then accumulates
             # straight into the bucket and there is nothing to copy.  set_to_none=True - what segmif_amd.train uses - gives
             # a fresh gradient tensor every step, copied here.)
@@ -86,6 +88,23 @@ class GradAllReducer:
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
+
+    def zero_buckets(self):
+        """Zero every gradient this reducer manages, in place (one fill per flat bucket); the parameters' .grad stay the bucket
+        views finish() left, so the next backward accumulates into the buckets directly.  -> False before the buckets exist
+        (first step) or when a .grad no longer is its bucket view (someone called zero_grad(set_to_none=True)): the caller then
+        clears the gradients its own way and the hook copies, as before."""
+        if self._buckets is None:
+            return False
+        for b, flat in zip(self._buckets, self._flat):
+            off = 0
+            for p in b:
+                if p.grad is None or p.grad.data_ptr() != flat[off:off + p.numel()].data_ptr():
+                    return False
+                off += p.numel()
+        for flat in self._flat:
+            flat.zero_()
+        return True
 
     def _launch(self, bi):
         flat = self._flat[bi]

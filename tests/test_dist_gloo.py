@@ -84,6 +84,20 @@ def _dp_worker(rank, world, port, q):
         red.finish()
         out.append([p.grad.tolist() if p.grad is not None else None for p in params])  # plain lists: no shared-memory handles
     mean_loss = allreduce_scalar_mean(float(loss.detach()))
+    # (r6) the way segmif_amd.train clears gradients under a reducer: buckets zeroed in place, autograd accumulates straight into
+    # them - the hook makes NO per-parameter copy after the first step, and the averages are the same
+    from segmif_amd.train import _zero_grads
+    opt = torch.optim.SGD(params, lr=0.0)
+    copies_before = red.copies
+    inplace_ok = copies_before > 0  # (the loop above cleared with p.grad = None: one copy per live parameter per step)
+    for step in range(2):
+        _zero_grads(opt, red)
+        ptrs = [p.grad.data_ptr() for p in params[:4]]
+        ((net(full_x[mine]) - full_y[mine]) ** 2).mean().backward()
+        red.finish()
+        inplace_ok &= ptrs == [p.grad.data_ptr() for p in params[:4]]
+        inplace_ok &= all(torch.allclose(p.grad, torch.tensor(g), atol=1e-7) for p, g in zip(params[:4], out[-1][:4]))
+    inplace_ok &= red.copies == copies_before and params[4].grad is None
     # the exchange used after a replayed hipGraph (no autograd hooks, p.grad must stay the same tensor): same averages
     red.close()
     red2 = GradAllReducer(params, bucket_mb=0.0002)
@@ -96,7 +110,7 @@ def _dp_worker(rank, world, port, q):
         red2.allreduce_static()
         static_ok &= ptrs == [p.grad.data_ptr() if p.grad is not None else 0 for p in params]
         static_ok &= all(torch.allclose(p.grad, torch.tensor(g), atol=1e-7) for p, g in zip(params[:4], out[-1][:4]))
-    q.put((rank, out, mean_loss, len(red._buckets), static_ok))
+    q.put((rank, out, mean_loss, len(red._buckets), static_ok, inplace_ok))
     sdist.shutdown()
 
 
@@ -127,6 +141,7 @@ def test_data_parallel_gradient_allreduce_matches_full_batch():
             assert grads[4] is None and grads[5] is None  # unused parameters stay grad-less
     assert abs(res[0][2] - res[1][2]) < 1e-12
     assert res[0][4] and res[1][4]  # GradAllReducer.allreduce_static: same averages, gradients updated in place
+    assert res[0][5] and res[1][5]  # train._zero_grads under a reducer: no per-parameter copy after step 1, same averages
 
 
 def test_bench_self_launch_entry_spawns_one_rank_per_gpu(tmp_path):

@@ -373,3 +373,68 @@ def test_mit_b0_at_256x256(golden_dir):
     assert rel_err(o0[:, :, 1::9, 2::11], g["fus0_sample"]) < TOL and rel_err(o1[:, :, 1::9, 2::11], g["fus1_sample"]) < TOL
     assert abs(float(o0.double().mean()) - float(g["fus0_mean"])) < 1e-6 and abs(float(o1.double().mean()) - float(g["fus1_mean"])) < 1e-6
     assert rel_err(so.network3_forward(sd, x, "mit_b0"), g["seg"]) < TOL
+
+
+# ---- (r6) the ablation / variant classes (oracle/make_golden_r6.py -> variants.npz, variants_keys.json) ----
+VARIANT_INPUTS = {"ir": ("r6v_ir", (2, 1, 24, 40), 0.0), "vis": ("r6v_vis", (2, 3, 24, 40), 0.0), "out1": ("r6v_out1", (2, 64, 24, 40), -1.0),
+                  "out2": ("r6v_out2", (2, 128, 24, 40), -1.0), "x1": ("r6v_x1", (2, 32, 24, 40), -1.0), "x2": ("r6v_x2", (2, 32, 24, 40), -1.0),
+                  "x3": ("r6v_x3", (2, 32, 24, 40), -1.0)}
+
+
+def variant_inputs():
+    return {k: dw.det_input(n, shp, lo=lo, hi=1.0) for k, (n, shp, lo) in VARIANT_INPUTS.items()}
+
+
+def variant_outputs(g, name):
+    outs = [g[name + "|out"]]
+    i = 0
+    while f"{name}|extra{i}" in g:
+        outs.append(g[f"{name}|extra{i}"])
+        i += 1
+    return outs
+
+
+def _flat(res):
+    if torch.is_tensor(res):
+        return [res]
+    return [t for r in res for t in _flat(r)]
+
+
+def test_variant_networks_restatement_vs_reference(golden_dir):
+    g = load(golden_dir, "variants.npz")
+    meta = json.load(open(os.path.join(golden_dir, "variants_keys.json")))
+    inp = variant_inputs()
+    tok = lambda t: t.flatten(2).transpose(1, 2).contiguous()
+    for name in ("Fusion_Network3", "Fusion_Network3_S", "Fusion_Network3_M", "Fusion_Network3_obtainattention", "Fusion_Network3_Con",
+                 "Fusion_Network3_Add", "Fusion_Network3_Average", "Fusion_Network_rmseg", "Fusion_Network_rmseg_att"):
+        sd = dw.det_state_dict(meta["keys"][name], seed=0)
+        if "rmseg" in name:
+            res = so.fusion_variant(sd, name, inp["ir"], inp["vis"])
+        else:
+            res = so.fusion_variant(sd, name, inp["ir"], inp["vis"], inp["out1"], inp["out2"])
+        for a, b in zip(_flat(res), variant_outputs(g, name), strict=True):
+            assert rel_err(a, b) < TOL, name
+    for name, use in (("CrossPath_M", "v"), ("CrossPath_S", "z"), ("CrossPath_showAttention", "zv")):
+        sd = {"cross." + k: v for k, v in dw.det_state_dict(meta["keys"][name], seed=0).items()}
+        res = so.cross_path_variant(sd, "cross", tok(inp["x1"]), tok(inp["x2"]), tok(inp["x3"]), use, want_maps=name.endswith("Attention"))
+        for a, b in zip(_flat(res), variant_outputs(g, name), strict=True):
+            assert rel_err(a, b) < TOL, name
+    for name, use in (("FeatureFusionModule_SoAM", "z"), ("FeatureFusionModule_MoAM", "v"), ("FeatureFusionModule_ShowAttention", "zv")):
+        sd = {"ffm." + k: v for k, v in dw.det_state_dict(meta["keys"][name], seed=0).items()}
+        res = list(so.ffm_variant(sd, "ffm", inp["x1"], inp["x2"], inp["x3"], use))
+        if name.endswith("ShowAttention"):
+            res += [inp["x1"], inp["x2"]]  # (the reference hands back copies of its inputs, model_fusion.py:612-624)
+        for a, b in zip(res, variant_outputs(g, name), strict=True):
+            assert rel_err(a, b) < TOL, name
+    sd = {"att." + k: v for k, v in dw.det_state_dict(meta["keys"]["AttentionModule"], seed=0).items()}
+    assert rel_err(so.attention_module(sd, "att", inp["x1"]), g["AttentionModule|out"]) < TOL
+    # Network_fused = WeTr without input normalisation + its stored criterion
+    sd = dw.det_state_dict(meta["keys"]["Network_fused"], seed=0)
+    img = dw.det_input("r6v_img", (1, 3, 64, 64))
+    feats = so.mit_forward_features(sd, "denoise_net.encoder.", img, "mit_b0")
+    logits = so.segformer_head(sd, "denoise_net.decoder.", feats)
+    assert rel_err(logits, g["Network_fused|out"]) < TOL
+    lab = dw.det_labels("r6v_lab", (1, 64, 64), 9)
+    up = torch.nn.functional.interpolate(logits, size=(64, 64), mode="bilinear", align_corners=False)
+    assert abs(float(torch.nn.functional.cross_entropy(up, lab, ignore_index=255)) - float(g["Network_fused|extra0"])) < 1e-5
+    assert "Fusion_Network" in meta["forward_raises"]  # upstream's own forward cannot run (64 channels into a 32-channel DRDB)
