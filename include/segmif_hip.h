@@ -475,6 +475,13 @@ int segmif_linattn_kvpartial_f32(const float* y, const float* wkv, double* parti
 int segmif_linattn_fold_f32(const double* partial, const float* wend, float* weff, int B, int nblk,
                             int heads, int d, int Nout, int ldw, int wofs, int ldweff, int kofs,
                             float scale, void* stream);
+/* (r6) Backward of segmif_linattn_fold_f32 (training path, heads = d = 8, C = 64): ktv (B, 8, 8, 8) = the per-head K^T V the fold
+ * read (fp64; the sum of its partials), wend / wofs / kofs / scale as in the forward, dweff (B, Nout, ldweff) the gradient of the folded
+ * weight.  Writes dktv (B, 8, 8, 8) fp64 - through the softmax over the k index - and, per image, this fold's share of d end_proj:
+ * dwend_part[b][n][wofs + c] (pitch ldp floats; the caller sums over b).  Replaces the torch softmax / einsum / cat of the training
+ * path's context fold (core/model_fusion.py:281-286, :316-326, :357-360 under autograd). */
+int segmif_linattn_fold_bwd_f32(const double* ktv, const float* wend, int ldw, int wofs, const float* dweff, int ldweff, int kofs,
+                                float scale, double* dktv, float* dwend_part, int ldp, int B, int Nout, void* stream);
 
 /*
  * CrossPath in inference without its 128-wide intermediates (csrc/crosspath.hip; core/model_fusion.py:329-361).
@@ -560,6 +567,9 @@ int segmif_pointwise2_f32(const float* a, int lda, const float* b, int ldb, floa
 int segmif_color3_f32(const float* in, const float* ysrc, float* out, int B, int64_t HW, int mode, int nout, void* stream);
 /* argmax over C of NHWC logits -> int32 labels (test_segmentation.py:174); ties -> lowest index */
 int segmif_argmax_nhwc_i32(const float* x, int32_t* labels, int64_t rows, int C, int ldx, void* stream);
+/* (r6) test_segmentation.py:169-174 in one pass: labels = argmax_c bilinear(x -> OH x OW) for NHWC logits x (B, IH, IW, C), pixel pitch
+ * ldx (align_corners = False, segmif_bilinear_nhwc_f32's arithmetic; ties -> lowest index): the resized logits are never written. */
+int segmif_bilinear_argmax_i32(const float* x, int32_t* labels, int B, int IH, int IW, int OH, int OW, int C, int ldx, void* stream);
 /* conf[t*K + p] += #{i : label[i] == t, pred[i] == p}, both inside [0, K) (K <= 32) — the accumulation of
  * test_segmentation.py:176-177 (sklearn confusion_matrix with labels=[0..K-1]: rows = ground truth,
  * columns = prediction, samples outside the label set ignored); conf is NOT cleared */

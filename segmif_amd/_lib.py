@@ -227,8 +227,11 @@ SIGNATURES = {
     "segmif_fuse_ycrcb_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "segmif_conv3x3_c1_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                       c_int, c_int, c_void_p, c_int, c_void_p]),
+    "segmif_linattn_fold_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
+                                          c_int, c_int, c_void_p]),
     "segmif_pointwise2_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "segmif_argmax_nhwc_i32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "segmif_bilinear_argmax_i32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

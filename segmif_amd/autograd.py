@@ -1054,6 +1054,41 @@ class KvContextFn(torch.autograd.Function):
         return dy, dw, None, None
 
 
+class ContextFoldFn(torch.autograd.Function):
+    """(r6) CrossPath's context fold on the training path as ONE node with HIP kernels on both sides:
+        Weff[b][n][0:64]   = sum_j softmax_i(ktv_a scale_a)[h][i][j] Wend[n][8h + j]        (the modality's own context: z half)
+        Weff[b][n][64:128] = sum_j softmax_i(ktv_3 scale_3)[h][i][j] Wend[n][64 + 8h + j]   (the segmentation context: v half)
+    so that cat(z_i, v_i) @ Wend^T == [y3 | u_i] @ Weff^T (core/model_fusion.py:281-286, :316-326, :357-360).  Forward = two
+    segmif_linattn_fold_f32 launches on the fp64 K^T V (one "partial" per image), backward = segmif_linattn_fold_bwd_f32 per half
+    + one column sum over the images for d end_proj - no torch softmax / einsum / cat."""
+
+    @staticmethod
+    def forward(ctx, ktv_a, ktv_3, wend, scale_a, scale_3):
+        B = ktv_a.shape[0]
+        ka, k3 = ktv_a.contiguous(), ktv_3.contiguous()
+        w = wend.contiguous()
+        weff = torch.empty((B, w.shape[0], 128), device=w.device, dtype=torch.float32)
+        ops.linattn_fold(ka.view(B, 1, 512), w, weff, wofs=0, kofs=0, scale=scale_a)
+        ops.linattn_fold(k3.view(B, 1, 512), w, weff, wofs=64, kofs=64, scale=scale_3)
+        ctx.save_for_backward(ka, k3, w)
+        ctx.scales = (float(scale_a), float(scale_3))
+        return weff
+
+    @staticmethod
+    def backward(ctx, dweff):
+        ka, k3, w = ctx.saved_tensors
+        B, Nout = ka.shape[0], w.shape[0]
+        dweff = dweff.contiguous()
+        dka, dk3 = torch.empty_like(ka), torch.empty_like(k3)
+        part = torch.empty((B, Nout, 128), device=w.device, dtype=torch.float32)
+        lib = _lib.load()
+        for k, dk, ofs, sc in ((ka, dka, 0, ctx.scales[0]), (k3, dk3, 64, ctx.scales[1])):
+            _lib.check(lib.segmif_linattn_fold_bwd_f32(k.data_ptr(), w.data_ptr(), 128, ofs, dweff.data_ptr(), 128, ofs, sc, dk.data_ptr(),
+                                                       part.data_ptr(), 128, B, Nout, _stream()), "segmif_linattn_fold_bwd_f32")
+        dw = colsum(part.view(B, Nout * 128)).view(Nout, 128) if ctx.needs_input_grad[2] else None
+        return dka, dk3, dw, None, None
+
+
 class BatchNormReluFn(torch.autograd.Function):
     """Train-mode BatchNorm (batch statistics, biased variance) + ReLU over NHWC rows (rows, C).
     Returns (y, batch_mean, batch_var_biased); the caller updates the running statistics."""
@@ -1368,6 +1403,10 @@ def batched_linear2(xa, xb, w, bias=None, res=None):
 
 def kv_context(y, wkv, sink=None, which=None):
     return KvContextFn.apply(y, wkv, sink, which)
+
+
+def context_fold(ktv_a, ktv_3, wend, scale_a, scale_3):
+    return ContextFoldFn.apply(ktv_a, ktv_3, wend, scale_a, scale_3)
 
 
 def cross_proj(x1, x2, x3, w1, b1, w2, b2, w3, b3, sink=None):

@@ -380,29 +380,24 @@ class CrossPath(nn.Module):
             and ops.aligned16(*(p for p in self.parameters() if p.dim() == 1))  # 16-byte bias / LayerNorm loads in the tail
 
     def forward_tokens_train(self, x1, x2, seg, out1=None, out2=None):
-        """autograd path: heavy contractions in HIP Functions, the 8x8 context softmax and the fold into
-        end_proj (tensors of a few KB) in torch autograd.  out_i: optional ag.Out placements of the two results.
+        """autograd path: every node a HIP Function - the heavy contractions and, (r6), the 8x8 context softmaxes with their fold
+        into end_proj (ag.context_fold; tensors of a few KB).  out_i: optional ag.Out placements of the two results.
         (r4) Three nodes carry the full-resolution tensors - ag.cross_proj (the three channel_proj with every 64-channel half
         its own output), ag.kv_context x 3, ag.tail_pair (both closing projections) - arranged so that each big tensor has one
         consumer: no autograd accumulation passes, no zero-padded slice gradients."""
         C = self.dim
-        heads, d = 8, 8
         cp = [getattr(self, f"channel_proj{i}") for i in (1, 2, 3)]
         # (the sink lets the consumers' backward GEMMs write each half's gradient through its ReLU mask into cross_proj's buffer)
         sink = ag.ProjSink()
         y1, u1, y2, u2, y3, u3, x1r, x2r = ag.cross_proj(x1, x2, seg, cp[0].weight, cp[0].bias, cp[1].weight, cp[1].bias,
                                                          cp[2].weight, cp[2].bias, sink)
-        ctx3 = torch.softmax(ag.kv_context(u3, self.cross_attn.kv3.weight, sink, (2, 1)) * self.cross_attn.scale, dim=-2)
-        ctx1 = torch.softmax(ag.kv_context(y1, self.cross_attn2.kv1.weight, sink, (0, 0)) * self.cross_attn2.scale, dim=-2)
-        ctx2 = torch.softmax(ag.kv_context(y2, self.cross_attn2.kv2.weight, sink, (1, 0)) * self.cross_attn2.scale, dim=-2)
-        B = x1.shape[0]
-        weffs = []
-        for end, ctx_i in ((self.end_proj1, ctx1), (self.end_proj2, ctx2)):
-            wz = end.weight[:, :C].reshape(C, heads, d).double()  # [n][h][j]; contexts are fp64
-            wv = end.weight[:, C:].reshape(C, heads, d).double()
-            # Weff[b][n][h*d+i] = sum_j ctx[b][h][i][j] * Wend[n][ofs + h*d + j]
-            weffs.append(torch.cat((torch.einsum("bhij,nhj->bnhi", ctx_i, wz).reshape(B, C, C),
-                                    torch.einsum("bhij,nhj->bnhi", ctx3, wv).reshape(B, C, C)), dim=-1).float())
+        # (r6) the 8 x 8 context softmaxes and their fold into end_proj are one autograd node with HIP kernels on both sides
+        # (ag.context_fold): no torch softmax / einsum / cat on the way
+        k3 = ag.kv_context(u3, self.cross_attn.kv3.weight, sink, (2, 1))
+        k1 = ag.kv_context(y1, self.cross_attn2.kv1.weight, sink, (0, 0))
+        k2 = ag.kv_context(y2, self.cross_attn2.kv2.weight, sink, (1, 0))
+        weffs = [ag.context_fold(k_i, k3, end.weight, self.cross_attn2.scale, self.cross_attn.scale)
+                 for end, k_i in ((self.end_proj1, k1), (self.end_proj2, k2))]
         # x_i + [y3 | u_i] @ Weff_i^T + b_i for both modalities as one node (two-source GEMMs, residual in the epilogue)
         t1, t2 = ag.tail_pair(y3, u1, u2, weffs[0], weffs[1], self.end_proj1.bias, self.end_proj2.bias, x1r, x2r, sink)
         return (ag.layernorm(t1, self.norm1.weight, self.norm1.bias, self.norm1.eps, out=out1),
@@ -751,7 +746,7 @@ class Network3(nn.Module):
         """test_segmentation.py:169-174 on device: logits -> bilinear to `size` -> argmax (int32, B,H,W)."""
         seg = self._segment_nhwc(fused)
         H, W = size if size is not None else fused.shape[2:]
-        return ops.argmax_nhwc(ops.bilinear(seg, H, W))
+        return ops.bilinear_argmax(seg, H, W)  # (r6: one pass - the resized logits, 708 MB per 64 images, are never written)
 
     def _loss(self, fused_seg1, label, criterion):
         """CE(bilinear-up(seg_map), label) (ref :1090-1097): seg_criterion_loss below."""

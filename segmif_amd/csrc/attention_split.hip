@@ -37,6 +37,10 @@
 
 namespace p16 = segmif::p16;
 
+#ifndef ATTN_ABL
+#define ATTN_ABL 0  // tuning aid (tools/attn_ablate.sh): 1 = no tile DMA after the first, 2 = no softmax arithmetic, 4 = no Q K^T MFMAs, 8 = no P V MFMAs, 16 = no per-tile barrier (with 1), 32 = no output stores
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   __syncthreads();
   for (int kt = 0; kt < ntiles; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < ntiles) stage(kt + 1, cur ^ 1);  // buffer cur^1 was last read in iteration kt-1, before its closing barrier
+    if (!(ATTN_ABL & 1) && kt + 1 < ntiles) stage(kt + 1, cur ^ 1);  // buffer cur^1 was last read in iteration kt-1, before its closing barrier
     const unsigned char* Kt = smem + cur * IMG;
     const unsigned char* Vt = Kt + K_BYTES;
     float kinv = 1.f, vinv = 1.f;
@@ -286,7 +290,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       u32x4 kf[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) kf[k] = *reinterpret_cast<const u32x4*>(Kt + r * KPITCH + k * 128 + (16 * st + 8 * h) * 2);
-      if constexpr (F16) s = mma3(kf, qh[st], s);
+      if (ATTN_ABL & 4) asm volatile("" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]));
+      else if constexpr (F16) s = mma3(kf, qh[st], s);
       else s = mma6(kf, qp[st].p, s);
     }
     // ---- per-lane online softmax over this lane's 16 keys (+ partner half) -----------------
@@ -298,6 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
     }
     float mx = s[0];
+#if !(ATTN_ABL & 2)
 #pragma unroll
     for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -322,6 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     l_run += psum;
     m_run = m_new;
+#endif
     // ---- O^T += V^T P^T: registers 8 sp .. 8 sp + 7 of s are the K-slots (keys) of step sp ------------
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
@@ -337,39 +344,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           vf[k] = *reinterpret_cast<const u32x4*>(Vt + (dt * 32 + r) * VPITCH + k * 64 + (16 * sp + 8 * h) * 2);
-        if constexpr (F16) o[dt] = mma3(vf, ph, o[dt]);
+        if (ATTN_ABL & 8) asm volatile("" ::"v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(ph.hi), "v"(ph.lo));
+        else if constexpr (F16) o[dt] = mma3(vf, ph, o[dt]);
         else o[dt] = mma6(vf, pk.p, o[dt]);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt + 1 has landed
-    __syncthreads();
+    if (!(ATTN_ABL & 16)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt + 1 has landed
+      __syncthreads();
+    }
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = vunit / l_tot;
   uint32_t oamx = 0u;
-  if (q_ok) {
-    float* orow = out + ((long long)b * N + qi) * ldo + head * 64;
+  // (r6) The output leaves through LDS.  A lane owns a QUERY: written straight from the accumulators, every store instruction was 64
+  // fragments of 8 (pairs) or 16 bytes (fp32) in 32 different rows - 16 / 8 such instructions per wave - and the ablation of
+  // tools/attn_ablate.sh put them at 31 % of the stage-3 call and 65 % of the stage-2 call (profiles/r06_attn_ablation.txt).  The
+  // key-tile buffers are free after the loop's last barrier: each wave parks its 32 x 256-byte tile there (row pitch 272: 16-byte
+  // aligned, 4 banks of skew per row) and stores it as 8 instructions of 4 rows x 256 contiguous bytes.  Both formats fill the same
+  // tile: fp32 rows are 64 channels x 4 bytes, PAIRS rows 4 groups of [16 hi | 16 lo] halves.
+  constexpr int OPITCH = 272;
+  unsigned char* T = smem + wave * (32 * OPITCH);
+  if (!(ATTN_ABL & 32)) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 w{o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
         if (F16 && out_pairs) {
-          // (r5) PAIRS output (gemm_pairs.hip: the proj Linear's A operand): channel c = 64 head + 32 dt + 8 g + 4 h .. + 3 lies in
+          // PAIRS output (gemm_pairs.hip: the proj Linear's A operand): channel c = 32 dt + 8 g + 4 h .. + 3 of the head lies in
           // 16-group c >> 4 at half position c & 15; same byte count as the fp32 row
           const int c = 32 * dt + 8 * g + 4 * h;
           uint32_t ha, la, hb, lb;
           p16::split2(w[0], w[1], ha, la);
           p16::split2(w[2], w[3], hb, lb);
-          unsigned char* d8 = reinterpret_cast<unsigned char*>(orow) + (c >> 4) * 64 + (c & 15) * 2;
+          unsigned char* d8 = T + r * OPITCH + (c >> 4) * 64 + (c & 15) * 2;
           *reinterpret_cast<u32x2*>(d8) = u32x2{ha, hb};
           *reinterpret_cast<u32x2*>(d8 + 32) = u32x2{la, lb};
-          oamx = p16::absmax_pk(p16::absmax_pk(oamx, ha, la), hb, lb);
+          if (q_ok) oamx = p16::absmax_pk(p16::absmax_pk(oamx, ha, la), hb, lb);
         } else {
-          *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) = w;
+          *reinterpret_cast<f32x4*>(T + r * OPITCH + (32 * dt + 8 * g + 4 * h) * 4) = w;
         }
       }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (wave-private tile: the wave's own LDS writes have landed; no barrier)
+    __builtin_amdgcn_wave_barrier();
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    unsigned char* obase = reinterpret_cast<unsigned char*>(out + ((long long)b * N + q0) * ldo + head * 64) + (lane & 15) * 16;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = 4 * it + (lane >> 4);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(T + row * OPITCH + (lane & 15) * 16);
+      if (q0 + row < N) *reinterpret_cast<u32x4*>(obase + (long long)row * ldo * 4) = v;
+    }
   }
   if constexpr (F16) {
     if (amax) p16::fold_pat(amax, amax_images > 1 ? b : 0, amax_images > 1 ? b : 0, q_ok ? amx : 0u);

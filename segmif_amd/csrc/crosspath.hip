@@ -443,9 +443,17 @@ __global__ __launch_bounds__(1024) void crosspath_fold_kernel(const double* __re
     const int ti = i >> 5, tj = j >> 5;
     const int a = ti == 0 ? tj : 2;                                            // tile (0,0), (0,1), (1,1); (1,0) mirrors (0,1)
     const int idx = (ti == 1 && tj == 0) ? 1024 + (j & 31) * 32 + (i & 31) : a * 1024 + (i & 31) * 32 + (j & 31);
-    double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += p[(long long)k * 3072 + idx];          // fixed order: deterministic
-    G[u] = s;
+    // fixed order: deterministic.  (r6) Eight independent running sums - partial k goes to sum k & 7 - so that eight loads are
+    // in flight per thread instead of one: the single dependent chain over >= 64 partials (24 KB apart) was most of this kernel's
+    // 165 us, which is 8 launches x one workgroup per image per pair forward - 9 % of a 4-pair step (profiles/r06_kstats_config1.txt)
+    double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int k = 0;
+    for (; k + 8 <= nblk; k += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s8[j] += p[(long long)(k + j) * 3072 + idx];
+    }
+    for (; k < nblk; ++k) s8[k & 7] += p[(long long)k * 3072 + idx];
+    G[u] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   }
   __syncthreads();
   double* D1 = ctx + 512;     // [64][64]  Wk (G o S): the Gram matrix under the probe pattern S (cond only)

@@ -285,6 +285,49 @@ __global__ __launch_bounds__(512) void linattn_fold_generic_kernel(const double*
   }
 }
 
+// (r6) Backward of segmif_linattn_fold_f32 for the training path (heads = d = 8): given ktv = K^T V per head (fp64, [h][i][j]), the
+// end_proj weight and dWeff, one workgroup per image forms
+//     ctx = softmax_i(ktv scale);   dctx[h][i][j] = sum_n dWeff[n][kofs + 8h + i] Wend[n][wofs + 8h + j]
+//     dktv[h][i][j] = scale ctx_ij (dctx_ij - sum_i' ctx_i'j dctx_i'j)                       (softmax over i = dim -2)
+//     dWend_part[b][n][wofs + 8h + j] = sum_i dWeff[n][kofs + 8h + i] ctx[h][i][j]           (summed over images by the caller)
+// - the softmax / einsum / cat that CrossPath's training path ran as torch ops on (B, 8, 8, 8) tensors (core/model_fusion.py:281-286,
+// :316-326, :357-360 under autograd).  fp64 where the forward is.
+__global__ __launch_bounds__(512) void linattn_fold_bwd_kernel(const double* __restrict__ ktv, const float* __restrict__ wend, int ldw,
+                                                               int wofs, const float* __restrict__ dweff, int ldweff, int kofs,
+                                                               float scale, double* __restrict__ dktv, float* __restrict__ dwend_part,
+                                                               int ldp, int Nout) {
+  __shared__ double ctx[512], dctx[512];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int hh = tid >> 6, i = (tid >> 3) & 7, j = tid & 7;
+  ctx[tid] = ktv[(long long)b * 512 + tid] * (double)scale;
+  __syncthreads();
+  if (tid < 64) {  // one (h, j) column per thread: softmax over i
+    const int h2 = tid >> 3, j2 = tid & 7;
+    double mx = -1e300, ev[8], sum = 0.0;
+    for (int q = 0; q < 8; ++q) mx = fmax(mx, ctx[h2 * 64 + q * 8 + j2]);
+    for (int q = 0; q < 8; ++q) {
+      ev[q] = exp(ctx[h2 * 64 + q * 8 + j2] - mx);
+      sum += ev[q];
+    }
+    for (int q = 0; q < 8; ++q) ctx[h2 * 64 + q * 8 + j2] = ev[q] / sum;
+  }
+  const float* dw = dweff + (long long)b * Nout * ldweff + kofs;
+  double acc = 0.0;
+  for (int n = 0; n < Nout; ++n) acc += (double)dw[(long long)n * ldweff + hh * 8 + i] * (double)wend[(long long)n * ldw + wofs + hh * 8 + j];
+  dctx[tid] = acc;
+  __syncthreads();
+  double dot = 0.0;
+  for (int q = 0; q < 8; ++q) dot += ctx[hh * 64 + q * 8 + j] * dctx[hh * 64 + q * 8 + j];
+  dktv[(long long)b * 512 + tid] = (double)scale * ctx[tid] * (dctx[tid] - dot);
+  float* dp = dwend_part + (long long)b * Nout * ldp + wofs;
+  for (int o = tid; o < Nout * 64; o += 512) {
+    const int n = o >> 6, c = o & 63, h2 = c >> 3, j2 = c & 7;
+    double a = 0.0;
+    for (int q = 0; q < 8; ++q) a += (double)dw[(long long)n * ldweff + h2 * 8 + q] * ctx[h2 * 64 + q * 8 + j2];
+    dp[(long long)n * ldp + c] = (float)a;
+  }
+}
+
 }  // namespace
 
 extern "C" int segmif_linattn_num_blocks(int64_t N) { return (int)((N + LA_ROWS - 1) / LA_ROWS); }
@@ -335,5 +378,17 @@ extern "C" int segmif_linattn_kvpartial_f32(const float* y, const float* wkv, do
   }
   hipLaunchKernelGGL(linattn_kvpartial_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), smem, (hipStream_t)stream,
                      y, wkv, partial, (long long)N, ldy, nblk);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_linattn_fold_bwd_f32(const double* ktv, const float* wend, int ldw, int wofs, const float* dweff, int ldweff,
+                                           int kofs, float scale, double* dktv, float* dwend_part, int ldp, int B, int Nout,
+                                           void* stream) {
+  if (!ktv || !wend || !dweff || !dktv || !dwend_part || B <= 0 || Nout <= 0 || wofs < 0 || kofs < 0 || ldw < wofs + 64 ||
+      ldweff < kofs + 64 || ldp < wofs + 64)
+    return SEGMIF_EINVAL;
+  if (((uintptr_t)ktv | (uintptr_t)dktv) & 7) return SEGMIF_EINVAL;
+  hipLaunchKernelGGL(linattn_fold_bwd_kernel, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, ktv, wend, ldw, wofs, dweff, ldweff,
+                     kofs, scale, dktv, dwend_part, ldp, Nout);
   return (int)hipGetLastError();
 }

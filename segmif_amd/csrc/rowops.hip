@@ -474,6 +474,40 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x
   labels[r] = bi;
 }
 
+// (r6) logits -> bilinear resize -> argmax in one pass (test_segmentation.py:169-174: F.interpolate(seg, size=labels.shape[1:],
+// mode='bilinear') then .argmax(1)): the (B, OH, OW, C) resized logits - 708 MB per 64 images at 480 x 640, written by
+// bilinear_kernel<1> at 1.4 TB/s (C = 9: scalar accesses) and read back by argmax_kernel - never exist.  One thread per output
+// pixel; the interpolation is bilinear_kernel's expression, the comparison argmax_kernel's (ties -> lowest index), so the labels
+// are those of the two-pass form.
+__global__ __launch_bounds__(256) void bilinear_argmax_kernel(const float* __restrict__ x, int32_t* __restrict__ labels, int IH, int IW,
+                                                              int OH, int OW, int C, int ldx, float sy, float sx) {
+  const int ox = blockIdx.x * 256 + threadIdx.x;
+  if (ox >= OW) return;
+  const int oy = blockIdx.y;
+  const long long b = blockIdx.z;
+  const float fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.f);
+  const float fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = min(y0 + 1, IH - 1), x1 = min(x0 + 1, IW - 1);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float* base = x + b * IH * IW * ldx;
+  const float* p00 = base + ((long long)y0 * IW + x0) * ldx;
+  const float* p01 = base + ((long long)y0 * IW + x1) * ldx;
+  const float* p10 = base + ((long long)y1 * IW + x0) * ldx;
+  const float* p11 = base + ((long long)y1 * IW + x1) * ldx;
+  float best = hy * (hx * p00[0] + lx * p01[0]) + ly * (hx * p10[0] + lx * p11[0]);
+  int bi = 0;
+  for (int c = 1; c < C; ++c) {
+    const float v = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+    if (v > best) {
+      best = v;
+      bi = c;
+    }
+  }
+  labels[(b * OH + oy) * OW + ox] = bi;
+}
+
 // out = act(base + bias + sum_s bilinear(x_s -> OH x OW)): the SegFormer head with linear_fuse applied per
 // scale BEFORE the resize (segformer_head.py:67-77 commuted) needs the sum of three
 // up-sampled maps, the full-resolution term, the folded BatchNorm shift and the ReLU in one pass.
@@ -504,16 +538,16 @@ __device__ __forceinline__ f32x4 bilinear_tap4(const UpSrc& s, long long b, int 
 __global__ __launch_bounds__(256) void upsum_act_kernel(const float* __restrict__ basep, int ldb, UpSrc s0, UpSrc s1, UpSrc s2,
                                                         int nsrc, const float* __restrict__ bias, float* __restrict__ out,
                                                         int ldo, int OH, int OW, int C, int act, long long total) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
+  // (r6) grid = (units of an output row, output row, image), like bilinear_kernel: the row terms are wave-uniform and the only
+  // division left is a 32-bit one (this kernel spent three 64-bit divisions per 16-byte store: 0.93 ms for 2.5 GB = 2.7 TB/s)
   const int c4n = C / 4;
-  const int c = (int)(idx % c4n) * 4;
-  long long pix = idx / c4n;
-  const int ox = (int)(pix % OW);
-  const long long row = pix;  // (b * OH + oy) * OW + ox
-  pix /= OW;
-  const int oy = (int)(pix % OH);
-  const long long b = pix / OH;
+  const unsigned t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= (unsigned)(OW * c4n)) return;
+  const int ox = (int)(t / (unsigned)c4n);
+  const int c = (int)(t - (unsigned)ox * c4n) * 4;
+  const int oy = blockIdx.y;
+  const long long b = blockIdx.z;
+  const long long row = (b * OH + oy) * OW + ox;
   f32x4 y = {0.f, 0.f, 0.f, 0.f};
   if (basep) y = *reinterpret_cast<const f32x4*>(basep + row * ldb + c);
   if (bias) {
@@ -895,6 +929,15 @@ extern "C" int segmif_argmax_nhwc_i32(const float* x, int32_t* labels, int64_t r
   return (int)hipGetLastError();
 }
 
+extern "C" int segmif_bilinear_argmax_i32(const float* x, int32_t* labels, int B, int IH, int IW, int OH, int OW, int C, int ldx,
+                                          void* stream) {
+  if (!x || !labels || B <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || ldx < C) return SEGMIF_EINVAL;
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;  // (as segmif_bilinear_nhwc_f32 forms them)
+  dim3 grid((unsigned)((OW + 255) / 256), (unsigned)OH, (unsigned)B);
+  hipLaunchKernelGGL(bilinear_argmax_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, labels, IH, IW, OH, OW, C, ldx, sy, sx);
+  return (int)hipGetLastError();
+}
+
 extern "C" int segmif_gauss_blur11_f32(const float* x, float* y, int planes, int H, int W, const float* taps11,
                                        void* stream) {
   if (!x || !y || !taps11 || planes <= 0 || H <= 0 || W <= 0) return SEGMIF_EINVAL;
@@ -922,7 +965,9 @@ extern "C" int segmif_upsum_act_nhwc_f32(const float* base, int ldb, const float
   }
   if ((((uintptr_t)out | (uintptr_t)(base ? base : out) | (uintptr_t)(bias ? bias : out)) & 15)) return SEGMIF_EINVAL;
   const long long total = (long long)B * OH * OW * (C / 4);
-  hipLaunchKernelGGL(upsum_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base, ldb,
+  if ((long long)OW * (C / 4) >= (1ll << 31) || OH > 65535 || B > 65535) return SEGMIF_EINVAL;
+  const dim3 grid((unsigned)(((long long)OW * (C / 4) + 255) / 256), (unsigned)OH, (unsigned)B);
+  hipLaunchKernelGGL(upsum_act_kernel, grid, dim3(256), 0, (hipStream_t)stream, base, ldb,
                      src[0], src[1], src[2], n, bias, out, ldo, OH, OW, C, act, total);
   return (int)hipGetLastError();
 }

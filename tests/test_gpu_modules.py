@@ -39,6 +39,24 @@ def rel(got, ref):
     return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
 
 
+def rel_elementwise(got, ref, floor=1e-2):
+    """(r6) ELEMENT-WISE relative error |got - ref| / |ref| over the elements with |ref| above `floor` x the
+    tensor's range -> (max, 99.9th percentile, RMS-relative over the whole tensor).  rel() above is a global max-norm, blind to
+    damage confined to small-magnitude regions; this is the figure "1e-3 rel" reads as when taken element by element (below the
+    floor a relative error is a statement about the rounding of numbers near zero, not about parity)."""
+    got = torch.as_tensor(got).detach().double().cpu().reshape(-1)
+    ref = torch.as_tensor(ref).double().reshape(-1)
+    big = ref.abs() > floor * ref.abs().max()
+    ew = ((got - ref).abs() / ref.abs().clamp_min(1e-300))[big]
+    if ew.numel() > 4_000_000:  # (torch.quantile's input limit; a strided subsample keeps the percentile honest)
+        ewq = ew[:: ew.numel() // 4_000_000 + 1]
+    else:
+        ewq = ew
+    p999 = float(torch.quantile(ewq, 0.999)) if ewq.numel() else 0.0
+    rms = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-300))
+    return (float(ew.max()) if ew.numel() else 0.0), p999, rms
+
+
 def build(core, cls, *a, **k):
     m = cls(*a, **k)
     dw.load_det_weights(m, seed=0)
@@ -177,7 +195,10 @@ def test_fusion_net_in_all_conv3x3_modes(net_b1, fus, golden_dir):
         ops.set_conv3x3_mode(prev)
     for mode in ("planes16", "planes", "bf16x6"):
         assert rel(outs[mode][0], outs["fp32"][0].cpu()) < 2e-6, mode
-        assert rel(outs[mode][1], outs["fp32"][1].cpu()) < 5e-6, mode
+        # (r6: under planes16 the CrossPath tail and conv1 run on f16x3 operands too - 22-23 significand bits in two more
+        # contractions - and the whole net lands 7.1e-6 from the exact-fp32 convs instead of < 5e-6; the bound that matters,
+        # 5 x TIGHT against the reference record, is asserted per mode above)
+        assert rel(outs[mode][1], outs["fp32"][1].cpu()) < (1.5e-5 if mode == "planes16" else 5e-6), mode
 
 
 def test_conv3_conv4_commute_with_the_resize(net_b1, fus, golden_dir):
@@ -282,6 +303,11 @@ def test_pair_b1_vs_reference(core, net_b1, fus, golden_dir):
     for k in ("y_fused", "fused", "seg", "logits"):
         assert rel(r[k], g[k]) < TOL, k
         assert rel(r[k], g[k]) < 5 * TIGHT, k
+        # (r6) the same tolerance ELEMENT by element, over every element above 1 % of the tensor's range, and RMS-relative
+        ew_max, ew_p999, rms = rel_elementwise(r[k], g[k])
+        from _observed import observed
+        observed(f"elementwise[pair_b1_64x96:{k}]", {"max_above_1pct": ew_max, "p999_above_1pct": ew_p999, "rms_rel": rms, "max_norm": rel(r[k], g[k])})
+        assert ew_max < TOL and rms < TIGHT, (k, ew_max, ew_p999, rms)
     stable = torch.from_numpy(g["margin"]) > 1e-3
     got = r["labels"].cpu().long()
     assert torch.equal(got[stable], torch.from_numpy(g["labels"]).long()[stable])
@@ -321,6 +347,8 @@ def test_oracle_parity_fresh_inputs_b1(core, net_b1, fus):
         r = pair_forward_hip(core, net_b1, fus, ir.cuda(), vis.cuda(), mask.cuda())
     for k in ("out0", "out1", "y_fused", "fused", "seg", "logits"):
         assert rel(r[k], ref[k]) < 5 * TIGHT, k
+        ew_max, _, rms = rel_elementwise(r[k], ref[k])  # (r6) element by element above 1 % of the range, and RMS-relative
+        assert ew_max < TOL and rms < TIGHT, (k, ew_max, rms)
     stable = so.top2_margin(ref["logits"]) > 1e-3
     assert torch.equal(r["labels"].cpu().long()[stable], ref["labels"][stable])
 
@@ -337,14 +365,8 @@ def test_full_size_b3_vs_reference_checksum(core, fus, golden_dir):
     mask = dw.det_input("b3_mask", (1, 1, H, W)).repeat(1, 3, 1, 1).cuda()
     with torch.no_grad():
         r = pair_forward_hip(core, net, fus, ir, vis, mask)
-    for name in ("out0", "out1", "y_fused", "fused", "seg", "logits"):
-        got = r[name].contiguous().reshape(-1)[torch.from_numpy(g[name + "_idx"]).cuda()].cpu()
-        scale = max(abs(g[name + "_stats"][2]), abs(g[name + "_stats"][3]))
-        e = float((got - torch.from_numpy(g[name + "_val"])).abs().max()) / scale
-        assert e < TOL, (name, e)
-        assert e < 5 * TIGHT, (name, e)
-    labels = r["labels"].cpu().long()
-    ref_labels = torch.from_numpy(g["labels"]).long()
+    # sampled values of every stage: max-norm gate + (r6) the element-wise relative gate above 1 % of the range (_check_samples)
+    labels, ref_labels = _check_samples(r, g, ("out0", "out1", "y_fused", "fused", "seg", "logits"))
     stable = torch.from_numpy(g["margin_f16"].astype(np.float32)) > 1e-3
     assert torch.equal(labels[stable], ref_labels[stable])
     mismatches = int((labels != ref_labels).sum())
@@ -365,8 +387,25 @@ def _check_samples(r, g, names):
     for name in names:
         got = r[name].contiguous().reshape(-1)[torch.from_numpy(g[name + "_idx"]).cuda()].cpu()
         scale = max(abs(g[name + "_stats"][2]), abs(g[name + "_stats"][3]))
-        e = float((got - torch.from_numpy(g[name + "_val"])).abs().max()) / scale
+        want = torch.from_numpy(g[name + "_val"])
+        e = float((got - want).abs().max()) / scale
+        # (r6) beside the max-norm figure: the ELEMENT-WISE relative error over the sampled elements above 1 % of
+        # the tensor's range - its maximum gates below, its 99.9th percentile and the RMS-relative error are recorded
+        # (profiles/r06_parity_observed/) - so that damage confined to small-magnitude regions cannot hide behind the largest value
+        big = want.abs() > 1e-2 * scale
+        ew = ((got - want).abs() / want.abs())[big].double()
+        ew_max = float(ew.max()) if ew.numel() else 0.0
+        import inspect
+        from _observed import observed
+        observed(f"fullsize_samples[{inspect.stack()[1].function}:{name}]",
+                 {"max_norm": e, "p999_elementwise_rel_above_1pct": float(torch.quantile(ew, 0.999)) if ew.numel() else 0.0,
+                  "max_elementwise_rel_above_1pct": ew_max,
+                  "rms_rel": float((got - want).double().pow(2).mean().sqrt() / want.double().pow(2).mean().sqrt().clamp_min(1e-30)),
+                  "samples": int(want.numel()), "samples_above_1pct": int(big.sum())})
         assert e < TOL and e < 5 * TIGHT, (name, e)
+        # (r6) gating as well: every sampled element above 1 % of the tensor's range is within 1e-3 of the reference's value,
+        # element-wise relative (observed: <= 1.3e-4 on the b3 / b5 full-size records)
+        assert ew_max < TOL, (name, ew_max)
     labels = r["labels"].cpu().long().reshape(g["labels"].shape)
     ref_labels = torch.from_numpy(g["labels"]).long()
     stable = torch.from_numpy(g["margin_f16"].astype(np.float32)) > 1e-3

@@ -323,7 +323,8 @@ def test_fusion_net_on_f16x3_planes_vs_reference_and_fallback(ops, golden_dir):
                 outs[mode] = (y, yf)
             assert fus.planes16_fallbacks == 0
             assert _rel(outs["planes16"][0], outs["fp32"][0].cpu()) < 2e-6
-            assert _rel(outs["planes16"][1], outs["fp32"][1].cpu()) < 5e-6
+            # (r6: 7.1e-6 since the CrossPath tail and conv1 run on f16x3 operands under planes16 as well; < 5e-6 before)
+            assert _rel(outs["planes16"][1], outs["fp32"][1].cpu()) < 1.5e-5
             ops.set_conv3x3_mode("planes16")
             big = torch.from_numpy(g["drdb_x"]).cuda() * 1.0e6
             yb = fus.DRDB1(big)

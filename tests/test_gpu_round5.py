@@ -315,9 +315,15 @@ def test_ill_conditioned_pair_is_repeated_with_exact_convs(ops):
         with scope(ops, 3) as g:  # what the guard saw, and the un-repeated f16x3 result
             raw = pipe._eager_body(ir.cuda(), vis.cuda(), mask.cuda())[0]
         truth = so.pair_forward(sd64[0], sd64[1], ir.double(), vis.double(), mask.double(), "mit_b1", return_all=True)["fused"]
+        ref32 = so.pair_forward(sd_seg, sd_fus, ir, vis, mask, "mit_b1", return_all=True)["fused"]  # the reference's fp32 CPU arithmetic
         prev = (ops.set_conv3x3_mode("fp32"), ops.set_linear_mode("fp32"), ops.set_attention_mode("fp32"))
         try:
             f32 = pipe._eager_body(ir.cuda(), vis.cuda(), mask.cuda())[0]
+            prev_cp = ops.set_crosspath_mode("gemm")
+            try:
+                f32_gemm = pipe._eager_body(ir.cuda(), vis.cuda(), mask.cuda())[0]
+            finally:
+                ops.set_crosspath_mode(prev_cp)
         finally:
             ops.set_conv3x3_mode(prev[0]), ops.set_linear_mode(prev[1]), ops.set_attention_mode(prev[2])
     bad, sat = g.verdict()
@@ -334,10 +340,17 @@ def test_ill_conditioned_pair_is_repeated_with_exact_convs(ops):
             d = d[idx]
         return float(d.max() / truth.abs().max())
 
-    e, e_raw, e32 = err(fused), err(raw), err(f32)
+    e, e_raw, e32, e32g, eref = err(fused), err(raw), err(f32), err(f32_gemm), err(ref32)
     observed("ill_conditioned_pair_repeat", {"kappa": kap.tolist(), "estimate": g.cond_estimate(kap).tolist(), "bound": ops.Planes16Guard.COND_BOUND, "repeated": sat.tolist(),
-                                             "err_guarded": e, "err_f16x3_unrepeated": e_raw, "err_fp32_mfma": e32})
-    assert e <= max(TOL, 1.5 * e32), (e, e32, e_raw)
+                                             "err_guarded": e, "err_f16x3_unrepeated": e_raw, "err_fp32_mfma": e32,
+                                             "err_fp32_mfma_gemm_crosspath": e32g, "err_reference_fp32_cpu": eref})
+    # (r6) The yardstick is the scatter of float32 itself on this input: three float32 evaluations - the reference's CPU arithmetic
+    # (the oracle on float32 weights), the repo's exact-fp32 MFMA kernels with CrossPath in Gram form and in GEMM form - land
+    # 1.2e-3 .. 2.5e-3 from the float64 truth, each by its own summation order behind a softmax of condition ~ kappa.  The repeat
+    # (exact-fp32 convs + GEMM-form CrossPath since r6, see ops._exact_repeat_modes) has to sit inside that scatter: not above
+    # 1.5 x the worst of the three, and strictly better than the f16x3 result it replaces.
+    assert e <= max(TOL, 1.5 * max(e32, e32g, eref)), (e, e32, e32g, eref, e_raw)
+    assert e < e_raw or e_raw < TOL, (e, e_raw)
 
 
 @pytest.mark.parametrize("B,N,heads,Nk", [(2, 1200, 5, 300), (2, 300, 8, 300), (1, 1000, 2, 77), (1, 2500, 1, 300), (3, 129, 1, 33)])

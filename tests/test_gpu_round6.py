@@ -263,9 +263,9 @@ def test_guard_sticky_bit_catches_tensors_below_the_high_halves_range(ops):
 
 def test_standalone_eval_repeat_for_conditioning_really_runs_exact_convs(ops, monkeypatch):
     """a standalone Fusion_Network3_ac call whose scope reports an ill-conditioned CrossPath softmax is
-    repeated under set_conv3x3_mode('fp32') - and that repeat must re-dispatch on the mode (exact-fp32 buffer path), not re-run
-    the planes body on bf16 triples.  Forced here through the bound; the repeat equals a plain SEGMIF_CONV3X3=fp32 forward
-    bit for bit."""
+    repeated under set_conv3x3_mode('fp32') (and, r6, CrossPath in GEMM form) - and that repeat must re-dispatch on the modes (exact-fp32
+    buffer path), not re-run the planes body on bf16 triples.  Forced here through the bound; the repeat equals a plain
+    SEGMIF_CONV3X3=fp32 SEGMIF_CROSSPATH=gemm forward bit for bit."""
     from segmif_amd.core import Fusion_Network3_ac
     fus = Fusion_Network3_ac()
     dw.load_det_weights(fus, seed=0)
@@ -276,11 +276,11 @@ def test_standalone_eval_repeat_for_conditioning_really_runs_exact_convs(ops, mo
     with torch.no_grad():
         monkeypatch.setattr(ops.Planes16Guard, "COND_BOUND", 1e30)  # (small images: the real bound may well ask for the repeat)
         base = fus(ir, vis, o1, o2)
-        prev = ops.set_conv3x3_mode("fp32")
+        prev = (ops.set_conv3x3_mode("fp32"), ops.set_crosspath_mode("gemm"))  # (what a conditioning repeat switches to: ops._exact_repeat_modes)
         try:
-            exact = fus(ir, vis, o1, o2)
+            exact = ops.run_unguarded(lambda: fus(ir, vis, o1, o2), images=0, repeated=0)
         finally:
-            ops.set_conv3x3_mode(prev)
+            ops.set_conv3x3_mode(prev[0]), ops.set_crosspath_mode(prev[1])
         before = ops.range_stats()["images_repeated_fp32conv"]
         monkeypatch.setattr(ops.Planes16Guard, "COND_BOUND", -1.0)  # every image "ill-conditioned"
         forced = fus(ir, vis, o1, o2)
@@ -396,3 +396,95 @@ def test_crosspath_tail_f16x3_arithmetic_vs_fp64(ops, B, ih, iw, H, W):
     hot[B - 1, 5] *= 1.0e6
     _, gh = run("f16x3", hot)
     assert gh.tripped().tolist() == [False] * (B - 1) + [True]
+
+
+@pytest.mark.parametrize("B,IH,IW,OH,OW,C", [(2, 12, 16, 48, 64, 9), (1, 15, 20, 60, 77, 9), (3, 7, 9, 30, 50, 20), (1, 120, 160, 480, 640, 9)])
+def test_bilinear_argmax_equals_the_two_pass_form(ops, B, IH, IW, OH, OW, C):
+    """predict_labels' resize + argmax in one kernel: the labels of ops.argmax_nhwc(ops.bilinear(x)), bit for bit (same
+    interpolation expression, same tie rule), also on a channel slice of a wider buffer."""
+    wide = rnd(B, IH, IW, C + 7, seed=71).cuda()
+    x = wide[..., 3:3 + C]
+    two = ops.argmax_nhwc(ops.bilinear(x.contiguous(), OH, OW))
+    one = ops.bilinear_argmax(x, OH, OW)
+    assert one.dtype == torch.int32 and tuple(one.shape) == (B, OH, OW)
+    assert torch.equal(one, two)
+    ref = torch.nn.functional.interpolate(x.double().cpu().permute(0, 3, 1, 2), size=(OH, OW), mode="bilinear", align_corners=False)
+    top2 = ref.topk(2, dim=1).values
+    stable = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert torch.equal(one.cpu().long()[stable], ref.argmax(1)[stable])
+
+
+def test_upsum_act_after_the_grid_change(ops):
+    """upsum_act (resize + sum + shift + ReLU of the SegFormer head) on its 3-D grid against float64 torch, ragged sizes."""
+    B, OH, OW, C = 2, 30, 41, 64
+    base = rnd(B, OH, OW, C, seed=81).cuda()
+    srcs = [rnd(B, 4, 6, C, seed=82).cuda(), rnd(B, 8, 11, C, seed=83).cuda(), rnd(B, 15, 21, C, seed=84).cuda()]
+    bias = rnd(C, seed=85).cuda()
+    out = ops.upsum_act(base, srcs, OH, OW, bias=bias, act=ops.ACT_RELU)
+    want = base.double().cpu() + bias.double().cpu()
+    for s_ in srcs:
+        want = want + torch.nn.functional.interpolate(s_.double().cpu().permute(0, 3, 1, 2), size=(OH, OW), mode="bilinear",
+                                                      align_corners=False).permute(0, 2, 3, 1)
+    assert rel(out, torch.relu(want)) < 1e-6
+
+
+def test_false_negative_of_the_round5_bound_is_now_repeated(ops):
+    """tools/cond_search.py found it (profiles/r06_cond_search.txt): U[0,1) inputs x 8 at 480 x 640, pair 3 of the 'cs_*_8' batch -
+    no range trip, conditioning estimate 3.97e-4 (below round 5's bound of 2e-3), f16x3 1.53e-3 from the float64 truth where the
+    exact-fp32 MFMA path sits at 6.5e-6.  With COND_BOUND = 2e-4 the guard repeats it - exact-fp32 3 x 3 convs AND CrossPath in GEMM form
+    (tools/r6_fn_bisect.py: the Gram form alone carries the 1.5e-3, whatever the other kernels run on): the guarded result
+    is within 1e-4 of the exact-fp32 MFMA result (hence within the tolerance of the truth), the un-repeated f16x3 result is not."""
+    from segmif_amd.core import Fusion_Network3_ac, Network3
+    from segmif_amd.pipeline import PairForward
+    assert ops.Planes16Guard.COND_BOUND <= 2e-4
+    seg, fus = Network3("mit_b1", 9, pretrained=None), Fusion_Network3_ac()
+    dw.load_det_weights(seg, seed=0), dw.load_det_weights(fus, seed=0)
+    seg, fus = seg.cuda().eval(), fus.cuda().eval()
+    pipe = PairForward(seg, fus)
+    H, W = 480, 640
+    ir = (dw.det_input("cs_ir_8", (8, 1, H, W))[3:4] * 8.0).cuda()
+    vis = (dw.det_input("cs_vis_8", (8, 3, H, W))[3:4] * 8.0).cuda()
+    mask = (dw.det_input("cs_mask_8", (8, 1, H, W))[3:4].repeat(1, 3, 1, 1) * 8.0).cuda()
+    s0 = ops.range_stats()
+    with torch.no_grad():
+        fused, _ = pipe.eager(ir, vis, mask)
+        s1 = ops.range_stats()
+        with scope(ops, 1) as g:
+            raw = pipe._eager_body(ir, vis, mask)[0]
+        prev = (ops.set_conv3x3_mode("fp32"), ops.set_linear_mode("fp32"), ops.set_attention_mode("fp32"), ops.set_crosspath_mode("gemm"))
+        try:
+            f32 = ops.run_unguarded(lambda: pipe._eager_body(ir, vis, mask), images=0, repeated=0)[0]
+        finally:
+            ops.set_conv3x3_mode(prev[0]), ops.set_linear_mode(prev[1]), ops.set_attention_mode(prev[2]), ops.set_crosspath_mode(prev[3])
+    est = float(g.cond_estimate()[0])
+    d_raw, d_guarded = rel(raw, f32), rel(fused, f32)
+    observed("r6_false_negative_pair", {"estimate": est, "f16x3_unrepeated_vs_fp32_mfma": d_raw, "guarded_vs_fp32_mfma": d_guarded})
+    assert not g.tripped().any() and 2e-4 < est < 2e-3
+    assert s1["images_repeated_fp32conv"] - s0["images_repeated_fp32conv"] == 1
+    assert d_raw > 1e-3 and d_guarded < 1e-4, (d_raw, d_guarded)
+
+
+@pytest.mark.parametrize("B,spread", [(2, 1.0), (5, 30.0)])
+def test_context_fold_node_vs_fp64_autograd(ops, B, spread):
+    """ag.context_fold (CrossPath's training-path context softmaxes + fold into end_proj, HIP forward and backward) against torch's
+    float64 autograd of the reference formulation (softmax over dim -2 of K^T V scale, einsum against the end_proj halves, cat);
+    spread 30: near-saturated softmax columns."""
+    from segmif_amd import autograd as ag
+    g0 = torch.Generator().manual_seed(int(B * 10 + spread))
+    ka = (torch.randn(B, 8, 8, 8, generator=g0, dtype=torch.float64) * spread).cuda().requires_grad_(True)
+    k3 = (torch.randn(B, 8, 8, 8, generator=g0, dtype=torch.float64) * spread).cuda().requires_grad_(True)
+    wend = (torch.randn(64, 128, generator=g0) * 0.1).cuda().requires_grad_(True)
+    dweff = torch.randn(B, 64, 128, generator=g0).cuda()
+    sa, s3 = 8 ** -0.5, 0.31
+    weff = ag.context_fold(ka, k3, wend, sa, s3)
+    weff.backward(dweff)
+    ka64, k364, w64 = (t.detach().double().cpu().requires_grad_(True) for t in (ka, k3, wend))
+    ca, c3 = torch.softmax(ka64 * sa, dim=-2), torch.softmax(k364 * s3, dim=-2)
+    wz, wv = w64[:, :64].reshape(64, 8, 8), w64[:, 64:].reshape(64, 8, 8)
+    ref = torch.cat((torch.einsum("bhij,nhj->bnhi", ca, wz).reshape(B, 64, 64), torch.einsum("bhij,nhj->bnhi", c3, wv).reshape(B, 64, 64)), dim=-1)
+    ref.backward(dweff.double().cpu())
+    assert rel(weff, ref.detach()) < 1e-6
+    for got, want, nm in ((ka.grad, ka64.grad, "dktv_a"), (k3.grad, k364.grad, "dktv_3"), (wend.grad, w64.grad, "dwend")):
+        e = rel(got, want)
+        observed(f"context_fold[{B},{spread:g}:{nm}]", e)
+        assert e < 2e-6, (nm, e)
