@@ -538,6 +538,10 @@ int segmif_crosspath_gram_f32(const float* x, int ldx, const float* w, const flo
  * W % 4 == 0 and an enlargement by three or more (3 iw <= W), else SEGMIF_EINVAL (the caller resizes first).  Replaces
  * F.interpolate (core/mix_transformer.py:364-373) + channel_proj3 (core/model_fusion.py:353) for cross_attn's context. */
 int segmif_crosspath_gram_lazy_f32(const float* s_low, int lds, int ih, int iw, int H, int W, double* partial, int B, void* stream);
+/* (r6) total (B, 3072) = the sum over an image's nblk Gram partials, in a fixed order, by 12 workgroups per image; the result is a
+ * one-partial image (nblk = 1) for segmif_crosspath_fold_f32, whose single workgroup per image otherwise spends its launch pulling
+ * 1.5 - 3 MB of partials through one CU. */
+int segmif_crosspath_gram_sum_f64(const double* partial, int nblk, double* total, int B, void* stream);
 int segmif_crosspath_fold_f32(const double* partial, int nblk, const float* wkv, const float* wend, float* weff, int B,
                               int Nout, int ldw, int wofs, int ldweff, int kofs, float scale, uint32_t* cond, void* stream);
 int segmif_crosspath_tail_f32(const SegmifCrossTail* desc, void* stream);

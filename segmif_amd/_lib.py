@@ -133,6 +133,7 @@ SIGNATURES = {
     "segmif_crosspath_gram_blocks": (c_int, [c_int64]),
     "segmif_crosspath_gram_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "segmif_crosspath_gram_lazy_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "segmif_crosspath_gram_sum_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "segmif_crosspath_fold_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_float, c_void_p, c_void_p]),
     "segmif_crosspath_tail_f32": (c_int, [POINTER(SegmifCrossTail), c_void_p]),

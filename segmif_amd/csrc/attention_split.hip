@@ -53,13 +53,23 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int KT = 32;                      // keys per tile
-constexpr int KPITCH = 3 * 128 + 16;        // K image row (one key): [plane][64 positions] bf16 + 16 B (conflict-free ds_read_b128)
-constexpr int VPITCH = 3 * 64 + 16;         // V^T image row (one head dimension): [plane][32 key positions] bf16 + 16 B
-constexpr int K_BYTES = KT * KPITCH;        // 12800
-constexpr int V_BYTES = 64 * VPITCH;        // 13312
-constexpr int IMG = 26624;                  // K image + V^T image, rounded up to 26 x 1 KB (one LDS-DMA wave instruction each)
-constexpr int O_TILE_SCALES = K_BYTES + V_BYTES;  // f16x3: floats 2^-eK, 2^-eV of the tile (in the round-up's slack)
-static_assert(O_TILE_SCALES + 8 <= IMG, "tile scales must fit the image");
+// Tile image, per operand format.  bf16x6: three bf16 planes.  f16x3 (r6): TWO half planes W0 | W - W0 - the third operand of the
+// f16x3 product, 2^-11 W0, is made in registers from W0 (v_pk_mul_f16 by 2^-11: exactly the value the pack kernel used to store;
+// gemm_pairs.hip does the same): a third less LDS-DMA traffic and a third fewer fragment reads, and the tile stream is what
+// bounds this kernel (profiles/r06_attn_ablation.txt: removing every MFMA and the softmax arithmetic gains 18 %, removing the
+// tile DMA alone 17 %).
+template <bool F16>
+struct Img {
+  static constexpr int NPL = F16 ? 2 : 3;             // planes stored per value
+  static constexpr int KPITCH = NPL * 128 + 16;       // K image row (one key): [plane][64 positions] + 16 B (conflict-free ds_read_b128)
+  static constexpr int VPITCH = NPL * 64 + 16;        // V^T image row (one head dimension): [plane][32 key positions] + 16 B
+  static constexpr int K_BYTES = KT * KPITCH;         // 12800 | 8704
+  static constexpr int V_BYTES = 64 * VPITCH;         // 13312 | 9216
+  static constexpr int BYTES = F16 ? 18432 : 26624;   // K image + V^T image, rounded up to whole 1 KB LDS-DMA wave instructions
+  static constexpr int O_TILE_SCALES = K_BYTES + V_BYTES;  // f16x3: floats 2^-eK, 2^-eV of the tile (in the round-up's slack)
+  static_assert(O_TILE_SCALES + 8 <= BYTES, "tile scales must fit the image");
+};
+constexpr int IMG_MAX = Img<false>::BYTES;  // what segmif_sr_attention_split_workspace sizes a tile for (either format)
 constexpr int PX6[6] = {2, 1, 0, 1, 0, 0};  // six products, least significant first: plane of the first operand ...
 constexpr int PY6[6] = {0, 1, 2, 0, 1, 0};  // ... and of the second
 
@@ -109,6 +119,11 @@ __device__ __forceinline__ Op2 split8h(const f32x4 a, const f32x4 b) {
   return o;
 }
 __device__ __forceinline__ f16x8 oph(const u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+__device__ __forceinline__ u32x4 times_2m11(const u32x4 v) {  // 8 halves x 2^-11 (v_pk_mul_f16; exact up to the half's own rounding)
+  const f16x8 s = {(_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f,
+                   (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f};
+  return __builtin_bit_cast(u32x4, oph(v) * s);
+}
 __device__ __forceinline__ f32x16 mma3(const u32x4* w, const Op2& x, f32x16 acc) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oph(w[2]), oph(x.lo), acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(oph(w[1]), oph(x.hi), acc, 0, 0, 0);
@@ -149,7 +164,8 @@ __global__ __launch_bounds__(256) void sr_attention_pack_kernel(const float* __r
   const int tid = threadIdx.x;
   const float* kb = k + (long long)b * Nk * ldkv + head * 64;
   const float* vb = v + (long long)b * Nk * ldkv + head * 64;
-  unsigned char* dst = img + (((long long)b * heads + head) * ntiles + kt) * IMG;
+  using I = Img<F16>;
+  unsigned char* dst = img + (((long long)b * heads + head) * ntiles + kt) * I::BYTES;
   // every thread's share stays in registers between the range pass and the split (KT * 32 / 256 = 4 K pairs, 4 V pairs)
   f32x2 kv2[4], vv2[4];
   float mk = 0.f, mv = 0.f;
@@ -184,8 +200,8 @@ __global__ __launch_bounds__(256) void sr_attention_pack_kernel(const float* __r
     sk = pow2_scale(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
     sv = pow2_scale(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
     if (tid == 0) {
-      reinterpret_cast<float*>(dst + O_TILE_SCALES)[0] = 1.f / sk;  // exact: powers of two
-      reinterpret_cast<float*>(dst + O_TILE_SCALES)[1] = 1.f / sv;
+      reinterpret_cast<float*>(dst + I::O_TILE_SCALES)[0] = 1.f / sk;  // exact: powers of two
+      reinterpret_cast<float*>(dst + I::O_TILE_SCALES)[1] = 1.f / sv;
     }
   }
 #pragma unroll
@@ -195,10 +211,10 @@ __global__ __launch_bounds__(256) void sr_attention_pack_kernel(const float* __r
     uint32_t a, bb, c;
     if constexpr (F16) split3h(kv2[i][0] * sk, kv2[i][1] * sk, a, bb, c);
     else split3(kv2[i][0], kv2[i][1], a, bb, c);
-    unsigned char* o = dst + row * KPITCH + pp * 2;
+    unsigned char* o = dst + row * I::KPITCH + pp * 2;
     *reinterpret_cast<uint32_t*>(o) = a;
     *reinterpret_cast<uint32_t*>(o + 128) = bb;
-    *reinterpret_cast<uint32_t*>(o + 256) = c;
+    if constexpr (!F16) *reinterpret_cast<uint32_t*>(o + 256) = c;  // (f16x3: 2^-11 W0 is made by the reader)
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -207,10 +223,10 @@ __global__ __launch_bounds__(256) void sr_attention_pack_kernel(const float* __r
     uint32_t a, bb, c;
     if constexpr (F16) split3h(vv2[i][0] * sv, vv2[i][1] * sv, a, bb, c);
     else split3(vv2[i][0], vv2[i][1], a, bb, c);
-    unsigned char* o = dst + K_BYTES + d * VPITCH + pp * 2;
+    unsigned char* o = dst + I::K_BYTES + d * I::VPITCH + pp * 2;
     *reinterpret_cast<uint32_t*>(o) = a;
     *reinterpret_cast<uint32_t*>(o + 64) = bb;
-    *reinterpret_cast<uint32_t*>(o + 128) = c;
+    if constexpr (!F16) *reinterpret_cast<uint32_t*>(o + 128) = c;
   }
 }
 
@@ -221,6 +237,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                                  float scale, int ntiles, uint32_t* amax, int amax_images,
                                                                  int out_pairs, uint32_t* out_amax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][IMG]
+  using I = Img<F16>;
+  constexpr int IMG = I::BYTES, NPL = I::NPL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
@@ -228,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const bool q_ok = qi < N;
   const unsigned char* src = img + ((long long)b * heads + head) * ntiles * IMG;
 
-  // 26 wave-sized (1 KB) DMA instructions per tile: waves 0, 1 issue 7, waves 2, 3 issue 6
+  // 26 (f16x3: 18) wave-sized (1 KB) DMA instructions per tile, dealt round-robin to the four waves
   auto stage = [&](int kt, int buf) {
     const unsigned char* s = src + (long long)kt * IMG;
     unsigned char* d = smem + buf * IMG;
@@ -274,11 +292,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int cur = kt & 1;
     if (!(ATTN_ABL & 1) && kt + 1 < ntiles) stage(kt + 1, cur ^ 1);  // buffer cur^1 was last read in iteration kt-1, before its closing barrier
     const unsigned char* Kt = smem + cur * IMG;
-    const unsigned char* Vt = Kt + K_BYTES;
+    const unsigned char* Vt = Kt + I::K_BYTES;
     float kinv = 1.f, vinv = 1.f;
     if constexpr (F16) {  // the tile's 2^-eK, 2^-eV (every lane reads the same two words)
-      kinv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(Kt + O_TILE_SCALES)));
-      vinv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(Kt + O_TILE_SCALES + 4)));
+      kinv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(Kt + I::O_TILE_SCALES)));
+      vinv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(Kt + I::O_TILE_SCALES + 4)));
     }
 
     // ---- S^T = K (scale log2(e) Q)^T: scores in the base-2 exponent domain -----------------------
@@ -289,7 +307,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int st = 0; st < 4; ++st) {
       u32x4 kf[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) kf[k] = *reinterpret_cast<const u32x4*>(Kt + r * KPITCH + k * 128 + (16 * st + 8 * h) * 2);
+      for (int k = 0; k < NPL; ++k) kf[k] = *reinterpret_cast<const u32x4*>(Kt + r * I::KPITCH + k * 128 + (16 * st + 8 * h) * 2);
+      if constexpr (F16) kf[2] = times_2m11(kf[0]);
       if (ATTN_ABL & 4) asm volatile("" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]));
       else if constexpr (F16) s = mma3(kf, qh[st], s);
       else s = mma6(kf, qp[st].p, s);
@@ -342,8 +361,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       for (int dt = 0; dt < 2; ++dt) {
         u32x4 vf[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-          vf[k] = *reinterpret_cast<const u32x4*>(Vt + (dt * 32 + r) * VPITCH + k * 64 + (16 * sp + 8 * h) * 2);
+        for (int k = 0; k < NPL; ++k)
+          vf[k] = *reinterpret_cast<const u32x4*>(Vt + (dt * 32 + r) * I::VPITCH + k * 64 + (16 * sp + 8 * h) * 2);
+        if constexpr (F16) vf[2] = times_2m11(vf[0]);
         if (ATTN_ABL & 8) asm volatile("" ::"v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(ph.hi), "v"(ph.lo));
         else if constexpr (F16) o[dt] = mma3(vf, ph, o[dt]);
         else o[dt] = mma6(vf, pk.p, o[dt]);
@@ -397,6 +417,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const u32x4 v = *reinterpret_cast<const u32x4*>(T + row * OPITCH + (lane & 15) * 16);
       if (q0 + row < N) *reinterpret_cast<u32x4*>(obase + (long long)row * ldo * 4) = v;
     }
+  } else {  // (ablation 32: the accumulators stay live - without this the whole key loop is dead code)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(o[dt][e] * inv));
   }
   if constexpr (F16) {
     if (amax) p16::fold_pat(amax, amax_images > 1 ? b : 0, amax_images > 1 ? b : 0, q_ok ? amx : 0u);
@@ -408,7 +433,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 extern "C" int64_t segmif_sr_attention_split_workspace(int B, int heads, int Nk) {
   if (B <= 0 || heads <= 0 || Nk <= 0) return 0;
-  return (int64_t)B * heads * ((Nk + KT - 1) / KT) * IMG;
+  return (int64_t)B * heads * ((Nk + KT - 1) / KT) * IMG_MAX;
 }
 
 static int sr_attention_split_impl(bool f16, const float* q, const float* k, const float* v, float* out, void* workspace, int B,
@@ -424,19 +449,19 @@ static int sr_attention_split_impl(bool f16, const float* q, const float* k, con
   static segmif::PerDeviceFlag raised_flag;
   bool& raised = raised_flag.here();
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)sr_attention_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sr_attention_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
+    hipError_t e = hipFuncSetAttribute((const void*)sr_attention_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Img<false>::BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sr_attention_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Img<true>::BYTES);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
   const dim3 pgrid((unsigned)ntiles, (unsigned)heads, (unsigned)B), grid((unsigned)((N + 127) / 128), (unsigned)heads, (unsigned)B);
   if (f16) {
     hipLaunchKernelGGL(sr_attention_pack_kernel<true>, pgrid, dim3(256), 0, s, k, v, (unsigned char*)workspace, Nk, ldkv, ntiles);
-    hipLaunchKernelGGL(sr_attention_split_kernel<true>, grid, dim3(256), 2 * IMG, s, q, (const unsigned char*)workspace, out, N, Nk,
+    hipLaunchKernelGGL(sr_attention_split_kernel<true>, grid, dim3(256), 2 * Img<true>::BYTES, s, q, (const unsigned char*)workspace, out, N, Nk,
                        ldq, ldo, scale, ntiles, amax, amax_images, out_pairs, out_amax);
   } else {
     hipLaunchKernelGGL(sr_attention_pack_kernel<false>, pgrid, dim3(256), 0, s, k, v, (unsigned char*)workspace, Nk, ldkv, ntiles);
-    hipLaunchKernelGGL(sr_attention_split_kernel<false>, grid, dim3(256), 2 * IMG, s, q, (const unsigned char*)workspace, out, N, Nk,
+    hipLaunchKernelGGL(sr_attention_split_kernel<false>, grid, dim3(256), 2 * Img<false>::BYTES, s, q, (const unsigned char*)workspace, out, N, Nk,
                        ldq, ldo, scale, ntiles, (uint32_t*)nullptr, 1, 0, (uint32_t*)nullptr);
   }
   return (int)hipGetLastError();

@@ -426,6 +426,23 @@ __global__ __launch_bounds__(512, 4) void crosspath_gram_lazy_kernel(const float
   gram_reduce_store(g, Red, partial, b, tid, lane, wave);
 }
 
+// (r6) total[b][u] = sum_k partial[b][k][u] in a fixed order (eight interleaved running sums, then a fixed tree): the fold below runs
+// ONE workgroup per image, and pulling an image's 64 - 128 partials (1.5 - 3 MB, 24 KB apart per element) through one CU was
+// 165 - 300 us of its launch - 8 launches per pair forward, 8.6 % of a 4-pair step, 4.5 % of the 1024 x 1024 one
+// (profiles/r06_config1_kernel_stats.txt, r06_config4_kernel_stats.txt).  Here 12 workgroups per image share the read.
+__global__ __launch_bounds__(256) void crosspath_gram_sum_kernel(const double* __restrict__ partial, int nblk, double* __restrict__ total) {
+  const int u = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  const double* p = partial + (long long)b * nblk * 3072 + u;
+  double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int k = 0;
+  for (; k + 8 <= nblk; k += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s8[j] += p[(long long)(k + j) * 3072];
+  }
+  for (; k < nblk; ++k) s8[k & 7] += p[(long long)k * 3072];
+  total[(long long)b * 3072 + u] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+}
+
 // G = sum of the partial Gram matrices (fp64), ctx_h = softmax_{dim -2}((Wk_h G Wv_h^T) scale), folded into end_proj:
 //   Weff[b][n][kofs + h*8 + i] = sum_j ctx[b][h][i][j] * Wend[n][wofs + h*8 + j]      (as segmif_linattn_fold_f32)
 __global__ __launch_bounds__(1024) void crosspath_fold_kernel(const double* __restrict__ partial, int nblk,
@@ -1027,6 +1044,12 @@ extern "C" int segmif_crosspath_gram_lazy_f32(const float* s_low, int lds, int i
   constexpr size_t smem = 3 * 16 * 64 * sizeof(double) + CP_WAVES * 2 * 32 * (sizeof(u32x4) + sizeof(f32x4));
   hipLaunchKernelGGL(crosspath_gram_lazy_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(512), smem, (hipStream_t)stream, s_low, lds,
                      ih, iw, W, (float)ih / (float)H, (float)iw / (float)W, partial, N);
+  return (int)hipGetLastError();
+}
+
+extern "C" int segmif_crosspath_gram_sum_f64(const double* partial, int nblk, double* total, int B, void* stream) {
+  if (!partial || !total || nblk <= 0 || B <= 0 || (((uintptr_t)partial | (uintptr_t)total) & 7)) return SEGMIF_EINVAL;
+  hipLaunchKernelGGL(crosspath_gram_sum_kernel, dim3(12u, (unsigned)B), dim3(256), 0, (hipStream_t)stream, partial, nblk, total);
   return (int)hipGetLastError();
 }
 

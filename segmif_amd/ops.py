@@ -1609,7 +1609,18 @@ def crosspath_gram_lazy(s_low, H, W):
     _side("cp_gram_lazy", lambda: _lib.check(lib.segmif_crosspath_gram_lazy_f32(
         s_low.data_ptr(), s_low.stride(2), ih, iw, H, W, part.data_ptr(), B, _stream()), "segmif_crosspath_gram_lazy_f32"),
         256.0 * B * ih * iw)
-    return part
+    return _gram_total(part)
+
+
+def _gram_total(part):
+    """(r6) (B, nblk, 3072) Gram partials -> (B, 1, 3072): their fixed-order sum by segmif_crosspath_gram_sum_f64 (12 workgroups per
+    image), so that crosspath_fold's one workgroup per image reads 24 KB instead of 1.5 - 3 MB."""
+    B, nblk, _ = part.shape
+    if nblk <= 2:
+        return part
+    total = torch.empty((B, 1, 3072), device=part.device, dtype=torch.float64)
+    _lib.check(_lib.load().segmif_crosspath_gram_sum_f64(part.data_ptr(), nblk, total.data_ptr(), B, _stream()), "segmif_crosspath_gram_sum_f64")
+    return total
 
 
 def crosspath_gram(x, w_half, b_half):
@@ -1627,7 +1638,7 @@ def crosspath_gram(x, w_half, b_half):
     _side("cp_gram", lambda: _lib.check(lib.segmif_crosspath_gram_f32(
         x.data_ptr(), x.stride(1), w_half.data_ptr(), _req(b_half, "bias").data_ptr() if b_half is not None else None,
         part.data_ptr(), B, N, _stream()), "segmif_crosspath_gram_f32"), 256.0 * B * N)
-    return part
+    return _gram_total(part)
 
 
 def crosspath_fold(part, wkv, wend, weff, wofs, kofs, scale):

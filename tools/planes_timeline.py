@@ -17,12 +17,30 @@ import torch
 from segmif_amd import ops
 
 cin = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+F16 = "f16" in sys.argv[2:]    # (r6) the f16x3 kernels: half-pair planes, SUB = 4 for the plain conv
+TAIL = "tail" in sys.argv[2:]  # (r6) the fused tail (conv + 1x1 224 -> 64 + ReLU + residual); Cin is then 192
 B, H, W = 8, 480, 640
 x = torch.randn(B, H, W, 192, device="cuda")
-pl = ops.Planes(B, H, W, 14, "cuda").load_f32(x)
-wpl = ops.pack_weight_planes(torch.randn(32, cin, 3, 3, device="cuda") * 0.05)
+if F16:
+    guard = ops.Planes16Guard("cuda")
+    guard.slot = lambda images=None: (guard.amax.data_ptr(), 1)
+    pl = ops.Planes(B, H, W, 14, "cuda", guard).load_f32(x)
+else:
+    pl = ops.Planes(B, H, W, 14, "cuda").load_f32(x)
+pack = ops.pack_weight_planes16 if F16 else ops.pack_weight_planes
+if TAIL:
+    cin = 192
+wpl = pack(torch.randn(32, cin, 3, 3, device="cuda") * 0.05)
+if TAIL:
+    w1 = pack(torch.randn(64, 224, device="cuda") * 0.05)
+    b1 = torch.randn(64, device="cuda")
+    out = torch.empty(B, H, W, 64, device="cuda")
+    x64 = x[..., :64]
+    run = lambda: ops.conv3x3_planes(pl, cin, wpl, dil=2, act=1, tail=(w1, b1, x64, out, 1))
+else:
+    run = lambda: ops.conv3x3_planes(pl, cin, wpl, dil=2, act=1, out_chunk0=12)
 for _ in range(3):
-    ops.conv3x3_planes(pl, cin, wpl, dil=2, act=1, out_chunk0=12)
+    run()
 torch.cuda.synchronize()
 lib = ctypes.CDLL(os.environ["SEGMIF_HIP_LIB"])
 NI = 64
@@ -45,4 +63,4 @@ for team in (0, 1):
         v = seg[:, team, :, i].ravel()
         print(f"  {n:26s} {v.mean():8.0f} {np.percentile(v, 10):8.0f} {np.percentile(v, 90):8.0f}")
     per = (t[:, team, 1:, 0] - t[:, team, :-1, 0]).ravel()
-    print(f"  {'item period (2 phases)':26s} {per.mean():8.0f} {np.percentile(per, 10):8.0f} {np.percentile(per, 90):8.0f}   (MFMA alone: 2 x 108 x 32 = 6912)")
+    print(f"  {'item period (2 phases)':26s} {per.mean():8.0f} {np.percentile(per, 10):8.0f} {np.percentile(per, 90):8.0f}   (MFMA alone per phase: bf16x6 108 x 32 = 3456 ticks; f16x3 SUB=4 108 x 32; f16x3 tail 66 x 32 = 2112)")
