@@ -462,7 +462,7 @@ __global__ __launch_bounds__(1024) void crosspath_fold_kernel(const double* __re
     const int idx = (ti == 1 && tj == 0) ? 1024 + (j & 31) * 32 + (i & 31) : a * 1024 + (i & 31) * 32 + (j & 31);
     // fixed order: deterministic.  (r6) Eight independent running sums - partial k goes to sum k & 7 - so that eight loads are
     // in flight per thread instead of one: the single dependent chain over >= 64 partials (24 KB apart) was most of this kernel's
-    // 165 us, which is 8 launches x one workgroup per image per pair forward - 9 % of a 4-pair step (profiles/r06_kstats_config1.txt)
+    // 165 us, which is 8 launches x one workgroup per image per pair forward - 9 % of a 4-pair step (profiles/r06_config1_kernel_stats.txt)
     double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     int k = 0;
     for (; k + 8 <= nblk; k += 8) {
