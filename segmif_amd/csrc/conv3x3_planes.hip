@@ -52,9 +52,6 @@
 #ifndef PLANES_DBG
 #define PLANES_DBG 0  // tuning aid: 32 = s_memtime timeline probe (tools/planes_timeline.py), 64 = no planes stores, 128 = s_setprio 1 around the MFMA block
 #endif
-#ifndef PLANES_W2REG
-#define PLANES_W2REG 1  // f16x3: the weights' third plane (2^-11 W0) is made in registers from W0 instead of read from LDS
-#endif
 #if PLANES_DBG & 32
 #define PLANES_TL_ITEMS 64
 __device__ unsigned long long planes_timeline[256][2][PLANES_TL_ITEMS][8];
@@ -112,12 +109,6 @@ __device__ __forceinline__ void split8(const float* y, u32x4& p0, u32x4& p1, u32
     p1[e] = b;
     p2[e] = c;
   }
-}
-
-__device__ __forceinline__ u32x4 times_2m11(const u32x4 v) {  // 8 halves x 2^-11 (v_pk_mul_f16): bit for bit the stored W0s plane
-  const f16x8 s = {(_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f,
-                   (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f};
-  return __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8, v) * s);
 }
 
 template <bool F16>
@@ -346,8 +337,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto ld_w = [&](u32x4* dst, int kx, int ky) {
 #pragma unroll
-      for (int pl = 0; pl < (F16 && PLANES_W2REG ? 2 : 3); ++pl) dst[pl] = *reinterpret_cast<const u32x4*>(w_lane + ((ky * 3 + kx) * 32) * PXB + pl * 32);
-      if constexpr (F16 && PLANES_W2REG) dst[2] = times_2m11(dst[0]);
+      for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const u32x4*>(w_lane + ((ky * 3 + kx) * 32) * PXB + pl * 32);
     };
     auto mm = [&](const u32x4* wa, const u32x4* fa, const u32x4* wb, const u32x4* fb) {
 #pragma unroll
@@ -440,8 +430,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int nt = 0; nt < 2; ++nt) {
           u32x4 W1f[3];
 #pragma unroll
-          for (int pl = 0; pl < (F16 && PLANES_W2REG ? 2 : 3); ++pl) W1f[pl] = *reinterpret_cast<const u32x4*>(w1_lane + (nt * 32) * PXB + pl * 32);
-          if constexpr (F16 && PLANES_W2REG) W1f[2] = times_2m11(W1f[0]);
+          for (int pl = 0; pl < 3; ++pl) W1f[pl] = *reinterpret_cast<const u32x4*>(w1_lane + (nt * 32) * PXB + pl * 32);
 #pragma unroll
           for (int t = 0; t < NPROD; ++t) acc1[0][nt] = mfma_split<F16>(W1f[PW[t]], Fa[c][PA[t]], acc1[0][nt]);
         }
@@ -456,8 +445,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int nt = 0; nt < 2; ++nt) {
           u32x4 W1f[3];
 #pragma unroll
-          for (int pl = 0; pl < (F16 && PLANES_W2REG ? 2 : 3); ++pl) W1f[pl] = *reinterpret_cast<const u32x4*>(w1_lane + (nt * 32) * PXB + pl * 32);
-          if constexpr (F16 && PLANES_W2REG) W1f[2] = times_2m11(W1f[0]);
+          for (int pl = 0; pl < 3; ++pl) W1f[pl] = *reinterpret_cast<const u32x4*>(w1_lane + (nt * 32) * PXB + pl * 32);
 #pragma unroll
           for (int t = 0; t < NPROD; ++t) acc1[1][nt] = mfma_split<F16>(W1f[PW[t]], Fb[PA[t]], acc1[1][nt]);
         }
@@ -553,9 +541,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int nt = 0; nt < 2; ++nt) {
             u32x4 W1g[3];
 #pragma unroll
-            for (int k = 0; k < (F16 && PLANES_W2REG ? 2 : 3); ++k)
+            for (int k = 0; k < 3; ++k)
               W1g[k] = *reinterpret_cast<const u32x4*>(p.w1 + z + ((long long)(p.nchunks + q) * 64 + nt * 32 + r) * PXB + k * 32 + wsw);
-            if constexpr (F16 && PLANES_W2REG) W1g[2] = times_2m11(W1g[0]);
 #pragma unroll
             for (int t = 0; t < NPROD; ++t) acc1[i][nt] = mfma_split<F16>(W1g[PW[t]], pl[PA[t]], acc1[i][nt]);
           }
