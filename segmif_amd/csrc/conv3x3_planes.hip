@@ -50,7 +50,10 @@
 #include "segmif_hip.h"
 
 #ifndef PLANES_DBG
-#define PLANES_DBG 0  // tuning aid: 32 = s_memtime timeline probe (tools/planes_timeline.py), 64 = no planes stores, 128 = s_setprio 1 around the MFMA block
+#define PLANES_DBG 0  // tuning aid: 32 = s_memtime timeline probe (tools/planes_timeline.py), 64 = no planes stores, 128 = s_setprio 1 around the MFMA block; fused tail's epilogue: 256 = no out1 stores, 512 = no residual, 1024 = no 1x1 MFMAs on the conv's own channels, 2048 = no epilogue at all
+#endif
+#ifndef PLANES_DEFER
+#define PLANES_DEFER 2  // (r6) plain f16x3 four-sub-tile conv: a patch's plane stores leave in the team's NEXT LOAD phase (1: before its DMA burst, 2: after it); 0: at the end of the COMPUTE phase
 #endif
 #if PLANES_DBG & 32
 #define PLANES_TL_ITEMS 64
@@ -60,8 +63,20 @@ __device__ unsigned long long planes_timeline[256][2][PLANES_TL_ITEMS][8];
     if (wave == 0 && lane == 0 && blockIdx.x < 256 && i < PLANES_TL_ITEMS)                         \
       planes_timeline[blockIdx.x][team][i][slot] = __builtin_amdgcn_s_memtime();                  \
   } while (0)
+// stamps INSIDE the epilogue (slots: 0 entry | 1 constants in registers | 2 sub-tile 0 activated | 3 its 1x1 MFMAs done | 4 its out1
+// values ready | 5 its stores issued | 6 sub-tile 1 done); `keep` = registers the stamp must come after
+__device__ unsigned long long planes_epi_timeline[256][2][PLANES_TL_ITEMS][8];
+#define ETL(slot, ...)                                                                             \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    asm volatile("" ::__VA_ARGS__);                                                                \
+    if (wave == 0 && lane == 0 && blockIdx.x < 256 && item < PLANES_TL_ITEMS)                      \
+      planes_epi_timeline[blockIdx.x][team][item][slot] = __builtin_amdgcn_s_memtime();           \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
 #else
 #define TL(slot) do {} while (0)
+#define ETL(slot, ...) do {} while (0)
 #endif
 
 namespace segmif {
@@ -187,6 +202,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned char* Wsb = smem_b + 2 * A_BYTES;                      // [2][W3_BYTES], shared by the teams
   unsigned char* W1sb = Wsb + 2 * W3_BYTES;                       // [2][W1_BYTES] (FUSE)
   unsigned char* Cst = W1sb + (FUSE ? 2 * W1_BYTES : 0);          // 512 B: bias[32], bias1[64], act slopes (+ 512 B f16x3: row scales)
+  unsigned char* W1res = Cst + (F16 ? 1024 : 512);                // (r6) f16x3 fused tail: the 1x1 weights of the conv's own 32 channels (chunks nchunks, nchunks + 1), resident
 
   // patch pairs of this workgroup: XCD x (= blockIdx % 8 under round-robin dispatch) owns a contiguous range of
   // pairs and its workgroups stride through it together, so vertically adjacent patches meet in one L2
@@ -275,6 +291,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   } else if (F16 && tid >= 128 && tid < 224) {  // row scales 2^-e(n): floats [128, 160) conv, [160, 224) fused 1x1
     const int n = tid - 128;
     reinterpret_cast<float*>(Cst)[tid] = n < 32 ? p.wscale[n] : (FUSE ? p.w1scale[n - 32] : 1.f);
+  }
+  if constexpr (FUSE && F16) {  // 12 KB = 12 wave-level DMA instructions: waves 0..3 of each team take 3 / 0 (landed before the first barrier's s_waitcnt vmcnt(0))
+    if (team == 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) dma16(p.w1 + (long long)p.nchunks * W1_BYTES + (j * 4 + wave) * 1024 + lane * 16, W1res + (j * 4 + wave) * 1024);
+    }
   }
   uint32_t amx = 0u;  // f16x3: largest |output| this lane has split for image amx_b (p16::absmax_pk patterns)
   int amx_b = 0;
@@ -466,6 +488,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto epilogue = [&](const Patch& pt, int item) {
     int z = 0;  // opaque zero added to the weight pointer below: keeps loop-invariant loads of the epilogue from being
     asm volatile("" : "+s"(z));  // hoisted out of the phase loop
+    ETL(0, "s"(z));
     // branch-free: act(t) = t >= 0 ? t : nslope * t with nslope = 0 (ReLU), the PReLU slope, or 1 (none).  Biases and
     // slope were parked in LDS at kernel start: a global load here costs a loaded-memory-system round trip (2 000+
     // cycles measured) in a phase the other team is waiting on, and per-element "pointer ? load : 0" code cost 5 000.
@@ -495,7 +518,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int e = 0; e < 4; ++e) sv[4 * g + e] = t[e];
       }
     }
+    ETL(1, "v"(bv[0]), "v"(bv[15]), "v"(sv[0]), "v"(sv[F16 ? 15 : 0]));
     const int ox = pt.x0 + r;
+    // (r6) f16x3 fused tail: nothing in this epilogue waits for global memory where it is used.  Before, the 1x1 weights of the
+    // conv's own 32 channels and the residual pieces were loaded at their point of use - 32 dependent round trips per patch (load,
+    // s_waitcnt vmcnt(0) - which also waits for the previous store -, use, store), ~700 ticks each under the other team's DMA
+    // burst: the 21 900-tick epilogue of profiles/r06_planes16_timeline_before.txt, 38 % of the kernel's time with no MFMA running
+    // on the CU.  Now those weights (12 KB) are resident in LDS for the kernel's life (W1res), a sub-tile's residual - this lane's
+    // 16-byte pieces of chunks 0..3, hi and lo: 8 loads - is requested in one batch a sub-tile ahead, and the 8 stores of a
+    // sub-tile leave together after its arithmetic.
+    constexpr bool PRE = FUSE && F16;
+    u32x4 rp[2][2][2];                            // [nt][chunk 2 nt + c2][plane]: one sub-tile's residual pieces
+    const bool res_pl = PRE && !p.res && p.res_planes && !(PLANES_DBG & 512);  // (uniform)
+    auto request_residual = [&](int i) {  // (the padded planes image holds every pixel of a rounded-up or clamped patch: no bounds needed)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            rp[nt][c2][k] = *reinterpret_cast<const u32x4*>(
+                p.pin + ((long long)pt.b * p.in_total + 2 * nt + c2) * chunk_bytes +
+                ((long long)(pt.y0 + R0 + i * DIL + PB) * p.Wp + ox + PB) * PXA + h * 16 + k * 32);
+    };
+    if constexpr (PRE) {
+      if (res_pl) request_residual(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < SUB; ++i) {
       const int oy = pt.y0 + R0 + i * DIL;
@@ -506,6 +555,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float t = F16 ? fmaf(acc[i][v], sv[F16 ? v : 0], bv[v]) : acc[i][v] + bv[v];
         y[v] = t >= 0.f ? t : nslope * t;
       }
+      if (i == 0) ETL(2, "v"(y[0]), "v"(y[7]), "v"(y[8]), "v"(y[15]));
 #if PLANES_DBG & 32
       if (i == 0 && wave == 0 && lane == 0 && blockIdx.x < 256 && item < PLANES_TL_ITEMS) {
         asm volatile("" ::"v"(y[0]), "v"(y[15]));
@@ -541,54 +591,154 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int nt = 0; nt < 2; ++nt) {
             u32x4 W1g[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-              W1g[k] = *reinterpret_cast<const u32x4*>(p.w1 + z + ((long long)(p.nchunks + q) * 64 + nt * 32 + r) * PXB + k * 32 + wsw);
+            for (int k = 0; k < 3; ++k) {
+              if constexpr (PRE) W1g[k] = *reinterpret_cast<const u32x4*>(W1res + (q * 64 + nt * 32 + r) * PXB + k * 32 + wsw);
+              else W1g[k] = *reinterpret_cast<const u32x4*>(p.w1 + z + ((long long)(p.nchunks + q) * 64 + nt * 32 + r) * PXB + k * 32 + wsw);
+            }
+            if (PLANES_DBG & 1024) asm volatile("" ::"v"(W1g[0]), "v"(W1g[1]), "v"(W1g[2]), "v"(pl[0]), "v"(pl[1]));
+            else
 #pragma unroll
-            for (int t = 0; t < NPROD; ++t) acc1[i][nt] = mfma_split<F16>(W1g[PW[t]], pl[PA[t]], acc1[i][nt]);
+              for (int t = 0; t < NPROD; ++t) acc1[i][nt] = mfma_split<F16>(W1g[PW[t]], pl[PA[t]], acc1[i][nt]);
           }
         }
       }
-      if (FUSE && ok) {
+      if constexpr (FUSE) {
+        if (i == 0) ETL(3, "v"(acc1[0][0][0]), "v"(acc1[0][1][0]), "v"(acc1[0][0][15]), "v"(acc1[0][1][15]));
+        // out1 = act1(1x1) + residual for all 64 channels of the pixel first (in registers), the stores last: nothing between the
+        // residual's arrival and the stores waits on memory, and the next sub-tile's residual is requested before the stores
         const float nslope1 = cst[97];
+        f32x4 o[2][4];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int n0 = nt * 32 + 8 * g + 4 * h;
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(cst + 32 + n0);
-            f32x4 o;
             f32x4 s1 = {1.f, 1.f, 1.f, 1.f};
             if constexpr (F16) s1 = *reinterpret_cast<const f32x4*>(cst + 160 + n0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float t = F16 ? fmaf(acc1[i][nt][4 * g + e], s1[e], b1[e]) : acc1[i][nt][4 * g + e] + b1[e];
-              o[e] = t >= 0.f ? t : nslope1 * t;
+              o[nt][g][e] = t >= 0.f ? t : nslope1 * t;
             }
             if (p.res) {
-              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n0);
-              o += rv;
-            } else if (F16 && p.res_planes) {
+              if (ok) o[nt][g] += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n0);
+            } else if (F16 && p.res_planes && !(PLANES_DBG & 512)) {
               // (r4) residual = the DRDB's own input, read back from its planes: channel n0 + e is element 4 (g & 1) + e of this
               // lane's piece of chunk 2 nt + (g >> 1) - the order the accumulators hand out; x = hi + 2^-11 lo (23 bits)
-              const unsigned char* src = p.pin + ((long long)pt.b * p.in_total + 2 * nt + (g >> 1)) * chunk_bytes +
-                                         ((long long)(oy + PB) * p.Wp + ox + PB) * PXA + h * 16 + (g & 1) * 8;
-              const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
-              const uint32_t hw[2] = {s32[0], s32[1]}, lw[2] = {s32[8], s32[9]};  // (plane 1 = + 32 bytes)
+              // (r6: from the pieces requested at the top of the epilogue / during the previous sub-tile)
+              const uint32_t hw[2] = {rp[nt][g >> 1][0][2 * (g & 1)], rp[nt][g >> 1][0][2 * (g & 1) + 1]};
+              const uint32_t lw[2] = {rp[nt][g >> 1][1][2 * (g & 1)], rp[nt][g >> 1][1][2 * (g & 1) + 1]};
 #pragma unroll
               for (int e2 = 0; e2 < 2; ++e2) {
                 const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[e2] & 0xffffu));
                 const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[e2] >> 16));
                 const float l0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(lw[e2] & 0xffffu));
                 const float l1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(lw[e2] >> 16));
-                o[2 * e2] += fmaf(l0, 1.f / LSCALE, h0);
-                o[2 * e2 + 1] += fmaf(l1, 1.f / LSCALE, h1);
+                o[nt][g][2 * e2] += fmaf(l0, 1.f / LSCALE, h0);
+                o[nt][g][2 * e2 + 1] += fmaf(l1, 1.f / LSCALE, h1);
               }
             }
-            *reinterpret_cast<f32x4*>(p.out1 + m * p.ldo1 + n0) = o;
+          }
+        }
+        if (i == 0) ETL(4, "v"(o[0][0]), "v"(o[0][3]), "v"(o[1][0]), "v"(o[1][3]));
+        if constexpr (PRE) {
+          if (res_pl && i + 1 < SUB) {
+            __builtin_amdgcn_sched_barrier(0);
+            request_residual(i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (PLANES_DBG & 256) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(o[nt][g]));
+        } else if (ok) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(p.out1 + m * p.ldo1 + nt * 32 + 8 * g + 4 * h) = o[nt][g];
+        }
+        if (i == 0) ETL(5, "s"(z));
+        if (i == SUB - 1) ETL(6, "s"(z));
+      }
+    }
+  };
+
+  // ---- (r6) deferred stores ---------------------------------------------------------------------------
+  // profiles/r06_planes16_timeline_before.txt: the epilogue of a 16 x 32 patch at the end of its last COMPUTE phase took 13 000
+  // ticks - as long as three COMPUTE phases, with no MFMA running on the CU meanwhile, twice per patch pair; 64 values of vector
+  // arithmetic per lane do not take that long: its 16 store instructions per wave queue in the CU's in-order vector-memory path.
+  // DEFER: the COMPUTE phase ends with the arithmetic only (bias, activation, split into half pairs - in registers that are free
+  // once the phase's fragments are dead), the workgroup barrier follows at once, and the 16 stores leave at the start of the
+  // team's next LOAD phase, beside the other team's MFMA stream, where this wave would only be waiting for vector-memory issue.
+  constexpr bool DEFER = PLANES_DEFER && F16 && !FUSE && SUB == 4;
+  u32x4 dpk[DEFER ? SUB : 1][4];  // [sub-tile][2 * q + plane]
+  Patch dpt = {0, 0, 0, false};
+  bool dpending = false;          // (wave-uniform)
+  auto defer_math = [&](const Patch& pt) {
+    const float* cst = reinterpret_cast<const float*>(Cst);
+    const float nslope = cst[96];
+    {
+      const int pb = p.amax_images > 1 ? pt.b : 0;  // (wave-uniform)
+      if (pb != amx_b) {
+        if (p.amax) p16::fold_pat(p.amax, amx_b, amx_b, amx);
+        amx = 0u;
+        amx_b = pb;
+      }
+    }
+    f32x4 bv[4], sv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bv[g] = *reinterpret_cast<const f32x4*>(cst + 8 * g + 4 * h);
+      sv[g] = *reinterpret_cast<const f32x4*>(cst + 128 + 8 * g + 4 * h);
+    }
+    const int ox = pt.x0 + r;
+#pragma unroll
+    for (int i = 0; i < SUB; ++i) {
+      const int oy = pt.y0 + R0 + i * DIL;
+      const bool ok = pt.valid && oy < p.H && ox < p.W;
+      const long long m = ((long long)pt.b * p.H + oy) * p.W + ox;
+      float y[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const float t = fmaf(acc[i][v], sv[v >> 2][v & 3], bv[v >> 2][v & 3]);
+        y[v] = t >= 0.f ? t : nslope * t;
+      }
+      if (p.out && ok) {  // (the optional fp32 copy is not deferred: no caller of the hot path asks for it)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(p.out + m * p.ldo + 8 * g + 4 * h) = f32x4{y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]};
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        p16::split8(y + 8 * q, dpk[i][2 * q], dpk[i][2 * q + 1]);
+        const uint32_t mx = p16::absmax_pk4(amx, dpk[i][2 * q], dpk[i][2 * q + 1]);
+        amx = ok ? mx : amx;
+      }
+    }
+    dpt = pt;
+    dpending = true;
+  };
+  auto defer_stores = [&]() {
+    if (p.pout && !(PLANES_DBG & 64)) {
+      const int ox = dpt.x0 + r;
+#pragma unroll
+      for (int i = 0; i < SUB; ++i) {
+        const int oy = dpt.y0 + R0 + i * DIL;
+        if (dpt.valid && oy < p.H && ox < p.W) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            unsigned char* dst = p.pout + ((long long)dpt.b * p.out_total + p.out_chunk0 + q) * chunk_bytes +
+                                 ((long long)(oy + PB) * p.Wp + ox + PB) * PXA + h * 16;
+            *reinterpret_cast<u32x4*>(dst) = dpk[i][2 * q];
+            *reinterpret_cast<u32x4*>(dst + 32) = dpk[i][2 * q + 1];
           }
         }
       }
     }
+    dpending = false;
   };
 
   // ---- phase loop -----------------------------------------------------------------------------------
@@ -607,9 +757,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // LOAD phase: this item's DMA and nothing else (a vector instruction issued here competes with the other team's
       // MFMA stream for the SIMD's issue port and gets a slot every ~16 cycles: the epilogue took 5 500 cycles here)
       TL(0);
+      if (DEFER && PLANES_DEFER == 1 && dpending) {
+        defer_stores();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       stage(cur, c);
       if (team == 0) stage_w(c, i & 1);
       else if (i + 1 < n_items) stage_w(c + 1 == p.nchunks ? 0 : c + 1, (i + 1) & 1);
+      if (DEFER && PLANES_DEFER == 2 && dpending) {
+        __builtin_amdgcn_sched_barrier(0);
+        defer_stores();
+      }
       TL(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       TL(3);
@@ -623,7 +781,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (PLANES_DBG & 128) __builtin_amdgcn_s_setprio(0);
       TL(1);
       if (c + 1 == p.nchunks) {
-        epilogue(cur, i);
+        if constexpr (DEFER) defer_math(cur);
+        else if (!(FUSE && (PLANES_DBG & 2048))) epilogue(cur, i);
         zero_acc();
       }
       TL(5);
@@ -635,6 +794,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
     if (team == 0) __syncthreads();
+    if (DEFER && dpending) defer_stores();  // the workgroup's last patch
   }
   if constexpr (F16) {
     if (p.amax) p16::fold_pat(p.amax, amx_b, amx_b, amx);
@@ -644,7 +804,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int DIL, bool FUSE, bool F16, int SUB = 2>
 int launch(PlanesConvK k, hipStream_t stream) {
   constexpr int A_UNITS = (4 * SUB + 2 * DIL) * (TW + 2 * DIL) * (F16 ? PXH : PXB) / 16;
-  constexpr size_t smem = 2 * ((size_t)((A_UNITS + 63) / 64) * 1024 + W3_BYTES + (FUSE ? W1_BYTES : 0)) + (F16 ? 1024 : 512);
+  constexpr size_t smem = 2 * ((size_t)((A_UNITS + 63) / 64) * 1024 + W3_BYTES + (FUSE ? W1_BYTES : 0)) + (F16 ? 1024 : 512) +
+                          (FUSE && F16 ? 2 * W1_BYTES : 0);
   static_assert(smem <= 160 * 1024, "LDS budget");
   k.tiles_y = (k.H + 4 * SUB - 1) / (4 * SUB);
   auto fn = conv3x3_planes_kernel<DIL, FUSE, F16, SUB>;
@@ -865,6 +1026,9 @@ __global__ void planes16_pack_weight_kernel(const float* __restrict__ w, int N, 
 using namespace segmif;
 
 #if PLANES_DBG & 32
+extern "C" int segmif_debug_planes_epi_timeline(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(planes_epi_timeline), bytes < sizeof(planes_epi_timeline) ? bytes : sizeof(planes_epi_timeline));
+}
 extern "C" int segmif_debug_planes_timeline(void* dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(planes_timeline), bytes < sizeof(planes_timeline) ? bytes : sizeof(planes_timeline));
 }

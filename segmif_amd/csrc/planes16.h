@@ -73,14 +73,25 @@ __device__ __forceinline__ uint32_t absmax_pk(uint32_t m, uint32_t halves) {
 // (pattern 1 = 2^-24): a tensor whose LARGEST magnitude is that small reports a maximum below the guard's lower bound and is
 // repeated on bf16 triples; a healthy tensor's maximum is unaffected (its patterns are far above 1).  v_and + v_pk_min_u16 +
 // v_pk_max_u16 per pair of values, in epilogues only.
+// (r6, later) min(|lo|, 1) is written as v_pk_min_u16 by hand: from __builtin_elementwise_min against the constant {1, 1} hipcc makes
+// "lo != 0 ? 1 : 0" per half - v_bfe, two v_cmp_ne_u16 + s_nop + v_cndmask, v_perm: 12 instructions and 4 wait states per pair of values,
+// ~800 per 16 x 32 patch of the dominant conv's epilogue (found in the ISA behind profiles/r06_tail_epilogue_timeline.txt).
+__device__ __forceinline__ uint32_t sticky_pk(uint32_t lo_abs) {  // per half: 1 where the (sign-stripped) half is non-zero
+  uint32_t s;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(s) : "v"(lo_abs), "v"(0x00010001u));
+  return s;
+}
 __device__ __forceinline__ uint32_t absmax_pk(uint32_t m, uint32_t hi, uint32_t lo) {
-  const us2 one = {1, 1};
-  const us2 s = __builtin_elementwise_min(__builtin_bit_cast(us2, lo & 0x7fff7fffu), one);
-  return absmax_pk(__builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, m), s)), hi);
+  const uint32_t s = sticky_pk(lo & 0x7fff7fffu);
+  return absmax_pk(__builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, m), __builtin_bit_cast(us2, s))), hi);
 }
 
+// four dwords of each plane at once: the sticky bits of the four low dwords are OR-ed first (a half of the OR is non-zero exactly when
+// one of its four halves is: the same maximum as four absmax_pk calls, 14 instructions instead of 20)
 __device__ __forceinline__ uint32_t absmax_pk4(uint32_t m, const u4& hi, const u4& lo) {
-  return absmax_pk(absmax_pk(absmax_pk(absmax_pk(m, hi[0], lo[0]), hi[1], lo[1]), hi[2], lo[2]), hi[3], lo[3]);
+  const uint32_t s = sticky_pk((lo[0] | lo[1] | lo[2] | lo[3]) & 0x7fff7fffu);
+  m = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, m), __builtin_bit_cast(us2, s)));
+  return absmax_pk(absmax_pk(absmax_pk(absmax_pk(m, hi[0]), hi[1]), hi[2]), hi[3]);
 }
 
 __device__ __forceinline__ uint32_t wave_umax(uint32_t v) {

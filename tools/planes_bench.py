@@ -87,6 +87,7 @@ def main():
     fns = {"split + 1x1 gemm (r1)": r1,
            "planes fused tail": lambda: ops.conv3x3_planes(pl, cin, wpl, dil=2, bias=bias, act=1, tail=(w1pl, b1, x64, out, 1)),
            "planes16 fused tail": lambda: ops.conv3x3_planes(pl16, cin, wpl16, dil=2, bias=bias, act=1, tail=(w1pl16, b1, x64, out, 1)),
+           "planes16 fused tail, residual from planes": lambda: ops.conv3x3_planes(pl16, cin, wpl16, dil=2, bias=bias, act=1, tail=(w1pl16, b1, None, out, 1, True)),
            "planes_from_f32 64ch": lambda: pl.load_f32(x64, 0),
            "planes16_from_f32 64ch": lambda: pl16.load_f32(x64, 0),
            "1x1 gemm 224->64 alone": lambda: ops.linear(buf, w1pk, 64, bias=b1, act=1, res=x64, out=out)}

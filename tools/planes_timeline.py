@@ -36,7 +36,7 @@ if TAIL:
     b1 = torch.randn(64, device="cuda")
     out = torch.empty(B, H, W, 64, device="cuda")
     x64 = x[..., :64]
-    run = lambda: ops.conv3x3_planes(pl, cin, wpl, dil=2, act=1, tail=(w1, b1, x64, out, 1))
+    run = lambda: ops.conv3x3_planes(pl, cin, wpl, dil=2, act=1, tail=(w1, b1, None, out, 1, True) if F16 else (w1, b1, x64, out, 1))  # (f16x3: residual from the input planes, as DRDB.forward_planes calls it)
 else:
     run = lambda: ops.conv3x3_planes(pl, cin, wpl, dil=2, act=1, out_chunk0=12)
 for _ in range(3):
@@ -64,3 +64,19 @@ for team in (0, 1):
         print(f"  {n:26s} {v.mean():8.0f} {np.percentile(v, 10):8.0f} {np.percentile(v, 90):8.0f}")
     per = (t[:, team, 1:, 0] - t[:, team, :-1, 0]).ravel()
     print(f"  {'item period (2 phases)':26s} {per.mean():8.0f} {np.percentile(per, 10):8.0f} {np.percentile(per, 90):8.0f}   (MFMA alone per phase: bf16x6 108 x 32 = 3456 ticks; f16x3 SUB=4 108 x 32; f16x3 tail 66 x 32 = 2112)")
+
+if TAIL and hasattr(lib, "segmif_debug_planes_epi_timeline"):
+    # (r6) stamps inside the fused tail's epilogue (conv3x3_planes.hip, ETL): where its ticks go, on the items that end a patch
+    eb = np.zeros((256, 2, NI, 8), dtype=np.uint64)
+    assert lib.segmif_debug_planes_epi_timeline(ctypes.c_void_p(eb.ctypes.data), ctypes.c_size_t(eb.nbytes)) == 0
+    e = eb[:, :, 8:56, :7].astype(np.int64)[:, :, fresh, :]
+    t1 = buf[:, :, 8:56, 1].astype(np.int64)[:, :, fresh]   # stamp 1: MFMA steps done
+    t5 = buf[:, :, 8:56, 5].astype(np.int64)[:, :, fresh]   # stamp 5: epilogue + clear done
+    names = ["MFMA steps done -> epilogue entry", "constants in registers (LDS)", "sub-tile 0 activated", "sub-tile 0: split + 1x1 MFMAs",
+             "sub-tile 0: out1 values (residual arrived)", "sub-tile 0: stores issued", "sub-tile 1, all of it", "-> accumulators cleared"]
+    pts = np.concatenate([t1[..., None], e, t5[..., None]], axis=-1)
+    d = np.diff(pts, axis=-1)
+    print("fused tail, inside the epilogue (ticks; mean / p10 / p90 over workgroups x patches):")
+    for i, n in enumerate(names):
+        v = d[..., i].ravel()
+        print(f"  {n:44s} {v.mean():8.0f} {np.percentile(v, 10):8.0f} {np.percentile(v, 90):8.0f}")
