@@ -132,6 +132,17 @@ __device__ __forceinline__ f32x16 mfma_split(const u32x4& a, const u32x4& b, con
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// x = hi + 2^-11 lo of element E (0 | 1) of a dword of high halves and the matching dword of low halves: ONE v_fma_mix_f32 (the halves
+// are read in place - op_sel picks the half, op_sel_hi marks the f16 sources; exact in fp32) instead of two conversions and an fma
+template <int E>
+__device__ __forceinline__ float pair_value(uint32_t hi2, uint32_t lo2) {
+  float d;
+  const float c = 1.f / LSCALE;
+  if constexpr (E == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(lo2), "v"(c), "v"(hi2));
+  else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(lo2), "v"(c), "v"(hi2));
+  return d;
+}
+
 __host__ __device__ inline int sigma16(int j) { return (j & 3) + 4 * (j >> 3) + 8 * ((j >> 2) & 1); }
 
 struct PlanesConvK {
@@ -175,8 +186,15 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
 // 2i and multiplied in phase 2i + 1; team 1 runs one phase later and finds the weights of item i still in W[i & 1].
 // SUB = sub-tiles (patch rows) per wave: 2 (a team's patch is 8 x 32) or 4 (16 x 32: the plain f16x3 conv on heights that
 // are whole 16-row patches - 0.58 fragment reads per MFMA instead of 0.94, halo overhead 1.41x instead of 1.69x).
-template <int DIL, bool FUSE, bool F16, int SUB = 2>
+// LEAN (r6): the instantiations an inference forward runs - f16x3, no fp32 copy of the conv's output; plain conv: planes out, any
+// activation; fused tail: ReLU after the conv and after the 1x1, residual from the input planes, no planes out.  Its epilogue
+// carries none of the other cases' (uniform, but per-element and per-store) branches - 53 s_cbranch in the general tail - and its
+// ReLU is ONE instruction: biases and row scales are parked in LDS HALVED, t' = t / 2 comes out of the same fma exactly, and
+// relu(t) = t' + |t'| (v_add_f32 with the |.| source modifier; bit for bit max(t, 0) for finite t, NaN stays NaN; -inf gives NaN
+// where max gives 0 - both are overflow signals the range guard repeats the pair for) instead of v_cmp + 2 wait states + v_cndmask.
+template <int DIL, bool FUSE, bool F16, int SUB = 2, bool LEAN = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_planes_kernel(const PlanesConvK p) {
+  static_assert(!LEAN || F16, "the lean epilogue is the f16x3 kernels'");
   static_assert(SUB == 2 || (SUB == 4 && !FUSE), "four sub-tiles per wave: plain conv only (the fused tail's accumulators do not fit)");
   constexpr int THS = 4 * SUB;                    // patch rows of a team
   constexpr int HH = THS + 2 * DIL, HW = TW + 2 * DIL;
@@ -283,14 +301,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   if (tid < 98) {  // epilogue constants -> LDS (first read is after at least one workgroup barrier)
     float v;
-    if (tid < 32) v = p.bias[tid];
-    else if (tid < 96) v = FUSE ? p.bias1[tid - 32] : 0.f;
+    constexpr float HALF = LEAN ? 0.5f : 1.f;  // (LEAN: see the kernel's header - exact, a power of two)
+    if (tid < 32) v = HALF * p.bias[tid];
+    else if (tid < 96) v = FUSE ? HALF * p.bias1[tid - 32] : 0.f;
     else if (tid == 96) v = p.act == SEGMIF_ACT_RELU ? 0.f : (p.act == SEGMIF_ACT_PRELU ? *p.prelu : 1.f);
     else v = p.act1 == SEGMIF_ACT_RELU ? 0.f : 1.f;
     reinterpret_cast<float*>(Cst)[tid] = v;
   } else if (F16 && tid >= 128 && tid < 224) {  // row scales 2^-e(n): floats [128, 160) conv, [160, 224) fused 1x1
     const int n = tid - 128;
-    reinterpret_cast<float*>(Cst)[tid] = n < 32 ? p.wscale[n] : (FUSE ? p.w1scale[n - 32] : 1.f);
+    reinterpret_cast<float*>(Cst)[tid] = (LEAN ? 0.5f : 1.f) * (n < 32 ? p.wscale[n] : (FUSE ? p.w1scale[n - 32] : 1.f));
   }
   if constexpr (FUSE && F16) {  // 12 KB = 12 wave-level DMA instructions: waves 0..3 of each team take 3 / 0 (landed before the first barrier's s_waitcnt vmcnt(0))
     if (team == 0) {
@@ -529,7 +548,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // sub-tile leave together after its arithmetic.
     constexpr bool PRE = FUSE && F16;
     u32x4 rp[2][2][2];                            // [nt][chunk 2 nt + c2][plane]: one sub-tile's residual pieces
-    const bool res_pl = PRE && !p.res && p.res_planes && !(PLANES_DBG & 512);  // (uniform)
+    const bool res_pl = PRE && (LEAN || (!p.res && p.res_planes)) && !(PLANES_DBG & 512);  // (uniform)
     auto request_residual = [&](int i) {  // (the padded planes image holds every pixel of a rounded-up or clamped patch: no bounds needed)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
@@ -553,7 +572,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const float t = F16 ? fmaf(acc[i][v], sv[F16 ? v : 0], bv[v]) : acc[i][v] + bv[v];
-        y[v] = t >= 0.f ? t : nslope * t;
+        y[v] = LEAN ? t + __builtin_fabsf(t) : (t >= 0.f ? t : nslope * t);
       }
       if (i == 0) ETL(2, "v"(y[0]), "v"(y[7]), "v"(y[8]), "v"(y[15]));
 #if PLANES_DBG & 32
@@ -563,7 +582,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
 #endif
       const long long m = ((long long)pt.b * p.H + oy) * p.W + ox;
-      if (p.out && ok) {
+      if (!LEAN && p.out && ok) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<f32x4*>(p.out + m * p.ldo + 8 * g + 4 * h) = f32x4{y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]};
@@ -580,7 +599,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           split8(y + 8 * q, pl[0], pl[1], pl[2]);
         }
         if (PLANES_DBG & 64) asm volatile("" ::"v"(pl[0]), "v"(pl[1]), "v"(pl[2]));
-        if (p.pout && ok && !(PLANES_DBG & 64)) {
+        if (!(LEAN && FUSE) && p.pout && ok && !(PLANES_DBG & 64)) {
           unsigned char* dst = p.pout + ((long long)pt.b * p.out_total + p.out_chunk0 + q) * chunk_bytes +
                                ((long long)(oy + PB) * p.Wp + ox + PB) * PXA + h * 16;
 #pragma unroll
@@ -601,29 +620,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               for (int t = 0; t < NPROD; ++t) acc1[i][nt] = mfma_split<F16>(W1g[PW[t]], pl[PA[t]], acc1[i][nt]);
           }
         }
+        if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (FUSE) {
         if (i == 0) ETL(3, "v"(acc1[0][0][0]), "v"(acc1[0][1][0]), "v"(acc1[0][0][15]), "v"(acc1[0][1][15]));
-        // out1 = act1(1x1) + residual for all 64 channels of the pixel first (in registers), the stores last: nothing between the
-        // residual's arrival and the stores waits on memory, and the next sub-tile's residual is requested before the stores
+        // out1 = act1(1x1) + residual, 32 channels of the pixel at a time: arithmetic first (in registers), then their four stores;
+        // nothing between the residual's arrival and the stores waits on memory
         const float nslope1 = cst[97];
-        f32x4 o[2][4];
+        // (r6) the 1x1's biases and row scales in batches of 8 LDS reads (one per half of this lane's 32 channels; read where
+        // they were used, each of the 16 reads was its own round trip of a few hundred ticks under the other team's LDS-DMA writes)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
+          f32x4 cb1[4], cs1[4], o[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            cb1[g] = *reinterpret_cast<const f32x4*>(cst + z + 32 + nt * 32 + 8 * g + 4 * h);
+            if constexpr (F16) cs1[g] = *reinterpret_cast<const f32x4*>(cst + z + 160 + nt * 32 + 8 * g + 4 * h);
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int n0 = nt * 32 + 8 * g + 4 * h;
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(cst + 32 + n0);
+            const f32x4 b1 = cb1[g];
             f32x4 s1 = {1.f, 1.f, 1.f, 1.f};
-            if constexpr (F16) s1 = *reinterpret_cast<const f32x4*>(cst + 160 + n0);
+            if constexpr (F16) s1 = cs1[g];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float t = F16 ? fmaf(acc1[i][nt][4 * g + e], s1[e], b1[e]) : acc1[i][nt][4 * g + e] + b1[e];
-              o[nt][g][e] = t >= 0.f ? t : nslope1 * t;
+              o[g][e] = LEAN ? t + __builtin_fabsf(t) : (t >= 0.f ? t : nslope1 * t);
             }
-            if (p.res) {
-              if (ok) o[nt][g] += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n0);
-            } else if (F16 && p.res_planes && !(PLANES_DBG & 512)) {
+            if (!LEAN && p.res) {
+              if (ok) o[g] += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n0);
+            } else if (F16 && (LEAN || p.res_planes) && !(PLANES_DBG & 512)) {
               // (r4) residual = the DRDB's own input, read back from its planes: channel n0 + e is element 4 (g & 1) + e of this
               // lane's piece of chunk 2 nt + (g >> 1) - the order the accumulators hand out; x = hi + 2^-11 lo (23 bits)
               // (r6: from the pieces requested at the top of the epilogue / during the previous sub-tile)
@@ -631,37 +659,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               const uint32_t lw[2] = {rp[nt][g >> 1][1][2 * (g & 1)], rp[nt][g >> 1][1][2 * (g & 1) + 1]};
 #pragma unroll
               for (int e2 = 0; e2 < 2; ++e2) {
-                const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[e2] & 0xffffu));
-                const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[e2] >> 16));
-                const float l0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(lw[e2] & 0xffffu));
-                const float l1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(lw[e2] >> 16));
-                o[nt][g][2 * e2] += fmaf(l0, 1.f / LSCALE, h0);
-                o[nt][g][2 * e2 + 1] += fmaf(l1, 1.f / LSCALE, h1);
+                o[g][2 * e2] += pair_value<0>(hw[e2], lw[e2]);
+                o[g][2 * e2 + 1] += pair_value<1>(hw[e2], lw[e2]);
               }
             }
           }
-        }
-        if (i == 0) ETL(4, "v"(o[0][0]), "v"(o[0][3]), "v"(o[1][0]), "v"(o[1][3]));
-        if constexpr (PRE) {
-          if (res_pl && i + 1 < SUB) {
-            __builtin_amdgcn_sched_barrier(0);
-            request_residual(i + 1);
-            __builtin_amdgcn_sched_barrier(0);
+          if (i == 0 && nt == 1) ETL(4, "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+          if constexpr (PRE) {
+            if (nt == 1 && res_pl && i + 1 < SUB) {  // (this sub-tile's pieces are consumed: the next one's ride ahead of the stores)
+              __builtin_amdgcn_sched_barrier(0);
+              request_residual(i + 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
-        }
-        if (PLANES_DBG & 256) {
+          if (PLANES_DBG & 256) {
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+            for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(o[g]));
+          } else if (ok) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(o[nt][g]));
-        } else if (ok) {
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(p.out1 + m * p.ldo1 + nt * 32 + 8 * g + 4 * h) = o[nt][g];
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(p.out1 + m * p.ldo1 + nt * 32 + 8 * g + 4 * h) = o[g];
+          }
+          if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
         }
         if (i == 0) ETL(5, "s"(z));
         if (i == SUB - 1) ETL(6, "s"(z));
+        if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);  // (branch-free, the scheduler would hoist the next sub-tile's arithmetic above these stores and spill)
       }
     }
   };
@@ -704,9 +726,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const float t = fmaf(acc[i][v], sv[v >> 2][v & 3], bv[v >> 2][v & 3]);
-        y[v] = t >= 0.f ? t : nslope * t;
+        y[v] = LEAN ? t + __builtin_fabsf(t) : (t >= 0.f ? t : nslope * t);
       }
-      if (p.out && ok) {  // (the optional fp32 copy is not deferred: no caller of the hot path asks for it)
+      if constexpr (LEAN) {
+        // PReLU / no activation (uniform; the dilation-1 convs): y = max(t, 0) + slope min(t, 0), both parts from the halved t
+        // without a compare - t' + |t'| and t' - |t'| are exact, the product rounds once as slope * t did
+        if (nslope != 0.f) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const float th = fmaf(acc[i][v], sv[v >> 2][v & 3], bv[v >> 2][v & 3]);
+            y[v] = fmaf(nslope, th - __builtin_fabsf(th), y[v]);
+          }
+        }
+      }
+      if (!LEAN && p.out && ok) {  // (the optional fp32 copy is not deferred: no caller of the hot path asks for it)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<f32x4*>(p.out + m * p.ldo + 8 * g + 4 * h) = f32x4{y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]};
@@ -722,7 +755,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     dpending = true;
   };
   auto defer_stores = [&]() {
-    if (p.pout && !(PLANES_DBG & 64)) {
+    if ((LEAN || p.pout) && !(PLANES_DBG & 64)) {
       const int ox = dpt.x0 + r;
 #pragma unroll
       for (int i = 0; i < SUB; ++i) {
@@ -801,14 +834,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-template <int DIL, bool FUSE, bool F16, int SUB = 2>
+template <int DIL, bool FUSE, bool F16, int SUB = 2, bool LEAN = false>
 int launch(PlanesConvK k, hipStream_t stream) {
   constexpr int A_UNITS = (4 * SUB + 2 * DIL) * (TW + 2 * DIL) * (F16 ? PXH : PXB) / 16;
   constexpr size_t smem = 2 * ((size_t)((A_UNITS + 63) / 64) * 1024 + W3_BYTES + (FUSE ? W1_BYTES : 0)) + (F16 ? 1024 : 512) +
                           (FUSE && F16 ? 2 * W1_BYTES : 0);
   static_assert(smem <= 160 * 1024, "LDS budget");
   k.tiles_y = (k.H + 4 * SUB - 1) / (4 * SUB);
-  auto fn = conv3x3_planes_kernel<DIL, FUSE, F16, SUB>;
+  auto fn = conv3x3_planes_kernel<DIL, FUSE, F16, SUB, LEAN>;
   static segmif::PerDeviceFlag raised_flag;  // idempotent attribute; benign race
   bool& raised = raised_flag.here();
   if (!raised) {
@@ -1199,6 +1232,13 @@ static int conv3x3_planes_impl(const SegmifConvPlanes* d, bool f16, uint32_t* am
     // plain conv on heights that are whole 16-row patches: four sub-tiles per wave (16 x 32 patches; +5..6 % over two,
     // profiles/r04_planes_sub4_ab.txt).  SEGMIF_PLANES_SUB=2 (read once per process) keeps the two-sub-tile kernel for A/B runs.
     static const bool sub4 = [] { const char* e = getenv("SEGMIF_PLANES_SUB"); return !(e && e[0] == '2'); }();
+    // (r6) the DRDB shapes of an inference forward take the LEAN instantiations (see the kernel); SEGMIF_PLANES_LEAN=0 keeps the general ones
+    static const bool lean_on = [] { const char* e = getenv("SEGMIF_PLANES_LEAN"); return !(e && e[0] == '0'); }();
+    const bool relu = d->act == SEGMIF_ACT_RELU && !d->out;
+    if (lean_on && !d->out) {
+      if (!fuse && sub4 && d->H % 16 == 0 && k.pout) return d->dil == 2 ? launch<2, false, true, 4, true>(k, s) : launch<1, false, true, 4, true>(k, s);
+      if (fuse && relu && d->dil == 2 && d->act1 == SEGMIF_ACT_RELU && !d->res && k.res_planes && !k.pout) return launch<2, true, true, 2, true>(k, s);
+    }
     if (sub4 && !fuse && d->H % 16 == 0) return d->dil == 2 ? launch<2, false, true, 4>(k, s) : launch<1, false, true, 4>(k, s);
     if (d->dil == 2) return fuse ? launch<2, true, true>(k, s) : launch<2, false, true>(k, s);
     return fuse ? launch<1, true, true>(k, s) : launch<1, false, true>(k, s);

@@ -41,6 +41,7 @@ void run(const char* name, K k, int instr_per_rep) {
   }
   (void)hipFree(d);
 }
+#ifndef TEAMS
 int main() {
   run("v_mov", k_mov, 1);
   run("v_fma", k_fma, 1);
@@ -50,3 +51,43 @@ int main() {
   run("cvt_pk", k_cvt, 1);
   return 0;
 }
+#endif
+// ---- second question: does a team of four waves parked at s_barrier (or holding LDS-DMA loads in flight) slow the other team's VALU? ----
+// build with -DTEAMS: 512 threads; waves 4-7 optionally issue `ndma` LDS-DMA instructions each, then wait at the workgroup barrier;
+// waves 0-3 run the v_fma block, then join the barrier.
+#ifdef TEAMS
+__global__ __launch_bounds__(512) void k_teams(unsigned long long* out, const unsigned char* src, int ndma) {
+  extern __shared__ unsigned char lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long t0 = 0, t1 = 0;
+  float a = threadIdx.x, b = 1.5f, c = 2.5f;
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    if (wave >= 4) {
+      for (int i = 0; i < ndma; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((size_t)blockIdx.x * 64 + (wave - 4) * 16 + i) * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(lds + ((wave - 4) * 16 + i) * 1024), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      t0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)\n .rept " STR(N) "\n v_fma_f32 v40, %1, %2, %1\n .endr\n" : "+v"(a) : "v"(b), "v"(c) : "v40");
+      t1 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
+  if (wave < 4 && lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
+  if (a == 12345.f) out[0] = 0;
+}
+int main() {
+  unsigned long long* d; (void)hipMalloc(&d, 4096 * 8);
+  unsigned char* src; (void)hipMalloc(&src, (size_t)256 * 64 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_teams, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  for (int ndma : {0, 4, 16}) {
+    hipLaunchKernelGGL(k_teams, dim3(256), dim3(512), 65536, 0, d, src, ndma);
+    unsigned long long h[8]; (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    printf("teams: other team issues %2d LDS-DMA instructions per wave then waits at the barrier: %6.2f ticks per v_fma\n", ndma, (double)h[0] / N);
+  }
+  return 0;
+}
+#endif
