@@ -20,8 +20,13 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
   const f2 v = {x0, x1};
   const h2 a = __builtin_convertvector(v, h2);  // v_cvt_pk_f16_f32, round to nearest even
   hi = __builtin_bit_cast(uint32_t, a);
-  const f2 back = __builtin_convertvector(a, f2);
-  const f2 res = {(x0 - back[0]) * LSCALE, (x1 - back[1]) * LSCALE};
+  // (r6) 2^11 (x - hi) as ONE v_fma_mix_f32 per value - hi read in place as a half, times -2^11, plus 2^11 x: the same real number as
+  // (x - float(hi)) * 2^11 (every step of either form is exact), without the two v_cvt_f32_f16 and the subtraction
+  const f2 xs = v * LSCALE;
+  f2 res;
+  const float m = -LSCALE;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(res[0]) : "v"(hi), "v"(m), "v"(xs[0]));
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(res[1]) : "v"(hi), "v"(m), "v"(xs[1]));
   lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(res, h2));
 }
 
