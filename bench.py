@@ -219,6 +219,13 @@ def train_leg(args, rank, world, seg, fus):
                    "grad_bytes": red.gradient_bytes() if red is not None else
                    4 * sum(p.numel() for p in (fus.parameters() if name == "fusion" else [q for grp in g for q in grp])
                            if p.grad is not None)}
+            if rec["tflops_per_gpu"] is not None:
+                # (r6) the step's rate against the two matrix pipes it runs on: the f16x3 ceiling the forward is
+                # priced against (dense F16 2500 / 3 products) and the exact-fp32 MFMA pipe most of the segmentation step still uses
+                rec["peak_tflops"] = 2500.0 / 3
+                rec["frac"] = rec["tflops_per_gpu"] / (2500.0 / 3)
+                rec["frac_of_fp32_mfma_pipe"] = rec["tflops_per_gpu"] / 157.3
+                rec["dominant_kernel"] = TRAIN_DOMINANT[name]
             if world > 1:  # (r5) so that the first real multi-GPU run is diagnosable from this one line
                 rec.update(timed.last)
             if name == "fusion" and trainer.last_lap is not None:
@@ -255,6 +262,16 @@ def train_leg(args, rank, world, seg, fus):
                              "overlap": "buckets launched from post-accumulate-grad hooks during backward"}
     out["peak_mem_GB"] = torch.cuda.max_memory_allocated() / 2 ** 30
     return out
+
+
+# the kernel with the largest share of each training step's kernel time (static record: the rocprofv3 tables named here, taken with
+# tools/kstats.sh over tools/train_bench.py on this code; not re-measured by a bench run)
+TRAIN_DOMINANT = {
+    "seg": {"kernel": "igemm_kernel<64,64,32,32,16,0,2> (the ~290 small Linears of the MiT blocks at 8 images: exact-fp32 MFMA tiles)",
+            "share_of_kernel_time": 0.24, "source": "profiles/r06_segtrain_kernel_stats.txt"},
+    "fusion": {"kernel": "conv3x3_split_kernel<32,2,8,f16x3> (DRDB dilated convs, forward and input gradients, range made on the device)",
+               "share_of_kernel_time": 0.129, "source": "profiles/r06_fusiontrain_kernel_stats.txt"},
+}
 
 
 def config_leg(backbone, B, H, W, steps, graph=False):
@@ -516,7 +533,7 @@ def main():
             traffic, traffic_src = None, None
             mode = ops.conv3x3_mode()
             peak = PEAK_FP32_MFMA_TFLOPS if mode == "fp32" else (PEAK_BF16X6_TFLOPS * 2.0 if mode == "planes16" else PEAK_BF16X6_TFLOPS)
-            p16_name = next((n for n in (f"r05_pmc_dominant_b{B}_planes16.json", f"r04_pmc_dominant_b{B}_planes16.json")
+            p16_name = next((n for n in (f"r06_pmc_dominant_b{B}_planes16.json", f"r05_pmc_dominant_b{B}_planes16.json", f"r04_pmc_dominant_b{B}_planes16.json")
                              if os.path.exists(os.path.join(ROOT, "profiles", n))), f"r03_pmc_dominant_b{B}_planes16.json")
             pmc_name = {"planes16": p16_name, "planes": f"r03_pmc_dominant_b{B}_planes.json" if os.path.exists(os.path.join(ROOT, "profiles", f"r03_pmc_dominant_b{B}_planes.json")) else f"r02_pmc_dominant_b{B}_planes.json", "bf16x6": f"r01_pmc_dominant_b{B}_bf16x6.json",
                         "fp32": "r01_pmc_dominant.json" if B == 8 else f"r01_pmc_dominant_b{B}.json"}[mode]
