@@ -49,6 +49,7 @@
 // below fp32's own resolution of a sum that contains the maximum.  A NaN / inf maximum makes the scale NaN: the output is
 // all NaN instead of quietly wrong.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "device_once.h"
 #include <stdint.h>
 
@@ -332,72 +333,78 @@ __global__ __launch_bounds__(STH * 32) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 #endif
 
-  // ---- epilogue (same contract as the fp32 halo kernel) ----------------------------------------
-  const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
-  const long long img = (long long)b * p.H * p.W;
-  // f16x3: the rows' own power-of-two scales sit behind the weight image (one float per padded output channel)
-  const float* wdesc = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.wt) +
-                                                      (long long)gridDim.y * nchunks * B_UNITS * 16);
-  uint32_t amx = 0u;  // largest |output| this lane wrote (bit pattern), for the consumer's scale
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int oy = y0 + R0 + i * DIL;
-    if (oy >= p.H) continue;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = nbase + j * 32 + r;
-      if (n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
-      const float desc = F16 ? s_out * wdesc[n] : 1.f;
-      // residual and mask values first, all sixteen of each in flight at once (unconditional loads from clamped columns):
-      // fetched one by one between the stores they were a chain of exposed latencies at the end of a 25 us workgroup
-      float rv[16], mv[16];
-      const long long row = img + (long long)oy * p.W;
-      if (p.res) {
-#pragma unroll
+  // (r6) one uniform branch on "the activation is a GELU" in front of the epilogue: inside the per-element switch every accumulator
+  // element carried its own copy of the erf GELU (see igemm.hip) - tens of KB of ISA for an activation these kernels' callers never ask for
+  auto epilogue_r6 = [&](auto gelu_c) {
+    constexpr bool GELU_EPI = decltype(gelu_c)::value;
+    // ---- epilogue (same contract as the fp32 halo kernel) ----------------------------------------
+    const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
+    const long long img = (long long)b * p.H * p.W;
+    // f16x3: the rows' own power-of-two scales sit behind the weight image (one float per padded output channel)
+    const float* wdesc = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.wt) +
+                                                        (long long)gridDim.y * nchunks * B_UNITS * 16);
+    uint32_t amx = 0u;  // largest |output| this lane wrote (bit pattern), for the consumer's scale
+  #pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oy = y0 + R0 + i * DIL;
+      if (oy >= p.H) continue;
+  #pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nbase + j * 32 + r;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+        const float desc = F16 ? s_out * wdesc[n] : 1.f;
+        // residual and mask values first, all sixteen of each in flight at once (unconditional loads from clamped columns):
+        // fetched one by one between the stores they were a chain of exposed latencies at the end of a 25 us workgroup
+        float rv[16], mv[16];
+        const long long row = img + (long long)oy * p.W;
+        if (p.res) {
+  #pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int ox = min(x0 + (v & 3) + 8 * (v >> 2) + 4 * h, p.W - 1);
+            rv[v] = p.res[(row + ox) * p.ldr + n];
+          }
+        }
+        if (p.mask) {
+  #pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int ox = min(x0 + (v & 3) + 8 * (v >> 2) + 4 * h, p.W - 1);
+            mv[v] = p.mask[(row + ox) * p.ldm + n];
+          }
+        }
+  #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          const int ox = min(x0 + (v & 3) + 8 * (v >> 2) + 4 * h, p.W - 1);
-          rv[v] = p.res[(row + ox) * p.ldr + n];
+          const int ox = x0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+          if (ox >= p.W) continue;
+          float y = (F16 ? acc[i][j][v] * desc : acc[i][j][v]) + bv;
+          if constexpr (GELU_EPI) { y = gelu_exact(y); } else if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
+          else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
+          if (p.res) y += rv[v];
+          if (p.mask && !(mv[v] > 0.f)) y = 0.f;  // DRDB backward: through the receiving block's ReLU
+          p.out[(row + ox) * p.ldo + n] = y;
+          amx = p16::absmax_bits(amx, y, 0.f);
         }
       }
-      if (p.mask) {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const int ox = min(x0 + (v & 3) + 8 * (v >> 2) + 4 * h, p.W - 1);
-          mv[v] = p.mask[(row + ox) * p.ldm + n];
-        }
-      }
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int ox = x0 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (ox >= p.W) continue;
-        float y = (F16 ? acc[i][j][v] * desc : acc[i][j][v]) + bv;
-        if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
-        else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
-        else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
-        if (p.res) y += rv[v];
-        if (p.mask && !(mv[v] > 0.f)) y = 0.f;  // DRDB backward: through the receiving block's ReLU
-        p.out[(row + ox) * p.ldo + n] = y;
-        amx = p16::absmax_bits(amx, y, 0.f);
+    }
+    if (p.out_amax) {
+      // One atomic per WORKGROUP, spread over out_amax_n words by workgroup index (the consumer takes the maximum over all of
+      // them).  (Measured against one atomic per wave on a single cold word at 8 x 480 x 640: no difference either way -
+      // tools/split_conv_bench.py "1-word report"; kept because it cannot be worse and the slots are per-launch anyway.)
+      amx = p16::wave_umax(amx);
+      uint32_t* red = reinterpret_cast<uint32_t*>(smem_b);  // (every wave is past the chunk loop's closing barrier: the staging area is free)
+      if (lane == 0) red[wave] = amx;
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t m = red[0];
+  #pragma unroll
+        for (int w = 1; w < NT / 64; ++w) m = red[w] > m ? red[w] : m;
+        uint32_t* slot = p.out_amax + (blockIdx.x & (p.out_amax_n - 1));
+        if (m > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, m);
       }
     }
-  }
-  if (p.out_amax) {
-    // One atomic per WORKGROUP, spread over out_amax_n words by workgroup index (the consumer takes the maximum over all of
-    // them).  (Measured against one atomic per wave on a single cold word at 8 x 480 x 640: no difference either way -
-    // tools/split_conv_bench.py "1-word report"; kept because it cannot be worse and the slots are per-launch anyway.)
-    amx = p16::wave_umax(amx);
-    uint32_t* red = reinterpret_cast<uint32_t*>(smem_b);  // (every wave is past the chunk loop's closing barrier: the staging area is free)
-    if (lane == 0) red[wave] = amx;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t m = red[0];
-#pragma unroll
-      for (int w = 1; w < NT / 64; ++w) m = red[w] > m ? red[w] : m;
-      uint32_t* slot = p.out_amax + (blockIdx.x & (p.out_amax_n - 1));
-      if (m > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, m);
-    }
-  }
+  };
+  if (p.act == SEGMIF_ACT_GELU) epilogue_r6(std::true_type{});
+  else epilogue_r6(std::false_type{});
 }
 
 template <int NOUT, int DIL, int STH, bool F16>

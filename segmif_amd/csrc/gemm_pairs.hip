@@ -29,6 +29,7 @@
 // Per K step a workgroup moves 24 KB into LDS for 96 MFMAs = 768 CU cycles: 31 B/clk per CU, inside what LDS-DMA sustains
 // beside a busy matrix pipe (~39 B/clk from eight issuing waves); gemm_split's 128 x 128 x 32 step needs 55.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -260,40 +261,67 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM == 
   const bool en_ok = en < p.N;
   const f32x4 esc = *reinterpret_cast<const f32x4*>(p.wscale + en);  // (the scale array covers the padded columns)
   const f32x4 ebi = (p.bias && en_ok) ? *reinterpret_cast<const f32x4*>(p.bias + en) : f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 rres[2][8];
+  // (r6) The case every Linear of the encoder is - no activation - gets a straight-line epilogue of its own (with / without the
+  // residual), chosen by ONE uniform branch.  Written with `p.act` and `p.res` tested where they are used, each of a lane's 64
+  // elements carried the whole activation switch - 64 copies of the erf GELU behind ~480 uniform branches, 7 000 lines of ISA
+  // (45 KB: most of the 64 KB instruction cache two CUs share) of which such a Linear executed a fraction, one taken branch every
+  // few instructions; the epilogue was 25 % of a workgroup's life (profiles/r05_gemm_pairs_timeline.txt).  The general code
+  // stays for the activations.
+  auto epilogue = [&](auto lean_c, auto res_c) {
+    constexpr bool LEANE = decltype(lean_c)::value;  // no activation: the case every Linear of the encoder is
+    constexpr bool RESC = decltype(res_c)::value;    // (LEANE only) residual known at compile time
+    const bool has_res = LEANE ? RESC : (p.res != nullptr);
+    f32x4 rres[LEANE ? 2 : 1][8];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(T + r * 68 + j * 32 + 8 * g + 4 * h) =
-            f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-    if (i == 0 && p.res) {  // (uniform) both halves' residual rows, while nothing has been stored yet
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(T + r * 68 + j * 32 + 8 * g + 4 * h) =
+              f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+      if constexpr (LEANE) __builtin_amdgcn_sched_barrier(0);  // (the residual rows only after the first half's accumulators are in LDS, i.e. dead: 64 + 64 registers do not fit)
+      if (LEANE && i == 0 && has_res) {  // (uniform) both halves' residual rows, while nothing has been stored yet
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const long long m = m0 + wm * 64 + ii * 32 + t * 4 + (lane >> 4);
-          rres[ii][t] = (m < p.M && en_ok) ? *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + en) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: the wave's own LDS writes have landed
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int row = t * 4 + (lane >> 4);
-      const long long m = m0 + wm * 64 + i * 32 + row;
-      f32x4 y = *reinterpret_cast<const f32x4*>(T + row * 68 + ecl) * esc + ebi;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (p.act == SEGMIF_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
-        else if (p.act == SEGMIF_ACT_PRELU) y[e] = y[e] >= 0.f ? y[e] : slope * y[e];
-        else if (p.act == SEGMIF_ACT_GELU) y[e] = gelu_exact(y[e]);
+          for (int t = 0; t < 8; ++t) {
+            const long long m = m0 + wm * 64 + ii * 32 + t * 4 + (lane >> 4);
+            rres[LEANE ? ii : 0][t] = (m < p.M && en_ok) ? *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + en) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
       }
-      if (p.res) y += rres[i][t];
-      if (m < p.M && en_ok) *reinterpret_cast<f32x4*>(p.out + m * p.ldo + en) = y;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: the wave's own LDS writes have landed
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int row = t * 4 + (lane >> 4);
+        const long long m = m0 + wm * 64 + i * 32 + row;
+        f32x4 y = *reinterpret_cast<const f32x4*>(T + row * 68 + ecl) * esc + ebi;
+        if constexpr (!LEANE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (p.act == SEGMIF_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+            else if (p.act == SEGMIF_ACT_PRELU) y[e] = y[e] >= 0.f ? y[e] : slope * y[e];
+            else if (p.act == SEGMIF_ACT_GELU) y[e] = gelu_exact(y[e]);
+          }
+        }
+        if constexpr (LEANE) {
+          if (has_res) y += rres[LEANE ? i : 0][t];
+        } else if (has_res && m < p.M && en_ok) {  // (an activation AND a residual: no caller on the measured path; loaded where it is used)
+          y += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + en);
+        }
+        if (m < p.M && en_ok) *reinterpret_cast<f32x4*>(p.out + m * p.ldo + en) = y;
+        if constexpr (LEANE) {
+          if (t & 1) __builtin_amdgcn_sched_barrier(0);  // (two rows in flight: branch-free, the scheduler would hoist all eight tile reads and spill)
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites the tile
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites the tile
+  };
+  if (p.act == SEGMIF_ACT_NONE) {
+    if (p.res) epilogue(std::true_type{}, std::true_type{});
+    else epilogue(std::true_type{}, std::false_type{});
+  } else {
+    epilogue(std::false_type{}, std::false_type{});
   }
 #if PAIRS_DBG
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

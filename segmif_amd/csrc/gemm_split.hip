@@ -17,6 +17,7 @@
 // its 208-byte rows with the planes W0 | W - W0 | 2^-11 W0 of the row scaled by 2^e(n), three products per MAC, the
 // epilogue multiplies by 2^-e(n); max |A| of what a workgroup staged is folded into the guard slot.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "device_once.h"
 #include <stdint.h>
 #include <stdlib.h>
@@ -267,71 +268,76 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
   // lane owns one output row and its registers 4g .. 4g+3 are four consecutive columns: 16-byte stores, a quarter of the
   // vector-memory instructions of a row-per-register layout.  (tools/gemm_timeline.py: the epilogue is 20 000+ cycles of a
   // K = 320 tile's 95 000 - every workgroup of a round stores at the same time and the burst drains at HBM write rate.)
-  const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
-  if (p.epi) {
-    // Through LDS: a lane owns an output ROW of the accumulators, so a direct store instruction touches 32 rows x 32 bytes;
-    // staged in a wave-private [32][68] tile (the K loop's buffers are free after its last barrier) the same data leaves as
-    // 4 rows x 256 contiguous bytes per instruction, and the residual is read the same way.
-    float* T = reinterpret_cast<float*>(smem_g) + wave * (32 * 68);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cl = j * 32 + 8 * g + 4 * h;
-          const int n = n0 + wn * 64 + cl;
-          f32x4 y = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if constexpr (F16) y *= *reinterpret_cast<const f32x4*>(p.wscale + n);  // (the scale array covers the padded columns)
-          if (p.bias && n < p.N) y += *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (p.act == SEGMIF_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
-            else if (p.act == SEGMIF_ACT_PRELU) y[e] = y[e] >= 0.f ? y[e] : slope * y[e];
-            else if (p.act == SEGMIF_ACT_GELU) y[e] = gelu_exact(y[e]);
+  // (r6) one uniform branch on "the activation is a GELU" in front of the epilogue: inside the per-element switch every accumulator
+  // element carried its own copy of the erf GELU (see igemm.hip) - tens of KB of ISA for an activation these kernels' callers never ask for
+  auto epilogue_r6 = [&](auto gelu_c) {
+    constexpr bool GELU_EPI = decltype(gelu_c)::value;
+    const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
+    if (p.epi) {
+      // Through LDS: a lane owns an output ROW of the accumulators, so a direct store instruction touches 32 rows x 32 bytes;
+      // staged in a wave-private [32][68] tile (the K loop's buffers are free after its last barrier) the same data leaves as
+      // 4 rows x 256 contiguous bytes per instruction, and the residual is read the same way.
+      float* T = reinterpret_cast<float*>(smem_g) + wave * (32 * 68);
+  #pragma unroll
+      for (int i = 0; i < 2; ++i) {
+  #pragma unroll
+        for (int j = 0; j < 2; ++j)
+  #pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cl = j * 32 + 8 * g + 4 * h;
+            const int n = n0 + wn * 64 + cl;
+            f32x4 y = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            if constexpr (F16) y *= *reinterpret_cast<const f32x4*>(p.wscale + n);  // (the scale array covers the padded columns)
+            if (p.bias && n < p.N) y += *reinterpret_cast<const f32x4*>(p.bias + n);
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if constexpr (GELU_EPI) { y[e] = gelu_exact(y[e]); } else if (p.act == SEGMIF_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+              else if (p.act == SEGMIF_ACT_PRELU) y[e] = y[e] >= 0.f ? y[e] : slope * y[e];
+            }
+            *reinterpret_cast<f32x4*>(T + r * 68 + cl) = y;
           }
-          *reinterpret_cast<f32x4*>(T + r * 68 + cl) = y;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: the wave's own LDS writes have landed
+  #pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int row = t * 4 + (lane >> 4), cl = (lane & 15) * 4;
+          const long long m = m0 + wm * 64 + i * 32 + row;
+          const int n = n0 + wn * 64 + cl;
+          f32x4 y = *reinterpret_cast<const f32x4*>(T + row * 68 + cl);
+          if (m < p.M && n < p.N) {
+            if (p.res) y += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n);
+            *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = y;
+          }
         }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: the wave's own LDS writes have landed
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int row = t * 4 + (lane >> 4), cl = (lane & 15) * 4;
-        const long long m = m0 + wm * 64 + i * 32 + row;
-        const int n = n0 + wn * 64 + cl;
-        f32x4 y = *reinterpret_cast<const f32x4*>(T + row * 68 + cl);
-        if (m < p.M && n < p.N) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites the tile
+      }
+      return;
+    }
+  #pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long long m = m0 + wm * 64 + i * 32 + r;
+      if (m >= p.M) continue;
+  #pragma unroll
+      for (int j = 0; j < 2; ++j)
+  #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
+          if (n >= p.N) continue;  // N % 4 == 0: a group of four is inside or outside as a whole
+          f32x4 y = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if constexpr (F16) y *= *reinterpret_cast<const f32x4*>(p.wscale + n);
+          if (p.bias) y += *reinterpret_cast<const f32x4*>(p.bias + n);
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (GELU_EPI) { y[e] = gelu_exact(y[e]); } else if (p.act == SEGMIF_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+            else if (p.act == SEGMIF_ACT_PRELU) y[e] = y[e] >= 0.f ? y[e] : slope * y[e];
+          }
           if (p.res) y += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n);
           *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = y;
         }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites the tile
     }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const long long m = m0 + wm * 64 + i * 32 + r;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
-        if (n >= p.N) continue;  // N % 4 == 0: a group of four is inside or outside as a whole
-        f32x4 y = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        if constexpr (F16) y *= *reinterpret_cast<const f32x4*>(p.wscale + n);
-        if (p.bias) y += *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (p.act == SEGMIF_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
-          else if (p.act == SEGMIF_ACT_PRELU) y[e] = y[e] >= 0.f ? y[e] : slope * y[e];
-          else if (p.act == SEGMIF_ACT_GELU) y[e] = gelu_exact(y[e]);
-        }
-        if (p.res) y += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n);
-        *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = y;
-      }
-  }
-  GEMM_TL(14, 7);
+    GEMM_TL(14, 7);
+  };
+  if (p.act == SEGMIF_ACT_GELU) epilogue_r6(std::true_type{});
+  else epilogue_r6(std::false_type{});
 }
 
 // fp32 [N][ldw] -> [n-tile][k-step][128 rows][K half][plane][16] bf16 with 208-byte rows, zero filled past N / K

@@ -21,6 +21,7 @@
 //   Block ids are remapped so that each XCD (private L2) owns a contiguous range of M tiles:
 //   neighbouring tiles share their 3x3 halo rows.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "device_once.h"
 #include <stdint.h>
 
@@ -380,120 +381,130 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
       return;
     }
   }
-  const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
-  auto activate = [&](float y) {
-    if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
-    else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
-    else if (p.act == SEGMIF_ACT_GELU) y = gelu_exact(y);
-    return y;
-  };
-  if (p.vec4) {
-    // the planes copy exists in the generic-gather instantiations only (a conv that asks for it is routed there: its one
-    // user is conv1 with Cin = 1); the dense and 16-channel-chunk conv tiles stay free of its registers (20-30 VGPRs)
-    constexpr bool PLANES = MODE == MODE_GENERIC;
-    const int pl_pitch = PLANES && p.pl_f16 ? p16::PIXEL_BYTES : 96;
-    uint32_t pl_amx = 0u;  // f16x3 planes: largest |output| this lane wrote (p16::absmax_pk patterns)
-    f32x4 rr[TM][TN][4];
-    if (res) {
-#pragma unroll
+  // (r6) ONE uniform branch on "is the activation a GELU" in front of the whole epilogue.  Written with the erf GELU inside the
+  // per-element activation switch, every accumulator element of a lane carried its own copy of it: 9 000 - 23 000 lines of ISA per
+  // instantiation (54 KB and more - the 64 KB instruction cache two CUs share does not hold one kernel), for an activation no GEMM
+  // of the measured paths applies (GELU follows the depthwise conv).  The 40-us Linears of a training step paid for it in
+  // instruction fetch.  (Same finding as gemm_pairs.hip's epilogue.)
+  auto epilogue = [&](auto gelu_c) {
+    constexpr bool GELU = decltype(gelu_c)::value;
+    const float slope = (p.act == SEGMIF_ACT_PRELU) ? *p.prelu : 0.f;
+    auto activate = [&](float y) {
+      if constexpr (GELU) return gelu_exact(y);
+      if (p.act == SEGMIF_ACT_RELU) y = fmaxf(y, 0.f);
+      else if (p.act == SEGMIF_ACT_PRELU) y = y >= 0.f ? y : slope * y;
+      return y;
+    };
+    if (p.vec4) {
+      // the planes copy exists in the generic-gather instantiations only (a conv that asks for it is routed there: its one
+      // user is conv1 with Cin = 1); the dense and 16-channel-chunk conv tiles stay free of its registers (20-30 VGPRs)
+      constexpr bool PLANES = MODE == MODE_GENERIC;
+      const int pl_pitch = PLANES && p.pl_f16 ? p16::PIXEL_BYTES : 96;
+      uint32_t pl_amx = 0u;  // f16x3 planes: largest |output| this lane wrote (p16::absmax_pk patterns)
+      f32x4 rr[TM][TN][4];
+      if (res) {
+  #pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const long long m = row_of(i);
+  #pragma unroll
+          for (int j = 0; j < TN; ++j)
+  #pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int n = col_of(j, g);
+              rr[i][j][g] = (m < p.M && n < p.N) ? *reinterpret_cast<const f32x4*>(res + m * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+      }
+  #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const long long m = row_of(i);
-#pragma unroll
+        if (m >= p.M) continue;
+        unsigned char* pl_px = nullptr;
+        if (PLANES && p.planes) {  // output pixel m = (b, oy, ox) -> its 96-byte (f16x3: 64-byte) slot in chunk image 0 of batch element b
+          const long long ohw = (long long)p.OH * p.OW;
+          const long long b = m / ohw;
+          const int rem = (int)(m - b * ohw);
+          const int oy = rem / p.OW, ox = rem - oy * p.OW;
+          pl_px = p.planes + ((((long long)b * p.pl_chunks + p.pl_chunk0) * p.pl_Hp + oy + 2) * p.pl_Wp + ox + 2) * pl_pitch + eh * 16;
+        }
+  #pragma unroll
         for (int j = 0; j < TN; ++j)
-#pragma unroll
+  #pragma unroll
+          for (int q = 0; q < 2; ++q) {  // columns 32 j + 16 q .. + 15 = planes chunk (n0 + wn WN + 32 j) / 16 + q
+            float yy[8];
+  #pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+              const int g = 2 * q + gg;
+              const int n = col_of(j, g);
+              if (n >= p.N) continue;  // N % 4 == 0: a group of four is inside or outside as a whole
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(cl + 32 * j + 8 * g);
+              f32x4 y;
+  #pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                y[e] = activate(acc[i][j][4 * g + e] + bb[e]);
+                if (res) y[e] += rr[i][j][g][e];
+                yy[4 * gg + e] = y[e];
+              }
+              if (mask) {  // through a ReLU whose OUTPUT the mask tensor is (the consumer's forward activation)
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + m * p.ldm + n);
+  #pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = mk[e] > 0.f ? y[e] : 0.f;
+              }
+              if (p.out) *reinterpret_cast<f32x4*>(out + m * p.ldo + n) = y;
+            }
+            if (PLANES && p.planes && col_of(j, 2 * q) < p.N) {
+              // this lane's 8 of the chunk's 16 channels are positions 8 h .. 8 h + 7 of the chunk (sigma order): one
+              // 16-byte store per plane
+              const int chunk = (n0 + wn * WN + 32 * j) / 16 + q;
+              unsigned char* dst = pl_px + (long long)chunk * p.pl_Hp * p.pl_Wp * pl_pitch;
+              if (p.pl_f16) {
+                ig_u32x4 hi, lo;
+                p16::split8(yy, hi, lo);
+                *reinterpret_cast<ig_u32x4*>(dst) = hi;
+                *reinterpret_cast<ig_u32x4*>(dst + 32) = lo;
+                pl_amx = p16::absmax_pk4(pl_amx, hi, lo);
+              } else {
+                ig_u32x4 pp[3];
+  #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  uint32_t a, b, c;
+                  ig_split3(yy[2 * e], yy[2 * e + 1], a, b, c);
+                  pp[0][e] = a; pp[1][e] = b; pp[2][e] = c;
+                }
+  #pragma unroll
+                for (int k = 0; k < 3; ++k) *reinterpret_cast<ig_u32x4*>(dst + k * 32) = pp[k];
+              }
+            }
+          }
+      }
+      if (PLANES && p.pl_amax) {  // (kernel argument: uniform over the grid) this wave's rows -> their images' range slots
+        const long long ohw = (long long)p.OH * p.OW;
+        const long long ma = m0 + wm * WM, mb = ma + TM * 32 - 1 < p.M ? ma + TM * 32 - 1 : p.M - 1;
+        if (ma < p.M) p16::fold_pat(p.pl_amax, p.pl_amax_images > 1 ? (int)(ma / ohw) : 0, p.pl_amax_images > 1 ? (int)(mb / ohw) : 0, pl_amx);
+      }
+    } else {  // ragged N or unaligned views: element by element
+  #pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const long long m = row_of(i);
+        if (m >= p.M) continue;
+  #pragma unroll
+        for (int j = 0; j < TN; ++j)
+  #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int n = col_of(j, g);
-            rr[i][j][g] = (m < p.M && n < p.N) ? *reinterpret_cast<const f32x4*>(res + m * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const long long m = row_of(i);
-      if (m >= p.M) continue;
-      unsigned char* pl_px = nullptr;
-      if (PLANES && p.planes) {  // output pixel m = (b, oy, ox) -> its 96-byte (f16x3: 64-byte) slot in chunk image 0 of batch element b
-        const long long ohw = (long long)p.OH * p.OW;
-        const long long b = m / ohw;
-        const int rem = (int)(m - b * ohw);
-        const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        pl_px = p.planes + ((((long long)b * p.pl_chunks + p.pl_chunk0) * p.pl_Hp + oy + 2) * p.pl_Wp + ox + 2) * pl_pitch + eh * 16;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {  // columns 32 j + 16 q .. + 15 = planes chunk (n0 + wn WN + 32 j) / 16 + q
-          float yy[8];
-#pragma unroll
-          for (int gg = 0; gg < 2; ++gg) {
-            const int g = 2 * q + gg;
-            const int n = col_of(j, g);
-            if (n >= p.N) continue;  // N % 4 == 0: a group of four is inside or outside as a whole
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(cl + 32 * j + 8 * g);
-            f32x4 y;
-#pragma unroll
+  #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              y[e] = activate(acc[i][j][4 * g + e] + bb[e]);
-              if (res) y[e] += rr[i][j][g][e];
-              yy[4 * gg + e] = y[e];
-            }
-            if (mask) {  // through a ReLU whose OUTPUT the mask tensor is (the consumer's forward activation)
-              const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + m * p.ldm + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) y[e] = mk[e] > 0.f ? y[e] : 0.f;
-            }
-            if (p.out) *reinterpret_cast<f32x4*>(out + m * p.ldo + n) = y;
-          }
-          if (PLANES && p.planes && col_of(j, 2 * q) < p.N) {
-            // this lane's 8 of the chunk's 16 channels are positions 8 h .. 8 h + 7 of the chunk (sigma order): one
-            // 16-byte store per plane
-            const int chunk = (n0 + wn * WN + 32 * j) / 16 + q;
-            unsigned char* dst = pl_px + (long long)chunk * p.pl_Hp * p.pl_Wp * pl_pitch;
-            if (p.pl_f16) {
-              ig_u32x4 hi, lo;
-              p16::split8(yy, hi, lo);
-              *reinterpret_cast<ig_u32x4*>(dst) = hi;
-              *reinterpret_cast<ig_u32x4*>(dst + 32) = lo;
-              pl_amx = p16::absmax_pk4(pl_amx, hi, lo);
-            } else {
-              ig_u32x4 pp[3];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                uint32_t a, b, c;
-                ig_split3(yy[2 * e], yy[2 * e + 1], a, b, c);
-                pp[0][e] = a; pp[1][e] = b; pp[2][e] = c;
-              }
-#pragma unroll
-              for (int k = 0; k < 3; ++k) *reinterpret_cast<ig_u32x4*>(dst + k * 32) = pp[k];
+              if (n + e >= p.N) continue;
+              float y = activate(acc[i][j][4 * g + e] + cl[32 * j + 8 * g + e]);
+              if (res) y += res[m * p.ldr + n + e];
+              out[m * p.ldo + n + e] = y;
             }
           }
-        }
+      }
     }
-    if (PLANES && p.pl_amax) {  // (kernel argument: uniform over the grid) this wave's rows -> their images' range slots
-      const long long ohw = (long long)p.OH * p.OW;
-      const long long ma = m0 + wm * WM, mb = ma + TM * 32 - 1 < p.M ? ma + TM * 32 - 1 : p.M - 1;
-      if (ma < p.M) p16::fold_pat(p.pl_amax, p.pl_amax_images > 1 ? (int)(ma / ohw) : 0, p.pl_amax_images > 1 ? (int)(mb / ohw) : 0, pl_amx);
-    }
-  } else {  // ragged N or unaligned views: element by element
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const long long m = row_of(i);
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = col_of(j, g);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (n + e >= p.N) continue;
-            float y = activate(acc[i][j][4 * g + e] + cl[32 * j + 8 * g + e]);
-            if (res) y += res[m * p.ldr + n + e];
-            out[m * p.ldo + n + e] = y;
-          }
-        }
-    }
-  }
+  };
+  if (p.act == SEGMIF_ACT_GELU) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
 }
 
 struct TileCfg {
