@@ -426,3 +426,63 @@ def test_conv3x3_planes_f16x3_four_subtiles(ops, case):
     mask[:, :, 2:2 + H, 2:2 + W] = False
     assert float(raw[mask].abs().max()) == 0.0
     assert guard.ok()
+
+
+@pytest.mark.parametrize("case", [(2, 32, 40, 64, 2, 1), (1, 16, 70, 160, 2, 1), (1, 48, 33, 96, 1, 2), (3, 16, 32, 128, 1, 0),
+                                  (2, 16, 64, 32, 2, 2)])
+def test_lean_plain_conv_equals_the_general_instantiation(ops, case):
+    """(r6) conv3x3_planes_kernel<.., LEAN> - the instantiation an inference forward takes when no fp32 copy is asked for: halved
+    constants, relu(t) = t' + |t'|, PReLU / none from the same halved value, plane stores deferred into the next LOAD phase - against
+    the GENERAL instantiation (asking for the fp32 copy selects it) on the same planes: the written chunks must hold the same VALUES
+    element for element (only the sign of a zero may differ), the border stays zero, the range slot reports the same maximum.
+    Heights are whole 16-row patches (the four-sub-tile kernels); the last case has fewer chunks (2) than sub-tiles."""
+    B, H, W, Cin, d, act = case
+    x, w, b = rnd(B, Cin, H, W, seed=21), rnd(32, Cin, 3, 3, seed=22) * 0.3, rnd(32, seed=23)
+    slope = torch.tensor([0.25], device="cuda") if act == 2 else None
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = ops.pack_weight_planes16(w.cuda())
+    res = []
+    for lean in (False, True):
+        guard = ops.Planes16Guard("cuda")
+        pl = ops.Planes(B, H, W, Cin // 16 + 2, "cuda", guard).load_f32(xh)
+        kw = {} if lean else {"out": torch.empty(B, H, W, 32, device="cuda")}
+        ops.conv3x3_planes(pl, Cin, wp, dil=d, bias=b.cuda(), act=act, prelu=slope, out_chunk0=Cin // 16, **kw)
+        torch.cuda.synchronize()
+        got, raw = _decode(pl, Cin // 16, 2)
+        assert guard.ok()
+        res.append((got, raw, guard.maxima().clone()))
+    (g0, r0, m0), (g1, r1, m1) = res
+    assert torch.equal(g0, g1)                      # (+0 == -0)
+    assert torch.equal(r0.abs(), r1.abs())          # every half of the padded image, border included
+    assert torch.equal(m0, m1)
+    pre = F.conv2d(x.double(), w.double(), b.double(), padding=d, dilation=d)
+    ref = (F.relu(pre) if act == 1 else torch.where(pre >= 0, pre, 0.25 * pre) if act == 2 else pre).permute(0, 2, 3, 1)
+    assert float((g1 - ref).abs().max() / ref.abs().max()) < TOL
+
+
+def test_lean_fused_tail_equals_the_general_instantiation(ops):
+    """(r6) the LEAN fused tail (ReLU / ReLU, residual from the input planes, no planes out: 1x1 weights of the conv's own channels
+    resident in LDS, residual pieces requested a sub-tile ahead, v_fma_mix_f32 reconstruction) against the general fused kernel, which
+    asking for the conv's planes copy selects: out1 bit for bit (same products in the same order; only a zero's sign may differ)."""
+    B, H, W, Cin = 2, 24, 70, 192
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(B, H, W, Cin, generator=g) * 2 - 1) * 10.0 ** (torch.rand(B, H, W, Cin, generator=g) * 4 - 3)
+    w, b = rnd(32, Cin, 3, 3, seed=41) * 0.05, rnd(32, seed=42)
+    w1, b1 = rnd(64, Cin + 32, seed=43) * 0.1, rnd(64, seed=44)
+    wp, w1p = ops.pack_weight_planes16(w.cuda()), ops.pack_weight_planes16(w1.cuda())
+    outs = []
+    for lean in (False, True):
+        guard = ops.Planes16Guard("cuda")
+        pl = ops.Planes(B, H, W, Cin // 16 + 2, "cuda", guard).load_f32(x.cuda())
+        out = torch.full((B, H, W, 64), 7.0, device="cuda")
+        ops.conv3x3_planes(pl, Cin, wp, dil=2, bias=b.cuda(), act=1, out_chunk0=None if lean else Cin // 16,
+                           tail=(w1p, b1.cuda(), None, out, 1, True))
+        torch.cuda.synchronize()
+        assert guard.ok()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    xd = x.double().permute(0, 3, 1, 2)
+    mid = F.relu(F.conv2d(xd, w.double(), b.double(), padding=2, dilation=2))
+    pre = F.conv2d(torch.cat((xd, mid), dim=1), w1.double()[:, :, None, None], b1.double())
+    ref = (xd[:, :64] + F.relu(pre)).permute(0, 2, 3, 1)
+    assert err(outs[1].cuda(), ref) < TOL
