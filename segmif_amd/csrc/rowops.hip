@@ -197,6 +197,22 @@ constexpr int DW_TY = 8;
 __device__ __forceinline__ float gelu_exact(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
+// (r6) The erf GELU as csrc/mixffn.hip computes it for stages 1-2 (Abramowitz & Stegun 7.1.26: |error of erf| <= 1.5e-7, i.e.
+// <= 7.5e-8 |x| on GELU - about one fp32 ulp of x; 12 instructions instead of erff's ~35), for the PAIRS producer of stages 3-4:
+// the same function on both halves of the encoder, inside the same guarded inference scope; the fp32 kernel (training, and the
+// path a tripped pair is repeated on) keeps erff.
+__device__ __forceinline__ float gelu_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+  float q = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);  // (coefficients carry the 1/2 of erfc / 2)
+  q = fmaf(q, t, 0.5f * 1.421413741f);
+  q = fmaf(q, t, 0.5f * -0.284496736f);
+  q = fmaf(q, t, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // exp(-x^2 / 2)
+  const float half_erfc = q * t * e;
+  const float phi = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+  return x * phi;
+}
 
 template <bool GELU>
 __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __restrict__ x, const float* __restrict__ w9,
@@ -695,7 +711,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_xt_kernel(const float* __restri
         for (int kx = 0; kx < 3; ++kx) a += win[ky][kx + j] * wv[ky * 3 + kx];
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = GELU ? gelu_exact(a[e]) : a[e];
+      for (int e = 0; e < 4; ++e) o[e] = GELU ? (PAIRS ? gelu_as(a[e]) : gelu_exact(a[e])) : a[e];
       if constexpr (PAIRS) {
         if (live && x0 + j < W) {
           uint32_t ha, la, hb, lb;

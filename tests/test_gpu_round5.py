@@ -154,7 +154,21 @@ def test_pairs_producers_match_their_fp32_kernels_and_report_ranges(ops):
     w9, db = ops.pack_dw_weight(rnd(C, 1, 3, 3, seed=35).cuda()), rnd(C, seed=36).cuda()
     with scope(ops, B) as gd:
         hp = ops.dwconv3x3_gelu_pairs(h.cuda(), w9, db, Hh, Ww)
-        close(ops.pairs_to_f32(hp), ops.dwconv3x3_gelu(h.cuda(), w9, db, Hh, Ww), "dwconv_gelu")
+        # (r6) the PAIRS producer computes the erf of its GELU as csrc/mixffn.hip does (Abramowitz & Stegun 7.1.26: |error of erf| <=
+        # 1.5e-7, i.e. <= 7.5e-8 |pre-activation| on the output), the fp32 kernel with erff: decoded, the two agree within one
+        # half-pair rounding of the value PLUS that bound, element by element - and the pairs result is held to the float64 GELU
+        got, ref32 = ops.pairs_to_f32(hp).double().cpu(), ops.dwconv3x3_gelu(h.cuda(), w9, db, Hh, Ww).double().cpu()
+        wd = rnd(C, 1, 3, 3, seed=35).double()
+        pre = torch.nn.functional.conv2d(h.double().view(B, Hh, Ww, C).permute(0, 3, 1, 2), wd, rnd(C, seed=36).double(), padding=1,
+                                         groups=C).permute(0, 2, 3, 1).reshape(B, N, C)
+        ref64 = 0.5 * pre * (1.0 + torch.erf(pre * 0.70710678118654752440))
+        bound = 2.0 ** -21 * ref32.abs() + 1.0e-7 * pre.abs() + 2.0 ** -35
+        worst = float(((got - ref32).abs() / bound).max())
+        observed("pairs_producer[dwconv_gelu: |pairs - fp32 kernel| / (2^-21 |y| + 1e-7 |pre|)]", worst)
+        assert worst < 1.0, worst
+        cond = torch.nn.functional.conv2d(h.double().abs().view(B, Hh, Ww, C).permute(0, 3, 1, 2), wd.abs(), rnd(C, seed=36).double().abs(),
+                                          padding=1, groups=C).permute(0, 2, 3, 1).reshape(B, N, C)  # (the fp32 stencil's own conditioning)
+        assert float(((got - ref64).abs() / (2.0 ** -20 * ref64.abs() + 4.0e-7 * cond + 2.0 ** -30)).max()) < 1.0
     assert gd.maxima().shape == (1, B) and not gd.tripped().any()
     hot = h.clone()
     hot[2] *= 1.0e5
