@@ -486,3 +486,30 @@ def test_lean_fused_tail_equals_the_general_instantiation(ops):
     pre = F.conv2d(torch.cat((xd, mid), dim=1), w1.double()[:, :, None, None], b1.double())
     ref = (xd[:, :64] + F.relu(pre)).permute(0, 2, 3, 1)
     assert err(outs[1].cuda(), ref) < TOL
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_lean_conv_reports_overflow_nan_and_vanishing_outputs(ops, act):
+    """(r6) the LEAN plain conv's compare-free activation (relu(t) = t' + |t'|, slope min(t, 0) = slope (t' - |t'|)) under the range
+    contract: an output past the half's range (inf after the split), a NaN carried in from the input, an output of -inf (where
+    t' + |t'| is NaN instead of the select's 0) and a vanishing tensor must all trip the guard; a healthy tensor must not."""
+    B, H, W, Cin = 1, 16, 32, 64
+    x, w, b = rnd(B, H, W, Cin, seed=51), rnd(32, Cin, 3, 3, seed=52) * 0.1, rnd(32, seed=53) * 0.1
+    wt = ops.pack_weight_planes16(w.cuda())
+    slope = torch.tensor([0.25], device="cuda") if act == 2 else None
+    cases = {"healthy": (x, True), "overflow": (x * 3.0e4, False), "vanishing": (x * 1.0e-6, act == 1 and False)}
+    xn = x.clone(); xn[0, 5, 7, 3] = float("nan")
+    cases["nan"] = (xn, False)
+    xi = x.clone(); xi[0, 9, 11, :] = -6.0e4          # (within the half's range on the way in; the sums leave it on the negative side)
+    cases["negative overflow"] = (xi * 1.0, None)       # (trips unless the ReLU maps the whole region to exact zeros: checked below)
+    for name, (xin, fine) in cases.items():
+        guard = ops.Planes16Guard("cuda")
+        pl = ops.Planes(B, H, W, 6, "cuda", guard).load_f32(xin.cuda())
+        bias = b if name != "vanishing" else torch.zeros(32)
+        ops.conv3x3_planes(pl, Cin, wt, dil=2, bias=bias.cuda(), act=act, prelu=slope, out_chunk0=4)
+        torch.cuda.synchronize()
+        if fine is None:
+            got, _ = _decode(pl, 4, 2)
+            assert guard.ok() == bool(torch.isfinite(got).all() and got.abs().max() < 65504), name
+        else:
+            assert guard.ok() == fine, (name, guard.maxima())
