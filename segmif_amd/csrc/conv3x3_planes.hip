@@ -173,6 +173,18 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+#ifndef PLANES_SADDR
+#define PLANES_SADDR 1  // (r6) LDS-DMA with a scalar base + a 32-bit lane offset (no address arithmetic per instruction)
+#endif
+// (r6) The same instruction in its SADDR form: a wave-uniform 64-bit base in SGPRs + a 32-bit per-lane offset.  From the builtin
+// hipcc makes, per DMA instruction, a v_lshl_add_u64 into ONE shared 64-bit address register pair and the load from it - the next
+// instruction's address write has to wait until the load in front has read that pair (a write-after-read interlock on a
+// vector-memory operand: tens to hundreds of cycles beside the other team's MFMA stream), and every address costs two VGPR reads.
+// Here the offsets sit in their own registers for the kernel's life and a DMA instruction is an s_mov of M0 and the load.
+__device__ __forceinline__ void dma16s(const unsigned char* sbase, uint32_t voff, unsigned char* lds_wave_base) {
+  const uint32_t m = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m) : "memory", "m0");
+}
 
 // One persistent workgroup per CU, 8 waves = two TEAMS of four (one wave per SIMD each).  A team owns one 8 x 32
 // patch at a time and alternates between two roles, the teams in anti-phase, one workgroup barrier per phase:
@@ -272,7 +284,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
         const int i = j * 4 + wave;
-        if (j < AJ - 1 || i * 64 + lane < A_UNITS) dma16(ab + a_rel[j], As + i * 1024);
+        if (j < AJ - 1 || i * 64 + lane < A_UNITS) {
+          if constexpr (PLANES_SADDR && F16) dma16s(ab, a_rel[j], As + i * 1024);
+          else dma16(ab + a_rel[j], As + i * 1024);
+        }
       }
     }
   };
@@ -286,7 +301,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int j = 0; j < (W_SPLIT + 3) / 4; ++j) {
       const int i = lo + j * 4 + wave;
-      if (i < hi) dma16(wb + i * 1024, wd + i * 1024);
+      if (i < hi) {
+        if constexpr (PLANES_SADDR && F16) dma16s(p.wt + (long long)c * W3_BYTES + i * 1024, (uint32_t)(lane * 16), wd + i * 1024);
+        else dma16(wb + i * 1024, wd + i * 1024);
+      }
     }
     if (FUSE && team == 1) {
       const unsigned char* __restrict__ w1b = p.w1 + (long long)c * W1_BYTES + lane * 16;
