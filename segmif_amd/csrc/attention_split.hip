@@ -151,6 +151,17 @@ __device__ __forceinline__ int slot_to_index(int pos) {  // position 16 s + 8 h 
   const int s = pos >> 4, hh = (pos >> 3) & 1, j = pos & 7;
   return 16 * s + 4 * hh + (j & 3) + 8 * (j >> 2);
 }
+__device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char* p) {  // a wave-uniform pointer, into SGPRs
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const unsigned char*>((uintptr_t)(((uint64_t)hi << 32) | lo));
+}
+// (r6) the SADDR form of the same instruction: wave-uniform base in SGPRs + a 32-bit lane offset (csrc/conv3x3_planes.hip, dma16s: no
+// per-instruction address arithmetic, one VGPR read per lane instead of two, no write-after-read interlock on a shared address pair)
+__device__ __forceinline__ void dma16s(const unsigned char* sbase, uint32_t voff, unsigned char* lds_wave_base) {
+  const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m) : "memory", "m0");
+}
 __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][IMG]
   using I = Img<F16>;
   constexpr int IMG = I::BYTES, NPL = I::NPL;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
   const int qi = blockIdx.x * 128 + wave * 32 + r;
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   auto stage = [&](int kt, int buf) {
     const unsigned char* s = src + (long long)kt * IMG;
     unsigned char* d = smem + buf * IMG;
-    for (int i = wave; i < IMG / 1024; i += 4) dma16(s + i * 1024 + lane * 16, d + i * 1024);
+    for (int i = wave; i < IMG / 1024; i += 4) dma16s(uniform_ptr(s + i * 1024), (uint32_t)(lane * 16), d + i * 1024);
   };
   stage(0, 0);
 

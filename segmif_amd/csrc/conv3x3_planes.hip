@@ -312,7 +312,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int i = j * 4 + wave;
-        if (i < W1_INSTR) dma16(w1b + i * 1024, w1d + i * 1024);
+        if (i < W1_INSTR) {
+          if constexpr (PLANES_SADDR && F16) dma16s(p.w1 + (long long)c * W1_BYTES + i * 1024, (uint32_t)(lane * 16), w1d + i * 1024);
+          else dma16(w1b + i * 1024, w1d + i * 1024);
+        }
       }
     }
   };

@@ -80,7 +80,16 @@ struct GemmPairsK {
   // patch mode (patch_k > 0): A row (b, oy, ox) is the k x k patch at (st oy - pad, st ox - pad) of a dense NHWC pairs image
   // (B, H, W, C), C % 16 == 0, pixel pitch 4 C bytes; K = k k C in (ky, kx, c) order; a K step lies inside one tap
   int patch_k, patch_st, patch_pad, patch_H, patch_W, patch_OH, patch_OW, patch_C;
+  int saddr;                  // (r6) plain rows whose byte offsets from `a` fit 32 bits: LDS-DMA in SADDR form (below)
 };
+
+// (r6) global_load_lds_dwordx4 in its SADDR form - a wave-uniform 64-bit base in SGPRs + a 32-bit per-lane offset (see
+// csrc/conv3x3_planes.hip, dma16s: per-lane 64-bit address pairs cost two VGPR reads per instruction and, advanced by vector adds, a
+// write-after-read interlock on a vector-memory operand; here the lane offsets are constants of the kernel and the base moves by SALU)
+__device__ __forceinline__ void dma16s(const unsigned char* sbase, uint32_t voff, unsigned char* lds_wave_base) {
+  const uint32_t m = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m) : "memory", "m0");
+}
 
 __device__ __forceinline__ u32x4 times_2m11(const u32x4 v) {  // 8 halves x 2^-11 (v_pk_mul_f16; exact up to the half's own rounding)
   const f16x8 s = {(_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f,
@@ -152,6 +161,10 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM == 
       a_src[q] = p.a + m * p.lda + j * 16;
     }
   }
+  uint32_t a_off[APW];  // (SADDR form) the same sources as 32-bit offsets from p.a
+#pragma unroll
+  for (int q = 0; q < APW; ++q) a_off[q] = PATCH ? 0u : (uint32_t)(a_src[q] - p.a);
+  const bool sa = !PATCH && p.saddr;  // (uniform)
   const unsigned char* w_src = p.w + (long long)nt * nks * PWSTEP + (wave * WPW) * 1024 + lane * 16;
   const unsigned char* zsrc = p.zero + (lane & 3) * 16;
   int t_ky = 0, t_kx = 0, t_c0 = 0;  // patch mode: tap and channel offset of the NEXT step to be issued (uniform)
@@ -174,16 +187,25 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM == 
           ++t_ky;
         }
       }
+    } else if (sa) {
+#pragma unroll
+      for (int q = 0; q < APW; ++q) dma16s(p.a + (long long)ks * PROW, a_off[q], base + (wave * APW + q) * 1024);
     } else {
 #pragma unroll
       for (int q = 0; q < APW; ++q)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + (long long)ks * PROW),
                                          (__attribute__((address_space(3))) void*)(base + (wave * APW + q) * 1024), 16, 0, 0);
     }
+    if (sa) {
+      const unsigned char* wb = p.w + (long long)nt * nks * PWSTEP + (wave * WPW) * 1024 + (long long)ks * PWSTEP;  // (uniform)
 #pragma unroll
-    for (int q = 0; q < WPW; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src + (long long)ks * PWSTEP + q * 1024),
-                                       (__attribute__((address_space(3))) void*)(base + MT * PROW + (wave * WPW + q) * 1024), 16, 0, 0);
+      for (int q = 0; q < WPW; ++q) dma16s(wb + q * 1024, (uint32_t)(lane * 16), base + MT * PROW + (wave * WPW + q) * 1024);
+    } else {
+#pragma unroll
+      for (int q = 0; q < WPW; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src + (long long)ks * PWSTEP + q * 1024),
+                                         (__attribute__((address_space(3))) void*)(base + MT * PROW + (wave * WPW + q) * 1024), 16, 0, 0);
+    }
   };
 
   f32x16 acc[2][2];
@@ -494,6 +516,10 @@ extern "C" int segmif_gemm_pairs_f32(const SegmifGemmPairs* d, void* stream) {
   k.a = (const unsigned char*)d->a; k.w = (const unsigned char*)d->w; k.bias = d->bias; k.res = d->res; k.prelu = d->prelu;
   k.out = d->out; k.zero = zp;
   k.M = d->M; k.N = d->N; k.K = d->K; k.lda = d->lda_bytes; k.ldo = d->ldo; k.ldr = d->ldr; k.act = d->act;
+  {  // SADDR form of the LDS-DMA: every A byte the kernel touches within 2^32 of `a` (SEGMIF_GEMM_PAIRS_SADDR=0: the builtin's form, for A/B)
+    static const bool on = [] { const char* e = getenv("SEGMIF_GEMM_PAIRS_SADDR"); return !(e && e[0] == '0'); }();
+    k.saddr = on && (unsigned long long)d->M * (unsigned long long)d->lda_bytes < (1ull << 32) ? 1 : 0;
+  }
   k.ntn = (d->N + PNT - 1) / PNT;
   k.wscale = reinterpret_cast<const float*>(k.w + (int64_t)k.ntn * (d->K / PBK) * PWSTEP);
   k.patch_k = patch ? d->patch_k : 0; k.patch_st = d->patch_st; k.patch_pad = d->patch_pad;

@@ -113,6 +113,11 @@ __device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// (r6) SADDR form (csrc/conv3x3_planes.hip, dma16s): wave-uniform base in SGPRs + 32-bit lane offset
+__device__ __forceinline__ void mf_dma16s(const unsigned char* sbase, uint32_t voff, unsigned char* lds_wave_base) {
+  const uint32_t m = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m) : "memory", "m0");
+}
 __device__ __forceinline__ void mf_dma16(const unsigned char* src, unsigned char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -148,9 +153,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // chunk j's image -> Wb[j & 1] by LDS-DMA, issued a whole chunk ahead (right after the barrier that opens chunk j - 1: by
   // then every wave is done with chunk j - 2, the buffer's previous tenant)
   auto dma = [&](int j) {
-    const unsigned char* src = p.wimg + (long long)j * G::CHB + lane * 16;
+    const unsigned char* src = p.wimg + (long long)j * G::CHB;  // (uniform: SADDR form, the lane offset is a constant)
     unsigned char* dst = Wb + (j & 1) * G::CHB;
-    for (int i = wave; i < G::CHB / 1024; i += NW) mf_dma16(src + i * 1024, dst + i * 1024);
+    for (int i = wave; i < G::CHB / 1024; i += NW) mf_dma16s(src + i * 1024, (uint32_t)(lane * 16), dst + i * 1024);
   };
   dma(0);
 
