@@ -187,21 +187,15 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmSplitK p) {
       }
     }
   };
-  // (r6) LDS-DMA in SADDR form (csrc/conv3x3_planes.hip, dma16s): wave-uniform base in SGPRs + a constant 32-bit lane offset - the
-  // builtin's shared 64-bit address pair serialises back-to-back DMA instructions on a write-after-read interlock
-  const unsigned char* wt = p.w + (long long)nt * nks * GTILE;  // (uniform)
+  const unsigned char* __restrict__ wt = p.w + (long long)nt * nks * GTILE + lane * 16;
   auto b_dma = [&](int ks) {
     const unsigned char* src = wt + (long long)ks * GTILE;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const int i = j * 4 + wave;
-      if (i < GTILE / 1024) {
-        const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(Bs + i * 1024));
-        const uint64_t sb = (uint64_t)(uintptr_t)(src + i * 1024);
-        const unsigned char* sbase = reinterpret_cast<const unsigned char*>((uintptr_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
-                                                                                      __builtin_amdgcn_readfirstlane((uint32_t)sb)));
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"((uint32_t)(lane * 16)), "s"(sbase), "s"(m) : "memory", "m0");
-      }
+      if (i < GTILE / 1024)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(Bs + i * 1024), 16, 0, 0);
     }
   };
 
