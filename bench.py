@@ -268,9 +268,9 @@ def train_leg(args, rank, world, seg, fus):
 # tools/kstats.sh over tools/train_bench.py on this code; not re-measured by a bench run)
 TRAIN_DOMINANT = {
     "seg": {"kernel": "igemm_kernel<64,64,32,32,16,0,2> (the ~290 small Linears of the MiT blocks at 8 images: exact-fp32 MFMA tiles)",
-            "share_of_kernel_time": 0.24, "source": "profiles/r06_segtrain_kernel_stats.txt"},
+            "share_of_kernel_time": 0.242, "source": "profiles/r06_segtrain_kernel_stats.txt"},
     "fusion": {"kernel": "conv3x3_split_kernel<32,2,8,f16x3> (DRDB dilated convs, forward and input gradients, range made on the device)",
-               "share_of_kernel_time": 0.129, "source": "profiles/r06_fusiontrain_kernel_stats.txt"},
+               "share_of_kernel_time": 0.134, "source": "profiles/r06_fusiontrain_kernel_stats.txt"},
 }
 
 
